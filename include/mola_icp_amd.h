@@ -1,0 +1,232 @@
+/*
+ * mola_icp_amd.h -- C-ABI of the MI355X-native ICP registration core.
+ *
+ * This is the drop-in boundary for the one hot path of MOLAorg/mola-fe-lidar:
+ * `LidarOdometry::run_one_icp()` (src/LidarOdometry.cpp:851-895) delegating to
+ * `mp2p_icp::ICP::align(from, to, init_guess_to_wrt_from, params, result)`
+ * (src/LidarOdometry.cpp:869-871).  Plain pointers and sizes only: no C++,
+ * torch, MRPT or HIP types cross it.  Reference-side binding: INTEGRATION.md.
+ *
+ * Conventions (all from the reference):
+ *  - `from` = global cloud / map (M points), `to` = local cloud / queries
+ *    (N points): include/mola-fe-lidar/LidarOdometry.h:121, src/LidarOdometry.cpp:278-279.
+ *  - poses are `to` w.r.t. `from` (LidarOdometry.h:122,131): g ~= T (+) l.
+ *    4x4 row-major doubles; helpers convert from/to MRPT TPose3D
+ *    (x,y,z,yaw,pitch,roll), R = Rz(yaw)Ry(pitch)Rx(roll) (src/LidarOdometry.cpp:272-275).
+ *  - clouds are fp32 structure-of-arrays x[], y[], z[].
+ *  - every function returns MOLA_ICP_OK (0) or a negative MOLA_ICP_E_* code; the
+ *    message of the calling thread's last error is mola_icp_last_error().
+ *    Nothing aborts or throws across this boundary (the reference's own error
+ *    convention is C++ exceptions caught per task: src/LidarOdometry.cpp:510-513,
+ *    845-848; the C++ shim turns codes back into exceptions).
+ *  - mola_icp_align() is re-entrant per handle (the reference calls align() on
+ *    one ICP object from several pool threads: src/LidarOdometry.cpp:94-96,869)
+ *    and takes the parameters per call (src/LidarOdometry.cpp:287-290).
+ */
+#ifndef MOLA_ICP_AMD_H
+#define MOLA_ICP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOLA_ICP_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+    MOLA_ICP_OK            = 0,
+    MOLA_ICP_E_BADARG      = -1,  /* null pointer, bad size, bad enum          */
+    MOLA_ICP_E_CONFIG      = -2,  /* YAML / class-name error (cf. cpp:70-75)   */
+    MOLA_ICP_E_HIP         = -3,  /* a HIP runtime call failed                 */
+    MOLA_ICP_E_OOM         = -4,  /* device or host allocation failed          */
+    MOLA_ICP_E_NODEVICE    = -5,  /* no gfx950 device / HIP kernels unusable   */
+    MOLA_ICP_E_UNSUPPORTED = -6,  /* valid config this build does not run      */
+    MOLA_ICP_E_COMM        = -7,  /* the all-reduce hook reported a failure    */
+    MOLA_ICP_E_INTERNAL    = -8
+};
+
+/* ---- termination reasons: mp2p_icp::IterTermReason, read at cpp:888 ---- */
+enum {
+    MOLA_ICP_TERM_UNDEFINED      = 0,
+    MOLA_ICP_TERM_NO_PAIRINGS    = 1,
+    MOLA_ICP_TERM_SOLVER_ERROR   = 2,
+    MOLA_ICP_TERM_MAX_ITERATIONS = 3,
+    MOLA_ICP_TERM_STALLED        = 4
+};
+
+/* ---- matcher / solver / quality classes (params/icp-settings-regular.yaml:23-46) */
+enum { MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD = 0, MOLA_ICP_MATCHER_POINT2PLANE = 1 };
+enum { MOLA_ICP_SOLVER_HORN = 0, MOLA_ICP_SOLVER_GAUSS_NEWTON = 1 };
+enum { MOLA_ICP_QUALITY_PAIRED_RATIO = 0 };
+/* nearest-neighbour kernel selection (new key `nn_kernel`, default auto) */
+enum { MOLA_ICP_NN_AUTO = 0, MOLA_ICP_NN_VALU = 1, MOLA_ICP_NN_MFMA = 2 };
+
+/* ---- per-call parameters == mp2p_icp::Parameters + the per-object pipeline
+ *      settings the YAML carries (params/icp-settings-regular.yaml:10-46).
+ *      Replaces `mp2p_icp::Parameters` (include/mola-fe-lidar/LidarOdometry.h:99,123). */
+typedef struct mola_icp_params {
+    uint32_t max_iterations;             /* params.maxIterations            icpreg:11 */
+    double   min_abs_step_trans;         /* params.minAbsStep_trans [m]     icpreg:12 */
+    double   min_abs_step_rot;           /* params.minAbsStep_rot [rad]     icpreg:13 */
+    int32_t  use_scale_outlier_detector; /* pairingsWeightParameters        icpreg:16 */
+    double   scale_outlier_threshold;    /*                                 icpreg:17 */
+    int32_t  use_robust_kernel;          /*                                 icpreg:19 */
+    double   robust_kernel_param;        /* RADIANS (YAML is degrees)       icpreg:20 */
+    double   robust_kernel_scale;        /*                                 icpreg:21 */
+    int32_t  solver_class;               /* MOLA_ICP_SOLVER_*               icpreg:24 */
+    uint32_t solver_max_iterations;      /* solvers[].params.maxIterations  icpreg:26 */
+    int32_t  matcher_class;              /* MOLA_ICP_MATCHER_*              icpreg:33 */
+    double   matcher_threshold;          /* threshold / distanceThreshold [m] icpreg:35 */
+    double   plane_eigen_threshold;      /* planeEigenThreshold             icpreg:36 */
+    uint32_t knn;                        /* knn                             icpreg:37 */
+    uint32_t run_from_iteration;         /* runFromIteration                icpreg:38 */
+    uint32_t run_up_to_iteration;        /* runUpToIteration (0 = no limit) icpreg:39 */
+    int32_t  quality_class;              /* MOLA_ICP_QUALITY_*              icpreg:44 */
+    double   quality_threshold;          /* thresholdDistance [m]           icpreg:46 */
+    /* keys that do not exist in the reference (default 0 = reference behaviour) */
+    int32_t  fixed_iterations;           /* !=0: never stop on the stall test (benchmarks) */
+    int32_t  nn_kernel;                  /* MOLA_ICP_NN_*                                */
+    int32_t  skip_quality;               /* !=0: skip the quality pass, quality = -1 (benchmarks) */
+} mola_icp_params;
+
+/* ---- result == the fields of mp2p_icp::Results that the reference consumes
+ *      (src/LidarOdometry.cpp:873-888) + per-call statistics. */
+typedef struct mola_icp_result {
+    double   T[16];          /* optimal_tf.mean (cpp:876,879), row-major 4x4               */
+    double   cov[36];        /* optimal_tf.cov, 6x6 row-major, order (x,y,z,wx,wy,wz)      */
+    double   quality;        /* Results::quality (cpp:873,880) in [0,1]                    */
+    uint32_t n_iterations;   /* Results::nIterations (cpp:886)                             */
+    uint32_t termination;    /* Results::terminationReason (cpp:888), MOLA_ICP_TERM_*      */
+    uint64_t n_pairs;        /* pairings that fed the last solve                           */
+    double   rmse;           /* sqrt(mean d^2) over those pairings [m]                     */
+    double   ms_upload;      /* host->HBM copies + map preparation                         */
+    double   ms_iterations;  /* the iteration loop                                         */
+    double   ms_quality;     /* the quality pass                                           */
+    double   ms_nn_kernel;   /* sum of HIP-event durations of the NN kernel launches       */
+    uint32_t n_nn_launches;  /* number of NN kernel launches timed in ms_nn_kernel         */
+    uint32_t nn_kernel_used; /* MOLA_ICP_NN_VALU / MOLA_ICP_NN_MFMA                        */
+} mola_icp_result;
+
+#define MOLA_ICP_NACC 24
+/* Per-iteration accumulator block (fp64) -- the ONLY data reduced across GPUs:
+ *  [0] W = sum w          [1..3] sum w*l        [4..6] sum w*g
+ *  [7..15] sum w*l*g^T (row-major, l_r*g_c)     [16] pairs with w>0
+ *  [17] sum d^2 over those pairs                [18..23] sum w*l*l^T (xx,xy,xz,yy,yz,zz) */
+
+/* All-reduce hook for the query-sharded multi-GPU path: must sum `n` doubles
+ * in place across ranks and return 0.  `device_ptr`!=0 means buf is in HBM
+ * (ordered on the handle's stream), else it is host memory. */
+typedef int (*mola_icp_allreduce_fn)(double* buf, int n, int device_ptr, void* user);
+
+typedef struct mola_icp_handle mola_icp_handle; /* one per `mp2p_icp::ICP` object (LidarOdometry.h:98) */
+
+/* ---- library ---------------------------------------------------------- */
+int         mola_icp_abi_version(void);
+const char* mola_icp_last_error(void);            /* thread-local, never NULL */
+const char* mola_icp_status_string(int status);
+int         mola_icp_device_count(int* count);    /* gfx950 devices visible   */
+
+/* ---- parameters ------------------------------------------------------- */
+/* the defaults of mp2p_icp::Parameters + Points_DistanceThreshold/Horn/PairedRatio */
+int mola_icp_params_default(mola_icp_params* p);
+
+/* Replaces load_icp_set_of_params() (src/LidarOdometry.cpp:57-88): parses one
+ * `icp-settings-*.yaml` document (text), accepts every key of
+ * params/icp-settings-regular.yaml:7-46, checks `icp_class`, and fills *p.
+ * Unknown class names -> MOLA_ICP_E_CONFIG naming the class (cf. cpp:70-75). */
+int mola_icp_params_from_yaml(const char* yaml_text, mola_icp_params* p);
+/* same from a file; resolves `$include{...}` and `$(mola-dir PKG)` (-> mola_dir)
+ * like params/kitti-default.yaml:43,46,50; `key` selects a sub-map
+ * (e.g. "icp_settings_with_vel"), NULL/"" = the document root. */
+int mola_icp_params_from_yaml_file(const char* path, const char* mola_dir, const char* key, mola_icp_params* p);
+
+/* ---- handle ----------------------------------------------------------- */
+/* device < 0: current HIP device.  Replaces mrpt::rtti::classFactory(icp_class)
+ * (src/LidarOdometry.cpp:66-68).  Fails with MOLA_ICP_E_NODEVICE when no GPU
+ * is present: there is no CPU fallback. */
+int mola_icp_create(int device, mola_icp_handle** out);
+int mola_icp_destroy(mola_icp_handle* h);
+/* run this handle's work on an existing HIP stream (hipStream_t as void*); NULL = own stream */
+int mola_icp_set_stream(mola_icp_handle* h, void* hip_stream);
+/* query-sharded multi-GPU: install the accumulator all-reduce (NULL = single GPU) */
+int mola_icp_set_allreduce(mola_icp_handle* h, mola_icp_allreduce_fn fn, void* user);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* Replaces mp2p_icp::ICP::align() as called at src/LidarOdometry.cpp:869-871.
+ * Host pointers; copies both clouds to HBM, runs every iteration on the GPU,
+ * never retains caller pointers.  Thread-safe per handle. */
+int mola_icp_align(mola_icp_handle* h,
+                   const float* from_x, const float* from_y, const float* from_z, size_t M,
+                   const float* to_x, const float* to_y, const float* to_z, size_t N,
+                   const double init_T[16], const mola_icp_params* p, mola_icp_result* out);
+
+/* Loop-closure / nearby-KF batch (src/LidarOdometry.cpp:704-741, 767-788):
+ * n_pairs independent problems, stream-per-pair on this handle's device.
+ * Arrays of per-pair pointers/sizes; init_T = n_pairs x 16; out = n_pairs results. */
+int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs,
+                         const float* const* from_x, const float* const* from_y, const float* const* from_z,
+                         const size_t* M,
+                         const float* const* to_x, const float* const* to_y, const float* const* to_z,
+                         const size_t* N,
+                         const double* init_T, const mola_icp_params* p, mola_icp_result* out);
+
+/* ---- resident-cloud API (inputs already in HBM; bench + sharded path) ---
+ * *_device take DEVICE pointers (fp32 SoA) that must stay valid until the
+ * next set_* / destroy; *_host copy from host memory. */
+int mola_icp_set_map_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M);
+int mola_icp_set_map_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t M);
+int mola_icp_set_local_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t N);
+int mola_icp_set_local_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t N);
+/* total sizes for the quality ratio when this rank holds only a shard (0 = use own sizes) */
+int mola_icp_set_global_sizes(mola_icp_handle* h, uint64_t n_local_total, uint64_t n_map_total);
+/* full align on the resident clouds (uses the all-reduce hook if installed) */
+int mola_icp_align_resident(mola_icp_handle* h, const double init_T[16], const mola_icp_params* p,
+                            mola_icp_result* out);
+
+/* ---- single stages, for parity tests (rows a7, a8 of SURVEY.md §8) ------ */
+/* matcher: transform + NN + gate at pose T; optionally copies the pairing to
+ * host: idx[i] = map index or -1, d2[i] = squared distance of the NN (N each, may be NULL). */
+int mola_icp_match(mola_icp_handle* h, const double T[16], double threshold, int nn_kernel,
+                   int32_t* idx_out, float* d2_out, uint64_t* n_pairs_out);
+/* accumulation over the stored pairing.  stage 0: unit weights, skips pairs
+ * flagged outlier; stage 1: centroid-relative tests/weights with centroids
+ * cl,cg (flags new outliers).  reset_outliers!=0 clears the flags first.
+ * No all-reduce is applied here. */
+int mola_icp_accumulate(mola_icp_handle* h, const mola_icp_params* p, const double Tcur[16], int stage,
+                        const double cl[3], const double cg[3], int reset_outliers,
+                        double acc_out[MOLA_ICP_NACC]);
+
+/* ---- host-side math (no GPU needed) ------------------------------------ */
+/* Horn closed form on an accumulator block (row a9).  cl/cg may be NULL
+ * (weighted means of acc).  Returns MOLA_ICP_E_BADARG if W<=0. */
+int mola_icp_solve_horn(const double acc[MOLA_ICP_NACC], const double* cl, const double* cg, double T_out[16]);
+/* stall test quantities (row a10): |v|,|w| of log(Tprev^-1 * T) */
+int mola_icp_stall_deltas(const double T[16], const double Tprev[16], double* d_xyz, double* d_rot);
+int mola_icp_se3_log(const double T[16], double out6[6]);
+int mola_icp_pose_from_xyzypr(const double xyzypr[6], double T_out[16]);
+int mola_icp_pose_to_xyzypr(const double T[16], double xyzypr_out[6]);
+
+/* The iteration-control loop (rows a1, a10, a11, a12) over caller-supplied
+ * stages -- the SAME host code mola_icp_align* runs over the HIP stages.
+ * Lets the host logic and the sharded reduction be exercised without a GPU. */
+typedef struct mola_icp_stage_callbacks {
+    /* matcher at pose T with gate `threshold`; stores the pairing; *n_pairs = local count */
+    int (*match)(void* user, const double T[16], double threshold, uint64_t* n_pairs);
+    /* accumulate over the stored pairing (see mola_icp_accumulate) */
+    int (*accumulate)(void* user, const mola_icp_params* p, const double Tcur[16], int stage,
+                      const double cl[3], const double cg[3], int reset_outliers,
+                      double acc_out[MOLA_ICP_NACC]);
+    mola_icp_allreduce_fn allreduce; /* may be NULL */
+    void*    user;
+    uint64_t n_local_total, n_map_total; /* for the quality ratio */
+} mola_icp_stage_callbacks;
+int mola_icp_run_loop(const mola_icp_stage_callbacks* cb, const double init_T[16], const mola_icp_params* p,
+                      mola_icp_result* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLA_ICP_AMD_H */

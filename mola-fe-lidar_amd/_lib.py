@@ -1,0 +1,157 @@
+"""ctypes view of the C-ABI in include/mola_icp_amd.h (nothing else is bound).
+
+The shared library is the product; if it is missing this module raises -- there
+is no Python/CPU fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmola_icp_amd.so")
+
+NACC = 24
+
+OK = 0
+E_BADARG, E_CONFIG, E_HIP, E_OOM, E_NODEVICE, E_UNSUPPORTED, E_COMM, E_INTERNAL = -1, -2, -3, -4, -5, -6, -7, -8
+TERM_UNDEFINED, TERM_NO_PAIRINGS, TERM_SOLVER_ERROR, TERM_MAX_ITERATIONS, TERM_STALLED = 0, 1, 2, 3, 4
+MATCHER_POINTS_DISTANCE_THRESHOLD, MATCHER_POINT2PLANE = 0, 1
+SOLVER_HORN, SOLVER_GAUSS_NEWTON = 0, 1
+QUALITY_PAIRED_RATIO = 0
+NN_AUTO, NN_VALU, NN_MFMA = 0, 1, 2
+
+
+class CParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_uint32),
+        ("min_abs_step_trans", C.c_double),
+        ("min_abs_step_rot", C.c_double),
+        ("use_scale_outlier_detector", C.c_int32),
+        ("scale_outlier_threshold", C.c_double),
+        ("use_robust_kernel", C.c_int32),
+        ("robust_kernel_param", C.c_double),
+        ("robust_kernel_scale", C.c_double),
+        ("solver_class", C.c_int32),
+        ("solver_max_iterations", C.c_uint32),
+        ("matcher_class", C.c_int32),
+        ("matcher_threshold", C.c_double),
+        ("plane_eigen_threshold", C.c_double),
+        ("knn", C.c_uint32),
+        ("run_from_iteration", C.c_uint32),
+        ("run_up_to_iteration", C.c_uint32),
+        ("quality_class", C.c_int32),
+        ("quality_threshold", C.c_double),
+        ("fixed_iterations", C.c_int32),
+        ("nn_kernel", C.c_int32),
+        ("skip_quality", C.c_int32),
+    ]
+
+
+class CResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_double * 16),
+        ("cov", C.c_double * 36),
+        ("quality", C.c_double),
+        ("n_iterations", C.c_uint32),
+        ("termination", C.c_uint32),
+        ("n_pairs", C.c_uint64),
+        ("rmse", C.c_double),
+        ("ms_upload", C.c_double),
+        ("ms_iterations", C.c_double),
+        ("ms_quality", C.c_double),
+        ("ms_nn_kernel", C.c_double),
+        ("n_nn_launches", C.c_uint32),
+        ("nn_kernel_used", C.c_uint32),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_void_p)
+MATCH_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_uint64))
+ACCUM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(CParams), C.POINTER(C.c_double), C.c_int,
+                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+
+
+class CStageCallbacks(C.Structure):
+    _fields_ = [
+        ("match", MATCH_CB),
+        ("accumulate", ACCUM_CB),
+        ("allreduce", ALLREDUCE_FN),
+        ("user", C.c_void_p),
+        ("n_local_total", C.c_uint64),
+        ("n_map_total", C.c_uint64),
+    ]
+
+
+_FP = C.POINTER(C.c_float)
+_DP = C.POINTER(C.c_double)
+_H = C.c_void_p
+
+#: every symbol include/mola_icp_amd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mola_icp_abi_version": (C.c_int, []),
+    "mola_icp_last_error": (C.c_char_p, []),
+    "mola_icp_status_string": (C.c_char_p, [C.c_int]),
+    "mola_icp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mola_icp_params_default": (C.c_int, [C.POINTER(CParams)]),
+    "mola_icp_params_from_yaml": (C.c_int, [C.c_char_p, C.POINTER(CParams)]),
+    "mola_icp_params_from_yaml_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CParams)]),
+    "mola_icp_create": (C.c_int, [C.c_int, C.POINTER(_H)]),
+    "mola_icp_destroy": (C.c_int, [_H]),
+    "mola_icp_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "mola_icp_set_allreduce": (C.c_int, [_H, ALLREDUCE_FN, C.c_void_p]),
+    "mola_icp_align": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, _FP, _FP, _FP, C.c_size_t, _DP,
+                                 C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_icp_align_batch": (C.c_int, [_H, C.c_size_t, C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
+                                       C.POINTER(C.c_size_t), C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
+                                       C.POINTER(C.c_size_t), _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_icp_set_map_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t]),
+    "mola_icp_set_map_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mola_icp_set_local_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t]),
+    "mola_icp_set_local_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mola_icp_set_global_sizes": (C.c_int, [_H, C.c_uint64, C.c_uint64]),
+    "mola_icp_align_resident": (C.c_int, [_H, _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_icp_match": (C.c_int, [_H, _DP, C.c_double, C.c_int, C.POINTER(C.c_int32), _FP, C.POINTER(C.c_uint64)]),
+    "mola_icp_accumulate": (C.c_int, [_H, C.POINTER(CParams), _DP, C.c_int, _DP, _DP, C.c_int, _DP]),
+    "mola_icp_solve_horn": (C.c_int, [_DP, _DP, _DP, _DP]),
+    "mola_icp_stall_deltas": (C.c_int, [_DP, _DP, _DP, _DP]),
+    "mola_icp_se3_log": (C.c_int, [_DP, _DP]),
+    "mola_icp_pose_from_xyzypr": (C.c_int, [_DP, _DP]),
+    "mola_icp_pose_to_xyzypr": (C.c_int, [_DP, _DP]),
+    "mola_icp_run_loop": (C.c_int, [C.POINTER(CStageCallbacks), _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+}
+
+_lib = None
+
+
+class IcpError(RuntimeError):
+    """A MOLA_ICP_E_* status, carrying the library's message (the reference's own
+    error convention is exceptions: src/LidarOdometry.cpp:70-75, 860-861)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[{status}] {message}")
+        self.status = status
+        self.message = message
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C mola-fe-lidar_amd/csrc`). There is no fallback implementation.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        if L.mola_icp_abi_version() != 1:
+            raise ImportError("libmola_icp_amd.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        msg = lib().mola_icp_last_error().decode("utf-8", "replace")
+        raise IcpError(status, msg or lib().mola_icp_status_string(status).decode())

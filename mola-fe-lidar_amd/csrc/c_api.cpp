@@ -1,0 +1,454 @@
+// c_api.cpp -- the extern "C" boundary declared in include/mola_icp_amd.h.
+// No exception, C++ type or HIP type crosses it.
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mola_icp_amd.h"
+#include "hip_backend.hpp"
+#include "icp_loop.hpp"
+#include "yaml_lite.hpp"
+
+namespace mola_icp_amd {
+void params_default(mola_icp_params& p);
+void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p);
+}  // namespace mola_icp_amd
+
+using namespace mola_icp_amd;
+
+struct mola_icp_handle {
+    int device = -1;
+    std::mutex mtx;                                   // guards pool + resident
+    std::vector<std::unique_ptr<HipWorkspace>> pool;  // idle workspaces for mola_icp_align()
+    std::unique_ptr<HipWorkspace> resident;           // the resident-cloud API's workspace
+    mola_icp_allreduce_fn ar_fn = nullptr;
+    void* ar_user = nullptr;
+};
+
+namespace {
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <class F> int guarded(F&& f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(MOLA_ICP_E_OOM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(MOLA_ICP_E_INTERNAL, e.what());
+    } catch (...) {
+        return fail(MOLA_ICP_E_INTERNAL, "unknown C++ exception");
+    }
+}
+
+Mat4 mat_from(const double T[16])
+{
+    Mat4 m;
+    std::memcpy(m.m, T, sizeof m.m);
+    return m;
+}
+
+int check_pose(const double T[16])
+{
+    if (!T) return fail(MOLA_ICP_E_BADARG, "null pose");
+    for (int i = 0; i < 16; ++i)
+        if (!std::isfinite(T[i])) return fail(MOLA_ICP_E_BADARG, "pose has a non-finite entry");
+    return MOLA_ICP_OK;
+}
+
+// borrows a workspace from the handle's pool for one align() call
+struct Lease {
+    mola_icp_handle* h;
+    std::unique_ptr<HipWorkspace> ws;
+    int rc = MOLA_ICP_OK;
+    explicit Lease(mola_icp_handle* hh) : h(hh)
+    {
+        {
+            std::lock_guard<std::mutex> lk(h->mtx);
+            if (!h->pool.empty()) {
+                ws = std::move(h->pool.back());
+                h->pool.pop_back();
+            }
+        }
+        if (!ws) {
+            ws.reset(new HipWorkspace(h->device));
+            rc = ws->init();
+        }
+    }
+    ~Lease()
+    {
+        if (ws && rc == MOLA_ICP_OK) {
+            std::lock_guard<std::mutex> lk(h->mtx);
+            h->pool.push_back(std::move(ws));
+        }
+    }
+};
+
+int align_on(HipWorkspace& ws, const double init_T[16], const mola_icp_params* p, mola_icp_result* out)
+{
+    ws.reset_stats();
+    int rc = run_icp_loop(ws, mat_from(init_T), *p, out);
+    if (rc) return rc;
+    double ms = 0;
+    uint32_t n = 0, k = 0;
+    if ((rc = ws.collect_stats(&ms, &n, &k))) return rc;
+    out->ms_nn_kernel = ms;
+    out->n_nn_launches = n;
+    out->nn_kernel_used = k;
+    return MOLA_ICP_OK;
+}
+
+int align_host_clouds(mola_icp_handle* h, const float* fx, const float* fy, const float* fz, size_t M, const float* tx,
+                      const float* ty, const float* tz, size_t N, const double init_T[16], const mola_icp_params* p,
+                      mola_icp_result* out)
+{
+    int rc;
+    if ((rc = check_pose(init_T))) return rc;
+    if ((rc = validate_params(*p))) return rc;
+    Lease lease(h);
+    if (lease.rc) return lease.rc;
+    HipWorkspace& ws = *lease.ws;
+    std::memset(out, 0, sizeof *out);
+    const double t0 = now_ms();
+    if ((rc = ws.set_map_host(fx, fy, fz, M))) { lease.rc = rc; return rc; }
+    if ((rc = ws.set_local_host(tx, ty, tz, N))) { lease.rc = rc; return rc; }
+    ws.set_global_sizes(0, 0);
+    ws.set_allreduce(nullptr, nullptr);
+    const double t1 = now_ms();
+    rc = align_on(ws, init_T, p, out);
+    out->ms_upload = t1 - t0;
+    if (rc) lease.rc = rc;  // a workspace that failed is dropped, not pooled
+    return rc;
+}
+
+struct CallbackStages final : Stages {
+    const mola_icp_stage_callbacks* cb;
+    explicit CallbackStages(const mola_icp_stage_callbacks* c) : cb(c) {}
+    int match(const Mat4& T, double thr, const mola_icp_params&, uint64_t* n) override
+    {
+        uint64_t dummy = 0;
+        const int rc = cb->match(cb->user, T.m, thr, n ? n : &dummy);
+        return rc ? fail(rc < 0 ? rc : MOLA_ICP_E_INTERNAL, "match callback failed") : MOLA_ICP_OK;
+    }
+    int accumulate(const mola_icp_params& p, const Mat4& Tcur, int stage, const double cl[3], const double cg[3],
+                   bool reset, double acc[kNAcc]) override
+    {
+        const int rc = cb->accumulate(cb->user, &p, Tcur.m, stage, cl, cg, reset ? 1 : 0, acc);
+        return rc ? fail(rc < 0 ? rc : MOLA_ICP_E_INTERNAL, "accumulate callback failed") : MOLA_ICP_OK;
+    }
+    int allreduce(double acc[kNAcc]) override
+    {
+        if (!cb->allreduce) return MOLA_ICP_OK;
+        const int rc = cb->allreduce(acc, kNAcc, 0, cb->user);
+        return rc ? fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(rc)) : MOLA_ICP_OK;
+    }
+    uint64_t n_local_total() const override { return cb->n_local_total; }
+    uint64_t n_map_total() const override { return cb->n_map_total; }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mola_icp_abi_version(void) { return MOLA_ICP_ABI_VERSION; }
+const char* mola_icp_last_error(void) { return last_error(); }
+
+const char* mola_icp_status_string(int s)
+{
+    switch (s) {
+        case MOLA_ICP_OK: return "ok";
+        case MOLA_ICP_E_BADARG: return "bad argument";
+        case MOLA_ICP_E_CONFIG: return "configuration error";
+        case MOLA_ICP_E_HIP: return "HIP runtime error";
+        case MOLA_ICP_E_OOM: return "out of memory";
+        case MOLA_ICP_E_NODEVICE: return "no usable gfx950 device";
+        case MOLA_ICP_E_UNSUPPORTED: return "unsupported configuration";
+        case MOLA_ICP_E_COMM: return "all-reduce failure";
+        case MOLA_ICP_E_INTERNAL: return "internal error";
+        default: return "unknown status";
+    }
+}
+
+int mola_icp_device_count(int* count)
+{
+    return guarded([&]() -> int {
+        if (!count) return fail(MOLA_ICP_E_BADARG, "null count");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        *count = n;
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_params_default(mola_icp_params* p)
+{
+    if (!p) return fail(MOLA_ICP_E_BADARG, "null params");
+    params_default(*p);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_params_from_yaml(const char* yaml_text, mola_icp_params* p)
+{
+    if (!yaml_text || !p) return fail(MOLA_ICP_E_BADARG, "null argument");
+    try {
+        YamlNode root = yaml_parse(yaml_text);
+        params_from_yaml_node(root, *p);
+        return MOLA_ICP_OK;
+    } catch (const std::exception& e) {
+        return fail(MOLA_ICP_E_CONFIG, e.what());
+    }
+}
+
+int mola_icp_params_from_yaml_file(const char* path, const char* mola_dir, const char* key, mola_icp_params* p)
+{
+    if (!path || !p) return fail(MOLA_ICP_E_BADARG, "null argument");
+    try {
+        const std::string sp(path);
+        YamlNode root = yaml_parse(read_text_file(sp));
+        const size_t slash = sp.find_last_of('/');
+        yaml_resolve_includes(root, slash == std::string::npos ? std::string(".") : sp.substr(0, slash),
+                              mola_dir ? std::string(mola_dir) : std::string());
+        const YamlNode* n = &root;
+        if (key && *key) {
+            // the reference nests the settings under `params:` in a full MOLA system file
+            // (cfg = c["params"], src/LidarOdometry.cpp:102); accept both layouts
+            if (!root.has(key) && root.has("params") && root.at("params").has(key)) n = &root.at("params");
+            n = &n->at(key);
+        }
+        params_from_yaml_node(*n, *p);
+        return MOLA_ICP_OK;
+    } catch (const std::exception& e) {
+        return fail(MOLA_ICP_E_CONFIG, e.what());
+    }
+}
+
+int mola_icp_create(int device, mola_icp_handle** out)
+{
+    return guarded([&]() -> int {
+        if (!out) return fail(MOLA_ICP_E_BADARG, "null out");
+        *out = nullptr;
+        std::unique_ptr<mola_icp_handle> h(new mola_icp_handle);
+        h->resident.reset(new HipWorkspace(device));
+        const int rc = h->resident->init();
+        if (rc) return rc;
+        h->device = h->resident->device();
+        *out = h.release();
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_destroy(mola_icp_handle* h)
+{
+    return guarded([&]() -> int {
+        delete h;
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_set_stream(mola_icp_handle* h, void* hip_stream)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        return h->resident->set_external_stream(hip_stream);
+    });
+}
+
+int mola_icp_set_allreduce(mola_icp_handle* h, mola_icp_allreduce_fn fn, void* user)
+{
+    if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+    std::lock_guard<std::mutex> lk(h->mtx);
+    h->ar_fn = fn;
+    h->ar_user = user;
+    h->resident->set_allreduce(fn, user);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_align(mola_icp_handle* h, const float* fx, const float* fy, const float* fz, size_t M, const float* tx,
+                   const float* ty, const float* tz, size_t N, const double init_T[16], const mola_icp_params* p,
+                   mola_icp_result* out)
+{
+    return guarded([&]() -> int {
+        if (!h || !p || !out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        return align_host_clouds(h, fx, fy, fz, M, tx, ty, tz, N, init_T, p, out);
+    });
+}
+
+int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const* fx, const float* const* fy,
+                         const float* const* fz, const size_t* M, const float* const* tx, const float* const* ty,
+                         const float* const* tz, const size_t* N, const double* init_T, const mola_icp_params* p,
+                         mola_icp_result* out)
+{
+    return guarded([&]() -> int {
+        if (!h || !p || !out || !init_T) return fail(MOLA_ICP_E_BADARG, "null argument");
+        if (n_pairs && (!fx || !fy || !fz || !M || !tx || !ty || !tz || !N))
+            return fail(MOLA_ICP_E_BADARG, "null batch array");
+        // stream-per-pair: a few host threads, each driving its own workspace/stream
+        // (the analogue of worker_pool_past_KFs_, src/LidarOdometry.cpp:94-96)
+        const size_t n_threads = n_pairs < 8 ? n_pairs : 8;
+        std::atomic<size_t> next{0};
+        std::atomic<int> first_err{MOLA_ICP_OK};
+        std::string err_msg;
+        std::mutex err_mtx;
+        auto worker = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n_pairs) break;
+                const int rc = guarded([&]() -> int {
+                    return align_host_clouds(h, fx[i], fy[i], fz[i], M[i], tx[i], ty[i], tz[i], N[i], init_T + 16 * i,
+                                             p, &out[i]);
+                });
+                if (rc) {
+                    std::lock_guard<std::mutex> lk(err_mtx);
+                    if (first_err.load() == MOLA_ICP_OK) {
+                        first_err = rc;
+                        err_msg = "pair " + std::to_string(i) + ": " + last_error();
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < n_threads; ++t) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+        if (first_err.load()) return fail(first_err.load(), err_msg);
+        return MOLA_ICP_OK;
+    });
+}
+
+#define RESIDENT_CALL(expr)                                             \
+    return guarded([&]() -> int {                                       \
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");          \
+        std::lock_guard<std::mutex> lk(h->mtx);                         \
+        HipWorkspace& ws = *h->resident;                                \
+        (void)ws;                                                       \
+        return (expr);                                                  \
+    })
+
+int mola_icp_set_map_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M)
+{
+    RESIDENT_CALL(ws.set_map_host(x, y, z, M));
+}
+int mola_icp_set_map_device(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M)
+{
+    RESIDENT_CALL(ws.set_map_device(x, y, z, M));
+}
+int mola_icp_set_local_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t N)
+{
+    RESIDENT_CALL(ws.set_local_host(x, y, z, N));
+}
+int mola_icp_set_local_device(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t N)
+{
+    RESIDENT_CALL(ws.set_local_device(x, y, z, N));
+}
+int mola_icp_set_global_sizes(mola_icp_handle* h, uint64_t nl, uint64_t nm)
+{
+    RESIDENT_CALL((ws.set_global_sizes(nl, nm), MOLA_ICP_OK));
+}
+
+int mola_icp_align_resident(mola_icp_handle* h, const double init_T[16], const mola_icp_params* p,
+                            mola_icp_result* out)
+{
+    return guarded([&]() -> int {
+        if (!h || !p || !out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        int rc;
+        if ((rc = check_pose(init_T))) return rc;
+        std::lock_guard<std::mutex> lk(h->mtx);
+        std::memset(out, 0, sizeof *out);
+        return align_on(*h->resident, init_T, p, out);
+    });
+}
+
+int mola_icp_match(mola_icp_handle* h, const double T[16], double threshold, int nn_kernel, int32_t* idx_out,
+                   float* d2_out, uint64_t* n_pairs_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        int rc;
+        if ((rc = check_pose(T))) return rc;
+        std::lock_guard<std::mutex> lk(h->mtx);
+        mola_icp_params p;
+        params_default(p);
+        p.nn_kernel = nn_kernel;
+        uint64_t n = 0;
+        if ((rc = h->resident->match(mat_from(T), threshold, p, &n))) return rc;
+        if (n_pairs_out) *n_pairs_out = n;
+        if (idx_out || d2_out) return h->resident->copy_pairing(idx_out, d2_out);
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_accumulate(mola_icp_handle* h, const mola_icp_params* p, const double Tcur[16], int stage,
+                        const double cl[3], const double cg[3], int reset_outliers, double acc_out[MOLA_ICP_NACC])
+{
+    return guarded([&]() -> int {
+        if (!h || !p || !acc_out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        int rc;
+        if ((rc = check_pose(Tcur))) return rc;
+        std::lock_guard<std::mutex> lk(h->mtx);
+        return h->resident->accumulate(*p, mat_from(Tcur), stage, cl, cg, reset_outliers != 0, acc_out);
+    });
+}
+
+int mola_icp_solve_horn(const double acc[MOLA_ICP_NACC], const double* cl, const double* cg, double T_out[16])
+{
+    if (!acc || !T_out) return fail(MOLA_ICP_E_BADARG, "null argument");
+    Mat4 T;
+    if (!solve_horn(acc, cl, cg, T)) return fail(MOLA_ICP_E_BADARG, "Horn: no weight / degenerate accumulators");
+    std::memcpy(T_out, T.m, sizeof T.m);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_stall_deltas(const double T[16], const double Tprev[16], double* d_xyz, double* d_rot)
+{
+    if (!T || !Tprev || !d_xyz || !d_rot) return fail(MOLA_ICP_E_BADARG, "null argument");
+    stall_deltas(mat_from(T), mat_from(Tprev), *d_xyz, *d_rot);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_se3_log(const double T[16], double out6[6])
+{
+    if (!T || !out6) return fail(MOLA_ICP_E_BADARG, "null argument");
+    se3_log(mat_from(T), out6);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_pose_from_xyzypr(const double p[6], double T_out[16])
+{
+    if (!p || !T_out) return fail(MOLA_ICP_E_BADARG, "null argument");
+    const Mat4 T = pose_from_xyzypr(p);
+    std::memcpy(T_out, T.m, sizeof T.m);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_pose_to_xyzypr(const double T[16], double out[6])
+{
+    if (!T || !out) return fail(MOLA_ICP_E_BADARG, "null argument");
+    pose_to_xyzypr(mat_from(T), out);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_run_loop(const mola_icp_stage_callbacks* cb, const double init_T[16], const mola_icp_params* p,
+                      mola_icp_result* out)
+{
+    return guarded([&]() -> int {
+        if (!cb || !cb->match || !cb->accumulate || !p || !out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        int rc;
+        if ((rc = check_pose(init_T))) return rc;
+        std::memset(out, 0, sizeof *out);
+        CallbackStages st(cb);
+        return run_icp_loop(st, mat_from(init_T), *p, out);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// config.cpp -- `icp-settings-*.yaml` -> mola_icp_params.
+//
+// Replaces load_icp_set_of_params() (src/LidarOdometry.cpp:57-88): the same
+// five required entries (`icp_class` cpp:63, `params` cpp:77, `solvers` cpp:80,
+// `matchers` cpp:83, `quality` cpp:86), the same "class must be known" rule
+// (cpp:66-75), and every key of params/icp-settings-regular.yaml:7-46.
+#include <cmath>
+#include <string>
+
+#include "icp_loop.hpp"
+#include "yaml_lite.hpp"
+
+namespace mola_icp_amd {
+
+void params_default(mola_icp_params& p)
+{
+    p = mola_icp_params{};
+    // [EXT] mp2p_icp::Parameters defaults
+    p.max_iterations = 40;
+    p.min_abs_step_trans = 5e-4;
+    p.min_abs_step_rot = 1e-4;
+    p.use_scale_outlier_detector = 0;
+    p.scale_outlier_threshold = 1.20;
+    p.use_robust_kernel = 0;
+    p.robust_kernel_param = 0.05 * M_PI / 180.0;
+    p.robust_kernel_scale = 400.0;
+    p.solver_class = MOLA_ICP_SOLVER_HORN;
+    p.solver_max_iterations = 0;
+    p.matcher_class = MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD;
+    p.matcher_threshold = 0.50;
+    p.plane_eigen_threshold = 0.07;
+    p.knn = 6;
+    p.run_from_iteration = 0;
+    p.run_up_to_iteration = 0;
+    p.quality_class = MOLA_ICP_QUALITY_PAIRED_RATIO;
+    p.quality_threshold = 0.10;
+    p.fixed_iterations = 0;
+    p.nn_kernel = MOLA_ICP_NN_AUTO;
+    p.skip_quality = 0;
+}
+
+static const char* kKnownIcpClasses[] = {"mp2p_icp::ICP", "mola_icp_amd::ICP_MI355X"};
+
+static void require(const YamlNode& cfg, const char* key)
+{
+    if (!cfg.is_map() || !cfg.has(key)) throw std::runtime_error(std::string("Missing YAML required entry `") + key + "`");
+}
+
+static const YamlNode& first_of_seq(const YamlNode& n, const char* what)
+{
+    if (!n.is_seq() || n.seq.empty())
+        throw std::runtime_error(std::string("`") + what + "` must be a non-empty sequence of {class, params}");
+    if (n.seq.size() > 1)
+        throw std::runtime_error(std::string("`") + what + "`: this build runs exactly one entry per pipeline stage");
+    const YamlNode& e = n.seq[0];
+    if (!e.is_map() || !e.has("class")) throw std::runtime_error(std::string("`") + what + "[0]` lacks a `class`");
+    return e;
+}
+
+void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p)
+{
+    params_default(p);
+    if (!cfg.is_map()) throw std::runtime_error("ICP settings must be a YAML map");
+    require(cfg, "icp_class");  // YAML_LOAD_REQ(icp_class) cpp:63
+    const std::string icp_class = cfg.at("icp_class").as_string();
+    bool known = false;
+    for (const char* k : kKnownIcpClasses) known |= (icp_class == k);
+    if (!known)
+        throw std::runtime_error("icp_class=`" + icp_class +
+                                 "` is a non-registered or incompatible class. Known classes: `mp2p_icp::ICP`, "
+                                 "`mola_icp_amd::ICP_MI355X`.");
+    require(cfg, "params");
+    require(cfg, "solvers");
+    require(cfg, "matchers");
+    require(cfg, "quality");
+
+    const YamlNode& pr = cfg.at("params");
+    if (pr.is_map()) {
+        if (auto* n = pr.find("maxIterations")) p.max_iterations = (uint32_t)n->as_int();
+        if (auto* n = pr.find("minAbsStep_trans")) p.min_abs_step_trans = n->as_double();
+        if (auto* n = pr.find("minAbsStep_rot")) p.min_abs_step_rot = n->as_double();
+        if (auto* w = pr.find("pairingsWeightParameters")) {
+            if (auto* n = w->find("use_scale_outlier_detector")) p.use_scale_outlier_detector = n->as_bool();
+            if (auto* n = w->find("scale_outlier_threshold")) p.scale_outlier_threshold = n->as_double();
+            if (auto* n = w->find("use_robust_kernel")) p.use_robust_kernel = n->as_bool();
+            if (auto* n = w->find("robust_kernel_param")) p.robust_kernel_param = n->as_double() * M_PI / 180.0;  // [deg]
+            if (auto* n = w->find("robust_kernel_scale")) p.robust_kernel_scale = n->as_double();
+        }
+        // keys of this implementation (absent in the reference -> defaults)
+        if (auto* n = pr.find("fixed_iterations")) p.fixed_iterations = n->as_bool();
+        if (auto* n = pr.find("skip_quality")) p.skip_quality = n->as_bool();
+        if (auto* n = pr.find("nn_kernel")) {
+            const std::string s = n->as_string();
+            if (s == "auto") p.nn_kernel = MOLA_ICP_NN_AUTO;
+            else if (s == "valu") p.nn_kernel = MOLA_ICP_NN_VALU;
+            else if (s == "mfma") p.nn_kernel = MOLA_ICP_NN_MFMA;
+            else throw std::runtime_error("nn_kernel=`" + s + "` is not one of auto|valu|mfma");
+        }
+    }
+
+    {
+        const YamlNode& s = first_of_seq(cfg.at("solvers"), "solvers");
+        const std::string cls = s.at("class").as_string();
+        if (cls == "mp2p_icp::Solver_Horn") p.solver_class = MOLA_ICP_SOLVER_HORN;
+        else if (cls == "mp2p_icp::Solver_GaussNewton") p.solver_class = MOLA_ICP_SOLVER_GAUSS_NEWTON;
+        else throw std::runtime_error("solver class=`" + cls + "` is a non-registered class. Known: "
+                                      "`mp2p_icp::Solver_Horn`, `mp2p_icp::Solver_GaussNewton`.");
+        if (auto* sp = s.find("params"))
+            if (auto* n = sp->find("maxIterations")) p.solver_max_iterations = (uint32_t)n->as_int();
+    }
+    {
+        const YamlNode& m = first_of_seq(cfg.at("matchers"), "matchers");
+        const std::string cls = m.at("class").as_string();
+        const YamlNode* mp = m.find("params");
+        if (cls == "mp2p_icp::Matcher_Points_DistanceThreshold") {
+            p.matcher_class = MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD;
+            if (mp)
+                if (auto* n = mp->find("threshold")) p.matcher_threshold = n->as_double();
+        } else if (cls == "mp2p_icp::Matcher_Point2Plane") {
+            p.matcher_class = MOLA_ICP_MATCHER_POINT2PLANE;
+            if (mp) {
+                if (auto* n = mp->find("distanceThreshold")) p.matcher_threshold = n->as_double();
+                if (auto* n = mp->find("planeEigenThreshold")) p.plane_eigen_threshold = n->as_double();
+                if (auto* n = mp->find("knn")) p.knn = (uint32_t)n->as_int();
+            }
+        } else
+            throw std::runtime_error("matcher class=`" + cls + "` is a non-registered class. Known: "
+                                     "`mp2p_icp::Matcher_Points_DistanceThreshold`, `mp2p_icp::Matcher_Point2Plane`.");
+        if (mp) {
+            if (auto* n = mp->find("runFromIteration")) p.run_from_iteration = (uint32_t)n->as_int();
+            if (auto* n = mp->find("runUpToIteration")) p.run_up_to_iteration = (uint32_t)n->as_int();
+        }
+    }
+    {
+        const YamlNode& q = first_of_seq(cfg.at("quality"), "quality");
+        const std::string cls = q.at("class").as_string();
+        if (cls != "mp2p_icp::QualityEvaluator_PairedRatio")
+            throw std::runtime_error("quality class=`" + cls + "` is a non-registered class. Known: "
+                                     "`mp2p_icp::QualityEvaluator_PairedRatio`.");
+        p.quality_class = MOLA_ICP_QUALITY_PAIRED_RATIO;
+        if (auto* qp = q.find("params"))
+            if (auto* n = qp->find("thresholdDistance")) p.quality_threshold = n->as_double();
+    }
+}
+
+}  // namespace mola_icp_amd

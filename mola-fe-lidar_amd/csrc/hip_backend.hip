@@ -1,0 +1,548 @@
+// hip_backend.hip -- gfx950 kernels + HipWorkspace (see hip_backend.hpp).
+//
+// Hot path rows: a7 nearest-neighbour matcher, a8 weighted
+// centroid/covariance accumulation.  The reference reaches both through
+// mp2p_icp::ICP::align() at src/LidarOdometry.cpp:869-871 (CPU kd-tree +
+// serial sums); here they are brute-force tiled kernels over HBM-resident SoA
+// clouds.
+//
+// Numeric contract (DESIGN.md "numeric contract"; the CPU checker restates it, so NN indices compare
+// bit-exactly; this file is compiled with -ffp-contract=off so only the
+// explicit fmaf() calls fuse):
+//   q  = fmaf-chain R*l+t in fp32;  d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx));
+//   NN = argmin d2, ties -> lowest map index; kept iff d2 < thr2.
+#include "hip_backend.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+
+namespace mola_icp_amd {
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP,                          \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                   \
+    } while (0)
+
+// ------------------------------------------------------------------ device code
+
+struct PoseF {
+    float R[9];
+    float t[3];
+};
+
+__device__ __forceinline__ void xform(const PoseF& P, float lx, float ly, float lz, float& qx, float& qy, float& qz)
+{
+    float a;
+    a = fmaf(P.R[0], lx, P.t[0]); a = fmaf(P.R[1], ly, a); qx = fmaf(P.R[2], lz, a);
+    a = fmaf(P.R[3], lx, P.t[1]); a = fmaf(P.R[4], ly, a); qy = fmaf(P.R[5], lz, a);
+    a = fmaf(P.R[6], lx, P.t[2]); a = fmaf(P.R[7], ly, a); qz = fmaf(P.R[8], lz, a);
+}
+
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, float gx, float gy, float gz)
+{
+    const float dx = qx - gx, dy = qy - gy, dz = qz - gz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+constexpr float kPadCoord = 1.0e18f;  // padding map points: d2 ~ 3e36, finite, never the minimum
+
+// ---- NN matcher, exact VALU form -------------------------------------------------
+// Block = 256 threads, each thread owns QPT queries in registers (coalesced SoA
+// loads).  The map streams HBM -> LDS in SoA tiles of TM points; every lane reads
+// the same LDS address (broadcast, conflict-free) as ds_read_b128 of 4 points.
+// Per pair: 3 sub + mul + 2 fma + ~1 min; the argmin is tracked per 8-point chunk
+// (first chunk that lowers the minimum) and resolved to the exact lowest index
+// after the sweep by re-evaluating that chunk -- bit-identical arithmetic.
+template <int QPT, int TM>
+__global__ __launch_bounds__(256) void k_nn_valu(const float* __restrict__ lx, const float* __restrict__ ly,
+                                                 const float* __restrict__ lz, int N, const float* __restrict__ gx,
+                                                 const float* __restrict__ gy, const float* __restrict__ gz, int M,
+                                                 PoseF P, float thr2, int* __restrict__ out_idx,
+                                                 float* __restrict__ out_d2, unsigned int* __restrict__ kept_counter)
+{
+    __shared__ __attribute__((aligned(16))) float sx[TM];
+    __shared__ __attribute__((aligned(16))) float sy[TM];
+    __shared__ __attribute__((aligned(16))) float sz[TM];
+    const int tid = threadIdx.x;
+    const int qbase = blockIdx.x * (256 * QPT);
+
+    float qx[QPT], qy[QPT], qz[QPT], best[QPT];
+    int bchunk[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+        const int i = qbase + k * 256 + tid;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i < N) { x = lx[i]; y = ly[i]; z = lz[i]; }
+        xform(P, x, y, z, qx[k], qy[k], qz[k]);
+        best[k] = thr2;  // gate: only d2 < thr2 can ever be kept
+        bchunk[k] = -1;
+    }
+
+    for (int tile0 = 0; tile0 < M; tile0 += TM) {
+        __syncthreads();
+#pragma unroll
+        for (int j = tid; j < TM; j += 256) {
+            const int gj = tile0 + j;
+            const bool in = gj < M;
+            sx[j] = in ? gx[gj] : kPadCoord;
+            sy[j] = in ? gy[gj] : kPadCoord;
+            sz[j] = in ? gz[gj] : kPadCoord;
+        }
+        __syncthreads();
+        const int lim = min(TM, M - tile0);
+        for (int c = 0; c < lim; c += 8) {
+            const float4 xa = *reinterpret_cast<const float4*>(&sx[c]);
+            const float4 xb = *reinterpret_cast<const float4*>(&sx[c + 4]);
+            const float4 ya = *reinterpret_cast<const float4*>(&sy[c]);
+            const float4 yb = *reinterpret_cast<const float4*>(&sy[c + 4]);
+            const float4 za = *reinterpret_cast<const float4*>(&sz[c]);
+            const float4 zb = *reinterpret_cast<const float4*>(&sz[c + 4]);
+#pragma unroll
+            for (int k = 0; k < QPT; ++k) {
+                const float d0 = dist2(qx[k], qy[k], qz[k], xa.x, ya.x, za.x);
+                const float d1 = dist2(qx[k], qy[k], qz[k], xa.y, ya.y, za.y);
+                const float d2 = dist2(qx[k], qy[k], qz[k], xa.z, ya.z, za.z);
+                const float d3 = dist2(qx[k], qy[k], qz[k], xa.w, ya.w, za.w);
+                const float d4 = dist2(qx[k], qy[k], qz[k], xb.x, yb.x, zb.x);
+                const float d5 = dist2(qx[k], qy[k], qz[k], xb.y, yb.y, zb.y);
+                const float d6 = dist2(qx[k], qy[k], qz[k], xb.z, yb.z, zb.z);
+                const float d7 = dist2(qx[k], qy[k], qz[k], xb.w, yb.w, zb.w);
+                const float m = fminf(fminf(fminf(d0, d1), fminf(d2, d3)), fminf(fminf(d4, d5), fminf(d6, d7)));
+                if (m < best[k]) { best[k] = m; bchunk[k] = tile0 + c; }
+            }
+        }
+    }
+
+    unsigned int kept = 0;
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+        const int i = qbase + k * 256 + tid;
+        int idx = -1;
+        if (bchunk[k] >= 0) {
+            for (int r = 7; r >= 0; --r) {  // descending: the lowest matching index wins
+                const int gj = bchunk[k] + r;
+                if (gj < M) {
+                    const float d = dist2(qx[k], qy[k], qz[k], gx[gj], gy[gj], gz[gj]);
+                    if (d == best[k]) idx = gj;
+                }
+            }
+        }
+        if (i < N) {
+            out_idx[i] = idx;
+            out_d2[i] = best[k];
+            kept += (idx >= 0);
+        }
+    }
+    // one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
+    if ((tid & 63) == 0 && kept) atomicAdd(kept_counter, kept);
+}
+
+// ---- accumulation (row a8) ---------------------------------------------------------
+struct AccArgs {
+    const float *lx, *ly, *lz, *gx, *gy, *gz;
+    const int* idx;
+    const float* d2;
+    unsigned char* outlier;
+    int N;
+    int stage;
+    int use_scale;
+    int use_robust;
+    double scale_thr, rk_param, rk_scale;
+    double cl[3], cg[3];
+    double R[9];
+};
+
+constexpr int kAccThreads = 256;
+
+__global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* __restrict__ partials)
+{
+    double s[kNAcc];
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) s[k] = 0.0;
+    const int stride = gridDim.x * kAccThreads;
+    for (int i = blockIdx.x * kAccThreads + threadIdx.x; i < a.N; i += stride) {
+        const int j = a.idx[i];
+        if (j < 0) continue;
+        if (a.outlier[i]) continue;
+        const double l0 = a.lx[i], l1 = a.ly[i], l2 = a.lz[i];
+        const double g0 = a.gx[j], g1 = a.gy[j], g2 = a.gz[j];
+        double w = 1.0;
+        if (a.stage == 1) {
+            double b0 = g0 - a.cg[0], b1 = g1 - a.cg[1], b2 = g2 - a.cg[2];
+            double r0 = l0 - a.cl[0], r1 = l1 - a.cl[1], r2 = l2 - a.cl[2];
+            const double bn = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+            const double rn = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+            if (bn < 1e-4 || rn < 1e-4) continue;
+            if (a.use_scale) {
+                const double hi = bn > rn ? bn : rn, lo = bn > rn ? rn : bn;
+                if (hi / lo > a.scale_thr) {
+                    a.outlier[i] = 1;
+                    continue;
+                }
+            }
+            if (a.use_robust) {
+                b0 /= bn; b1 /= bn; b2 /= bn;
+                r0 /= rn; r1 /= rn; r2 /= rn;
+                const double x = a.R[0] * r0 + a.R[1] * r1 + a.R[2] * r2;
+                const double y = a.R[3] * r0 + a.R[4] * r1 + a.R[5] * r2;
+                const double z = a.R[6] * r0 + a.R[7] * r1 + a.R[8] * r2;
+                double c = x * b0 + y * b1 + z * b2;
+                c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+                const double ang = acos(c);
+                if (ang > a.rk_param) {
+                    const double e = ang - a.rk_param;
+                    w *= 1.0 / (1.0 + a.rk_scale * e * e);
+                }
+            }
+        }
+        s[0] += w;
+        s[1] += w * l0; s[2] += w * l1; s[3] += w * l2;
+        s[4] += w * g0; s[5] += w * g1; s[6] += w * g2;
+        s[7] += w * l0 * g0; s[8] += w * l0 * g1; s[9] += w * l0 * g2;
+        s[10] += w * l1 * g0; s[11] += w * l1 * g1; s[12] += w * l1 * g2;
+        s[13] += w * l2 * g0; s[14] += w * l2 * g1; s[15] += w * l2 * g2;
+        s[16] += 1.0;
+        s[17] += (double)a.d2[i];
+        s[18] += w * l0 * l0; s[19] += w * l0 * l1; s[20] += w * l0 * l2;
+        s[21] += w * l1 * l1; s[22] += w * l1 * l2; s[23] += w * l2 * l2;
+    }
+    // fixed-order reduction: lanes (shuffle tree) -> waves (LDS, in wave order) -> one row per block
+    __shared__ double sm[kAccThreads / 64][kNAcc];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) {
+        double v = s[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNAcc) {
+        double v = 0.0;
+        for (int w = 0; w < kAccThreads / 64; ++w) v += sm[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNAcc + threadIdx.x] = v;
+    }
+}
+
+// sums the per-block rows in a fixed order: 8 interleaved slices per accumulator, then the slices in order
+__global__ __launch_bounds__(192) void k_reduce_partials(const double* __restrict__ partials, int nblocks,
+                                                         double* __restrict__ acc)
+{
+    __shared__ double sm[8][kNAcc];
+    const int k = threadIdx.x % kNAcc, sl = threadIdx.x / kNAcc;
+    double v = 0.0;
+    for (int b = sl; b < nblocks; b += 8) v += partials[(size_t)b * kNAcc + k];
+    sm[sl][k] = v;
+    __syncthreads();
+    if (threadIdx.x < kNAcc) {
+        double t = 0.0;
+        for (int s = 0; s < 8; ++s) t += sm[s][threadIdx.x];
+        acc[threadIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------ host code
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap && p) return MOLA_ICP_OK;
+    release();
+    const size_t want = bytes < 256 ? 256 : bytes;
+    HIPCHK(hipMalloc(&p, want));
+    cap = want;
+    return MOLA_ICP_OK;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+HipWorkspace::HipWorkspace(int device) : device_(device) {}
+
+HipWorkspace::~HipWorkspace()
+{
+    if (!inited_) return;
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+    map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
+    idx_.release(); d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
+    if (acc_host_) (void)hipHostFree(acc_host_);
+    if (meta_host_) (void)hipHostFree(meta_host_);
+    if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+int HipWorkspace::init()
+{
+    if (inited_) return MOLA_ICP_OK;
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(MOLA_ICP_E_NODEVICE, std::string("no HIP device available (") +
+                                             (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) +
+                                             "); this library has no CPU fallback");
+    if (device_ < 0) HIPCHK(hipGetDevice(&device_));
+    if (device_ >= count) return fail(MOLA_ICP_E_BADARG, "device index out of range");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MOLA_ICP_E_NODEVICE,
+                    std::string("device is ") + prop.gcnArchName + " but the kernels are built for gfx950 only");
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    own_stream_ = true;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * (kNAcc + 8), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocDefault));
+    int rc;
+    if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8)))) return rc;
+    inited_ = true;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::set_external_stream(void* s)
+{
+    int rc = init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device_));
+    if (own_stream_ && stream_) {
+        HIPCHK(hipStreamSynchronize(stream_));
+        HIPCHK(hipStreamDestroy(stream_));
+    }
+    if (s) {
+        stream_ = static_cast<hipStream_t>(s);
+        own_stream_ = false;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        own_stream_ = true;
+    }
+    return MOLA_ICP_OK;
+}
+
+static int upload_soa(DevBuf& buf, hipStream_t st, const float* x, const float* y, const float* z, size_t n,
+                      const float** dx, const float** dy, const float** dz)
+{
+    // padded to a multiple of 64 floats per component so the three arrays stay 256-B aligned
+    const size_t np = (n + 63) / 64 * 64;
+    int rc = buf.reserve(sizeof(float) * 3 * (np ? np : 64));
+    if (rc) return rc;
+    float* base = buf.as<float>();
+    if (n) {
+        HIPCHK(hipMemcpyAsync(base, x, sizeof(float) * n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(base + np, y, sizeof(float) * n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(base + 2 * np, z, sizeof(float) * n, hipMemcpyHostToDevice, st));
+    }
+    *dx = base; *dy = base + np; *dz = base + 2 * np;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, size_t M)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (M && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null map pointer");
+    if (M > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "map too large for 32-bit indices");
+    HIPCHK(hipSetDevice(device_));
+    if ((rc = upload_soa(map_own_, stream_, x, y, z, M, &gx_, &gy_, &gz_))) return rc;
+    // the host buffers may be pageable: finish the copies before returning (never retain caller pointers)
+    HIPCHK(hipStreamSynchronize(stream_));
+    M_ = M;
+    map_img_valid_ = false;
+    pairing_valid_ = false;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::set_map_device(const float* x, const float* y, const float* z, size_t M)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (M && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null map pointer");
+    if (M > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "map too large for 32-bit indices");
+    gx_ = x; gy_ = y; gz_ = z;
+    M_ = M;
+    map_img_valid_ = false;
+    pairing_valid_ = false;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::set_local_host(const float* x, const float* y, const float* z, size_t N)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (N && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null local-cloud pointer");
+    if (N > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "local cloud too large for 32-bit indices");
+    HIPCHK(hipSetDevice(device_));
+    if ((rc = upload_soa(loc_own_, stream_, x, y, z, N, &lx_, &ly_, &lz_))) return rc;
+    HIPCHK(hipStreamSynchronize(stream_));
+    N_ = N;
+    pairing_valid_ = false;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::set_local_device(const float* x, const float* y, const float* z, size_t N)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (N && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null local-cloud pointer");
+    if (N > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "local cloud too large for 32-bit indices");
+    lx_ = x; ly_ = y; lz_ = z;
+    N_ = N;
+    pairing_valid_ = false;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::prepare_map() { return MOLA_ICP_OK; }
+
+void HipWorkspace::reset_stats()
+{
+    ev_used_ = 0;
+    last_kernel_ = 0;
+}
+
+int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used)
+{
+    double tot = 0;
+    if (ev_used_) {
+        HIPCHK(hipSetDevice(device_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (size_t i = 0; i + 1 < ev_used_; i += 2) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev_[i], ev_[i + 1]));
+            tot += ms;
+        }
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = (uint32_t)(ev_used_ / 2);
+    if (kernel_used) *kernel_used = last_kernel_;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
+{
+    PoseF P;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) P.R[3 * r + c] = (float)T(r, c);
+        P.t[r] = (float)T(r, 3);
+    }
+    while (ev_.size() < ev_used_ + 2) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ev_.push_back(e);
+    }
+    unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream_));
+    HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
+    (void)kernel;
+    {
+        constexpr int QPT = 4, TM = 1024;
+        const int grid = (int)((N_ + 256 * QPT - 1) / (256 * QPT));
+        hipLaunchKernelGGL((k_nn_valu<QPT, TM>), dim3(grid), dim3(256), 0, stream_, lx_, ly_, lz_, (int)N_, gx_, gy_,
+                           gz_, (int)M_, P, thr2, idx_.as<int>(), d2_.as<float>(), counter);
+        last_kernel_ = MOLA_ICP_NN_VALU;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
+    ev_used_ += 2;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& p, uint64_t* n_pairs)
+{
+    int rc = init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device_));
+    if (!(threshold > 0)) return fail(MOLA_ICP_E_BADARG, "matcher threshold must be > 0");
+    if ((rc = idx_.reserve(sizeof(int) * (N_ ? N_ : 1)))) return rc;
+    if ((rc = d2_.reserve(sizeof(float) * (N_ ? N_ : 1)))) return rc;
+    if ((rc = outlier_.reserve(N_ ? N_ : 1))) return rc;
+    const float thr2 = (float)(threshold * threshold);
+    if (N_ == 0 || M_ == 0) {
+        if (N_) HIPCHK(hipMemsetAsync(idx_.p, 0xff, sizeof(int) * N_, stream_));
+        pairing_valid_ = true;
+        if (n_pairs) *n_pairs = 0;
+        return MOLA_ICP_OK;
+    }
+    if ((rc = launch_nn(T, thr2, p.nn_kernel))) return rc;
+    pairing_valid_ = true;
+    if (n_pairs) {
+        unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
+        unsigned int* hc = reinterpret_cast<unsigned int*>(acc_host_ + kNAcc);
+        HIPCHK(hipMemcpyAsync(hc, counter, sizeof(unsigned int), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        *n_pairs = *hc;
+    }
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int stage, const double cl[3],
+                             const double cg[3], bool reset_outliers, double acc[kNAcc])
+{
+    int rc = init();
+    if (rc) return rc;
+    if (!pairing_valid_) return fail(MOLA_ICP_E_BADARG, "accumulate() called before match()");
+    if (stage != 0 && stage != 1) return fail(MOLA_ICP_E_BADARG, "stage must be 0 or 1");
+    if (stage == 1 && (!cl || !cg)) return fail(MOLA_ICP_E_BADARG, "stage 1 needs the centroids");
+    HIPCHK(hipSetDevice(device_));
+    if (N_ == 0) {
+        for (int k = 0; k < kNAcc; ++k) acc[k] = 0;
+        return MOLA_ICP_OK;
+    }
+    if (reset_outliers) HIPCHK(hipMemsetAsync(outlier_.p, 0, N_, stream_));
+    int nblocks = (int)((N_ + kAccThreads - 1) / kAccThreads);
+    if (nblocks > 512) nblocks = 512;
+    if ((rc = partials_.reserve(sizeof(double) * kNAcc * 512))) return rc;
+    AccArgs a{};
+    a.lx = lx_; a.ly = ly_; a.lz = lz_; a.gx = gx_; a.gy = gy_; a.gz = gz_;
+    a.idx = idx_.as<int>(); a.d2 = d2_.as<float>(); a.outlier = outlier_.as<unsigned char>();
+    a.N = (int)N_; a.stage = stage;
+    a.use_scale = p.use_scale_outlier_detector; a.use_robust = p.use_robust_kernel;
+    a.scale_thr = p.scale_outlier_threshold; a.rk_param = p.robust_kernel_param; a.rk_scale = p.robust_kernel_scale;
+    for (int k = 0; k < 3; ++k) { a.cl[k] = cl ? cl[k] : 0.0; a.cg[k] = cg ? cg[k] : 0.0; }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) a.R[3 * r + c] = Tcur(r, c);
+    hipLaunchKernelGGL(k_accumulate, dim3(nblocks), dim3(kAccThreads), 0, stream_, a, partials_.as<double>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(192), 0, stream_, partials_.as<double>(), nblocks,
+                       acc_dev_.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(acc_host_, acc_dev_.p, sizeof(double) * kNAcc, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::allreduce(double acc[kNAcc])
+{
+    if (!ar_fn_) return MOLA_ICP_OK;
+    const int rc = ar_fn_(acc, kNAcc, 0, ar_user_);
+    if (rc) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(rc));
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::copy_pairing(int32_t* idx_out, float* d2_out)
+{
+    if (!pairing_valid_) return fail(MOLA_ICP_E_BADARG, "no pairing stored: call match() first");
+    HIPCHK(hipSetDevice(device_));
+    if (N_) {
+        if (idx_out) HIPCHK(hipMemcpyAsync(idx_out, idx_.p, sizeof(int) * N_, hipMemcpyDeviceToHost, stream_));
+        if (d2_out) HIPCHK(hipMemcpyAsync(d2_out, d2_.p, sizeof(float) * N_, hipMemcpyDeviceToHost, stream_));
+    }
+    HIPCHK(hipStreamSynchronize(stream_));
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::sync()
+{
+    if (!inited_) return MOLA_ICP_OK;
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    return MOLA_ICP_OK;
+}
+
+}  // namespace mola_icp_amd

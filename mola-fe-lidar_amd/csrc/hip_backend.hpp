@@ -1,0 +1,94 @@
+// hip_backend.hpp -- device side of the ICP core: HBM-resident clouds, the NN
+// matcher kernels, the accumulation kernels.  One HipWorkspace = one in-flight
+// align (stream + scratch); handles keep a pool of them so mola_icp_align() is
+// re-entrant (the reference calls align() on one ICP object from several pool
+// threads: src/LidarOdometry.cpp:94-96, 869).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "icp_loop.hpp"
+
+namespace mola_icp_amd {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);  // grows (never shrinks); contents are NOT preserved
+    void release();
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+class HipWorkspace final : public Stages {
+   public:
+    explicit HipWorkspace(int device);
+    ~HipWorkspace() override;
+    HipWorkspace(const HipWorkspace&) = delete;
+    HipWorkspace& operator=(const HipWorkspace&) = delete;
+
+    int init();  // creates the stream / pinned buffers; MOLA_ICP_E_NODEVICE if no GPU
+    int set_external_stream(void* s);
+    void set_allreduce(mola_icp_allreduce_fn fn, void* user) { ar_fn_ = fn; ar_user_ = user; }
+    void set_global_sizes(uint64_t nl, uint64_t nm) { n_local_total_ = nl; n_map_total_ = nm; }
+
+    int set_map_host(const float* x, const float* y, const float* z, size_t M);
+    int set_map_device(const float* x, const float* y, const float* z, size_t M);
+    int set_local_host(const float* x, const float* y, const float* z, size_t N);
+    int set_local_device(const float* x, const float* y, const float* z, size_t N);
+
+    // Stages
+    int match(const Mat4& T, double threshold, const mola_icp_params& p, uint64_t* n_pairs) override;
+    int accumulate(const mola_icp_params& p, const Mat4& Tcur, int stage, const double cl[3], const double cg[3],
+                   bool reset_outliers, double acc[kNAcc]) override;
+    int allreduce(double acc[kNAcc]) override;
+    uint64_t n_local_total() const override { return n_local_total_ ? n_local_total_ : N_; }
+    uint64_t n_map_total() const override { return n_map_total_ ? n_map_total_ : M_; }
+
+    int copy_pairing(int32_t* idx_out, float* d2_out);  // after match(); syncs
+    int sync();
+
+    // NN-kernel timing (HIP events on this workspace's stream)
+    void reset_stats();
+    int collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used);
+
+    size_t N() const { return N_; }
+    size_t M() const { return M_; }
+    int device() const { return device_; }
+
+   private:
+    int prepare_map();  // derived map images for the MFMA matcher
+    int launch_nn(const Mat4& T, float thr2, int kernel);
+
+    int device_;
+    bool inited_ = false;
+    hipStream_t stream_ = nullptr;
+    bool own_stream_ = false;
+
+    size_t N_ = 0, M_ = 0;
+    uint64_t n_local_total_ = 0, n_map_total_ = 0;
+    // clouds: owned copies or borrowed device pointers
+    DevBuf map_own_, loc_own_;
+    const float *gx_ = nullptr, *gy_ = nullptr, *gz_ = nullptr;
+    const float *lx_ = nullptr, *ly_ = nullptr, *lz_ = nullptr;
+    // derived map image for the MFMA kernel ([tile][4][16] fp32) + its bounds
+    DevBuf map_img_, map_meta_;
+    bool map_img_valid_ = false;
+    float map_center_[3] = {0, 0, 0};
+    float map_radius_ = 0;
+    // pairing + scratch
+    DevBuf idx_, d2_, outlier_, partials_, acc_dev_;
+    double* acc_host_ = nullptr;  // pinned
+    float* meta_host_ = nullptr;  // pinned
+    bool pairing_valid_ = false;
+
+    mola_icp_allreduce_fn ar_fn_ = nullptr;
+    void* ar_user_ = nullptr;
+
+    std::vector<hipEvent_t> ev_;  // pairs: start, stop
+    size_t ev_used_ = 0;
+    uint32_t last_kernel_ = 0;
+};
+
+}  // namespace mola_icp_amd

@@ -1,0 +1,152 @@
+// icp_loop.cpp -- see icp_loop.hpp.
+#include "icp_loop.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace mola_icp_amd {
+
+namespace {
+thread_local std::string g_last_error;
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error() { return g_last_error.c_str(); }
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+int validate_params(const mola_icp_params& p)
+{
+    if (!(p.matcher_threshold > 0) || !std::isfinite(p.matcher_threshold))
+        return fail(MOLA_ICP_E_BADARG, "matcher threshold must be a positive finite distance");
+    if (!(p.quality_threshold > 0) || !std::isfinite(p.quality_threshold))
+        return fail(MOLA_ICP_E_BADARG, "quality thresholdDistance must be a positive finite distance");
+    if (p.use_scale_outlier_detector && !(p.scale_outlier_threshold >= 1.0))
+        return fail(MOLA_ICP_E_BADARG, "scale_outlier_threshold must be >= 1");
+    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE)
+        return fail(MOLA_ICP_E_UNSUPPORTED,
+                    "matcher class mp2p_icp::Matcher_Point2Plane is parsed but not runnable in this build; "
+                    "use mp2p_icp::Matcher_Points_DistanceThreshold");
+    if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD)
+        return fail(MOLA_ICP_E_BADARG, "unknown matcher_class");
+    if (p.solver_class == MOLA_ICP_SOLVER_GAUSS_NEWTON)
+        return fail(MOLA_ICP_E_UNSUPPORTED,
+                    "solver class mp2p_icp::Solver_GaussNewton is parsed but not runnable in this build; "
+                    "use mp2p_icp::Solver_Horn");
+    if (p.solver_class != MOLA_ICP_SOLVER_HORN) return fail(MOLA_ICP_E_BADARG, "unknown solver_class");
+    if (p.quality_class != MOLA_ICP_QUALITY_PAIRED_RATIO) return fail(MOLA_ICP_E_BADARG, "unknown quality_class");
+    return MOLA_ICP_OK;
+}
+
+// One solver invocation on the stored pairing (row a8 + a9).
+//  unweighted: acc0 -> Horn.
+//  weighted  : [mp2p_icp optimal_tf_horn behaviour, EXT-recalled] centroids from
+//              a unit-weight pass, then the centroid-relative tests/weights; with
+//              the scale outlier detector the whole thing runs twice, the second
+//              time with the centroids recomputed without the first pass's outliers.
+// pairs_global = acc0[16] of the first unit-weight pass (all gated pairings).
+static int solve_on_pairing(Stages& st, const mola_icp_params& p, const Mat4& Tcur, Mat4& Tnew, double acc[kNAcc],
+                            double* pairs_global, bool* solver_error)
+{
+    *solver_error = false;
+    int rc = st.accumulate(p, Tcur, 0, nullptr, nullptr, true, acc);
+    if (rc) return rc;
+    if ((rc = st.allreduce(acc))) return rc;
+    *pairs_global = acc[16];
+    if (!(acc[16] > 0)) return MOLA_ICP_OK;  // caller decides: NoPairings
+    const bool weighted = p.use_scale_outlier_detector || p.use_robust_kernel;
+    if (!weighted) {
+        if (!solve_horn(acc, nullptr, nullptr, Tnew)) *solver_error = true;
+        return MOLA_ICP_OK;
+    }
+    const int passes = p.use_scale_outlier_detector ? 2 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+        if (pass > 0) {
+            if ((rc = st.accumulate(p, Tcur, 0, nullptr, nullptr, false, acc))) return rc;
+            if ((rc = st.allreduce(acc))) return rc;
+        }
+        if (!(acc[0] > 0)) { *solver_error = true; return MOLA_ICP_OK; }
+        const double cl[3] = {acc[1] / acc[0], acc[2] / acc[0], acc[3] / acc[0]};
+        const double cg[3] = {acc[4] / acc[0], acc[5] / acc[0], acc[6] / acc[0]};
+        if ((rc = st.accumulate(p, Tcur, 1, cl, cg, false, acc))) return rc;
+        if ((rc = st.allreduce(acc))) return rc;
+        if (!solve_horn(acc, cl, cg, Tnew)) { *solver_error = true; return MOLA_ICP_OK; }
+    }
+    return MOLA_ICP_OK;
+}
+
+int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_icp_result* out)
+{
+    int rc = validate_params(p);
+    if (rc) return rc;
+    Mat4 T = init, Tprev = init;
+    uint32_t term = MOLA_ICP_TERM_UNDEFINED;
+    uint32_t it = 0;
+    double acc[kNAcc] = {};
+    double last_acc[kNAcc] = {};
+    bool have_solution = false;
+    const double t0 = now_ms();
+    for (; it < p.max_iterations; ++it) {
+        const bool run_matcher =
+            it >= p.run_from_iteration && (p.run_up_to_iteration == 0 || it <= p.run_up_to_iteration);
+        if (!run_matcher || st.n_local_total() == 0 || st.n_map_total() == 0) {
+            term = MOLA_ICP_TERM_NO_PAIRINGS;
+            break;
+        }
+        if ((rc = st.match(T, p.matcher_threshold, p, nullptr))) return rc;  // count comes from acc[16]
+        Mat4 Tn = T;
+        double pairs_global = 0;
+        bool solver_error = false;
+        if ((rc = solve_on_pairing(st, p, T, Tn, acc, &pairs_global, &solver_error))) return rc;
+        if (!(pairs_global > 0)) { term = MOLA_ICP_TERM_NO_PAIRINGS; break; }
+        if (solver_error) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }
+        std::memcpy(last_acc, acc, sizeof acc);
+        have_solution = true;
+        T = Tn;
+        double d_xyz, d_rot;
+        stall_deltas(T, Tprev, d_xyz, d_rot);
+        if (!p.fixed_iterations && std::fabs(d_xyz) < p.min_abs_step_trans && std::fabs(d_rot) < p.min_abs_step_rot) {
+            term = MOLA_ICP_TERM_STALLED;
+            ++it;  // this iteration did run
+            break;
+        }
+        Tprev = T;
+    }
+    if (term == MOLA_ICP_TERM_UNDEFINED) term = MOLA_ICP_TERM_MAX_ITERATIONS;
+    const double t1 = now_ms();
+
+    // quality (row a11): PairedRatio at the final pose = pairings / min(N, M)
+    double quality = 0;
+    if (p.skip_quality) quality = -1.0;
+    else if (st.n_local_total() > 0 && st.n_map_total() > 0) {
+        if ((rc = st.match(T, p.quality_threshold, p, nullptr))) return rc;
+        double qacc[kNAcc];
+        if ((rc = st.accumulate(p, T, 0, nullptr, nullptr, true, qacc))) return rc;
+        if ((rc = st.allreduce(qacc))) return rc;
+        const double denom = (double)(st.n_local_total() < st.n_map_total() ? st.n_local_total() : st.n_map_total());
+        quality = qacc[16] / denom;
+    }
+    const double t2 = now_ms();
+
+    std::memcpy(out->T, T.m, sizeof out->T);
+    out->quality = quality;
+    out->n_iterations = it;
+    out->termination = term;
+    out->n_pairs = have_solution ? (uint64_t)last_acc[16] : 0;
+    out->rmse = (have_solution && last_acc[16] > 0) ? std::sqrt(last_acc[17] / last_acc[16]) : 0.0;
+    if (!have_solution || !pose_covariance(last_acc, T, out->cov)) std::memset(out->cov, 0, sizeof out->cov);
+    out->ms_iterations = t1 - t0;
+    out->ms_quality = t2 - t1;
+    return MOLA_ICP_OK;
+}
+
+}  // namespace mola_icp_amd

@@ -1,0 +1,44 @@
+// icp_loop.hpp -- the iteration-control loop of the ICP core (host, fp64).
+//
+// SURVEY.md §8 rows a1 (driver), a10 (iteration control), a11 (quality), a12
+// (results).  Restates what `mp2p_icp::ICP::align()` does around its matcher
+// and solver stages, as invoked at src/LidarOdometry.cpp:869-871, over an
+// abstract `Stages` interface so the same code drives
+//   - the HIP stages (hip_backend.hip), single GPU or one query shard per rank
+//     with the accumulator all-reduce in between, and
+//   - caller-supplied stages (mola_icp_run_loop), which is how the host logic
+//     and the sharded reduction are tested on CPU.
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "../../include/mola_icp_amd.h"
+#include "se3_math.hpp"
+
+namespace mola_icp_amd {
+
+// thread-local last-error string behind mola_icp_last_error()
+void set_error(const std::string& msg);
+const char* last_error();
+int fail(int code, const std::string& msg);  // records msg, returns code
+
+struct Stages {
+    virtual ~Stages() = default;
+    // matcher: transform + NN + gate at pose T; stores the pairing; n_pairs = this rank's count
+    virtual int match(const Mat4& T, double threshold, const mola_icp_params& p, uint64_t* n_pairs) = 0;
+    // accumulate over the stored pairing -> acc[24] (this rank's partial sums, host memory)
+    virtual int accumulate(const mola_icp_params& p, const Mat4& Tcur, int stage, const double cl[3],
+                           const double cg[3], bool reset_outliers, double acc[kNAcc]) = 0;
+    // sum acc across ranks in place (no-op for a single rank)
+    virtual int allreduce(double acc[kNAcc]) { (void)acc; return MOLA_ICP_OK; }
+    virtual uint64_t n_local_total() const = 0;
+    virtual uint64_t n_map_total() const = 0;
+};
+
+// Runs the loop; fills T, quality, n_iterations, termination, n_pairs, rmse, cov,
+// ms_iterations, ms_quality of *out (other fields untouched).
+int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_icp_result* out);
+
+int validate_params(const mola_icp_params& p);
+
+}  // namespace mola_icp_amd

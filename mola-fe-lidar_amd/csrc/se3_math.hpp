@@ -1,0 +1,270 @@
+// se3_math.hpp -- fp64 host-side geometry for the ICP core: pose conversions,
+// SE(3) log / stall test, Horn's closed-form solve, 6x6 covariance.
+//
+// These are the O(1)-per-iteration pieces of the hot path (SURVEY.md §8 rows
+// a9, a10, a12).  The reference reaches them through mp2p_icp::Solver_Horn and
+// mp2p_icp::ICP::align (call site src/LidarOdometry.cpp:869-871); MRPT's
+// TPose3D convention comes from src/LidarOdometry.cpp:272-275.
+#pragma once
+#include <cmath>
+#include <cstring>
+
+namespace mola_icp_amd {
+
+struct Mat4 {
+    double m[16];
+    static Mat4 identity()
+    {
+        Mat4 r{};
+        r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0;
+        return r;
+    }
+    double& operator()(int r, int c) { return m[4 * r + c]; }
+    double operator()(int r, int c) const { return m[4 * r + c]; }
+};
+
+inline Mat4 mul(const Mat4& A, const Mat4& B)
+{
+    Mat4 C{};
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 4; ++k) {
+            const double a = A(i, k);
+            for (int j = 0; j < 4; ++j) C(i, j) += a * B(k, j);
+        }
+    return C;
+}
+
+inline Mat4 inverse_rigid(const Mat4& T)
+{
+    Mat4 I = Mat4::identity();
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) I(i, j) = T(j, i);
+    for (int i = 0; i < 3; ++i) I(i, 3) = -(I(i, 0) * T(0, 3) + I(i, 1) * T(1, 3) + I(i, 2) * T(2, 3));
+    return I;
+}
+
+// MRPT TPose3D(x,y,z,yaw,pitch,roll): R = Rz(yaw) Ry(pitch) Rx(roll)
+inline Mat4 pose_from_xyzypr(const double p[6])
+{
+    const double cy = std::cos(p[3]), sy = std::sin(p[3]);
+    const double cp = std::cos(p[4]), sp = std::sin(p[4]);
+    const double cr = std::cos(p[5]), sr = std::sin(p[5]);
+    Mat4 T = Mat4::identity();
+    T(0, 0) = cy * cp; T(0, 1) = cy * sp * sr - sy * cr; T(0, 2) = cy * sp * cr + sy * sr;
+    T(1, 0) = sy * cp; T(1, 1) = sy * sp * sr + cy * cr; T(1, 2) = sy * sp * cr - cy * sr;
+    T(2, 0) = -sp;     T(2, 1) = cp * sr;                T(2, 2) = cp * cr;
+    T(0, 3) = p[0]; T(1, 3) = p[1]; T(2, 3) = p[2];
+    return T;
+}
+
+inline void pose_to_xyzypr(const Mat4& T, double p[6])
+{
+    p[0] = T(0, 3); p[1] = T(1, 3); p[2] = T(2, 3);
+    const double sp = -T(2, 0);
+    if (std::fabs(sp) < 1.0 - 1e-12) {
+        p[4] = std::asin(sp);
+        p[3] = std::atan2(T(1, 0), T(0, 0));
+        p[5] = std::atan2(T(2, 1), T(2, 2));
+    } else {  // gimbal lock: put everything in yaw
+        p[4] = sp > 0 ? M_PI / 2 : -M_PI / 2;
+        p[3] = std::atan2(-T(0, 1), T(1, 1));
+        p[5] = 0;
+    }
+}
+
+// log: out = (v, w) with v = V(w)^-1 t, MRPT Lie::SE<3>::log ordering.
+inline void se3_log(const Mat4& T, double out[6])
+{
+    // rotation part via the quaternion (stable for all angles)
+    const double tr = T(0, 0) + T(1, 1) + T(2, 2);
+    double qw, qx, qy, qz;
+    if (tr > 0) {
+        const double s = std::sqrt(tr + 1.0) * 2;
+        qw = 0.25 * s; qx = (T(2, 1) - T(1, 2)) / s; qy = (T(0, 2) - T(2, 0)) / s; qz = (T(1, 0) - T(0, 1)) / s;
+    } else if (T(0, 0) > T(1, 1) && T(0, 0) > T(2, 2)) {
+        const double s = std::sqrt(1.0 + T(0, 0) - T(1, 1) - T(2, 2)) * 2;
+        qw = (T(2, 1) - T(1, 2)) / s; qx = 0.25 * s; qy = (T(0, 1) + T(1, 0)) / s; qz = (T(0, 2) + T(2, 0)) / s;
+    } else if (T(1, 1) > T(2, 2)) {
+        const double s = std::sqrt(1.0 + T(1, 1) - T(0, 0) - T(2, 2)) * 2;
+        qw = (T(0, 2) - T(2, 0)) / s; qx = (T(0, 1) + T(1, 0)) / s; qy = 0.25 * s; qz = (T(1, 2) + T(2, 1)) / s;
+    } else {
+        const double s = std::sqrt(1.0 + T(2, 2) - T(0, 0) - T(1, 1)) * 2;
+        qw = (T(1, 0) - T(0, 1)) / s; qx = (T(0, 2) + T(2, 0)) / s; qy = (T(1, 2) + T(2, 1)) / s; qz = 0.25 * s;
+    }
+    if (qw < 0) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }
+    const double vn = std::sqrt(qx * qx + qy * qy + qz * qz);
+    double w[3];
+    if (vn < 1e-12) {
+        w[0] = 2 * qx; w[1] = 2 * qy; w[2] = 2 * qz;
+    } else {
+        const double ang = 2.0 * std::atan2(vn, qw);
+        w[0] = ang * qx / vn; w[1] = ang * qy / vn; w[2] = ang * qz / vn;
+    }
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double c;  // V^-1 = I - 1/2 W + c W^2
+    if (th2 < 1e-10) c = 1.0 / 12.0 + th2 / 720.0;
+    else {
+        const double th = std::sqrt(th2);
+        c = (1.0 - 0.5 * th * std::sin(th) / (1.0 - std::cos(th))) / th2;
+    }
+    const double t[3] = {T(0, 3), T(1, 3), T(2, 3)};
+    const double a[3] = {w[1] * t[2] - w[2] * t[1], w[2] * t[0] - w[0] * t[2], w[0] * t[1] - w[1] * t[0]};
+    const double b[3] = {w[1] * a[2] - w[2] * a[1], w[2] * a[0] - w[0] * a[2], w[0] * a[1] - w[1] * a[0]};
+    for (int i = 0; i < 3; ++i) {
+        out[i] = t[i] - 0.5 * a[i] + c * b[i];
+        out[3 + i] = w[i];
+    }
+}
+
+// |v|, |w| of log(Tprev^-1 T): the stall-test quantities (icp-settings-regular.yaml:12-13)
+inline void stall_deltas(const Mat4& T, const Mat4& Tprev, double& d_xyz, double& d_rot)
+{
+    double lg[6];
+    se3_log(mul(inverse_rigid(Tprev), T), lg);
+    d_xyz = std::sqrt(lg[0] * lg[0] + lg[1] * lg[1] + lg[2] * lg[2]);
+    d_rot = std::sqrt(lg[3] * lg[3] + lg[4] * lg[4] + lg[5] * lg[5]);
+}
+
+// Cyclic Jacobi on a symmetric 4x4; returns the unit eigenvector of the largest eigenvalue.
+inline void max_eigvec_sym4(double A[4][4], double q[4])
+{
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        double off = 0, dg = 0;
+        for (int i = 0; i < 4; ++i) {
+            dg += A[i][i] * A[i][i];
+            for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+        }
+        if (off == 0 || off < 1e-34 * dg) break;
+        for (int p = 0; p < 3; ++p)
+            for (int r = p + 1; r < 4; ++r) {
+                const double apr = A[p][r];
+                if (apr == 0) continue;
+                const double tau = (A[r][r] - A[p][p]) / (2 * apr);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1 + tau * tau));
+                const double c = 1 / std::sqrt(1 + t * t), s = t * c;
+                for (int k = 0; k < 4; ++k) {  // A <- A J
+                    const double x = A[k][p], y = A[k][r];
+                    A[k][p] = c * x - s * y;
+                    A[k][r] = s * x + c * y;
+                }
+                for (int k = 0; k < 4; ++k) {  // A <- J^T A
+                    const double x = A[p][k], y = A[r][k];
+                    A[p][k] = c * x - s * y;
+                    A[r][k] = s * x + c * y;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double x = V[k][p], y = V[k][r];
+                    V[k][p] = c * x - s * y;
+                    V[k][r] = s * x + c * y;
+                }
+            }
+    }
+    int b = 0;
+    for (int i = 1; i < 4; ++i)
+        if (A[i][i] > A[b][b]) b = i;
+    double n = 0;
+    for (int k = 0; k < 4; ++k) n += V[k][b] * V[k][b];
+    n = std::sqrt(n);
+    for (int k = 0; k < 4; ++k) q[k] = V[k][b] / n;
+}
+
+constexpr int kNAcc = 24;  // == MOLA_ICP_NACC
+
+// Horn (1987) closed form from the accumulator block.  false if W <= 0 / degenerate.
+inline bool solve_horn(const double acc[kNAcc], const double* cl_in, const double* cg_in, Mat4& T)
+{
+    const double W = acc[0];
+    if (!(W > 0) || !std::isfinite(W)) return false;
+    double cl[3], cg[3];
+    for (int k = 0; k < 3; ++k) {
+        cl[k] = cl_in ? cl_in[k] : acc[1 + k] / W;
+        cg[k] = cg_in ? cg_in[k] : acc[4 + k] / W;
+    }
+    double S[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            S[r][c] = acc[7 + 3 * r + c] - cl[r] * acc[4 + c] - acc[1 + r] * cg[c] + W * cl[r] * cg[c];
+    double N[4][4] = {
+        {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+        {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+        {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+        {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
+    double q[4];
+    max_eigvec_sym4(N, q);
+    for (int k = 0; k < 4; ++k)
+        if (!std::isfinite(q[k])) return false;
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    if (w < 0) { w = -w; x = -x; y = -y; z = -z; }
+    T = Mat4::identity();
+    T(0, 0) = 1 - 2 * (y * y + z * z); T(0, 1) = 2 * (x * y - w * z);     T(0, 2) = 2 * (x * z + w * y);
+    T(1, 0) = 2 * (x * y + w * z);     T(1, 1) = 1 - 2 * (x * x + z * z); T(1, 2) = 2 * (y * z - w * x);
+    T(2, 0) = 2 * (x * z - w * y);     T(2, 1) = 2 * (y * z + w * x);     T(2, 2) = 1 - 2 * (x * x + y * y);
+    for (int r = 0; r < 3; ++r) T(r, 3) = cg[r] - (T(r, 0) * cl[0] + T(r, 1) * cl[1] + T(r, 2) * cl[2]);
+    return true;
+}
+
+// 6x6 covariance of the pose (left perturbation, order x,y,z,wx,wy,wz):
+// cov = sigma^2 (J^T J)^-1 with J_i = [I | -[p_i]x], p_i = T l_i, sigma^2 = sum d^2 / (3n-6).
+// Own definition (the reference only consumes the mean: src/LidarOdometry.cpp:302,791).
+inline bool pose_covariance(const double acc[kNAcc], const Mat4& T, double cov[36])
+{
+    std::memset(cov, 0, sizeof(double) * 36);
+    const double W = acc[0], n = acc[16];
+    if (!(W > 0) || n < 3) return false;
+    double sl[3] = {acc[1], acc[2], acc[3]};
+    double L[3][3] = {{acc[18], acc[19], acc[20]}, {acc[19], acc[21], acc[22]}, {acc[20], acc[22], acc[23]}};
+    double R[3][3], t[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) R[i][j] = T(i, j);
+        t[i] = T(i, 3);
+    }
+    double sp[3], Rsl[3];
+    for (int i = 0; i < 3; ++i) {
+        Rsl[i] = R[i][0] * sl[0] + R[i][1] * sl[1] + R[i][2] * sl[2];
+        sp[i] = Rsl[i] + W * t[i];
+    }
+    double RL[3][3], P[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) RL[i][j] = R[i][0] * L[0][j] + R[i][1] * L[1][j] + R[i][2] * L[2][j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            P[i][j] = RL[i][0] * R[j][0] + RL[i][1] * R[j][1] + RL[i][2] * R[j][2] + Rsl[i] * t[j] + t[i] * Rsl[j] +
+                      W * t[i] * t[j];
+    const double trP = P[0][0] + P[1][1] + P[2][2];
+    double H[6][12] = {};
+    for (int i = 0; i < 3; ++i) H[i][i] = W;
+    // -[sp]x  in the upper-right block, its transpose (= [sp]x) lower-left
+    const double sx[3][3] = {{0, -sp[2], sp[1]}, {sp[2], 0, -sp[0]}, {-sp[1], sp[0], 0}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            H[i][3 + j] = -sx[i][j];
+            H[3 + i][j] = sx[i][j];
+            H[3 + i][3 + j] = (i == j ? trP : 0.0) - P[i][j];
+        }
+    for (int i = 0; i < 6; ++i) H[i][6 + i] = 1.0;
+    // Gauss-Jordan with partial pivoting
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r)
+            if (std::fabs(H[r][c]) > std::fabs(H[piv][c])) piv = r;
+        if (std::fabs(H[piv][c]) < 1e-300) return false;
+        if (piv != c)
+            for (int k = 0; k < 12; ++k) { const double tmp = H[c][k]; H[c][k] = H[piv][k]; H[piv][k] = tmp; }
+        const double inv = 1.0 / H[c][c];
+        for (int k = 0; k < 12; ++k) H[c][k] *= inv;
+        for (int r = 0; r < 6; ++r) {
+            if (r == c) continue;
+            const double f = H[r][c];
+            if (f == 0) continue;
+            for (int k = 0; k < 12; ++k) H[r][k] -= f * H[c][k];
+        }
+    }
+    const double dof = 3.0 * n - 6.0;
+    const double sigma2 = dof > 0 ? acc[17] / dof : 0.0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) cov[6 * i + j] = sigma2 * H[i][6 + j];
+    return true;
+}
+
+}  // namespace mola_icp_amd

@@ -1,0 +1,343 @@
+"""Host-side mirror of the reference's ICP surface for the one hot path.
+
+Names follow what `LidarOdometry` touches (src/LidarOdometry.cpp:57-88, 851-895):
+`ICP.align(pcs_from, pcs_to, init_guess, params) -> Results`, `Parameters.load_from`,
+`Results.{optimal_tf, quality, nIterations, terminationReason}`.  Everything here is
+argument marshalling over the C-ABI; the arithmetic lives in the shared library."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib as L
+
+IterTermReason = {0: "Undefined", 1: "NoPairings", 2: "SolverError", 3: "MaxIterations", 4: "Stalled"}
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _pose16(T) -> np.ndarray:
+    T = np.asarray(T, dtype=np.float64)
+    if T.shape == (6,):
+        return pose_from_xyzypr(T).reshape(16)
+    if T.shape != (4, 4):
+        raise ValueError("pose must be 4x4 or (x,y,z,yaw,pitch,roll)")
+    return np.ascontiguousarray(T).reshape(16)
+
+
+def _soa(pc) -> tuple[np.ndarray, np.ndarray, np.ndarray, int]:
+    """(3,n) float32 array -> three contiguous fp32 rows."""
+    a = np.asarray(pc)
+    if a.ndim != 2 or a.shape[0] != 3:
+        raise ValueError("a cloud is a (3, n) float32 structure-of-arrays")
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a[0], a[1], a[2], a.shape[1]
+
+
+# ------------------------------------------------------------------ host math
+
+
+def pose_from_xyzypr(p) -> np.ndarray:
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    T = np.empty(16)
+    L.check(L.lib().mola_icp_pose_from_xyzypr(_dp(p), _dp(T)))
+    return T.reshape(4, 4)
+
+
+def pose_to_xyzypr(T) -> np.ndarray:
+    T = _pose16(T)
+    p = np.empty(6)
+    L.check(L.lib().mola_icp_pose_to_xyzypr(_dp(T), _dp(p)))
+    return p
+
+
+def se3_log(T) -> np.ndarray:
+    T = _pose16(T)
+    o = np.empty(6)
+    L.check(L.lib().mola_icp_se3_log(_dp(T), _dp(o)))
+    return o
+
+
+def stall_deltas(T, Tprev) -> tuple[float, float]:
+    a, b = _pose16(T), _pose16(Tprev)
+    dx, dr = C.c_double(), C.c_double()
+    L.check(L.lib().mola_icp_stall_deltas(_dp(a), _dp(b), C.byref(dx), C.byref(dr)))
+    return dx.value, dr.value
+
+
+def solve_horn(acc, cl=None, cg=None) -> np.ndarray:
+    acc = np.ascontiguousarray(acc, dtype=np.float64)
+    assert acc.shape == (L.NACC,)
+    T = np.empty(16)
+    clp = _dp(np.ascontiguousarray(cl, dtype=np.float64)) if cl is not None else None
+    cgp = _dp(np.ascontiguousarray(cg, dtype=np.float64)) if cg is not None else None
+    L.check(L.lib().mola_icp_solve_horn(_dp(acc), clp, cgp, _dp(T)))
+    return T.reshape(4, 4)
+
+
+# ------------------------------------------------------------------ parameters / results
+
+
+@dataclass
+class Parameters:
+    """mp2p_icp::Parameters + the pipeline settings of one `icp-settings-*.yaml`
+    (params/icp-settings-regular.yaml:10-46)."""
+    c: L.CParams = field(default_factory=L.CParams)
+
+    def __post_init__(self):
+        if self.c.max_iterations == 0 and self.c.matcher_threshold == 0.0:
+            L.check(L.lib().mola_icp_params_default(C.byref(self.c)))
+
+    @classmethod
+    def load_from(cls, yaml_text: str) -> "Parameters":
+        p = cls()
+        L.check(L.lib().mola_icp_params_from_yaml(yaml_text.encode(), C.byref(p.c)))
+        return p
+
+    @classmethod
+    def load_from_file(cls, path: str, mola_dir: str | None = None, key: str | None = None) -> "Parameters":
+        p = cls()
+        L.check(L.lib().mola_icp_params_from_yaml_file(path.encode(), mola_dir.encode() if mola_dir else None,
+                                                       key.encode() if key else None, C.byref(p.c)))
+        return p
+
+    def __getattr__(self, name):
+        c = object.__getattribute__(self, "c")
+        if name in {f[0] for f in L.CParams._fields_}:
+            return getattr(c, name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name != "c" and name in {f[0] for f in L.CParams._fields_}:
+            setattr(self.c, name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+    def copy(self) -> "Parameters":
+        q = Parameters()
+        C.memmove(C.byref(q.c), C.byref(self.c), C.sizeof(L.CParams))
+        return q
+
+
+@dataclass
+class Results:
+    """The fields of mp2p_icp::Results consumed at src/LidarOdometry.cpp:873-888."""
+    optimal_tf: np.ndarray          # 4x4 mean (pose of `to` wrt `from`)
+    optimal_tf_cov: np.ndarray      # 6x6
+    quality: float
+    nIterations: int
+    terminationReason: int
+    n_pairs: int
+    rmse: float
+    ms_upload: float
+    ms_iterations: float
+    ms_quality: float
+    ms_nn_kernel: float
+    n_nn_launches: int
+    nn_kernel_used: int
+
+    @classmethod
+    def from_c(cls, r: L.CResult) -> "Results":
+        return cls(np.array(r.T).reshape(4, 4), np.array(r.cov).reshape(6, 6), r.quality, r.n_iterations,
+                   r.termination, r.n_pairs, r.rmse, r.ms_upload, r.ms_iterations, r.ms_quality, r.ms_nn_kernel,
+                   r.n_nn_launches, r.nn_kernel_used)
+
+    @property
+    def termination_name(self) -> str:
+        return IterTermReason.get(self.terminationReason, "?")
+
+
+# ------------------------------------------------------------------ the ICP object
+
+
+class ICP:
+    """One `mp2p_icp::ICP` object of `Parameters::ICP_case`
+    (include/mola-fe-lidar/LidarOdometry.h:96-102), backed by one MI355X."""
+
+    def __init__(self, device: int = -1):
+        self._h = L._H()
+        L.check(L.lib().mola_icp_create(device, C.byref(self._h)))
+        self._keep = []       # device tensors / callbacks that must outlive the handle's use of them
+        self._ar_cb = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            L.lib().mola_icp_destroy(self._h)
+            self._h = L._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the hot path, as called at src/LidarOdometry.cpp:869-871
+    def align(self, pcs_from, pcs_to, init_guess_to_wrt_from, params: Parameters) -> Results:
+        fx, fy, fz, M = _soa(pcs_from)
+        tx, ty, tz, N = _soa(pcs_to)
+        T = _pose16(init_guess_to_wrt_from)
+        r = L.CResult()
+        L.check(L.lib().mola_icp_align(self._h, _fp(fx), _fp(fy), _fp(fz), M, _fp(tx), _fp(ty), _fp(tz), N, _dp(T),
+                                       C.byref(params.c), C.byref(r)))
+        return Results.from_c(r)
+
+    def align_batch(self, pairs, init_guesses, params: Parameters) -> list[Results]:
+        """pairs = [(pcs_from, pcs_to), ...]: the nearby-KF / loop-closure batch
+        (src/LidarOdometry.cpp:704-741)."""
+        n = len(pairs)
+        keep = []
+        FPP = C.POINTER(C.c_float) * n
+        arrs = [FPP() for _ in range(6)]
+        Ms, Ns = (C.c_size_t * n)(), (C.c_size_t * n)()
+        for i, (f, t) in enumerate(pairs):
+            fx, fy, fz, M = _soa(f)
+            tx, ty, tz, N = _soa(t)
+            keep += [fx, fy, fz, tx, ty, tz]
+            for a, v in zip(arrs, (fx, fy, fz, tx, ty, tz)):
+                a[i] = _fp(v)
+            Ms[i], Ns[i] = M, N
+        Ts = np.ascontiguousarray(np.stack([_pose16(g) for g in init_guesses]) if n else np.zeros((0, 16)))
+        res = (L.CResult * n)()
+        L.check(L.lib().mola_icp_align_batch(self._h, n, arrs[0], arrs[1], arrs[2], Ms, arrs[3], arrs[4], arrs[5], Ns,
+                                             _dp(Ts), C.byref(params.c), res))
+        return [Results.from_c(r) for r in res]
+
+    # -- resident clouds (already in HBM): bench + sharded path
+    @staticmethod
+    def _is_device_tensor(x) -> bool:
+        return hasattr(x, "is_cuda") and x.is_cuda
+
+    def set_map(self, pc):
+        if self._is_device_tensor(pc):
+            import torch
+            assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[0] == 3 and pc.is_contiguous()
+            self._keep_map = pc
+            L.check(L.lib().mola_icp_set_map_device(self._h, pc[0].data_ptr(), pc[1].data_ptr(), pc[2].data_ptr(),
+                                                    pc.shape[1]))
+        else:
+            x, y, z, n = _soa(pc)
+            L.check(L.lib().mola_icp_set_map_host(self._h, _fp(x), _fp(y), _fp(z), n))
+
+    def set_local(self, pc):
+        if self._is_device_tensor(pc):
+            import torch
+            assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[0] == 3 and pc.is_contiguous()
+            self._keep_local = pc
+            L.check(L.lib().mola_icp_set_local_device(self._h, pc[0].data_ptr(), pc[1].data_ptr(), pc[2].data_ptr(),
+                                                      pc.shape[1]))
+        else:
+            x, y, z, n = _soa(pc)
+            L.check(L.lib().mola_icp_set_local_host(self._h, _fp(x), _fp(y), _fp(z), n))
+
+    def set_global_sizes(self, n_local_total: int, n_map_total: int):
+        L.check(L.lib().mola_icp_set_global_sizes(self._h, n_local_total, n_map_total))
+
+    def set_stream(self, hip_stream_ptr: int | None):
+        L.check(L.lib().mola_icp_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+
+    def set_allreduce(self, fn):
+        """fn(np.ndarray[float64] of 24) -> None, summing in place across ranks (None = single GPU)."""
+        if fn is None:
+            self._ar_cb = None
+            L.check(L.lib().mola_icp_set_allreduce(self._h, L.ALLREDUCE_FN(), None))
+            return
+
+        def _cb(buf, n, device_ptr, user):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                fn(a)
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._ar_cb = L.ALLREDUCE_FN(_cb)
+        L.check(L.lib().mola_icp_set_allreduce(self._h, self._ar_cb, None))
+
+    def align_resident(self, init_guess_to_wrt_from, params: Parameters) -> Results:
+        T = _pose16(init_guess_to_wrt_from)
+        r = L.CResult()
+        L.check(L.lib().mola_icp_align_resident(self._h, _dp(T), C.byref(params.c), C.byref(r)))
+        return Results.from_c(r)
+
+    # -- single stages (parity tests)
+    def match(self, T, threshold: float, n_local: int, nn_kernel: int = L.NN_AUTO, copy: bool = True):
+        T = _pose16(T)
+        idx = np.empty(n_local, dtype=np.int32) if copy else None
+        d2 = np.empty(n_local, dtype=np.float32) if copy else None
+        n = C.c_uint64()
+        L.check(L.lib().mola_icp_match(self._h, _dp(T), threshold, nn_kernel,
+                                       idx.ctypes.data_as(C.POINTER(C.c_int32)) if copy else None,
+                                       _fp(d2) if copy else None, C.byref(n)))
+        return idx, d2, n.value
+
+    def accumulate(self, params: Parameters, Tcur, stage: int = 0, cl=None, cg=None, reset_outliers: bool = True):
+        T = _pose16(Tcur)
+        acc = np.empty(L.NACC)
+        clp = _dp(np.ascontiguousarray(cl, dtype=np.float64)) if cl is not None else None
+        cgp = _dp(np.ascontiguousarray(cg, dtype=np.float64)) if cg is not None else None
+        L.check(L.lib().mola_icp_accumulate(self._h, C.byref(params.c), _dp(T), stage, clp, cgp,
+                                            1 if reset_outliers else 0, _dp(acc)))
+        return acc
+
+
+def run_loop(match_fn, accumulate_fn, init_guess, params: Parameters, n_local_total: int, n_map_total: int,
+             allreduce_fn=None) -> Results:
+    """The library's own iteration-control loop over caller-supplied stages
+    (mola_icp_run_loop): `match_fn(T4x4, threshold) -> n_pairs`,
+    `accumulate_fn(params, T4x4, stage, cl, cg, reset) -> acc[24]`, `allreduce_fn(acc) -> None`."""
+
+    def _m(user, Tp, thr, n_out):
+        try:
+            T = np.ctypeslib.as_array(Tp, shape=(16,)).reshape(4, 4).copy()
+            n_out[0] = int(match_fn(T, thr))
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return L.E_INTERNAL
+
+    def _a(user, pp, Tp, stage, clp, cgp, reset, acc_out):
+        try:
+            T = np.ctypeslib.as_array(Tp, shape=(16,)).reshape(4, 4).copy()
+            cl = np.ctypeslib.as_array(clp, shape=(3,)).copy() if clp else None
+            cg = np.ctypeslib.as_array(cgp, shape=(3,)).copy() if cgp else None
+            p = Parameters()
+            C.memmove(C.byref(p.c), pp, C.sizeof(L.CParams))
+            acc = np.asarray(accumulate_fn(p, T, stage, cl, cg, bool(reset)), dtype=np.float64)
+            np.ctypeslib.as_array(acc_out, shape=(L.NACC,))[:] = acc
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return L.E_INTERNAL
+
+    def _r(buf, n, device_ptr, user):
+        try:
+            allreduce_fn(np.ctypeslib.as_array(buf, shape=(n,)))
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    cb = L.CStageCallbacks()
+    cb.match = L.MATCH_CB(_m)
+    cb.accumulate = L.ACCUM_CB(_a)
+    cb.allreduce = L.ALLREDUCE_FN(_r) if allreduce_fn is not None else L.ALLREDUCE_FN()
+    cb.user = None
+    cb.n_local_total = n_local_total
+    cb.n_map_total = n_map_total
+    T = _pose16(init_guess)
+    r = L.CResult()
+    L.check(L.lib().mola_icp_run_loop(C.byref(cb), _dp(T), C.byref(params.c), C.byref(r)))
+    return Results.from_c(r)

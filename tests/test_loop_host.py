@@ -1,0 +1,113 @@
+"""The product's iteration-control loop (csrc/icp_loop.cpp, rows a1/a10/a11/a12) driven over
+oracle-computed stages must reproduce the oracle's own align() -- on CPU, no GPU."""
+import numpy as np
+import pytest
+
+from tests.helpers import OracleStages, p2p_params
+
+
+def _run(pkg, O, g, l, p, T0=None, allreduce=None):
+    st = OracleStages(O, g, l)
+    r = pkg.run_loop(st.match, st.accumulate, np.eye(4) if T0 is None else T0, p, l.shape[1], g.shape[1], allreduce)
+    return r, st
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(use_scale_outlier_detector=1, scale_outlier_threshold=1.1),
+    dict(use_robust_kernel=1, robust_kernel_param=np.deg2rad(0.1), robust_kernel_scale=400.0),
+    dict(use_scale_outlier_detector=1, scale_outlier_threshold=1.05, use_robust_kernel=1,
+         robust_kernel_param=np.deg2rad(0.05), robust_kernel_scale=100.0),
+    dict(fixed_iterations=1, max_iterations=12),
+    dict(matcher_threshold=0.4, max_iterations=100),
+])
+def test_loop_equals_oracle_align(pkg, O, golden, kw):
+    g, l = golden["A_map"], golden["A_local"]
+    p = p2p_params(pkg, **kw)
+    r, st = _run(pkg, O, g, l, p)
+    ref = O.align(g, l, np.eye(4), O.params_from_product(p))
+    assert r.nIterations == ref["n_iterations"]
+    assert r.terminationReason == ref["termination"]
+    np.testing.assert_allclose(r.optimal_tf, ref["T"], atol=1e-10)
+    assert r.quality == pytest.approx(ref["quality"], abs=1e-12)
+    assert r.n_pairs == ref["n_pairs"]
+    assert r.rmse == pytest.approx(ref["rmse"], rel=1e-9)
+    assert st.n_match == r.nIterations + 1  # one matcher pass per iteration + the quality pass
+
+
+def test_loop_matches_golden(pkg, O, golden):
+    g, l = golden["A_map"], golden["A_local"]
+    r, _ = _run(pkg, O, g, l, p2p_params(pkg, max_iterations=30))
+    assert r.nIterations == int(golden["A_nit"]) and r.terminationReason == int(golden["A_term"])
+    np.testing.assert_allclose(r.optimal_tf, golden["A_Tfinal"], atol=1e-9)
+    assert r.quality == pytest.approx(float(golden["A_quality"]), abs=1e-12)
+
+
+def test_termination_reasons(pkg, O, golden):
+    g, l = golden["A_map"], golden["A_local"]
+    # MaxIterations
+    r, _ = _run(pkg, O, g, l, p2p_params(pkg, max_iterations=3))
+    assert r.terminationReason == pkg.TERM_MAX_ITERATIONS and r.nIterations == 3
+    # Stalled at once when starting from the converged pose with loose thresholds
+    r0, _ = _run(pkg, O, g, l, p2p_params(pkg, max_iterations=60))
+    r, _ = _run(pkg, O, g, l, p2p_params(pkg, min_abs_step_trans=1e-2, min_abs_step_rot=1e-2), T0=r0.optimal_tf)
+    assert r.terminationReason == pkg.TERM_STALLED and r.nIterations == 1
+    # NoPairings: matcher disabled at iteration 0 / nothing inside the gate / empty clouds
+    r, st = _run(pkg, O, g, l, p2p_params(pkg, run_from_iteration=2))
+    assert r.terminationReason == pkg.TERM_NO_PAIRINGS and r.nIterations == 0
+    assert np.array_equal(r.optimal_tf, np.eye(4))
+    far = (l + np.float32(500)).astype(np.float32)
+    r, _ = _run(pkg, O, g, far, p2p_params(pkg))
+    assert r.terminationReason == pkg.TERM_NO_PAIRINGS and r.quality == 0 and r.n_pairs == 0
+    empty = np.zeros((3, 0), np.float32)
+    for gm, lm in ((empty, l), (g, empty)):
+        r, st = _run(pkg, O, gm, lm, p2p_params(pkg))
+        assert r.terminationReason == pkg.TERM_NO_PAIRINGS and r.quality == 0 and st.n_match == 0
+    # max_iterations = 0: no iteration, quality still evaluated at the guess
+    r, st = _run(pkg, O, g, l, p2p_params(pkg, max_iterations=0))
+    assert r.nIterations == 0 and r.terminationReason == pkg.TERM_MAX_ITERATIONS and st.n_match == 1
+
+
+def test_run_up_to_iteration(pkg, O, golden):
+    g, l = golden["A_map"], golden["A_local"]
+    p = p2p_params(pkg, run_up_to_iteration=2, max_iterations=10)
+    r, _ = _run(pkg, O, g, l, p)
+    ref = O.align(g, l, np.eye(4), O.params_from_product(p))
+    assert (r.nIterations, r.terminationReason) == (ref["n_iterations"], ref["termination"]) == (3, pkg.TERM_NO_PAIRINGS)
+    np.testing.assert_allclose(r.optimal_tf, ref["T"], atol=1e-10)
+
+
+def test_covariance_is_sane(pkg, O, golden):
+    g, l = golden["A_map"], golden["A_local"]
+    r, _ = _run(pkg, O, g, l, p2p_params(pkg))
+    C = r.optimal_tf_cov
+    np.testing.assert_allclose(C, C.T, rtol=1e-9, atol=1e-18)
+    assert (np.linalg.eigvalsh(C) > 0).all()
+    # sigma ~ rmse/sqrt(3); translation std ~ sigma/sqrt(n)
+    assert np.sqrt(C[0, 0]) == pytest.approx(r.rmse / np.sqrt(3) / np.sqrt(r.n_pairs), rel=0.5)
+
+
+def test_bad_arguments(pkg, O, golden):
+    g, l = golden["A_map"], golden["A_local"]
+    for kw in (dict(matcher_threshold=0.0), dict(quality_threshold=-1.0), dict(matcher_class=7), dict(solver_class=9),
+               dict(use_scale_outlier_detector=1, scale_outlier_threshold=0.5)):
+        with pytest.raises(pkg.IcpError) as e:
+            _run(pkg, O, g, l, p2p_params(pkg, **kw))
+        assert e.value.status == pkg._lib.E_BADARG
+    bad = np.eye(4)
+    bad[0, 3] = np.nan
+    with pytest.raises(pkg.IcpError):
+        _run(pkg, O, g, l, p2p_params(pkg), T0=bad)
+
+
+def test_stage_failure_propagates(pkg):
+    def boom(T, thr):
+        raise RuntimeError("stage exploded")
+    with pytest.raises(pkg.IcpError):
+        pkg.run_loop(boom, lambda *a: np.zeros(24), np.eye(4), p2p_params(pkg), 10, 10)
+
+    def bad_reduce(acc):
+        raise RuntimeError("link down")
+    with pytest.raises(pkg.IcpError) as e:
+        pkg.run_loop(lambda T, thr: 1, lambda *a: np.ones(24), np.eye(4), p2p_params(pkg), 10, 10, bad_reduce)
+    assert e.value.status == pkg._lib.E_COMM
