@@ -123,6 +123,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_shared_hip_runtime() -> None:
+    """PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  A process may hold only ONE HIP
+    runtime (device pointers and streams are exchanged with torch: ICP.set_map(tensor),
+    set_stream), so when torch is installed its runtime is loaded first and this library's
+    `libamdhip64.so.7` dependency resolves to it by SONAME.  Without torch the system ROCm is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("MOLA_ICP_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 class IcpError(RuntimeError):
     """A MOLA_ICP_E_* status, carrying the library's message (the reference's own
     error convention is exceptions: src/LidarOdometry.cpp:70-75, 860-861)."""
@@ -140,6 +165,7 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C mola-fe-lidar_amd/csrc`). There is no fallback implementation.")
+        _preload_shared_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)

@@ -14,6 +14,8 @@
 #include "hip_backend.hpp"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -140,6 +142,276 @@ __global__ __launch_bounds__(256) void k_nn_valu(const float* __restrict__ lx, c
     // one atomic per wave
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
     if ((tid & 63) == 0 && kept) atomicAdd(kept_counter, kept);
+}
+
+// ---- NN matcher, MFMA filter + exact re-evaluation ------------------------------------
+// The N x M x 3 distance contraction in expanded form,
+//     e(q,m) = |m'|^2 - 2 q'.m'  = [ -2m'x, -2m'y, -2m'z, |m'|^2 ] . [ q'x, q'y, q'z, 1 ]      (K = 4)
+// (primes: coordinates relative to the map's bounding-box centre c) is exactly one
+// v_mfma_f32_16x16x4_f32 per 16 map points x 16 queries.  e + |q'|^2 approximates d2 only to
+// ~1e-2 m^2 at 100 m range (fp32 cancellation), so the MFMA is used as a FILTER with a
+// rigorous error bound (DESIGN.md "MFMA filter bound"):
+//     | (e_mfma + |q'|^2_fl) - d2_contract |  <=  u*(18.6|q'|^2 + 18.6|m'|^2 + 6.2 g^2),  u = 2^-24, g = gate
+// The |m'|^2 share is folded into the A operand (k=3 row holds |m'|^2 (1 - 20u)), the rest into
+// the accumulator input C = -(best - |q'|^2 + 20u|q'|^2 + 8u g^2), so an output <= 0 means
+// "d2 may be <= the query's current best".  Only those survivors (a handful per query over the
+// whole map) are re-evaluated with the exact direct-difference contract on the original
+// coordinates (staged in LDS beside the image) -- the result is bit-identical to k_nn_valu /
+// the CPU checker, including the lowest-index tie rule.  The best is warm-started from the
+// previous iteration's pairing (an exact candidate), which removes most survivors.
+//
+// Layout: A = map tile, lane l holds A[i = l&15][k = l>>4]; the map image in HBM/LDS is
+// [tile][k][16] so that is word (tile*64 + l): one conflict-free ds_read_b32 feeds QT MFMAs.
+// B = 16 queries, lane l holds B[k = l>>4][j = l&15] (register-resident for the whole sweep).
+// D: lane l, reg r = pair (map row (l>>4)*4 + r, query l&15): each lane tracks the best of
+// "its" rows for query l&15; the four lane groups are merged once at the end.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kMapPadNorm = 1.0e30f;          // |m'|^2 of padding rows: e = 1e30, never a survivor
+constexpr float kUnitRoundoff = 5.9604645e-8f;  // u = 2^-24
+constexpr float kFoldCoef = 20.0f * kUnitRoundoff;  // >= 18.6u + the rounding of the folding itself
+constexpr float kGateCoef = 8.0f * kUnitRoundoff;   // >= 6.2u
+
+// accumulator input for a query with squared norm qq (centred) and current best d2
+__device__ __forceinline__ float filter_c(float qq, float best, float gate2)
+{
+    // -(best - qq + eps_q), rounded towards "more survivors"
+    return (qq - best) - (kFoldCoef * qq + kGateCoef * gate2) * 1.0001f - 1e-30f;
+}
+
+struct MapFrame {
+    float cx, cy, cz;  // bounding-box centre of the map (fp32)
+    float radius;      // >= max |m - c| over the map
+};
+
+// Work decomposition: the sweep is cut into ITEMS = (group of QT*16 queries) x (map segment).
+// Persistent waves pull items from an atomic queue (segment-major, so the waves running at any
+// time read the same ~2 MiB slice of the map image: it stays in every XCD's L2).  Each wave is
+// autonomous -- no block barrier anywhere: it streams the A operand straight from L2 through a
+// 4-deep register prefetch ring (one coalesced 256-B load per 16 map points; ~4 B/clk/CU, far
+// below what L2 delivers) and keeps its queries, thresholds and running best in registers.
+// Per-segment results are merged by k_nn_merge (lexicographic (d2,index) minimum).
+template <int QT>
+__global__ __launch_bounds__(256, 2) void k_nn_mfma(const float* __restrict__ lx, const float* __restrict__ ly,
+                                                    const float* __restrict__ lz, int N,
+                                                    const float* __restrict__ gx, const float* __restrict__ gy,
+                                                    const float* __restrict__ gz, int M,
+                                                    const float* __restrict__ map_img, int n_tiles, int seg_tiles,
+                                                    int n_segs, int n_qgroups, MapFrame F, PoseF P, float thr2,
+                                                    const int* __restrict__ seed_idx, int* __restrict__ seg_idx,
+                                                    float* __restrict__ seg_d2, unsigned int* __restrict__ queue,
+                                                    unsigned long long* __restrict__ dbg_stats)
+{
+    __shared__ float4 s_q[4 * QT * 16];  // per wave: (qx,qy,qz,|q'|^2) of its queries, for the exact re-evaluation
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, grp = lane >> 4;
+    float4* my_q = s_q + wave * (QT * 16);
+    const int n_items = n_qgroups * n_segs;
+
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = (int)atomicAdd(queue, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const int seg = item / n_qgroups, qg = item - seg * n_qgroups;
+        const int q0 = qg * (QT * 16);
+        const int t_beg = seg * seg_tiles, t_end = min(t_beg + seg_tiles, n_tiles);  // multiples of 4 tiles
+
+        float B[QT], best[QT];
+        int bidx[QT];
+        f32x4 C[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int i = q0 + t * 16 + col;
+            float qx = 0.f, qy = 0.f, qz = 0.f, cthr = kMapPadNorm;  // padding query: D = e + 1e30 > 0 always
+            float bx = 0.f, by = 0.f, bz = 0.f, qq = 0.f;
+            best[t] = thr2;  // gate: only d2 < thr2 can ever be kept
+            bidx[t] = -1;
+            if (i < N) {
+                xform(P, lx[i], ly[i], lz[i], qx, qy, qz);
+                bx = qx - F.cx; by = qy - F.cy; bz = qz - F.cz;
+                qq = fmaf(bz, bz, fmaf(by, by, bx * bx));
+                if (seed_idx) {  // warm start: last iteration's neighbour is an exact candidate
+                    const int j = seed_idx[i];
+                    if (j >= 0 && j < M) {
+                        const float d = dist2(qx, qy, qz, gx[j], gy[j], gz[j]);
+                        if (d < thr2) { best[t] = d; bidx[t] = j; }
+                    }
+                }
+                cthr = filter_c(qq, best[t], thr2);
+            }
+            B[t] = grp == 0 ? bx : (grp == 1 ? by : (grp == 2 ? bz : 1.0f));
+            C[t] = f32x4{cthr, cthr, cthr, cthr};
+            if (grp == 0) my_q[t * 16 + col] = make_float4(qx, qy, qz, qq);
+        }
+        // my_q is private to this wave: a wave-level fence is all the ordering it needs
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const float* img = map_img + (size_t)t_beg * 64 + lane;  // word (tile*64 + lane) = A[lane&15][lane>>4]
+        // prefetch ring (the image carries 4 padding tiles past n_tiles, so these never run off the end)
+        float a0 = img[0], a1 = img[64], a2 = img[128], a3 = img[192];
+        f32x4 Dp[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) Dp[t] = f32x4{1.f, 1.f, 1.f, 1.f};  // nothing pending before the first step
+
+        // consume(): reduce/test the PREVIOUS step's accumulators while this step's MFMAs run
+#define MOLA_NN_CONSUME(TILE)                                                                                     \
+    {                                                                                                             \
+        int r = min(min(__float_as_int(Dp[0][0]), __float_as_int(Dp[0][1])),                                      \
+                    min(__float_as_int(Dp[0][2]), __float_as_int(Dp[0][3])));                                     \
+        _Pragma("unroll") for (int t = 1; t < QT; ++t) {                                                          \
+            r = min(min(r, __float_as_int(Dp[t][0])), __float_as_int(Dp[t][1]));                                  \
+            r = min(min(r, __float_as_int(Dp[t][2])), __float_as_int(Dp[t][3]));                                  \
+        }                                                                                                         \
+        if (__any(r <= 0)) {                                                                                      \
+            const int row0 = (TILE)*16 + grp * 4;                                                                 \
+            if (dbg_stats && lane == 0) atomicAdd(&dbg_stats[0], 1ull);                                           \
+            _Pragma("unroll") for (int t = 0; t < QT; ++t) {                                                      \
+                const int mt = min(min(__float_as_int(Dp[t][0]), __float_as_int(Dp[t][1])),                       \
+                                   min(__float_as_int(Dp[t][2]), __float_as_int(Dp[t][3])));                      \
+                if (__any(mt <= 0)) {                                                                             \
+                    const float4 q = my_q[t * 16 + col];                                                          \
+                    _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                            \
+                        if (Dp[t][rr] <= 0.0f) {                                                                  \
+                            if (dbg_stats) atomicAdd(&dbg_stats[1], 1ull);                                        \
+                            const int j = row0 + rr; /* < M: padding rows never survive */                        \
+                            const float d = dist2(q.x, q.y, q.z, gx[j], gy[j], gz[j]);                            \
+                            if (d < best[t] || (d == best[t] && j < bidx[t])) { best[t] = d; bidx[t] = j; }       \
+                        }                                                                                         \
+                    }                                                                                             \
+                    float nb = best[t];                                                                           \
+                    nb = fminf(nb, __shfl_xor(nb, 16));                                                           \
+                    nb = fminf(nb, __shfl_xor(nb, 32));                                                           \
+                    if (q0 + t * 16 + col < N) {                                                                  \
+                        const float cthr = filter_c(q.w, nb, thr2);                                               \
+                        C[t] = f32x4{cthr, cthr, cthr, cthr};                                                     \
+                    }                                                                                             \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+#define MOLA_NN_STEP(AREG, TILE, NEXT_OFF)                                                                        \
+    {                                                                                                             \
+        f32x4 Dn[QT];                                                                                             \
+        const float a_cur = AREG;                                                                                 \
+        AREG = img[(NEXT_OFF)];                                                                                   \
+        _Pragma("unroll") for (int t = 0; t < QT; ++t)                                                            \
+            Dn[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, B[t], C[t], 0, 0, 0);                             \
+        MOLA_NN_CONSUME((TILE)-1)                                                                                 \
+        _Pragma("unroll") for (int t = 0; t < QT; ++t) Dp[t] = Dn[t];                                             \
+    }
+        for (int tile = t_beg; tile < t_end; tile += 4) {
+            MOLA_NN_STEP(a0, tile, 4 * 64)
+            MOLA_NN_STEP(a1, tile + 1, 5 * 64)
+            MOLA_NN_STEP(a2, tile + 2, 6 * 64)
+            MOLA_NN_STEP(a3, tile + 3, 7 * 64)
+            img += 4 * 64;
+        }
+        MOLA_NN_CONSUME(t_end - 1)
+#undef MOLA_NN_STEP
+#undef MOLA_NN_CONSUME
+
+        // merge the four lane groups: lexicographic (d2, index) minimum -> lowest index on ties
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float d = best[t];
+            int j = bidx[t] < 0 ? 0x7fffffff : bidx[t];
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float od = __shfl_xor(d, off);
+                const int oj = __shfl_xor(j, off);
+                if (od < d || (od == d && oj < j)) { d = od; j = oj; }
+            }
+            const int i = q0 + t * 16 + col;
+            if (grp == 0 && i < N) {
+                seg_idx[(size_t)seg * N + i] = j == 0x7fffffff ? -1 : j;
+                seg_d2[(size_t)seg * N + i] = d;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // my_q is rewritten by the next item
+    }
+}
+
+// per-segment results -> the pairing: lexicographic (d2, index) minimum over the segments
+__global__ __launch_bounds__(256) void k_nn_merge(const int* __restrict__ seg_idx, const float* __restrict__ seg_d2,
+                                                  int n_segs, int N, int* __restrict__ out_idx,
+                                                  float* __restrict__ out_d2, unsigned int* __restrict__ kept_counter)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned int kept = 0;
+    if (i < N) {
+        float d = seg_d2[i];
+        int j = seg_idx[i] < 0 ? 0x7fffffff : seg_idx[i];
+        for (int s = 1; s < n_segs; ++s) {
+            const float od = seg_d2[(size_t)s * N + i];
+            const int oj = seg_idx[(size_t)s * N + i] < 0 ? 0x7fffffff : seg_idx[(size_t)s * N + i];
+            if (od < d || (od == d && oj < j)) { d = od; j = oj; }
+        }
+        const int idx = j == 0x7fffffff ? -1 : j;
+        out_idx[i] = idx;
+        out_d2[i] = d;
+        kept = idx >= 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(kept_counter, kept);
+}
+
+// ---- map preparation for the MFMA matcher (once per map) -------------------------------
+// bounding box: per-block partial min/max -> [nblocks][6]; second stage on one block
+__global__ __launch_bounds__(256) void k_bbox_partial(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                      const float* __restrict__ gz, int M, float* __restrict__ part)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
+        const float v[3] = {gx[i], gy[i], gz[i]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+    }
+    __shared__ float sm[4][6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], off));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off));
+        }
+        if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][k] = mn[k]; sm[threadIdx.x >> 6][3 + k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bbox_final(const float* __restrict__ part, int nblocks, float* __restrict__ out)
+{
+    if (threadIdx.x < 6) {
+        float v = part[threadIdx.x];
+        for (int b = 1; b < nblocks; ++b)
+            v = threadIdx.x < 3 ? fminf(v, part[b * 6 + threadIdx.x]) : fmaxf(v, part[b * 6 + threadIdx.x]);
+        out[threadIdx.x] = v;
+    }
+}
+
+// map image [tile][k][16]: k<3 -> -2*(m_k - c_k), k=3 -> |m - c|^2 (1 - 20u) (the map-point share of
+// the filter's error bound, folded in).  Rows >= M are padding.
+__global__ __launch_bounds__(256) void k_map_image(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                   const float* __restrict__ gz, int M, int M_padded, MapFrame F,
+                                                   float* __restrict__ img)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= M_padded) return;
+    float ax = 0.f, ay = 0.f, az = 0.f, mm = kMapPadNorm;
+    if (p < M) {
+        const float x = gx[p] - F.cx, y = gy[p] - F.cy, z = gz[p] - F.cz;
+        const float n = fmaf(z, z, fmaf(y, y, x * x));
+        mm = n - kFoldCoef * n;
+        ax = -2.0f * x; ay = -2.0f * y; az = -2.0f * z;
+    }
+    float* t = img + (size_t)(p >> 4) * 64 + (p & 15);
+    t[0] = ax; t[16] = ay; t[32] = az; t[48] = mm;
 }
 
 // ---- accumulation (row a8) ---------------------------------------------------------
@@ -273,7 +545,7 @@ HipWorkspace::~HipWorkspace()
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
-    idx_.release(); d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
+    idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
     if (meta_host_) (void)hipHostFree(meta_host_);
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
@@ -295,6 +567,7 @@ int HipWorkspace::init()
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(MOLA_ICP_E_NODEVICE,
                     std::string("device is ") + prop.gcnArchName + " but the kernels are built for gfx950 only");
+    num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     own_stream_ = true;
@@ -302,6 +575,10 @@ int HipWorkspace::init()
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocDefault));
     int rc;
     if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8)))) return rc;
+    if (std::getenv("MOLA_ICP_DEBUG_STATS")) {  // diagnostic builds of a run, never on by default
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(dbg_stats_, 0, 4 * sizeof(unsigned long long)));
+    }
     inited_ = true;
     return MOLA_ICP_OK;
 }
@@ -355,6 +632,7 @@ int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, s
     M_ = M;
     map_img_valid_ = false;
     pairing_valid_ = false;
+    seed_valid_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -368,6 +646,7 @@ int HipWorkspace::set_map_device(const float* x, const float* y, const float* z,
     M_ = M;
     map_img_valid_ = false;
     pairing_valid_ = false;
+    seed_valid_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -382,6 +661,7 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     HIPCHK(hipStreamSynchronize(stream_));
     N_ = N;
     pairing_valid_ = false;
+    seed_valid_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -394,10 +674,57 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     lx_ = x; ly_ = y; lz_ = z;
     N_ = N;
     pairing_valid_ = false;
+    seed_valid_ = false;
     return MOLA_ICP_OK;
 }
 
-int HipWorkspace::prepare_map() { return MOLA_ICP_OK; }
+constexpr int kMfmaQT = 8;             // 128 queries per wave
+constexpr int kSegTilesTarget = 8192;  // 131072 map points = 2 MiB of image per segment: L2-resident per XCD
+
+// Builds the derived map image for the MFMA matcher: bounding box -> centre/radius, then
+// [tile][4][16] fp32 rows padded to whole LDS chunks.  Once per map.
+int HipWorkspace::prepare_map()
+{
+    if (map_img_valid_) return MOLA_ICP_OK;
+    int rc;
+    const int M = (int)M_;
+    const int nb = 256;
+    if ((rc = map_meta_.reserve(sizeof(float) * (6 * nb + 8)))) return rc;
+    float* part = map_meta_.as<float>();
+    float* bbox = part + 6 * nb;
+    hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(256), 0, stream_, gx_, gy_, gz_, M, part);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, stream_, part, nb, bbox);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(meta_host_, bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    double r2 = 0;
+    for (int k = 0; k < 3; ++k) {
+        const float lo = meta_host_[k], hi = meta_host_[3 + k];
+        if (!std::isfinite(lo) || !std::isfinite(hi))
+            return fail(MOLA_ICP_E_BADARG, "the map has non-finite coordinates");
+        const float c = 0.5f * lo + 0.5f * hi;
+        map_center_[k] = c;
+        const double h = std::fmax((double)hi - (double)c, (double)c - (double)lo);
+        r2 += h * h;
+    }
+    map_radius_ = (float)(std::sqrt(r2) * 1.00001) + 1e-30f;  // >= max |fl(m - c)|
+    if (!(map_radius_ < 1e15f)) return fail(MOLA_ICP_E_BADARG, "map extent too large for the fp32 MFMA filter");
+    // tiles of 16 points, rounded up to whole 4-tile steps, plus 4 tiles of prefetch slack
+    map_tiles_ = (int)(((M_ + 15) / 16 + 3) / 4 * 4);
+    map_segs_ = (map_tiles_ + kSegTilesTarget - 1) / kSegTilesTarget;
+    if (map_segs_ > 64) map_segs_ = 64;
+    map_seg_tiles_ = ((map_tiles_ + map_segs_ - 1) / map_segs_ + 3) / 4 * 4;
+    map_segs_ = (map_tiles_ + map_seg_tiles_ - 1) / map_seg_tiles_;
+    const size_t padded = (size_t)(map_tiles_ + 4) * 16;
+    if ((rc = map_img_.reserve(sizeof(float) * 4 * padded))) return rc;
+    MapFrame F{map_center_[0], map_center_[1], map_center_[2], map_radius_};
+    hipLaunchKernelGGL(k_map_image, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, stream_, gx_, gy_, gz_, M,
+                       (int)padded, F, map_img_.as<float>());
+    HIPCHK(hipGetLastError());
+    map_img_valid_ = true;
+    return MOLA_ICP_OK;
+}
 
 void HipWorkspace::reset_stats()
 {
@@ -417,6 +744,14 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
             tot += ms;
         }
     }
+    if (dbg_stats_) {
+        unsigned long long h[4] = {};
+        HIPCHK(hipStreamSynchronize(stream_));
+        HIPCHK(hipMemcpy(h, dbg_stats_, sizeof h, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[mola_icp debug] nn launches=%zu slow-path entries=%llu survivors=%llu (N=%zu M=%zu)\n",
+                     ev_used_ / 2, h[0], h[1], N_, M_);
+        HIPCHK(hipMemset(dbg_stats_, 0, sizeof h));
+    }
     if (ms_total) *ms_total = tot;
     if (launches) *launches = (uint32_t)(ev_used_ / 2);
     if (kernel_used) *kernel_used = last_kernel_;
@@ -435,11 +770,37 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         HIPCHK(hipEventCreate(&e));
         ev_.push_back(e);
     }
+    if (kernel == MOLA_ICP_NN_MFMA || (kernel == MOLA_ICP_NN_AUTO && N_ >= 4096 && M_ >= 1024)) {
+        const int rc = prepare_map();
+        if (rc) return rc;
+    }
     unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
-    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream_));
+    HIPCHK(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned int), stream_));  // [0] kept pairs, [1] work queue
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
-    (void)kernel;
-    {
+    // auto: the MFMA filter kernel wherever its per-wave tile (128 queries) is reasonably filled
+    const bool use_mfma = kernel == MOLA_ICP_NN_MFMA || (kernel == MOLA_ICP_NN_AUTO && N_ >= 4096 && M_ >= 1024);
+    if (use_mfma) {
+        const int n_qgroups = (int)((N_ + kMfmaQT * 16 - 1) / (kMfmaQT * 16));
+        const int n_items = n_qgroups * map_segs_;
+        int rc;
+        if ((rc = seg_idx_.reserve(sizeof(int) * (size_t)map_segs_ * N_))) return rc;
+        if ((rc = seg_d2_.reserve(sizeof(float) * (size_t)map_segs_ * N_))) return rc;
+        MapFrame F{map_center_[0], map_center_[1], map_center_[2], map_radius_};
+        // warm start from the pairing this workspace computed last for the same clouds
+        const int* seed = (seed_valid_ && !std::getenv("MOLA_ICP_NO_WARM_START")) ? idx_.as<int>() : nullptr;
+        // persistent grid: every CU gets its resident blocks (2-3 per CU at this register count)
+        int per_cu = 3;
+        if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 3;  // tuning knob
+        int grid = num_cus_ * per_cu;
+        if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
+        hipLaunchKernelGGL((k_nn_mfma<kMfmaQT>), dim3(grid), dim3(256), 0, stream_, lx_, ly_, lz_, (int)N_, gx_, gy_,
+                           gz_, (int)M_, map_img_.as<float>(), map_tiles_, map_seg_tiles_, map_segs_, n_qgroups, F, P,
+                           thr2, seed, seg_idx_.as<int>(), seg_d2_.as<float>(), counter + 1, dbg_stats_);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_nn_merge, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, seg_idx_.as<int>(),
+                           seg_d2_.as<float>(), map_segs_, (int)N_, idx_.as<int>(), d2_.as<float>(), counter);
+        last_kernel_ = MOLA_ICP_NN_MFMA;
+    } else {
         constexpr int QPT = 4, TM = 1024;
         const int grid = (int)((N_ + 256 * QPT - 1) / (256 * QPT));
         hipLaunchKernelGGL((k_nn_valu<QPT, TM>), dim3(grid), dim3(256), 0, stream_, lx_, ly_, lz_, (int)N_, gx_, gy_,
@@ -465,11 +826,13 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
     if (N_ == 0 || M_ == 0) {
         if (N_) HIPCHK(hipMemsetAsync(idx_.p, 0xff, sizeof(int) * N_, stream_));
         pairing_valid_ = true;
+        seed_valid_ = false;
         if (n_pairs) *n_pairs = 0;
         return MOLA_ICP_OK;
     }
     if ((rc = launch_nn(T, thr2, p.nn_kernel))) return rc;
     pairing_valid_ = true;
+    seed_valid_ = true;
     if (n_pairs) {
         unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
         unsigned int* hc = reinterpret_cast<unsigned int*>(acc_host_ + kNAcc);

@@ -77,11 +77,14 @@ class HipWorkspace final : public Stages {
     bool map_img_valid_ = false;
     float map_center_[3] = {0, 0, 0};
     float map_radius_ = 0;
+    int map_tiles_ = 0, map_segs_ = 0, map_seg_tiles_ = 0;
+    int num_cus_ = 256;
     // pairing + scratch
-    DevBuf idx_, d2_, outlier_, partials_, acc_dev_;
+    DevBuf idx_, d2_, seg_idx_, seg_d2_, outlier_, partials_, acc_dev_;
     double* acc_host_ = nullptr;  // pinned
     float* meta_host_ = nullptr;  // pinned
     bool pairing_valid_ = false;
+    bool seed_valid_ = false;  // idx_ holds a pairing of the CURRENT clouds: usable as the next match's warm start
 
     mola_icp_allreduce_fn ar_fn_ = nullptr;
     void* ar_user_ = nullptr;
@@ -89,6 +92,7 @@ class HipWorkspace final : public Stages {
     std::vector<hipEvent_t> ev_;  // pairs: start, stop
     size_t ev_used_ = 0;
     uint32_t last_kernel_ = 0;
+    unsigned long long* dbg_stats_ = nullptr;  // MOLA_ICP_DEBUG_STATS=1 only
 };
 
 }  // namespace mola_icp_amd
