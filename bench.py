@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--n-local", type=int, default=1_000_000)
     ap.add_argument("--n-map", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--nn-kernel", choices=["auto", "valu", "mfma"], default="auto")
+    ap.add_argument("--nn-kernel", choices=["auto", "valu", "mfma", "tiled"], default="auto")
     ap.add_argument("--cpu-baseline-iters", type=int, default=5, help="0 disables the CPU baseline leg")
     args = ap.parse_args()
 
@@ -80,7 +80,7 @@ def main():
     p.matcher_threshold = GATE_M
     p.fixed_iterations = 1
     p.skip_quality = 1
-    p.nn_kernel = {"auto": pkg.NN_AUTO, "valu": pkg.NN_VALU, "mfma": pkg.NN_MFMA}[args.nn_kernel]
+    p.nn_kernel = {"auto": pkg.NN_AUTO, "valu": pkg.NN_VALU, "mfma": pkg.NN_MFMA, "tiled": pkg.NN_TILED}[args.nn_kernel]
 
     def barrier():
         if world > 1:
@@ -130,7 +130,7 @@ def main():
                                f"iterations, point-to-point NN (gate {GATE_M} m) + Horn, seed {args.seed}",
                    "n_local": N, "n_map": M, "gate_m": GATE_M, "queries_per_gpu": hi - lo,
                    "parallelism": f"query-shard x{world}" if world > 1 else "single GPU",
-                   "nn_kernel": {1: "valu", 2: "mfma"}.get(res.nn_kernel_used, "?")},
+                   "nn_kernel": {1: "valu", 2: "mfma", 3: "tiled"}.get(res.nn_kernel_used, "?")},
         "roofline": {"bound": "mfma" if res.nn_kernel_used == 2 else "valu",
                      "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,

@@ -62,7 +62,12 @@ enum { MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD = 0, MOLA_ICP_MATCHER_POINT2PL
 enum { MOLA_ICP_SOLVER_HORN = 0, MOLA_ICP_SOLVER_GAUSS_NEWTON = 1 };
 enum { MOLA_ICP_QUALITY_PAIRED_RATIO = 0 };
 /* nearest-neighbour kernel selection (new key `nn_kernel`, default auto) */
-enum { MOLA_ICP_NN_AUTO = 0, MOLA_ICP_NN_VALU = 1, MOLA_ICP_NN_MFMA = 2 };
+enum {
+    MOLA_ICP_NN_AUTO  = 0,
+    MOLA_ICP_NN_VALU  = 1,  /* exact VALU brute force (reference kernel)                            */
+    MOLA_ICP_NN_MFMA  = 2,  /* dense N x M MFMA filter + exact re-evaluation of survivors           */
+    MOLA_ICP_NN_TILED = 3   /* dense N x M/32 MFMA test against Morton-sorted map tiles + exact refine */
+};
 
 /* ---- per-call parameters == mp2p_icp::Parameters + the per-object pipeline
  *      settings the YAML carries (params/icp-settings-regular.yaml:10-46).
@@ -107,7 +112,7 @@ typedef struct mola_icp_result {
     double   ms_quality;     /* the quality pass                                           */
     double   ms_nn_kernel;   /* sum of HIP-event durations of the NN kernel launches       */
     uint32_t n_nn_launches;  /* number of NN kernel launches timed in ms_nn_kernel         */
-    uint32_t nn_kernel_used; /* MOLA_ICP_NN_VALU / MOLA_ICP_NN_MFMA                        */
+    uint32_t nn_kernel_used; /* MOLA_ICP_NN_VALU / _MFMA / _TILED                              */
 } mola_icp_result;
 
 #define MOLA_ICP_NACC 24

@@ -18,7 +18,7 @@ TERM_UNDEFINED, TERM_NO_PAIRINGS, TERM_SOLVER_ERROR, TERM_MAX_ITERATIONS, TERM_S
 MATCHER_POINTS_DISTANCE_THRESHOLD, MATCHER_POINT2PLANE = 0, 1
 SOLVER_HORN, SOLVER_GAUSS_NEWTON = 0, 1
 QUALITY_PAIRED_RATIO = 0
-NN_AUTO, NN_VALU, NN_MFMA = 0, 1, 2
+NN_AUTO, NN_VALU, NN_MFMA, NN_TILED = 0, 1, 2, 3
 
 
 class CParams(C.Structure):

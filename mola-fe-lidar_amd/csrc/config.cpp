@@ -94,7 +94,8 @@ void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p)
             if (s == "auto") p.nn_kernel = MOLA_ICP_NN_AUTO;
             else if (s == "valu") p.nn_kernel = MOLA_ICP_NN_VALU;
             else if (s == "mfma") p.nn_kernel = MOLA_ICP_NN_MFMA;
-            else throw std::runtime_error("nn_kernel=`" + s + "` is not one of auto|valu|mfma");
+            else if (s == "tiled") p.nn_kernel = MOLA_ICP_NN_TILED;
+            else throw std::runtime_error("nn_kernel=`" + s + "` is not one of auto|valu|mfma|tiled");
         }
     }
 

@@ -50,6 +50,14 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, float gx, f
     return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
+// largest float <= x (HIP's __double2float_rd is not relied upon)
+__device__ __forceinline__ float down_f32(double x)
+{
+    float f = (float)x;
+    if ((double)f > x) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1u : (f < 0.f ? __float_as_uint(f) + 1u : 0x80000001u));
+    return f;
+}
+
 constexpr float kPadCoord = 1.0e18f;  // padding map points: d2 ~ 3e36, finite, never the minimum
 
 // ---- NN matcher, exact VALU form -------------------------------------------------
@@ -357,6 +365,225 @@ __global__ __launch_bounds__(256) void k_nn_merge(const int* __restrict__ seg_id
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(kept_counter, kept);
 }
 
+// ---- tiled matcher: exact brute force over the map tiles a wave's queries can reach ---------
+// Both clouds are put in Morton order once (map: per map; local cloud: per cloud).  The map is cut
+// into TILES of 32 consecutive points with an axis-aligned box, 64 tiles form a super-tile.  A
+// wave owns 128 consecutive (hence spatially compact) queries, two per lane.  Per iteration:
+//   1. transform the queries, warm-start each best from the previous iteration's neighbour,
+//      give each query the box [q - r, q + r], r = sqrt(best) (rounded up), and reduce the
+//      boxes to one wave box;
+//   2. cull: lanes test 64 super-tile boxes at a time against the wave box (ballot), then the 64
+//      tiles of each hit super-tile.  A tile whose box misses the wave box cannot hold, for any of
+//      the wave's queries, a point with d2 <= best -- skipping it is exact;
+//   3. every surviving tile is staged in LDS (two tiles = 64 points per pass) and ALL 128 queries
+//      are evaluated against ALL its points with the exact contract: tiled brute force, per-lane
+//      argmin on the packed key (d2 bits << 32 | ORIGINAL map index), i.e. lexicographic
+//      (d2, lowest index) -- bit-identical to the untiled kernels.
+// No tree, no per-query traversal, no data-dependent recursion: two flat box scans and dense
+// 128 x 64 tiles.
+constexpr int kTileG = 32;     // map points per tile
+constexpr int kSuper = 64;     // tiles per super-tile
+constexpr int kQPW = 128;      // queries per wave
+
+struct Box { float lo[3], hi[3]; };
+
+__device__ __forceinline__ bool box_overlap(const float* __restrict__ b, int stride, int i, const Box& w)
+{
+    // b: SoA [6][stride] = minx,miny,minz,maxx,maxy,maxz ; empty boxes are (+inf,-inf)
+    return b[i] <= w.hi[0] && b[stride + i] <= w.hi[1] && b[2 * stride + i] <= w.hi[2] &&
+           b[3 * stride + i] >= w.lo[0] && b[4 * stride + i] >= w.lo[1] && b[5 * stride + i] >= w.lo[2];
+}
+
+__global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                  const float* __restrict__ slz, const int* __restrict__ qperm, int N,
+                                                  const float* __restrict__ gx, const float* __restrict__ gy,
+                                                  const float* __restrict__ gz, int M,
+                                                  const float* __restrict__ sx, const float* __restrict__ sy,
+                                                  const float* __restrict__ sz, const int* __restrict__ perm,
+                                                  const float* __restrict__ tbox, int n_tiles_p,
+                                                  const float* __restrict__ sbox, int n_super, PoseF P, float thr2,
+                                                  const int* __restrict__ seed_idx, int* __restrict__ out_idx,
+                                                  float* __restrict__ out_d2, unsigned int* __restrict__ queue,
+                                                  unsigned int* __restrict__ kept_counter,
+                                                  unsigned long long* __restrict__ dbg_stats)
+{
+    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float(*sm)[64] = s_m[wave];
+    const int n_items = (N + kQPW - 1) / kQPW;
+    unsigned int kept = 0;
+
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = (int)atomicAdd(queue, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+
+        float qx[2], qy[2], qz[2], reach[2];
+        unsigned long long key[2];
+        int qo[2];
+        Box w;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { w.lo[k] = INFINITY; w.hi[k] = -INFINITY; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = item * kQPW + k * 64 + lane;
+            qx[k] = qy[k] = qz[k] = 1.0e18f;
+            reach[k] = -1.0f;  // padding lane: reaches nothing
+            key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
+            qo[k] = -1;
+            if (i < N) {
+                xform(P, slx[i], sly[i], slz[i], qx[k], qy[k], qz[k]);
+                qo[k] = qperm[i];
+                float best = thr2;
+                if (seed_idx) {  // warm start: last iteration's neighbour is an exact candidate
+                    const int j = seed_idx[qo[k]];
+                    if (j >= 0 && j < M) {
+                        const float d = dist2(qx[k], qy[k], qz[k], gx[j], gy[j], gz[j]);
+                        if (d < thr2) {
+                            best = d;
+                            key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)j;
+                        }
+                    }
+                }
+                // reach: any m with d2_contract <= best lies inside [q - r, q + r] (r rounded up, plus 2 ulp of q)
+                const float c[3] = {qx[k], qy[k], qz[k]};
+                const float cmax = fmaxf(fabsf(c[0]), fmaxf(fabsf(c[1]), fabsf(c[2])));
+                reach[k] = sqrtf(best * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    w.lo[a] = fminf(w.lo[a], c[a] - reach[k]);
+                    w.hi[a] = fmaxf(w.hi[a], c[a] + reach[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
+                w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
+            }
+        }
+
+        unsigned long long n_staged = 0;
+        for (int sb = 0; sb < n_super; sb += 64) {
+            const int si = sb + lane;
+            unsigned long long smask = __ballot(si < n_super && box_overlap(sbox, n_super, si, w));
+            while (smask) {
+                const int S = sb + __builtin_ctzll(smask);
+                smask &= smask - 1;
+                // this lane's tile: box in registers; first the wave box, then "does ANY query of the wave reach it"
+                const int ti = S * kSuper + lane;
+                const float b0 = tbox[ti], b1 = tbox[n_tiles_p + ti], b2 = tbox[2 * n_tiles_p + ti],
+                            b3 = tbox[3 * n_tiles_p + ti], b4 = tbox[4 * n_tiles_p + ti], b5 = tbox[5 * n_tiles_p + ti];
+                unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
+                                                   b4 >= w.lo[1] && b5 >= w.lo[2]);
+                unsigned long long tmask = 0;
+                while (cand) {
+                    const int t = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    const float m0 = __shfl(b0, t), m1 = __shfl(b1, t), m2 = __shfl(b2, t), m3 = __shfl(b3, t),
+                                m4 = __shfl(b4, t), m5 = __shfl(b5, t);
+                    bool need = false;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        need |= m0 <= qx[k] + reach[k] && m3 >= qx[k] - reach[k] && m1 <= qy[k] + reach[k] &&
+                                m4 >= qy[k] - reach[k] && m2 <= qz[k] + reach[k] && m5 >= qz[k] - reach[k];
+                    if (__any(need)) tmask |= 1ull << t;
+                }
+                while (tmask) {
+                    const int t0 = __builtin_ctzll(tmask);
+                    tmask &= tmask - 1;
+                    int t1 = -1;
+                    if (tmask) { t1 = __builtin_ctzll(tmask); tmask &= tmask - 1; }
+                    // stage two tiles (64 points): lanes 0-31 <- tile t0, lanes 32-63 <- tile t1 (or padding)
+                    const int tt = lane < 32 ? t0 : t1;
+                    float mx = 1.0e18f, my = 1.0e18f, mz = 1.0e18f;
+                    int mo = 0x7fffffff;
+                    if (tt >= 0) {
+                        const int j = (S * kSuper + tt) * kTileG + (lane & 31);
+                        mx = sx[j]; my = sy[j]; mz = sz[j]; mo = perm[j];
+                    }
+                    sm[0][lane] = mx; sm[1][lane] = my; sm[2][lane] = mz; sm[3][lane] = __int_as_float(mo);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int nm = t1 >= 0 ? 64 : 32;
+                    n_staged += nm;
+                    for (int m = 0; m < nm; m += 4) {
+                        const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+                        const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+                        const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
+                        const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+                        const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                        const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
+                                                    __float_as_uint(O.w)};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
+                                const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
+                                key[k] = ck < key[k] ? ck : key[k];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next pass
+                }
+            }
+        }
+        if (dbg_stats && lane == 0) { atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); }
+
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (qo[k] >= 0) {
+                const float d = __uint_as_float((unsigned int)(key[k] >> 32));
+                const bool ok = d < thr2;
+                out_idx[qo[k]] = ok ? (int)(unsigned int)(key[k] & 0xffffffffu) : -1;
+                out_d2[qo[k]] = d;
+                kept += ok;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
+    if (lane == 0 && kept) atomicAdd(kept_counter, kept);
+}
+
+// boxes of the map tiles (one thread per tile) and super-tiles (one thread per super-tile); SoA [6][n]
+__global__ __launch_bounds__(256) void k_tile_boxes(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                    const float* __restrict__ sz, int M, int n_tiles_p,
+                                                    float* __restrict__ tbox)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles_p) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const int j0 = t * kTileG, j1 = min(j0 + kTileG, M);
+    for (int j = j0; j < j1; ++j) {
+        mn[0] = fminf(mn[0], sx[j]); mx[0] = fmaxf(mx[0], sx[j]);
+        mn[1] = fminf(mn[1], sy[j]); mx[1] = fmaxf(mx[1], sy[j]);
+        mn[2] = fminf(mn[2], sz[j]); mx[2] = fmaxf(mx[2], sz[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { tbox[k * n_tiles_p + t] = mn[k]; tbox[(3 + k) * n_tiles_p + t] = mx[k]; }
+}
+
+__global__ __launch_bounds__(256) void k_super_boxes(const float* __restrict__ tbox, int n_tiles_p, int n_super,
+                                                     float* __restrict__ sbox)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_super) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int t = s * kSuper; t < (s + 1) * kSuper; ++t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], tbox[k * n_tiles_p + t]);
+            mx[k] = fmaxf(mx[k], tbox[(3 + k) * n_tiles_p + t]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { sbox[k * n_super + s] = mn[k]; sbox[(3 + k) * n_super + s] = mx[k]; }
+}
+
 // ---- map preparation for the MFMA matcher (once per map) -------------------------------
 // bounding box: per-block partial min/max -> [nblocks][6]; second stage on one block
 __global__ __launch_bounds__(256) void k_bbox_partial(const float* __restrict__ gx, const float* __restrict__ gy,
@@ -545,6 +772,8 @@ HipWorkspace::~HipWorkspace()
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
+    sorted_.release(); perm_.release(); tbox_.release(); sbox_.release(); lsorted_.release(); qperm_.release();
+    sort_scratch_.release();
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
     if (meta_host_) (void)hipHostFree(meta_host_);
@@ -631,6 +860,7 @@ int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, s
     HIPCHK(hipStreamSynchronize(stream_));
     M_ = M;
     map_img_valid_ = false;
+    tiles_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -645,6 +875,7 @@ int HipWorkspace::set_map_device(const float* x, const float* y, const float* z,
     gx_ = x; gy_ = y; gz_ = z;
     M_ = M;
     map_img_valid_ = false;
+    tiles_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -660,6 +891,7 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     if ((rc = upload_soa(loc_own_, stream_, x, y, z, N, &lx_, &ly_, &lz_))) return rc;
     HIPCHK(hipStreamSynchronize(stream_));
     N_ = N;
+    queries_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -673,6 +905,7 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     if (N > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "local cloud too large for 32-bit indices");
     lx_ = x; ly_ = y; lz_ = z;
     N_ = N;
+    queries_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -726,6 +959,92 @@ int HipWorkspace::prepare_map()
     return MOLA_ICP_OK;
 }
 
+int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
+                       const float bbox[6], DevBuf& scratch, float* sxyz, int* perm);
+
+int HipWorkspace::bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6])
+{
+    int rc;
+    const int nb = 256;
+    if ((rc = map_meta_.reserve(sizeof(float) * (6 * nb + 8)))) return rc;
+    float* part = map_meta_.as<float>();
+    float* bbox = part + 6 * nb;
+    hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(256), 0, stream_, x, y, z, (int)n, part);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, stream_, part, nb, bbox);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(meta_host_, bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    for (int k = 0; k < 6; ++k) {
+        if (!std::isfinite(meta_host_[k])) return fail(MOLA_ICP_E_BADARG, "a cloud has non-finite coordinates");
+        out[k] = meta_host_[k];
+    }
+    return MOLA_ICP_OK;
+}
+
+// Once per map: Morton order, tile boxes, super-tile boxes.
+int HipWorkspace::prepare_tiles()
+{
+    if (tiles_valid_) return MOLA_ICP_OK;
+    int rc;
+    float bbox[6];
+    if ((rc = bbox_of(gx_, gy_, gz_, M_, bbox))) return rc;
+    const size_t super_pts = (size_t)kTileG * kSuper;
+    n_super_ = (int)((M_ + super_pts - 1) / super_pts);
+    n_tiles_p_ = n_super_ * kSuper;
+    m_padded_ = (size_t)n_tiles_p_ * kTileG;
+    if ((rc = sorted_.reserve(sizeof(float) * 3 * m_padded_))) return rc;
+    if ((rc = perm_.reserve(sizeof(int) * m_padded_))) return rc;
+    if ((rc = tbox_.reserve(sizeof(float) * 6 * (size_t)n_tiles_p_))) return rc;
+    if ((rc = sbox_.reserve(sizeof(float) * 6 * (size_t)n_super_))) return rc;
+    if ((rc = morton_sort_points(stream_, gx_, gy_, gz_, M_, m_padded_, bbox, sort_scratch_, sorted_.as<float>(),
+                                 perm_.as<int>())))
+        return rc;
+    const float* sx = sorted_.as<float>();
+    hipLaunchKernelGGL(k_tile_boxes, dim3((unsigned)((n_tiles_p_ + 255) / 256)), dim3(256), 0, stream_, sx, sx + m_padded_,
+                       sx + 2 * m_padded_, (int)M_, n_tiles_p_, tbox_.as<float>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((n_super_ + 255) / 256)), dim3(256), 0, stream_, tbox_.as<float>(),
+                       n_tiles_p_, n_super_, sbox_.as<float>());
+    HIPCHK(hipGetLastError());
+    tiles_valid_ = true;
+    return MOLA_ICP_OK;
+}
+
+// Once per local cloud: Morton order of the queries (a rigid motion keeps them compact).
+int HipWorkspace::prepare_queries()
+{
+    if (queries_valid_) return MOLA_ICP_OK;
+    int rc;
+    float bbox[6];
+    if ((rc = bbox_of(lx_, ly_, lz_, N_, bbox))) return rc;
+    n_padded_ = (N_ + kQPW - 1) / kQPW * kQPW;
+    if ((rc = lsorted_.reserve(sizeof(float) * 3 * n_padded_))) return rc;
+    if ((rc = qperm_.reserve(sizeof(int) * n_padded_))) return rc;
+    if ((rc = morton_sort_points(stream_, lx_, ly_, lz_, N_, n_padded_, bbox, sort_scratch_, lsorted_.as<float>(),
+                                 qperm_.as<int>())))
+        return rc;
+    queries_valid_ = true;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::launch_tiled(const PoseF& P, float thr2, const int* seed, unsigned int* counter)
+{
+    const int n_items = (int)((N_ + kQPW - 1) / kQPW);
+    int per_cu = 4;
+    if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 4;  // tuning knob
+    int grid = num_cus_ * per_cu;
+    if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
+    const float* sl = lsorted_.as<float>();
+    const float* sx = sorted_.as<float>();
+    hipLaunchKernelGGL(k_nn_tiled, dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,
+                       qperm_.as<int>(), (int)N_, gx_, gy_, gz_, (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_,
+                       perm_.as<int>(), tbox_.as<float>(), n_tiles_p_, sbox_.as<float>(), n_super_, P, thr2, seed,
+                       idx_.as<int>(), d2_.as<float>(), counter + 1, counter, dbg_stats_);
+    HIPCHK(hipGetLastError());
+    return MOLA_ICP_OK;
+}
+
 void HipWorkspace::reset_stats()
 {
     ev_used_ = 0;
@@ -748,8 +1067,9 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
         unsigned long long h[4] = {};
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipMemcpy(h, dbg_stats_, sizeof h, hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[mola_icp debug] nn launches=%zu slow-path entries=%llu survivors=%llu (N=%zu M=%zu)\n",
-                     ev_used_ / 2, h[0], h[1], N_, M_);
+        std::fprintf(stderr, "[mola_icp debug] nn launches=%zu slow-path entries=%llu survivors=%llu (N=%zu M=%zu); "
+                             "tiled: staged points per wave item=%.1f (items=%llu)\n",
+                     ev_used_ / 2, h[0], h[1], N_, M_, h[3] ? (double)h[2] / (double)h[3] : 0.0, h[3]);
         HIPCHK(hipMemset(dbg_stats_, 0, sizeof h));
     }
     if (ms_total) *ms_total = tot;
@@ -770,15 +1090,33 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         HIPCHK(hipEventCreate(&e));
         ev_.push_back(e);
     }
-    if (kernel == MOLA_ICP_NN_MFMA || (kernel == MOLA_ICP_NN_AUTO && N_ >= 4096 && M_ >= 1024)) {
+    // auto: the tiled matcher wherever sorting pays (it prepares both clouds once), else the dense kernels
+    if (kernel == MOLA_ICP_NN_AUTO) {
+        if (N_ >= 8192 && M_ >= 8192) kernel = MOLA_ICP_NN_TILED;
+        else if (N_ >= 4096 && M_ >= 1024) kernel = MOLA_ICP_NN_MFMA;
+        else kernel = MOLA_ICP_NN_VALU;
+    }
+    if (kernel == MOLA_ICP_NN_TILED) {
+        int rc = prepare_tiles();
+        if (rc) return rc;
+        if ((rc = prepare_queries())) return rc;
+    } else if (kernel == MOLA_ICP_NN_MFMA) {
         const int rc = prepare_map();
         if (rc) return rc;
     }
     unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
-    HIPCHK(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned int), stream_));  // [0] kept pairs, [1] work queue
+    HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));  // [0] kept pairs [1] work queue [2] list count
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
-    // auto: the MFMA filter kernel wherever its per-wave tile (128 queries) is reasonably filled
-    const bool use_mfma = kernel == MOLA_ICP_NN_MFMA || (kernel == MOLA_ICP_NN_AUTO && N_ >= 4096 && M_ >= 1024);
+    if (kernel == MOLA_ICP_NN_TILED) {
+        const int* seed = (seed_valid_ && !std::getenv("MOLA_ICP_NO_WARM_START")) ? idx_.as<int>() : nullptr;
+        const int rc = launch_tiled(P, thr2, seed, counter);
+        if (rc) return rc;
+        last_kernel_ = MOLA_ICP_NN_TILED;
+        HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
+        ev_used_ += 2;
+        return MOLA_ICP_OK;
+    }
+    const bool use_mfma = kernel == MOLA_ICP_NN_MFMA;
     if (use_mfma) {
         const int n_qgroups = (int)((N_ + kMfmaQT * 16 - 1) / (kMfmaQT * 16));
         const int n_items = n_qgroups * map_segs_;

@@ -13,6 +13,8 @@
 
 namespace mola_icp_amd {
 
+struct PoseF;
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -58,7 +60,11 @@ class HipWorkspace final : public Stages {
     int device() const { return device_; }
 
    private:
-    int prepare_map();  // derived map images for the MFMA matcher
+    int prepare_map();    // derived map image for the MFMA matcher
+    int prepare_tiles();    // Morton-sorted map + tile boxes for the tiled matcher
+    int prepare_queries();  // Morton-sorted local cloud
+    int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);
+    int launch_tiled(const struct PoseF& P, float thr2, const int* seed, unsigned int* counter);
     int launch_nn(const Mat4& T, float thr2, int kernel);
 
     int device_;
@@ -79,6 +85,12 @@ class HipWorkspace final : public Stages {
     float map_radius_ = 0;
     int map_tiles_ = 0, map_segs_ = 0, map_seg_tiles_ = 0;
     int num_cus_ = 256;
+    // tiled matcher: Morton-sorted map (SoA, padded to whole super-tiles) + permutation + tile / super-tile boxes,
+    // Morton-sorted local cloud + permutation
+    DevBuf sorted_, perm_, tbox_, sbox_, lsorted_, qperm_, sort_scratch_;
+    bool tiles_valid_ = false, queries_valid_ = false;
+    int n_tiles_p_ = 0, n_super_ = 0;
+    size_t m_padded_ = 0, n_padded_ = 0;
     // pairing + scratch
     DevBuf idx_, d2_, seg_idx_, seg_d2_, outlier_, partials_, acc_dev_;
     double* acc_host_ = nullptr;  // pinned

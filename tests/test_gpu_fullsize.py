@@ -13,7 +13,7 @@ def big(synth):
     return synth.make_pair(1_000_000, 1_000_000, seed=42)
 
 
-@pytest.mark.parametrize("kern", [1, 2])
+@pytest.mark.parametrize("kern", [1, 2, 3])
 def test_1m_x_1m_properties(pkg, O, synth, big, kern):
     g, l, Tgt = big
     icp = pkg.ICP(device=0)

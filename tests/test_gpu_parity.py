@@ -38,7 +38,7 @@ def _check_match(pkg, O, icp, g, l, T, thr, kern):
     return idx, d2
 
 
-@pytest.mark.parametrize("kern", [1, 2])
+@pytest.mark.parametrize("kern", [1, 2, 3])
 def test_match_golden_bit_exact(pkg, O, icp, golden, kern):
     g, l = golden["A_map"], golden["A_local"]
     icp.set_map(g)
@@ -49,7 +49,7 @@ def test_match_golden_bit_exact(pkg, O, icp, golden, kern):
     assert np.array_equal(d2[k], golden["A_d20"][k]) and n == int(k.sum())
 
 
-@pytest.mark.parametrize("kern", [1, 2])
+@pytest.mark.parametrize("kern", [1, 2, 3])
 @pytest.mark.parametrize("N,M", [(1, 1), (1, 17), (63, 5), (64, 64), (257, 1023), (1000, 1025), (4099, 3001),
                                  (5000, 16), (30011, 20011)])
 def test_match_ragged_sizes(pkg, O, icp, synth, small_scene, kern, N, M):
@@ -58,7 +58,7 @@ def test_match_ragged_sizes(pkg, O, icp, synth, small_scene, kern, N, M):
     _check_match(pkg, O, icp, g, l, T, 0.7, kern)
 
 
-@pytest.mark.parametrize("kern", [1, 2])
+@pytest.mark.parametrize("kern", [1, 2, 3])
 def test_match_config2_100k(pkg, O, icp, synth, kern):
     """BASELINE config 2: synthetic 100k-vs-100k, single-iteration correctness."""
     g, l, Tgt = synth.make_pair(100000, 100000, seed=42)
@@ -71,7 +71,7 @@ def test_match_config2_100k(pkg, O, icp, synth, kern):
     assert rot < 1e-10 and trans < 1e-9
 
 
-@pytest.mark.parametrize("kern", [1, 2])
+@pytest.mark.parametrize("kern", [1, 2, 3])
 def test_match_ties_lowest_index(pkg, O, icp, kern):
     ax = np.arange(8, dtype=np.float32)
     g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij")).reshape(3, -1)
@@ -81,7 +81,7 @@ def test_match_ties_lowest_index(pkg, O, icp, kern):
     assert (idx < 512).all() and (idx >= 0).all()
 
 
-@pytest.mark.parametrize("kern", [1, 2])
+@pytest.mark.parametrize("kern", [1, 2, 3])
 def test_match_far_from_origin_and_gate_edges(pkg, O, icp, synth, small_scene, kern):
     # clouds 5 km from the origin (fp32 cancellation territory for an expanded-form distance)
     g, l, _ = synth.make_pair(3000, 3000, seed=9, scene=small_scene)

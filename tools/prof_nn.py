@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--m", type=int, default=1_000_000)
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--kernel", choices=["valu", "mfma"], default="mfma")
+ap.add_argument("--kernel", choices=["valu", "mfma", "tiled"], default="mfma")
 ap.add_argument("--gate", type=float, default=1.0)
 a = ap.parse_args()
 pkg = importlib.import_module("mola-fe-lidar_amd")
@@ -23,8 +23,10 @@ g, l, _ = synth.make_pair(a.n, a.m, seed=42)
 icp = pkg.ICP(device=0)
 icp.set_map(g)
 icp.set_local(l)
-k = pkg.NN_MFMA if a.kernel == "mfma" else pkg.NN_VALU
-icp.match(np.eye(4), a.gate, a.n, k, copy=False)  # warm-up (+ map image build)
+k = {"mfma": pkg.NN_MFMA, "valu": pkg.NN_VALU, "tiled": pkg.NN_TILED}[a.kernel]
+t0 = time.perf_counter()
+icp.match(np.eye(4), a.gate, a.n, k, copy=False)  # first call: map preparation + un-seeded match
+print(f"{a.kernel}: first match incl. map preparation {1e3*(time.perf_counter()-t0):.2f} ms")
 t0 = time.perf_counter()
 for _ in range(a.reps):
     _, _, n = icp.match(np.eye(4), a.gate, a.n, k, copy=False)
