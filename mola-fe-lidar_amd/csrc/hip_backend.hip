@@ -395,15 +395,14 @@ __device__ __forceinline__ bool box_overlap(const float* __restrict__ b, int str
 }
 
 __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
-                                                  const float* __restrict__ slz, const int* __restrict__ qperm, int N,
-                                                  const float* __restrict__ gx, const float* __restrict__ gy,
-                                                  const float* __restrict__ gz, int M,
+                                                  const float* __restrict__ slz, int N, int M,
                                                   const float* __restrict__ sx, const float* __restrict__ sy,
                                                   const float* __restrict__ sz, const int* __restrict__ perm,
                                                   const float* __restrict__ tbox, int n_tiles_p,
                                                   const float* __restrict__ sbox, int n_super, PoseF P, float thr2,
-                                                  const int* __restrict__ seed_idx, int* __restrict__ out_idx,
-                                                  float* __restrict__ out_d2, unsigned int* __restrict__ queue,
+                                                  int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
+                                                  float* __restrict__ d2_s, const int* __restrict__ item_order,
+                                                  unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
                                                   unsigned int* __restrict__ kept_counter,
                                                   unsigned long long* __restrict__ dbg_stats)
 {
@@ -418,10 +417,14 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
         if (lane == 0) item = (int)atomicAdd(queue, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
+        if (item_order) item = __builtin_amdgcn_readfirstlane(item_order[item]);  // heaviest items of the last launch first
+        const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
 
+        const unsigned long long ts0 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long tscan = 0, tstage = 0, tcomp = 0;
         float qx[2], qy[2], qz[2], reach[2];
         unsigned long long key[2];
-        int qo[2];
+        int bpos[2];  // sorted-map position of the current best (the pairing is kept in sorted order internally)
         Box w;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { w.lo[k] = INFINITY; w.hi[k] = -INFINITY; }
@@ -431,18 +434,18 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
             qx[k] = qy[k] = qz[k] = 1.0e18f;
             reach[k] = -1.0f;  // padding lane: reaches nothing
             key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
-            qo[k] = -1;
+            bpos[k] = -1;
             if (i < N) {
                 xform(P, slx[i], sly[i], slz[i], qx[k], qy[k], qz[k]);
-                qo[k] = qperm[i];
                 float best = thr2;
-                if (seed_idx) {  // warm start: last iteration's neighbour is an exact candidate
-                    const int j = seed_idx[qo[k]];
-                    if (j >= 0 && j < M) {
-                        const float d = dist2(qx[k], qy[k], qz[k], gx[j], gy[j], gz[j]);
+                if (use_seed) {  // warm start: last iteration's neighbour is an exact candidate
+                    const int js = pos_s[i];  // sorted-map position: neighbours of neighbours share cache lines
+                    if (js >= 0) {
+                        const float d = dist2(qx[k], qy[k], qz[k], sx[js], sy[js], sz[js]);
                         if (d < thr2) {
                             best = d;
-                            key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)j;
+                            bpos[k] = js;
+                            key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)perm[js];
                         }
                     }
                 }
@@ -467,13 +470,79 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
         }
 
         unsigned long long n_staged = 0;
+        const unsigned long long ts1 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long tmark = ts1;
+
+        // does ANY query of the wave reach the box (m0..m5 = min xyz, max xyz; wave-uniform values)?
+#define MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)                                                                    \
+    __any((m0 <= qx[0] + reach[0] && m3 >= qx[0] - reach[0] && m1 <= qy[0] + reach[0] && m4 >= qy[0] - reach[0] && \
+           m2 <= qz[0] + reach[0] && m5 >= qz[0] - reach[0]) ||                                                    \
+          (m0 <= qx[1] + reach[1] && m3 >= qx[1] - reach[1] && m1 <= qy[1] + reach[1] && m4 >= qy[1] - reach[1] && \
+           m2 <= qz[1] + reach[1] && m5 >= qz[1] - reach[1]))
+
+        // one staged pass = two tiles (64 points); the NEXT pass's loads are issued before this pass computes
+        int pend_a = -1, pend_b = -1;  // tile ids (global) whose points sit in the registers below
+        float px = 0.f, py = 0.f, pz = 0.f;
+        int po = 0;
+#define MOLA_LOAD_PAIR(TA, TB)                                                                                    \
+    {                                                                                                             \
+        const int tt_ = lane < 32 ? (TA) : (TB);                                                                  \
+        px = py = pz = 1.0e18f;                                                                                   \
+        po = 0x7fffffff;                                                                                          \
+        if (tt_ >= 0) {                                                                                           \
+            const int j_ = tt_ * kTileG + (lane & 31);                                                            \
+            px = sx[j_]; py = sy[j_]; pz = sz[j_]; po = perm[j_];                                                 \
+        }                                                                                                         \
+    }
+#define MOLA_COMPUTE_PENDING(NEXT_A, NEXT_B)                                                                      \
+    {                                                                                                             \
+        const int ca_ = pend_a, cb_ = pend_b;                                                                     \
+        sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz; sm[3][lane] = __int_as_float(po);                   \
+        pend_a = (NEXT_A); pend_b = (NEXT_B);                                                                     \
+        if (pend_a >= 0) MOLA_LOAD_PAIR(pend_a, pend_b)                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                    \
+        __builtin_amdgcn_wave_barrier();                                                                          \
+        const int nm_ = cb_ >= 0 ? 64 : 32;                                                                       \
+        const int jb0_ = ca_ * kTileG, jb1_ = (cb_ >= 0 ? cb_ : ca_) * kTileG;                                    \
+        n_staged += nm_;                                                                                          \
+        for (int m = 0; m < nm_; m += 4) {                                                                        \
+            const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);                                         \
+            const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);                                         \
+            const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);                                         \
+            const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);                                         \
+            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w}; \
+            const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),         \
+                                        __float_as_uint(O.w)};                                                    \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                   \
+                    const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);                              \
+                    const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];         \
+                    const bool better = ck < key[k];                                                              \
+                    key[k] = better ? ck : key[k];                                                                \
+                    bpos[k] = better ? ((m + u) < 32 ? jb0_ + m + u : jb1_ + m + u - 32) : bpos[k];               \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        __builtin_amdgcn_wave_barrier(); /* the staging area is rewritten by the next pass */                     \
+    }
+
         for (int sb = 0; sb < n_super; sb += 64) {
             const int si = sb + lane;
-            unsigned long long smask = __ballot(si < n_super && box_overlap(sbox, n_super, si, w));
-            while (smask) {
-                const int S = sb + __builtin_ctzll(smask);
-                smask &= smask - 1;
-                // this lane's tile: box in registers; first the wave box, then "does ANY query of the wave reach it"
+            const bool sin = si < n_super;
+            const float c0 = sin ? sbox[si] : INFINITY, c1 = sin ? sbox[n_super + si] : INFINITY,
+                        c2 = sin ? sbox[2 * n_super + si] : INFINITY, c3 = sin ? sbox[3 * n_super + si] : -INFINITY,
+                        c4 = sin ? sbox[4 * n_super + si] : -INFINITY, c5 = sin ? sbox[5 * n_super + si] : -INFINITY;
+            unsigned long long scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] &&
+                                                c4 >= w.lo[1] && c5 >= w.lo[2]);
+            while (scand) {
+                const int sl_ = __builtin_ctzll(scand);
+                scand &= scand - 1;
+                {   // super-tile vs the individual queries: a bimodal query group must not descend everywhere
+                    const float m0 = __shfl(c0, sl_), m1 = __shfl(c1, sl_), m2 = __shfl(c2, sl_), m3 = __shfl(c3, sl_),
+                                m4 = __shfl(c4, sl_), m5 = __shfl(c5, sl_);
+                    if (!MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)) continue;
+                }
+                const int S = sb + sl_;
                 const int ti = S * kSuper + lane;
                 const float b0 = tbox[ti], b1 = tbox[n_tiles_p + ti], b2 = tbox[2 * n_tiles_p + ti],
                             b3 = tbox[3 * n_tiles_p + ti], b4 = tbox[4 * n_tiles_p + ti], b5 = tbox[5 * n_tiles_p + ti];
@@ -485,68 +554,101 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
                     cand &= cand - 1;
                     const float m0 = __shfl(b0, t), m1 = __shfl(b1, t), m2 = __shfl(b2, t), m3 = __shfl(b3, t),
                                 m4 = __shfl(b4, t), m5 = __shfl(b5, t);
-                    bool need = false;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        need |= m0 <= qx[k] + reach[k] && m3 >= qx[k] - reach[k] && m1 <= qy[k] + reach[k] &&
-                                m4 >= qy[k] - reach[k] && m2 <= qz[k] + reach[k] && m5 >= qz[k] - reach[k];
-                    if (__any(need)) tmask |= 1ull << t;
+                    if (MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)) tmask |= 1ull << t;
                 }
+                if (dbg_stats) { const unsigned long long n = __builtin_amdgcn_s_memtime(); tscan += n - tmark; tmark = n; }
                 while (tmask) {
-                    const int t0 = __builtin_ctzll(tmask);
+                    const int t0 = S * kSuper + __builtin_ctzll(tmask);
                     tmask &= tmask - 1;
                     int t1 = -1;
-                    if (tmask) { t1 = __builtin_ctzll(tmask); tmask &= tmask - 1; }
-                    // stage two tiles (64 points): lanes 0-31 <- tile t0, lanes 32-63 <- tile t1 (or padding)
-                    const int tt = lane < 32 ? t0 : t1;
-                    float mx = 1.0e18f, my = 1.0e18f, mz = 1.0e18f;
-                    int mo = 0x7fffffff;
-                    if (tt >= 0) {
-                        const int j = (S * kSuper + tt) * kTileG + (lane & 31);
-                        mx = sx[j]; my = sy[j]; mz = sz[j]; mo = perm[j];
+                    if (tmask) { t1 = S * kSuper + __builtin_ctzll(tmask); tmask &= tmask - 1; }
+                    if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
+                        pend_a = t0; pend_b = t1;
+                        MOLA_LOAD_PAIR(t0, t1)
+                    } else {
+                        MOLA_COMPUTE_PENDING(t0, t1)
                     }
-                    sm[0][lane] = mx; sm[1][lane] = my; sm[2][lane] = mz; sm[3][lane] = __int_as_float(mo);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const int nm = t1 >= 0 ? 64 : 32;
-                    n_staged += nm;
-                    for (int m = 0; m < nm; m += 4) {
-                        const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
-                        const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
-                        const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
-                        const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
-                        const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
-                        const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
-                                                    __float_as_uint(O.w)};
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
-                                const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
-                                key[k] = ck < key[k] ? ck : key[k];
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next pass
                 }
+                if (dbg_stats) { const unsigned long long n = __builtin_amdgcn_s_memtime(); tcomp += n - tmark; tmark = n; }
             }
         }
-        if (dbg_stats && lane == 0) { atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); }
+        if (pend_a >= 0) MOLA_COMPUTE_PENDING(-1, -1)
+#undef MOLA_COMPUTE_PENDING
+#undef MOLA_LOAD_PAIR
+#undef MOLA_ANY_REACH
+        if (item_cost && lane == 0) {
+            const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
+            item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+        }
+        if (dbg_stats && lane == 0) {
+            const unsigned long long te = __builtin_amdgcn_s_memtime();
+            tscan += te - tmark;
+            atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged);
+            atomicAdd(&dbg_stats[5], ts1 - ts0);   // prologue
+            atomicAdd(&dbg_stats[6], tscan);       // box scans
+            atomicAdd(&dbg_stats[7], tstage);      // tile loads + LDS staging
+            atomicAdd(&dbg_stats[8], tcomp);       // distance evaluation
+            atomicMax(&dbg_stats[9], te - ts0);    // longest item
+        }
 
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (qo[k] >= 0) {
+            const int i = item * kQPW + k * 64 + lane;
+            if (i < N) {  // coalesced: the pairing stays in sorted query order
                 const float d = __uint_as_float((unsigned int)(key[k] >> 32));
                 const bool ok = d < thr2;
-                out_idx[qo[k]] = ok ? (int)(unsigned int)(key[k] & 0xffffffffu) : -1;
-                out_d2[qo[k]] = d;
+                pos_s[i] = ok ? bpos[k] : -1;
+                idx_s[i] = ok ? (int)(unsigned int)(key[k] & 0xffffffffu) : -1;
+                d2_s[i] = d;
                 kept += ok;
             }
         }
     }
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
     if (lane == 0 && kept) atomicAdd(kept_counter, kept);
+}
+
+// heavy-first work order for the next launch: counting sort of the items by the cycles they took in the
+// last launch (32 buckets relative to the maximum), one 1024-thread block.  Longest-processing-time-first
+// keeps the persistent waves' tail short when a few query groups are much heavier than the rest.
+__global__ __launch_bounds__(1024) void k_order_items(const unsigned int* __restrict__ cost, int n_items,
+                                                      int* __restrict__ order)
+{
+    __shared__ unsigned int s_max, s_cnt[32], s_off[32];
+    if (threadIdx.x == 0) s_max = 1u;
+    if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned int mx = 1u;
+    for (int i = threadIdx.x; i < n_items; i += 1024) mx = max(mx, cost[i]);
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    const float scale = 32.0f / (float)s_max;
+    for (int i = threadIdx.x; i < n_items; i += 1024) {
+        const int b = 31 - min(31, (int)((float)cost[i] * scale));  // bucket 0 = heaviest
+        atomicAdd(&s_cnt[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int o = 0;
+        for (int b = 0; b < 32; ++b) { s_off[b] = o; o += s_cnt[b]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_items; i += 1024) {
+        const int b = 31 - min(31, (int)((float)cost[i] * scale));
+        order[atomicAdd(&s_off[b], 1u)] = i;
+    }
+}
+
+// sorted-order pairing -> original query order (only when a caller asks for the pairing)
+__global__ __launch_bounds__(256) void k_unpermute_pairing(const int* __restrict__ qperm, const int* __restrict__ idx_s,
+                                                           const float* __restrict__ d2_s, int N,
+                                                           int* __restrict__ out_idx, float* __restrict__ out_d2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int o = qperm[i];
+    out_idx[o] = idx_s[i];
+    out_d2[o] = d2_s[i];
 }
 
 // boxes of the map tiles (one thread per tile) and super-tiles (one thread per super-tile); SoA [6][n]
@@ -773,6 +875,7 @@ HipWorkspace::~HipWorkspace()
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
     sorted_.release(); perm_.release(); tbox_.release(); sbox_.release(); lsorted_.release(); qperm_.release();
+    ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); item_cost_.release(); item_order_.release();
     sort_scratch_.release();
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
@@ -805,8 +908,8 @@ int HipWorkspace::init()
     int rc;
     if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8)))) return rc;
     if (std::getenv("MOLA_ICP_DEBUG_STATS")) {  // diagnostic builds of a run, never on by default
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), 4 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(dbg_stats_, 0, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(dbg_stats_, 0, 16 * sizeof(unsigned long long)));
     }
     inited_ = true;
     return MOLA_ICP_OK;
@@ -892,6 +995,7 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     HIPCHK(hipStreamSynchronize(stream_));
     N_ = N;
     queries_valid_ = false;
+    cost_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -906,6 +1010,7 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     lx_ = x; ly_ = y; lz_ = z;
     N_ = N;
     queries_valid_ = false;
+    cost_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -1028,19 +1133,33 @@ int HipWorkspace::prepare_queries()
     return MOLA_ICP_OK;
 }
 
-int HipWorkspace::launch_tiled(const PoseF& P, float thr2, const int* seed, unsigned int* counter)
+int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
 {
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
     int per_cu = 4;
     if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 4;  // tuning knob
     int grid = num_cus_ * per_cu;
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
+    int rc;
+    if ((rc = item_cost_.reserve(sizeof(unsigned int) * (size_t)n_items))) return rc;
+    if ((rc = item_order_.reserve(sizeof(int) * (size_t)n_items))) return rc;
+    const int* order = nullptr;
+    if (cost_valid_ && !std::getenv("MOLA_ICP_NO_LPT")) {
+        hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
+                           item_order_.as<int>());
+        HIPCHK(hipGetLastError());
+        order = item_order_.as<int>();
+    }
+    if ((rc = ts_pos_.reserve(sizeof(int) * n_padded_))) return rc;
+    if ((rc = ts_idx_.reserve(sizeof(int) * n_padded_))) return rc;
+    if ((rc = ts_d2_.reserve(sizeof(float) * n_padded_))) return rc;
     const float* sl = lsorted_.as<float>();
     const float* sx = sorted_.as<float>();
-    hipLaunchKernelGGL(k_nn_tiled, dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,
-                       qperm_.as<int>(), (int)N_, gx_, gy_, gz_, (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_,
-                       perm_.as<int>(), tbox_.as<float>(), n_tiles_p_, sbox_.as<float>(), n_super_, P, thr2, seed,
-                       idx_.as<int>(), d2_.as<float>(), counter + 1, counter, dbg_stats_);
+    hipLaunchKernelGGL(k_nn_tiled, dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_, (int)N_,
+                       (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(), tbox_.as<float>(), n_tiles_p_,
+                       sbox_.as<float>(), n_super_, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(),
+                       ts_d2_.as<float>(), order, item_cost_.as<unsigned int>(), counter + 1, counter, dbg_stats_);
+    cost_valid_ = true;
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
 }
@@ -1064,12 +1183,15 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
         }
     }
     if (dbg_stats_) {
-        unsigned long long h[4] = {};
+        unsigned long long h[16] = {};
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipMemcpy(h, dbg_stats_, sizeof h, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[mola_icp debug] nn launches=%zu slow-path entries=%llu survivors=%llu (N=%zu M=%zu); "
-                             "tiled: staged points per wave item=%.1f (items=%llu)\n",
-                     ev_used_ / 2, h[0], h[1], N_, M_, h[3] ? (double)h[2] / (double)h[3] : 0.0, h[3]);
+                             "tiled: staged points per wave item=%.1f (items=%llu, max=%llu); cycles per item: prologue %.0f "
+                             "scan %.0f stage %.0f compute %.0f, longest item %llu\n",
+                     ev_used_ / 2, h[0], h[1], N_, M_, h[3] ? (double)h[2] / (double)h[3] : 0.0, h[3], h[4],
+                     h[3] ? (double)h[5] / h[3] : 0.0, h[3] ? (double)h[6] / h[3] : 0.0, h[3] ? (double)h[7] / h[3] : 0.0,
+                     h[3] ? (double)h[8] / h[3] : 0.0, h[9]);
         HIPCHK(hipMemset(dbg_stats_, 0, sizeof h));
     }
     if (ms_total) *ms_total = tot;
@@ -1108,10 +1230,11 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
     HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));  // [0] kept pairs [1] work queue [2] list count
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     if (kernel == MOLA_ICP_NN_TILED) {
-        const int* seed = (seed_valid_ && !std::getenv("MOLA_ICP_NO_WARM_START")) ? idx_.as<int>() : nullptr;
-        const int rc = launch_tiled(P, thr2, seed, counter);
+        const bool use_seed = seed_valid_ && pairing_sorted_ && !std::getenv("MOLA_ICP_NO_WARM_START");
+        const int rc = launch_tiled(P, thr2, use_seed, counter);
         if (rc) return rc;
         last_kernel_ = MOLA_ICP_NN_TILED;
+        pairing_sorted_ = true;
         HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
         ev_used_ += 2;
         return MOLA_ICP_OK;
@@ -1125,7 +1248,8 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         if ((rc = seg_d2_.reserve(sizeof(float) * (size_t)map_segs_ * N_))) return rc;
         MapFrame F{map_center_[0], map_center_[1], map_center_[2], map_radius_};
         // warm start from the pairing this workspace computed last for the same clouds
-        const int* seed = (seed_valid_ && !std::getenv("MOLA_ICP_NO_WARM_START")) ? idx_.as<int>() : nullptr;
+        const int* seed = (seed_valid_ && !pairing_sorted_ && !std::getenv("MOLA_ICP_NO_WARM_START")) ? idx_.as<int>()
+                                                                                                        : nullptr;
         // persistent grid: every CU gets its resident blocks (2-3 per CU at this register count)
         int per_cu = 3;
         if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 3;  // tuning knob
@@ -1148,6 +1272,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
     ev_used_ += 2;
+    pairing_sorted_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -1165,6 +1290,7 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
         if (N_) HIPCHK(hipMemsetAsync(idx_.p, 0xff, sizeof(int) * N_, stream_));
         pairing_valid_ = true;
         seed_valid_ = false;
+        pairing_sorted_ = false;
         if (n_pairs) *n_pairs = 0;
         return MOLA_ICP_OK;
     }
@@ -1199,8 +1325,17 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     if (nblocks > 512) nblocks = 512;
     if ((rc = partials_.reserve(sizeof(double) * kNAcc * 512))) return rc;
     AccArgs a{};
-    a.lx = lx_; a.ly = ly_; a.lz = lz_; a.gx = gx_; a.gy = gy_; a.gz = gz_;
-    a.idx = idx_.as<int>(); a.d2 = d2_.as<float>(); a.outlier = outlier_.as<unsigned char>();
+    if (pairing_sorted_) {  // tiled matcher: sorted local cloud, neighbour = sorted-map position (local gathers)
+        const float* sl = lsorted_.as<float>();
+        const float* sm = sorted_.as<float>();
+        a.lx = sl; a.ly = sl + n_padded_; a.lz = sl + 2 * n_padded_;
+        a.gx = sm; a.gy = sm + m_padded_; a.gz = sm + 2 * m_padded_;
+        a.idx = ts_pos_.as<int>(); a.d2 = ts_d2_.as<float>();
+    } else {
+        a.lx = lx_; a.ly = ly_; a.lz = lz_; a.gx = gx_; a.gy = gy_; a.gz = gz_;
+        a.idx = idx_.as<int>(); a.d2 = d2_.as<float>();
+    }
+    a.outlier = outlier_.as<unsigned char>();
     a.N = (int)N_; a.stage = stage;
     a.use_scale = p.use_scale_outlier_detector; a.use_robust = p.use_robust_kernel;
     a.scale_thr = p.scale_outlier_threshold; a.rk_param = p.robust_kernel_param; a.rk_scale = p.robust_kernel_scale;
@@ -1230,6 +1365,12 @@ int HipWorkspace::copy_pairing(int32_t* idx_out, float* d2_out)
 {
     if (!pairing_valid_) return fail(MOLA_ICP_E_BADARG, "no pairing stored: call match() first");
     HIPCHK(hipSetDevice(device_));
+    if (N_ && pairing_sorted_) {
+        hipLaunchKernelGGL(k_unpermute_pairing, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_,
+                           qperm_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(), (int)N_, idx_.as<int>(),
+                           d2_.as<float>());
+        HIPCHK(hipGetLastError());
+    }
     if (N_) {
         if (idx_out) HIPCHK(hipMemcpyAsync(idx_out, idx_.p, sizeof(int) * N_, hipMemcpyDeviceToHost, stream_));
         if (d2_out) HIPCHK(hipMemcpyAsync(d2_out, d2_.p, sizeof(float) * N_, hipMemcpyDeviceToHost, stream_));

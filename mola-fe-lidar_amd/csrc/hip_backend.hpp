@@ -64,7 +64,7 @@ class HipWorkspace final : public Stages {
     int prepare_tiles();    // Morton-sorted map + tile boxes for the tiled matcher
     int prepare_queries();  // Morton-sorted local cloud
     int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);
-    int launch_tiled(const struct PoseF& P, float thr2, const int* seed, unsigned int* counter);
+    int launch_tiled(const struct PoseF& P, float thr2, bool use_seed, unsigned int* counter);
     int launch_nn(const Mat4& T, float thr2, int kernel);
 
     int device_;
@@ -88,6 +88,10 @@ class HipWorkspace final : public Stages {
     // tiled matcher: Morton-sorted map (SoA, padded to whole super-tiles) + permutation + tile / super-tile boxes,
     // Morton-sorted local cloud + permutation
     DevBuf sorted_, perm_, tbox_, sbox_, lsorted_, qperm_, sort_scratch_;
+    DevBuf ts_pos_, ts_idx_, ts_d2_;  // the tiled matcher's pairing, in SORTED query order
+    bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
+    DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
+    bool cost_valid_ = false;
     bool tiles_valid_ = false, queries_valid_ = false;
     int n_tiles_p_ = 0, n_super_ = 0;
     size_t m_padded_ = 0, n_padded_ = 0;
