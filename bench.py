@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--nn-kernel", choices=["auto", "valu", "mfma", "tiled"], default="auto")
     ap.add_argument("--cpu-baseline-iters", type=int, default=5, help="0 disables the CPU baseline leg")
+    ap.add_argument("--dense-iters", type=int, default=3, help="iterations of the dense MFMA kernel measured beside the default path (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -105,13 +106,28 @@ def main():
     assert res.nIterations == args.steps, (res.nIterations, args.steps)
 
     # dominant kernel: the NN matcher; duration from HIP events on the kernel's own stream
-    nn_ms = res.ms_nn_kernel / max(1, res.n_nn_launches)
-    flops_per_launch = 8.0 * (hi - lo) * M           # 8 flop per (query, map point) pair
-    achieved = flops_per_launch / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
+    def roofline_of(r, n_local):
+        nn_ms = r.ms_nn_kernel / max(1, r.n_nn_launches)
+        flops_alg = 8.0 * n_local * M            # 8 flop per (query, map point) pair, all N*M pairs
+        pairs_exec = r.nn_pairs_evaluated / max(1, r.n_nn_launches)
+        ach = flops_alg / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
+        exe = 8.0 * pairs_exec / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
+        kern = {1: "valu", 2: "mfma", 3: "tiled"}.get(r.nn_kernel_used, "?")
+        return {"bound": "mfma" if kern == "mfma" else "valu", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None, "kernel": "k_nn_" + kern,
+                "kernel_ms": nn_ms, "flops_per_launch": flops_alg,
+                # exact tile culling evaluates fewer pairs than N*M: `achieved` (algorithmic, can exceed the
+                # peak) and the executed rate are both reported, as SURVEY §8(d) asks
+                "culled": kern == "tiled", "pairs_evaluated_per_launch": pairs_exec,
+                "executed_tflops": exe, "executed_frac": exe / PEAK_FP32_TFLOPS}
+
+    roof = roofline_of(res, hi - lo)
+    roof["traffic"] = _recorded_traffic(roof["kernel"], N, M) if world == 1 else None
     if world > 1:
-        t = torch.tensor([achieved], dtype=torch.float64, device=dev)
+        t = torch.tensor([roof["achieved"], roof["executed_tflops"]], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)     # the slowest rank's kernel
-        achieved = float(t.item())
+        roof["achieved"], roof["executed_tflops"] = float(t[0]), float(t[1])
+        roof["frac"], roof["executed_frac"] = roof["achieved"] / PEAK_FP32_TFLOPS, roof["executed_tflops"] / PEAK_FP32_TFLOPS
 
     out = {
         "metric": "icp_iterations_per_sec_1Mx1M",
@@ -130,13 +146,24 @@ def main():
                                f"iterations, point-to-point NN (gate {GATE_M} m) + Horn, seed {args.seed}",
                    "n_local": N, "n_map": M, "gate_m": GATE_M, "queries_per_gpu": hi - lo,
                    "parallelism": f"query-shard x{world}" if world > 1 else "single GPU",
-                   "nn_kernel": {1: "valu", 2: "mfma", 3: "tiled"}.get(res.nn_kernel_used, "?")},
-        "roofline": {"bound": "mfma" if res.nn_kernel_used == 2 else "valu",
-                     "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                     "kernel_ms": nn_ms, "flops_per_launch": flops_per_launch},
+                   "nn_kernel": roof["kernel"]},
+        "roofline": roof,
         "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(res.optimal_tf, T_gt))),
     }
+
+    if rank == 0 and world == 1 and args.nn_kernel in ("auto", "tiled") and args.dense_iters > 0:
+        # the dense N x M kernel (no culling) on the same clouds, outside the timed region: its roofline
+        pd = p.copy()
+        pd.nn_kernel = pkg.NN_MFMA
+        pd.max_iterations = args.dense_iters
+        t0 = time.perf_counter()
+        rd = icp.align_resident(T0, pd)
+        torch.cuda.synchronize()
+        td = time.perf_counter() - t0
+        out["dense_mfma"] = {"value": args.dense_iters / td, "unit": "iterations/s", "iterations": args.dense_iters,
+                             "roofline": roofline_of(rd, hi - lo),
+                             "pose_err_vs_default_path": dict(zip(("rot_rad", "trans_m"), _pose_err(
+                                 rd.optimal_tf, _first_iters_pose(icp, T0, p, args.dense_iters))))}
 
     if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
         out["cpu_baseline"], ref_T = cpu_baseline(g, l, args.cpu_baseline_iters)
@@ -151,6 +178,28 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _recorded_traffic(kernel, N, M):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*/traffic.json, written by tools/rocprof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if not recorded."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+        try:
+            for e in json.load(open(f)):
+                if e.get("kernel") == kernel and e.get("n_local") == N and e.get("n_map") == M:
+                    best = e.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    return best
+
+
+def _first_iters_pose(icp, T0, p, iters):
+    q = p.copy()
+    q.max_iterations = iters
+    return icp.align_resident(T0, q).optimal_tf
 
 
 def _pose_err(T, Tref):

@@ -62,6 +62,7 @@ class CResult(C.Structure):
         ("ms_nn_kernel", C.c_double),
         ("n_nn_launches", C.c_uint32),
         ("nn_kernel_used", C.c_uint32),
+        ("nn_pairs_evaluated", C.c_uint64),
     ]
 
 

@@ -102,10 +102,12 @@ int align_on(HipWorkspace& ws, const double init_T[16], const mola_icp_params* p
     if (rc) return rc;
     double ms = 0;
     uint32_t n = 0, k = 0;
-    if ((rc = ws.collect_stats(&ms, &n, &k))) return rc;
+    uint64_t pairs = 0;
+    if ((rc = ws.collect_stats(&ms, &n, &k, &pairs))) return rc;
     out->ms_nn_kernel = ms;
     out->n_nn_launches = n;
     out->nn_kernel_used = k;
+    out->nn_pairs_evaluated = pairs;
     return MOLA_ICP_OK;
 }
 

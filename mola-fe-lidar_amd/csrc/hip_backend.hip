@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
                                                   float* __restrict__ d2_s, const int* __restrict__ item_order,
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
                                                   unsigned int* __restrict__ kept_counter,
+                                                  unsigned long long* __restrict__ staged_total,
                                                   unsigned long long* __restrict__ dbg_stats)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
@@ -576,9 +577,10 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
 #undef MOLA_COMPUTE_PENDING
 #undef MOLA_LOAD_PAIR
 #undef MOLA_ANY_REACH
-        if (item_cost && lane == 0) {
+        if (lane == 0) {
             const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
-            item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+            if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+            atomicAdd(staged_total, n_staged);  // executed work: staged points x 128 queries
         }
         if (dbg_stats && lane == 0) {
             const unsigned long long te = __builtin_amdgcn_s_memtime();
@@ -1158,7 +1160,8 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     hipLaunchKernelGGL(k_nn_tiled, dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_, (int)N_,
                        (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(), tbox_.as<float>(), n_tiles_p_,
                        sbox_.as<float>(), n_super_, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(),
-                       ts_d2_.as<float>(), order, item_cost_.as<unsigned int>(), counter + 1, counter, dbg_stats_);
+                       ts_d2_.as<float>(), order, item_cost_.as<unsigned int>(), counter + 1, counter,
+                       reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4), dbg_stats_);
     cost_valid_ = true;
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
@@ -1168,10 +1171,23 @@ void HipWorkspace::reset_stats()
 {
     ev_used_ = 0;
     last_kernel_ = 0;
+    dense_pairs_ = 0;
+    if (inited_) (void)hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 4, 0, sizeof(unsigned long long), stream_);
 }
 
-int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used)
+int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used, uint64_t* pairs)
 {
+    if (pairs) {
+        unsigned long long staged = 0;
+        if (inited_) {
+            HIPCHK(hipSetDevice(device_));
+            HIPCHK(hipMemcpyAsync(acc_host_ + kNAcc + 4, acc_dev_.as<double>() + kNAcc + 4, sizeof staged,
+                                  hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            std::memcpy(&staged, acc_host_ + kNAcc + 4, sizeof staged);
+        }
+        *pairs = dense_pairs_ + (uint64_t)staged * kQPW;
+    }
     double tot = 0;
     if (ev_used_) {
         HIPCHK(hipSetDevice(device_));
@@ -1273,6 +1289,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
     HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
     ev_used_ += 2;
     pairing_sorted_ = false;
+    dense_pairs_ += (uint64_t)N_ * (uint64_t)M_;
     return MOLA_ICP_OK;
 }
 

@@ -53,7 +53,7 @@ class HipWorkspace final : public Stages {
 
     // NN-kernel timing (HIP events on this workspace's stream)
     void reset_stats();
-    int collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used);
+    int collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used, uint64_t* pairs = nullptr);
 
     size_t N() const { return N_; }
     size_t M() const { return M_; }
@@ -108,6 +108,7 @@ class HipWorkspace final : public Stages {
     std::vector<hipEvent_t> ev_;  // pairs: start, stop
     size_t ev_used_ = 0;
     uint32_t last_kernel_ = 0;
+    uint64_t dense_pairs_ = 0;
     unsigned long long* dbg_stats_ = nullptr;  // MOLA_ICP_DEBUG_STATS=1 only
 };
 

@@ -143,12 +143,13 @@ class Results:
     ms_nn_kernel: float
     n_nn_launches: int
     nn_kernel_used: int
+    nn_pairs_evaluated: int
 
     @classmethod
     def from_c(cls, r: L.CResult) -> "Results":
         return cls(np.array(r.T).reshape(4, 4), np.array(r.cov).reshape(6, 6), r.quality, r.n_iterations,
                    r.termination, r.n_pairs, r.rmse, r.ms_upload, r.ms_iterations, r.ms_quality, r.ms_nn_kernel,
-                   r.n_nn_launches, r.nn_kernel_used)
+                   r.n_nn_launches, r.nn_kernel_used, r.nn_pairs_evaluated)
 
     @property
     def termination_name(self) -> str:
