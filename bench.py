@@ -41,6 +41,10 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--nn-kernel", choices=["auto", "valu", "mfma", "tiled"], default="auto")
     ap.add_argument("--cpu-baseline-iters", type=int, default=5, help="0 disables the CPU baseline leg")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the distributed code path (process group + RCCL communicator) even with one rank")
+    ap.add_argument("--allreduce", choices=["rccl", "hook"], default="rccl",
+                    help="rccl: native RCCL on the device block; hook: torch.distributed from the host hook")
     ap.add_argument("--dense-iters", type=int, default=3, help="iterations of the dense MFMA kernel measured beside the default path (0 = skip)")
     args = ap.parse_args()
 
@@ -54,8 +58,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("mola-fe-lidar_amd")
@@ -74,8 +82,11 @@ def main():
     icp.set_map(tg)
     icp.set_local(tl)
     icp.set_global_sizes(N, M)
-    if world > 1:
-        icp.set_allreduce(sharded.make_allreduce(device=dev))
+    if use_dist:
+        if args.allreduce == "rccl":
+            icp.comm_init()
+        else:
+            icp.set_allreduce(sharded.make_allreduce(device=dev))
 
     p = pkg.Parameters()
     p.matcher_threshold = GATE_M
@@ -84,7 +95,7 @@ def main():
     p.nn_kernel = {"auto": pkg.NN_AUTO, "valu": pkg.NN_VALU, "mfma": pkg.NN_MFMA, "tiled": pkg.NN_TILED}[args.nn_kernel]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +156,7 @@ def main():
         "config": {"workload": f"configs[2]: {N} scan points vs {M} local-map points, {args.steps} fixed ICP "
                                f"iterations, point-to-point NN (gate {GATE_M} m) + Horn, seed {args.seed}",
                    "n_local": N, "n_map": M, "gate_m": GATE_M, "queries_per_gpu": hi - lo,
-                   "parallelism": f"query-shard x{world}" if world > 1 else "single GPU",
+                   "parallelism": (f"query-shard x{world}, {args.allreduce} all-reduce" if use_dist else "single GPU"),
                    "nn_kernel": roof["kernel"]},
         "roofline": roof,
         "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(res.optimal_tf, T_gt))),
@@ -174,10 +185,15 @@ def main():
         out["pose_err_vs_cpu"] = {"rot_rad": rot, "trans_m": trans, "iterations": args.cpu_baseline_iters,
                                   "tolerance": "1e-4 rad / 1e-3 m"}
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        if args.allreduce == "rccl":
+            icp.comm_destroy()
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio: the JSON must be the LAST line
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def _recorded_traffic(kernel, N, M):

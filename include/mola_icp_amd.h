@@ -161,6 +161,17 @@ int mola_icp_set_stream(mola_icp_handle* h, void* hip_stream);
 /* query-sharded multi-GPU: install the accumulator all-reduce (NULL = single GPU) */
 int mola_icp_set_allreduce(mola_icp_handle* h, mola_icp_allreduce_fn fn, void* user);
 
+/* Native RCCL for the query-sharded path (one process per GPU).  Rank 0 calls
+ * mola_icp_comm_unique_id() and ships the 128 bytes to the other ranks by any means (MPI,
+ * torch.distributed, a file); then EVERY rank calls mola_icp_comm_init() (collective).  From then on the
+ * resident-cloud API all-reduces the accumulator block on the device, on the handle's stream, and the
+ * mola_icp_set_allreduce hook is ignored.  RCCL is loaded at run time: `path` (optional) names the
+ * library this process already uses (e.g. the one bundled with PyTorch). */
+int mola_icp_comm_set_library(const char* path);
+int mola_icp_comm_unique_id(uint8_t id_out[128]);
+int mola_icp_comm_init(mola_icp_handle* h, const uint8_t id[128], int nranks, int rank);
+int mola_icp_comm_destroy(mola_icp_handle* h);
+
 /* ---- the hot path ------------------------------------------------------ */
 /* Replaces mp2p_icp::ICP::align() as called at src/LidarOdometry.cpp:869-871.
  * Host pointers; copies both clouds to HBM, runs every iteration on the GPU,

@@ -100,6 +100,10 @@ SIGNATURES = {
     "mola_icp_destroy": (C.c_int, [_H]),
     "mola_icp_set_stream": (C.c_int, [_H, C.c_void_p]),
     "mola_icp_set_allreduce": (C.c_int, [_H, ALLREDUCE_FN, C.c_void_p]),
+    "mola_icp_comm_set_library": (C.c_int, [C.c_char_p]),
+    "mola_icp_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "mola_icp_comm_init": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "mola_icp_comm_destroy": (C.c_int, [_H]),
     "mola_icp_align": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, _FP, _FP, _FP, C.c_size_t, _DP,
                                  C.POINTER(CParams), C.POINTER(CResult)]),
     "mola_icp_align_batch": (C.c_int, [_H, C.c_size_t, C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),

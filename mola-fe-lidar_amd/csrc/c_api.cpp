@@ -29,6 +29,12 @@ struct mola_icp_handle {
     std::unique_ptr<HipWorkspace> resident;           // the resident-cloud API's workspace
     mola_icp_allreduce_fn ar_fn = nullptr;
     void* ar_user = nullptr;
+    void* comm = nullptr;  // RCCL communicator of the query-sharded path
+    ~mola_icp_handle()
+    {
+        if (resident) resident->sync();
+        if (comm) (void)rccl_comm_destroy(comm);
+    }
 };
 
 namespace {
@@ -275,6 +281,50 @@ int mola_icp_set_allreduce(mola_icp_handle* h, mola_icp_allreduce_fn fn, void* u
     h->ar_user = user;
     h->resident->set_allreduce(fn, user);
     return MOLA_ICP_OK;
+}
+
+int mola_icp_comm_set_library(const char* path) { return rccl_set_library(path); }
+
+int mola_icp_comm_unique_id(uint8_t id_out[128])
+{
+    return guarded([&]() -> int {
+        if (!id_out) return fail(MOLA_ICP_E_BADARG, "null id");
+        RcclUniqueId id;
+        const int rc = rccl_unique_id(&id);
+        if (rc) return rc;
+        std::memcpy(id_out, id.internal, 128);
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_comm_init(mola_icp_handle* h, const uint8_t id[128], int nranks, int rank)
+{
+    return guarded([&]() -> int {
+        if (!h || !id) return fail(MOLA_ICP_E_BADARG, "null argument");
+        if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MOLA_ICP_E_BADARG, "bad rank / nranks");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        if (h->comm) return fail(MOLA_ICP_E_BADARG, "communicator already initialised");
+        if (hipSetDevice(h->device) != hipSuccess) return fail(MOLA_ICP_E_HIP, "hipSetDevice failed");
+        RcclUniqueId uid;
+        std::memcpy(uid.internal, id, 128);
+        const int rc = rccl_comm_init(&h->comm, nranks, uid, rank);
+        if (rc) return rc;
+        h->resident->set_comm(h->comm);
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_comm_destroy(mola_icp_handle* h)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        h->resident->sync();
+        h->resident->set_comm(nullptr);
+        const int rc = h->comm ? rccl_comm_destroy(h->comm) : MOLA_ICP_OK;
+        h->comm = nullptr;
+        return rc;
+    });
 }
 
 int mola_icp_align(mola_icp_handle* h, const float* fx, const float* fy, const float* fz, size_t M, const float* tx,

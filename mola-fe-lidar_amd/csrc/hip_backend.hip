@@ -1333,8 +1333,17 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     if (stage != 0 && stage != 1) return fail(MOLA_ICP_E_BADARG, "stage must be 0 or 1");
     if (stage == 1 && (!cl || !cg)) return fail(MOLA_ICP_E_BADARG, "stage 1 needs the centroids");
     HIPCHK(hipSetDevice(device_));
-    if (N_ == 0) {
+    if (N_ == 0 && !comm_) {
         for (int k = 0; k < kNAcc; ++k) acc[k] = 0;
+        return MOLA_ICP_OK;
+    }
+    if (N_ == 0) {  // an empty shard still joins the all-reduce
+        HIPCHK(hipMemsetAsync(acc_dev_.p, 0, sizeof(double) * kNAcc, stream_));
+        const int rc2 = rccl_allreduce_sum_f64(comm_, acc_dev_.as<double>(), kNAcc, stream_);
+        if (rc2) return rc2;
+        HIPCHK(hipMemcpyAsync(acc_host_, acc_dev_.p, sizeof(double) * kNAcc, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);
         return MOLA_ICP_OK;
     }
     if (reset_outliers) HIPCHK(hipMemsetAsync(outlier_.p, 0, N_, stream_));
@@ -1364,6 +1373,10 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(192), 0, stream_, partials_.as<double>(), nblocks,
                        acc_dev_.as<double>());
     HIPCHK(hipGetLastError());
+    if (comm_) {  // query-sharded: the one collective of the path, in place on the device block (RCCL over xGMI)
+        const int rc2 = rccl_allreduce_sum_f64(comm_, acc_dev_.as<double>(), kNAcc, stream_);
+        if (rc2) return rc2;
+    }
     HIPCHK(hipMemcpyAsync(acc_host_, acc_dev_.p, sizeof(double) * kNAcc, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);
@@ -1372,6 +1385,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
 
 int HipWorkspace::allreduce(double acc[kNAcc])
 {
+    if (comm_) return MOLA_ICP_OK;  // accumulate() already reduced the device block over RCCL
     if (!ar_fn_) return MOLA_ICP_OK;
     const int rc = ar_fn_(acc, kNAcc, 0, ar_user_);
     if (rc) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(rc));

@@ -15,6 +15,14 @@ namespace mola_icp_amd {
 
 struct PoseF;
 
+// RCCL, loaded at run time (rccl_dl.cpp)
+struct RcclUniqueId { char internal[128]; };
+int rccl_set_library(const char* path);
+int rccl_unique_id(RcclUniqueId* id);
+int rccl_comm_init(void** comm, int nranks, const RcclUniqueId& id, int rank);
+int rccl_allreduce_sum_f64(void* comm, double* dev_buf, size_t n, hipStream_t stream);
+int rccl_comm_destroy(void* comm);
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -33,6 +41,8 @@ class HipWorkspace final : public Stages {
     int init();  // creates the stream / pinned buffers; MOLA_ICP_E_NODEVICE if no GPU
     int set_external_stream(void* s);
     void set_allreduce(mola_icp_allreduce_fn fn, void* user) { ar_fn_ = fn; ar_user_ = user; }
+    // native RCCL communicator (owned by the handle): accumulate() then all-reduces the device block itself
+    void set_comm(void* comm) { comm_ = comm; }
     void set_global_sizes(uint64_t nl, uint64_t nm) { n_local_total_ = nl; n_map_total_ = nm; }
 
     int set_map_host(const float* x, const float* y, const float* z, size_t M);
@@ -104,6 +114,7 @@ class HipWorkspace final : public Stages {
 
     mola_icp_allreduce_fn ar_fn_ = nullptr;
     void* ar_user_ = nullptr;
+    void* comm_ = nullptr;
 
     std::vector<hipEvent_t> ev_;  // pairs: start, stop
     size_t ev_used_ = 0;

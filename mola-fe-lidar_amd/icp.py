@@ -264,6 +264,31 @@ class ICP:
         self._ar_cb = L.ALLREDUCE_FN(_cb)
         L.check(L.lib().mola_icp_set_allreduce(self._h, self._ar_cb, None))
 
+    def comm_init(self, group=None):
+        """Native RCCL communicator for the query-sharded path: rank 0 creates the id, torch.distributed
+        carries its 128 bytes to the other ranks, every rank joins (collective call)."""
+        import os
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):  # the RCCL this process already uses
+            L.check(L.lib().mola_icp_comm_set_library(cand.encode()))
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            L.check(L.lib().mola_icp_comm_unique_id(ident))
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.tensor(list(ident), dtype=torch.uint8)
+        if on_gpu:
+            t = t.cuda()
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(t, src=src, group=group)
+        ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        L.check(L.lib().mola_icp_comm_init(self._h, ident, world, rank))
+
+    def comm_destroy(self):
+        L.check(L.lib().mola_icp_comm_destroy(self._h))
+
     def align_resident(self, init_guess_to_wrt_from, params: Parameters) -> Results:
         T = _pose16(init_guess_to_wrt_from)
         r = L.CResult()

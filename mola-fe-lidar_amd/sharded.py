@@ -52,8 +52,13 @@ class ShardedICP:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self._ar = make_allreduce(group) if self.world > 1 else None
-        icp.set_allreduce(self._ar)
+        self._ar = None
+        if self.world > 1:
+            if dist.get_backend(group) == "nccl":
+                icp.comm_init(group)  # native RCCL on the device accumulator block
+            else:
+                self._ar = make_allreduce(group)
+                icp.set_allreduce(self._ar)
 
     def set_clouds(self, map_pc, local_pc_full):
         n = local_pc_full.shape[1]

@@ -68,3 +68,12 @@ def test_product_never_references_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 for pat in banned:
                     assert not re.search(pat, txt), f"{f} uses the oracle ({pat})"
+
+
+def test_comm_api_without_gpu(pkg):
+    # argument checking of the RCCL entry points needs neither a GPU nor RCCL
+    lib = pkg._lib.lib()
+    assert lib.mola_icp_comm_unique_id(None) == pkg._lib.E_BADARG
+    assert lib.mola_icp_comm_init(None, None, 1, 0) == pkg._lib.E_BADARG
+    assert lib.mola_icp_comm_destroy(None) == pkg._lib.E_BADARG
+    assert lib.mola_icp_comm_set_library(None) == 0
