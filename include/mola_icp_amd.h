@@ -191,6 +191,16 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs,
                          const size_t* N,
                          const double* init_T, const mola_icp_params* p, mola_icp_result* out);
 
+/* Loop-closure Monte-Carlo (src/LidarOdometry.cpp:767-788): the SAME pair aligned from n_init initial
+ * poses (init_T = n_init x 16), keeping the attempt with the highest goodness (strictly greater, i.e. the
+ * first best, as `if (this_icp_out.goodness > icp_out.goodness)` cpp:785).  The clouds are uploaded and
+ * prepared once.  out = n_init results (may be NULL), *best_index = winner, -1 if every goodness is 0. */
+int mola_icp_align_multi_init(mola_icp_handle* h,
+                              const float* from_x, const float* from_y, const float* from_z, size_t M,
+                              const float* to_x, const float* to_y, const float* to_z, size_t N,
+                              size_t n_init, const double* init_T, const mola_icp_params* p,
+                              mola_icp_result* out, mola_icp_result* best, int* best_index);
+
 /* ---- resident-cloud API (inputs already in HBM; bench + sharded path) ---
  * *_device take DEVICE pointers (fp32 SoA) that must stay valid until the
  * next set_* / destroy; *_host copy from host memory. */
@@ -243,6 +253,62 @@ typedef struct mola_icp_stage_callbacks {
 } mola_icp_stage_callbacks;
 int mola_icp_run_loop(const mola_icp_stage_callbacks* cb, const double init_T[16], const mola_icp_params* p,
                       mola_icp_result* out);
+
+/* ======================================================================================
+ * Front-end logic around the ICP: LidarOdometry::doProcessNewObservation()
+ * (src/LidarOdometry.cpp:190-514) without MOLA's back-end / world-model / GUI plumbing: time gate,
+ * constant-velocity guess, run_one_icp, twist update, keyframe decision, relative-pose factor.
+ * ====================================================================================== */
+typedef struct mola_lo_params {
+    double min_time_between_scans;          /* [s]   LidarOdometry.h:57,  kitti-default.yaml:5, used cpp:202-206 */
+    double min_dist_xyz_between_keyframes;  /* [m]   h:61,  kitti:8,  used cpp:336 */
+    double min_rotation_between_keyframes;  /* [rad] h:66 (YAML in degrees, cpp:106), used cpp:337 */
+    double min_icp_goodness;                /* h:70, kitti:12, used cpp:334 */
+    mola_icp_params icp_with_vel;           /* params_.icp[LidarOdometry].icpParameters, cpp:122-124, 288-289 */
+    mola_icp_params icp_without_vel;        /* params_.icp[NearbyAlign].icpParameters,   cpp:125-126, 290 */
+} mola_lo_params;
+
+enum {
+    MOLA_LO_DROPPED_TOO_SOON = 0,  /* min_time_between_scans gate, cpp:202-212 */
+    MOLA_LO_FIRST_SCAN       = 1,  /* no previous cloud: no ICP, first keyframe, cpp:250-257 */
+    MOLA_LO_ICP_RAN          = 2,
+    MOLA_LO_EMPTY_CLOUD      = 3   /* cpp:238-245 */
+};
+
+typedef struct mola_lo_step {
+    int32_t  status;                  /* MOLA_LO_* */
+    int32_t  used_with_vel_params;    /* which parameter set the ICP got (cpp:287-290) */
+    double   dt;                      /* seconds since the previous processed scan (cpp:268-269) */
+    double   rel_pose[16];            /* icp_out.found_pose_to_wrt_from mean (cpp:301-302) */
+    double   twist[4];                /* last_iter_twist vx,vy,vz,wz after the update (cpp:305-311) */
+    double   dist_since_last_kf;      /* cpp:322-323 */
+    double   rot_since_last_kf;       /* cpp:324-327 */
+    int32_t  keyframe_created;        /* cpp:333-337 / 250-257 */
+    int32_t  kf_factor_valid;         /* a FactorRelativePose3 would be emitted (cpp:433-443) */
+    uint64_t kf_factor_from, kf_factor_to;
+    double   kf_factor_pose[16];      /* accum_since_last_kf at keyframe creation */
+    uint64_t reference_kf;            /* advertiseUpdatedLocalization.reference_kf (cpp:487) */
+    double   accum_since_last_kf[16]; /* ... .pose (cpp:488), after a possible reset (cpp:472-474) */
+    mola_icp_result icp;              /* the ICP's own result (goodness = icp.quality) */
+} mola_lo_step;
+
+typedef struct mola_lo mola_lo;
+/* align function with mola_icp_align's meaning, for hosts/tests that supply their own ICP */
+typedef int (*mola_lo_align_fn)(void* user, const float* from_x, const float* from_y, const float* from_z, size_t M,
+                                const float* to_x, const float* to_y, const float* to_z, size_t N,
+                                const double init_T[16], const mola_icp_params* p, mola_icp_result* out);
+
+int mola_lo_params_default(mola_lo_params* p);
+/* reads the keys LidarOdometry::initialize() reads (cpp:105-128) from a kitti-default.yaml-style file */
+int mola_lo_params_from_yaml_file(const char* path, const char* mola_dir, mola_lo_params* p);
+/* icp: the AlignKind::LidarOdometry ICP object (may be NULL if align_cb is given) */
+int mola_lo_create(mola_icp_handle* icp, mola_lo_align_fn align_cb, void* user, const mola_lo_params* params,
+                   mola_lo** out);
+int mola_lo_destroy(mola_lo* lo);
+int mola_lo_reset(mola_lo* lo);   /* LidarOdometry::reset(), cpp:160 */
+/* one observation: timestamp [s] + the (already filtered) cloud in the sensor/vehicle frame */
+int mola_lo_process_scan(mola_lo* lo, double timestamp, const float* x, const float* y, const float* z, size_t n,
+                         mola_lo_step* out);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,8 @@ from ._lib import (IcpError, NN_AUTO, NN_MFMA, NN_TILED, NN_VALU, TERM_MAX_ITERA
 from .icp import (ICP, Parameters, Results, pose_from_xyzypr, pose_to_xyzypr, run_loop, se3_log, solve_horn,
                   stall_deltas)
 
-__all__ = ["ICP", "Parameters", "Results", "IcpError", "pose_from_xyzypr", "pose_to_xyzypr", "se3_log",
+from .lidar_odometry import LidarOdometry, LidarOdometryParams, Step
+
+__all__ = ["LidarOdometry", "LidarOdometryParams", "Step", "ICP", "Parameters", "Results", "IcpError", "pose_from_xyzypr", "pose_to_xyzypr", "se3_log",
            "stall_deltas", "solve_horn", "run_loop", "NN_AUTO", "NN_VALU", "NN_MFMA", "NN_TILED", "TERM_UNDEFINED",
            "TERM_NO_PAIRINGS", "TERM_SOLVER_ERROR", "TERM_MAX_ITERATIONS", "TERM_STALLED"]

@@ -66,6 +66,42 @@ class CResult(C.Structure):
     ]
 
 
+class CLoParams(C.Structure):
+    _fields_ = [
+        ("min_time_between_scans", C.c_double),
+        ("min_dist_xyz_between_keyframes", C.c_double),
+        ("min_rotation_between_keyframes", C.c_double),
+        ("min_icp_goodness", C.c_double),
+        ("icp_with_vel", CParams),
+        ("icp_without_vel", CParams),
+    ]
+
+
+class CLoStep(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("used_with_vel_params", C.c_int32),
+        ("dt", C.c_double),
+        ("rel_pose", C.c_double * 16),
+        ("twist", C.c_double * 4),
+        ("dist_since_last_kf", C.c_double),
+        ("rot_since_last_kf", C.c_double),
+        ("keyframe_created", C.c_int32),
+        ("kf_factor_valid", C.c_int32),
+        ("kf_factor_from", C.c_uint64),
+        ("kf_factor_to", C.c_uint64),
+        ("kf_factor_pose", C.c_double * 16),
+        ("reference_kf", C.c_uint64),
+        ("accum_since_last_kf", C.c_double * 16),
+        ("icp", CResult),
+    ]
+
+
+LO_ALIGN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
+                          C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
+                          C.POINTER(C.c_double), C.POINTER(CParams), C.POINTER(CResult))
+LO_DROPPED_TOO_SOON, LO_FIRST_SCAN, LO_ICP_RAN, LO_EMPTY_CLOUD = 0, 1, 2, 3
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_void_p)
 MATCH_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_uint64))
 ACCUM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(CParams), C.POINTER(C.c_double), C.c_int,
@@ -109,6 +145,9 @@ SIGNATURES = {
     "mola_icp_align_batch": (C.c_int, [_H, C.c_size_t, C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
                                        C.POINTER(C.c_size_t), C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
                                        C.POINTER(C.c_size_t), _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_icp_align_multi_init": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, _FP, _FP, _FP, C.c_size_t, C.c_size_t, _DP,
+                                            C.POINTER(CParams), C.POINTER(CResult), C.POINTER(CResult),
+                                            C.POINTER(C.c_int)]),
     "mola_icp_set_map_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t]),
     "mola_icp_set_map_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mola_icp_set_local_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t]),
@@ -123,6 +162,12 @@ SIGNATURES = {
     "mola_icp_pose_from_xyzypr": (C.c_int, [_DP, _DP]),
     "mola_icp_pose_to_xyzypr": (C.c_int, [_DP, _DP]),
     "mola_icp_run_loop": (C.c_int, [C.POINTER(CStageCallbacks), _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_lo_params_default": (C.c_int, [C.POINTER(CLoParams)]),
+    "mola_lo_params_from_yaml_file": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(CLoParams)]),
+    "mola_lo_create": (C.c_int, [_H, LO_ALIGN_FN, C.c_void_p, C.POINTER(CLoParams), C.POINTER(_H)]),
+    "mola_lo_destroy": (C.c_int, [_H]),
+    "mola_lo_reset": (C.c_int, [_H]),
+    "mola_lo_process_scan": (C.c_int, [_H, C.c_double, _FP, _FP, _FP, C.c_size_t, C.POINTER(CLoStep)]),
 }
 
 _lib = None

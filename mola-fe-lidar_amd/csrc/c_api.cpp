@@ -378,6 +378,44 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const*
     });
 }
 
+int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* fy, const float* fz, size_t M,
+                              const float* tx, const float* ty, const float* tz, size_t N, size_t n_init,
+                              const double* init_T, const mola_icp_params* p, mola_icp_result* out,
+                              mola_icp_result* best, int* best_index)
+{
+    return guarded([&]() -> int {
+        if (!h || !p || !init_T || !best_index) return fail(MOLA_ICP_E_BADARG, "null argument");
+        int rc;
+        for (size_t k = 0; k < n_init; ++k)
+            if ((rc = check_pose(init_T + 16 * k))) return rc;
+        if ((rc = validate_params(*p))) return rc;
+        Lease lease(h);
+        if (lease.rc) return lease.rc;
+        HipWorkspace& ws = *lease.ws;
+        const double t0 = now_ms();
+        if ((rc = ws.set_map_host(fx, fy, fz, M))) { lease.rc = rc; return rc; }
+        if ((rc = ws.set_local_host(tx, ty, tz, N))) { lease.rc = rc; return rc; }
+        ws.set_global_sizes(0, 0);
+        ws.set_allreduce(nullptr, nullptr);
+        const double upload_ms = now_ms() - t0;
+        *best_index = -1;
+        double best_q = 0.0;  // ICP_Output::goodness starts at .0 (LidarOdometry.h:130)
+        for (size_t k = 0; k < n_init; ++k) {
+            mola_icp_result r;
+            std::memset(&r, 0, sizeof r);
+            if ((rc = align_on(ws, init_T + 16 * k, p, &r))) { lease.rc = rc; return rc; }
+            r.ms_upload = k == 0 ? upload_ms : 0.0;
+            if (out) out[k] = r;
+            if (r.quality > best_q) {
+                best_q = r.quality;
+                *best_index = (int)k;
+                if (best) *best = r;
+            }
+        }
+        return MOLA_ICP_OK;
+    });
+}
+
 #define RESIDENT_CALL(expr)                                             \
     return guarded([&]() -> int {                                       \
         if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");          \

@@ -211,6 +211,20 @@ class ICP:
                                              _dp(Ts), C.byref(params.c), res))
         return [Results.from_c(r) for r in res]
 
+    def align_multi_init(self, pcs_from, pcs_to, init_guesses, params: Parameters):
+        """Loop-closure Monte-Carlo (src/LidarOdometry.cpp:767-788): one pair, several initial poses, the
+        attempt with the highest goodness wins.  Returns (results, best_index or -1)."""
+        fx, fy, fz, M = _soa(pcs_from)
+        tx, ty, tz, N = _soa(pcs_to)
+        n = len(init_guesses)
+        Ts = np.ascontiguousarray(np.stack([_pose16(g) for g in init_guesses]) if n else np.zeros((0, 16)))
+        res = (L.CResult * max(1, n))()
+        best = L.CResult()
+        bi = C.c_int(-1)
+        L.check(L.lib().mola_icp_align_multi_init(self._h, _fp(fx), _fp(fy), _fp(fz), M, _fp(tx), _fp(ty), _fp(tz), N, n,
+                                                  _dp(Ts), C.byref(params.c), res, C.byref(best), C.byref(bi)))
+        return [Results.from_c(res[k]) for k in range(n)], bi.value
+
     # -- resident clouds (already in HBM): bench + sharded path
     @staticmethod
     def _is_device_tensor(x) -> bool:

@@ -1,0 +1,115 @@
+"""Host-side mirror of the `LidarOdometry` front-end logic around the ICP:
+`onNewObservation` -> time gate -> constant-velocity guess -> `run_one_icp` -> twist -> keyframe decision
+(src/LidarOdometry.cpp:190-514).  Marshalling only: the logic is csrc/lidar_odometry_core.cpp."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+from .icp import ICP, Parameters, Results, _fp, _soa
+
+
+@dataclass
+class Step:
+    status: int
+    used_with_vel_params: bool
+    dt: float
+    rel_pose: np.ndarray
+    twist: np.ndarray
+    dist_since_last_kf: float
+    rot_since_last_kf: float
+    keyframe_created: bool
+    kf_factor: tuple | None          # (from_kf, to_kf, 4x4 pose) when a FactorRelativePose3 would be emitted
+    reference_kf: int
+    accum_since_last_kf: np.ndarray
+    icp: Results | None
+
+
+class LidarOdometryParams:
+    """the scalar front-end parameters + the two ICP parameter sets the odometry path uses
+    (include/mola-fe-lidar/LidarOdometry.h:52-102, src/LidarOdometry.cpp:105-128)"""
+
+    def __init__(self):
+        self.c = L.CLoParams()
+        L.check(L.lib().mola_lo_params_default(C.byref(self.c)))
+
+    @classmethod
+    def load_from_file(cls, path: str, mola_dir: str | None = None) -> "LidarOdometryParams":
+        p = cls()
+        L.check(L.lib().mola_lo_params_from_yaml_file(path.encode(), mola_dir.encode() if mola_dir else None,
+                                                      C.byref(p.c)))
+        return p
+
+    def set_icp(self, with_vel: Parameters, without_vel: Parameters | None = None):
+        C.memmove(C.byref(self.c.icp_with_vel), C.byref(with_vel.c), C.sizeof(L.CParams))
+        C.memmove(C.byref(self.c.icp_without_vel), C.byref((without_vel or with_vel).c), C.sizeof(L.CParams))
+
+    def __getattr__(self, name):
+        c = object.__getattribute__(self, "c")
+        if name in ("min_time_between_scans", "min_dist_xyz_between_keyframes", "min_rotation_between_keyframes",
+                    "min_icp_goodness"):
+            return getattr(c, name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in ("min_time_between_scans", "min_dist_xyz_between_keyframes", "min_rotation_between_keyframes",
+                    "min_icp_goodness"):
+            setattr(self.c, name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+
+class LidarOdometry:
+    """`icp`: an `ICP` (GPU) -- or `align_fn(from(3,M), to(3,N), T0 4x4, Parameters) -> (T 4x4, quality, nIterations,
+    terminationReason)` to drive the same host logic with another registration (CPU tests)."""
+
+    def __init__(self, params: LidarOdometryParams, icp: ICP | None = None, align_fn=None):
+        assert (icp is None) != (align_fn is None)
+        self._icp = icp
+        self._cb = None
+        if align_fn is not None:
+            def _cb(user, fx, fy, fz, M, tx, ty, tz, N, T0, pp, out):
+                try:
+                    f = np.stack([np.ctypeslib.as_array(a, shape=(M,)) for a in (fx, fy, fz)]) if M else np.zeros((3, 0), np.float32)
+                    t = np.stack([np.ctypeslib.as_array(a, shape=(N,)) for a in (tx, ty, tz)]) if N else np.zeros((3, 0), np.float32)
+                    p = Parameters()
+                    C.memmove(C.byref(p.c), pp, C.sizeof(L.CParams))
+                    T, q, nit, term = align_fn(f, t, np.ctypeslib.as_array(T0, shape=(16,)).reshape(4, 4).copy(), p)
+                    out[0].T[:] = list(np.asarray(T, dtype=np.float64).reshape(16))
+                    out[0].quality, out[0].n_iterations, out[0].termination = float(q), int(nit), int(term)
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return L.E_INTERNAL
+            self._cb = L.LO_ALIGN_FN(_cb)
+        self._h = L._H()
+        L.check(L.lib().mola_lo_create(icp._h if icp is not None else None, self._cb or L.LO_ALIGN_FN(), None,
+                                       C.byref(params.c), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            L.lib().mola_lo_destroy(self._h)
+            self._h = L._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        L.check(L.lib().mola_lo_reset(self._h))
+
+    def on_new_observation(self, timestamp: float, cloud) -> Step:
+        x, y, z, n = _soa(cloud)
+        s = L.CLoStep()
+        L.check(L.lib().mola_lo_process_scan(self._h, float(timestamp), _fp(x), _fp(y), _fp(z), n, C.byref(s)))
+        fac = (s.kf_factor_from, s.kf_factor_to, np.array(s.kf_factor_pose).reshape(4, 4)) if s.kf_factor_valid else None
+        return Step(s.status, bool(s.used_with_vel_params), s.dt, np.array(s.rel_pose).reshape(4, 4), np.array(s.twist),
+                    s.dist_since_last_kf, s.rot_since_last_kf, bool(s.keyframe_created), fac, s.reference_kf,
+                    np.array(s.accum_since_last_kf).reshape(4, 4),
+                    Results.from_c(s.icp) if s.status == L.LO_ICP_RAN else None)

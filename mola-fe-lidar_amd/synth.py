@@ -165,7 +165,8 @@ def lidar_scan(pose: np.ndarray, n_rings: int = 64, n_az: int = 1875, max_range:
         den = dw @ nrm
         with np.errstate(divide="ignore", invalid="ignore"):
             t = ((O - o) @ nrm) / den
-        hit = o + t[:, None] * dw - O
+        with np.errstate(invalid="ignore"):
+            hit = o + t[:, None] * dw - O
         a = (hit @ U) / (U @ U)
         b = (hit @ V) / (V @ V)
         ok = (np.abs(den) > 1e-12) & (t > 0.5) & (t < max_range) & (a >= 0) & (a <= 1) & (b >= 0) & (b <= 1)

@@ -12,8 +12,8 @@ HEADER = os.path.join(ROOT, "include", "mola_icp_amd.h")
 def _declared_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = set(re.findall(r"\b(mola_icp_[a-z0-9_]+)\s*\(", txt))
-    names -= {"mola_icp_allreduce_fn"}
+    names = set(re.findall(r"\b(mola_(?:icp|lo)_[a-z0-9_]+)\s*\(", txt))
+    names -= {"mola_icp_allreduce_fn", "mola_lo_align_fn"}
     return sorted(names)
 
 

@@ -276,3 +276,29 @@ def test_resident_device_tensors(pkg, O, synth, small_scene):
     rot, trans = O.pose_error(r.optimal_tf, ref["T"])
     assert r.nIterations == ref["n_iterations"] and rot < 1e-8 and trans < 1e-8
     icp.close()
+
+
+def test_loop_closure_montecarlo_multi_init(pkg, O, icp, synth, small_scene):
+    """f2 (src/LidarOdometry.cpp:767-788): several perturbed guesses on one uploaded pair; the winner is the
+    first attempt with the highest goodness; every attempt equals a stand-alone align bit for bit."""
+    g, l, Tgt = synth.make_pair(12000, 10000, seed=61, scene=small_scene, noise_sigma=0.005)
+    p = p2p_params(pkg, max_iterations=40, matcher_threshold=0.6)
+    rng = np.random.default_rng(5)
+    guesses = [np.eye(4)]
+    for _ in range(5):
+        d = rng.normal(0, 1, 4) * np.array([0.3, 0.3, 0.3, np.deg2rad(2.0)])
+        guesses.append(synth.pose_from_xyzypr(d[0], d[1], d[2], d[3], 0, 0))
+    res, best = icp.align_multi_init(g, l, guesses, p)
+    singles = [icp.align(g, l, T0, p) for T0 in guesses]
+    for r, s in zip(res, singles):
+        assert r.nIterations == s.nIterations and r.terminationReason == s.terminationReason
+        assert np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality
+    q = [r.quality for r in res]
+    assert best == int(np.argmax(q)) and q[best] == max(q)
+    ref = O.align(g, l, guesses[best], O.params_from_product(p))
+    rot, trans = O.pose_error(res[best].optimal_tf, ref["T"])
+    assert rot < 1e-8 and trans < 1e-8
+    # nothing inside the gate for any guess -> no winner
+    far = np.ascontiguousarray(l + np.float32(500))
+    res, best = icp.align_multi_init(g, far, guesses[:2], p)
+    assert best == -1 and all(r.quality == 0 for r in res)
