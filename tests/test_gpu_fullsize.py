@@ -73,3 +73,61 @@ def test_1m_x_1m_config3_run(pkg, O, big):
     assert rot <= 1e-4 and trans <= 1e-3 and rot < 1e-8 and trans < 1e-8, (rot, trans)
     assert r3.n_pairs == ref["n_pairs"] and r3.quality == pytest.approx(ref["quality"], abs=1e-12)
     icp.close()
+
+
+def test_config1_kitti_like_pair_through_front_end(pkg, O, synth):
+    """BASELINE configs[0]: params/kitti-default.yaml + one KITTI-like 64-ring scan pair (~120k points each; no
+    real KITTI data exists in the image) through the front-end, GPU ICP vs the CPU oracle on the same pair."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lp = pkg.LidarOdometryParams.load_from_file(os.path.join(root, "params", "kitti-default.yaml"), root)
+    s0 = synth.lidar_scan(synth.pose_from_xyzypr(-10.0, 0.2, 0, 0.00, 0, 0), seed=11)
+    s1 = synth.lidar_scan(synth.pose_from_xyzypr(-9.0, 0.25, 0, 0.01, 0, 0), seed=12)   # 1 m forward, 0.1 s later
+    assert 100_000 <= s0.shape[1] <= 130_000
+    icp = pkg.ICP(device=0)
+    lo = pkg.LidarOdometry(lp, icp=icp)
+    a = lo.on_new_observation(10.0, s0)
+    b = lo.on_new_observation(10.1, s1)
+    assert a.status == pkg._lib.LO_FIRST_SCAN and a.keyframe_created
+    assert b.status == pkg._lib.LO_ICP_RAN and not b.used_with_vel_params
+    p = pkg.Parameters()
+    import ctypes
+    ctypes.memmove(ctypes.byref(p.c), ctypes.byref(lp.c.icp_without_vel), ctypes.sizeof(pkg._lib.CParams))
+    ref = O.align(s0, s1, np.eye(4), O.params_from_product(p))
+    assert b.icp.nIterations == ref["n_iterations"] and b.icp.terminationReason == ref["termination"]
+    rot, trans = O.pose_error(b.rel_pose, ref["T"])
+    assert rot <= 1e-4 and trans <= 1e-3 and rot < 1e-7 and trans < 1e-7, (rot, trans)
+    assert b.icp.quality == pytest.approx(ref["quality"], abs=1e-12)
+    assert b.icp.nn_kernel_used == pkg.NN_TILED          # auto picks the tiled matcher at this size
+    lo.close()
+    icp.close()
+
+
+def test_config5_10m_map_sequential_shards(pkg, O, synth):
+    """BASELINE configs[4]: 10M-point map vs 1M queries, 8 query shards of 125k run one after another on one
+    GPU: the summed shard accumulators equal the un-sharded ones (the reduction RCCL performs on 8 GPUs), and a
+    sample of the pairing equals the oracle's exact kd-tree bit for bit."""
+    import importlib
+    sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+    g, l, _ = synth.make_pair(1_000_000, 10_000_000, seed=7)
+    p = p2p_params(pkg)
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    idx, d2, n = icp.match(np.eye(4), 1.0, l.shape[1])
+    full = icp.accumulate(p, np.eye(4))
+    assert full[16] == n
+    sel = np.arange(0, l.shape[1], 200)
+    oidx, od2, _ = O.match(g, np.ascontiguousarray(l[:, sel]), np.eye(4), 1.0, O.KdTree(g))
+    assert np.array_equal(idx[sel], oidx)
+    k = oidx >= 0
+    assert np.array_equal(d2[sel][k], od2[k])
+    tot = np.zeros(24)
+    for r in range(8):
+        lo_, hi_ = sharded.shard_bounds(l.shape[1], r, 8)
+        icp.set_local(np.ascontiguousarray(l[:, lo_:hi_]))
+        i_r, _, _ = icp.match(np.eye(4), 1.0, hi_ - lo_)
+        assert np.array_equal(i_r, idx[lo_:hi_])
+        tot += icp.accumulate(p, np.eye(4))
+    np.testing.assert_allclose(tot, full, rtol=1e-12, atol=1e-6)
+    icp.close()
