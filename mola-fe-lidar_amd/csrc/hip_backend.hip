@@ -394,38 +394,52 @@ __device__ __forceinline__ bool box_overlap(const float* __restrict__ b, int str
            b[3 * stride + i] >= w.lo[0] && b[4 * stride + i] >= w.lo[1] && b[5 * stride + i] >= w.lo[2];
 }
 
+__device__ __forceinline__ float bcast_lane(float v, int lane_uniform)
+{
+    // lane_uniform is wave-uniform (ctz of a ballot): a v_readlane, not an LDS round trip
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
+// EXACT = false: the fast sweep.  Per (query, 4-point chunk) only the chunk minimum is compared with the
+//   running best (~6 VALU ops per pair); the winning chunk is re-evaluated once at the end to recover the
+//   exact point and the lowest-original-index rule inside it.  If an EQUAL minimum showed up in a different
+//   chunk (exact ties: duplicate points, lattices) the item is queued for the exact pass.
+// EXACT = true : the exact-key sweep over the queued items: per-pair argmin on the packed key
+//   (d2 bits << 32 | original index), i.e. the full lexicographic rule (~10 ops per pair).
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, int M,
                                                   const float* __restrict__ sx, const float* __restrict__ sy,
                                                   const float* __restrict__ sz, const int* __restrict__ perm,
                                                   const float* __restrict__ tbox, int n_tiles_p,
-                                                  const float* __restrict__ sbox, int n_super, PoseF P, float thr2,
+                                                  const float* __restrict__ sbox, int n_super,
+                                                  const float* __restrict__ ubox, int n_top, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
                                                   float* __restrict__ d2_s, const int* __restrict__ item_order,
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
-                                                  unsigned int* __restrict__ kept_counter,
+                                                  unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
                                                   unsigned long long* __restrict__ staged_total,
                                                   unsigned long long* __restrict__ dbg_stats)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float(*sm)[64] = s_m[wave];
-    const int n_items = (N + kQPW - 1) / kQPW;
-    unsigned int kept = 0;
+    const int n_items = EXACT ? (int)*redo_count : (N + kQPW - 1) / kQPW;
 
     for (;;) {
         int item = 0;
         if (lane == 0) item = (int)atomicAdd(queue, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
-        if (item_order) item = __builtin_amdgcn_readfirstlane(item_order[item]);  // heaviest items of the last launch first
+        if (EXACT) item = __builtin_amdgcn_readfirstlane(redo_list[item]);
+        else if (item_order) item = __builtin_amdgcn_readfirstlane(item_order[item]);  // heaviest items of the last launch first
         const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
 
-        const unsigned long long ts0 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
-        unsigned long long tscan = 0, tstage = 0, tcomp = 0;
         float qx[2], qy[2], qz[2], reach[2];
-        unsigned long long key[2];
-        int bpos[2];  // sorted-map position of the current best (the pairing is kept in sorted order internally)
+        unsigned long long key[2];  // EXACT: packed (d2, original index)
+        float best[2];              // fast: running minimum
+        int bpos[2];                // EXACT: sorted position of the best point; fast: of its 4-point chunk
+        bool tie[2] = {false, false};
         Box w;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { w.lo[k] = INFINITY; w.hi[k] = -INFINITY; }
@@ -435,25 +449,25 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
             qx[k] = qy[k] = qz[k] = 1.0e18f;
             reach[k] = -1.0f;  // padding lane: reaches nothing
             key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
+            best[k] = thr2;
             bpos[k] = -1;
             if (i < N) {
                 xform(P, slx[i], sly[i], slz[i], qx[k], qy[k], qz[k]);
-                float best = thr2;
                 if (use_seed) {  // warm start: last iteration's neighbour is an exact candidate
                     const int js = pos_s[i];  // sorted-map position: neighbours of neighbours share cache lines
                     if (js >= 0) {
                         const float d = dist2(qx[k], qy[k], qz[k], sx[js], sy[js], sz[js]);
                         if (d < thr2) {
-                            best = d;
-                            bpos[k] = js;
-                            key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)perm[js];
+                            best[k] = d;
+                            bpos[k] = EXACT ? js : (js & ~3);
+                            if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)perm[js];
                         }
                     }
                 }
                 // reach: any m with d2_contract <= best lies inside [q - r, q + r] (r rounded up, plus 2 ulp of q)
                 const float c[3] = {qx[k], qy[k], qz[k]};
                 const float cmax = fmaxf(fabsf(c[0]), fmaxf(fabsf(c[1]), fabsf(c[2])));
-                reach[k] = sqrtf(best * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
+                reach[k] = sqrtf(best[k] * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     w.lo[a] = fminf(w.lo[a], c[a] - reach[k]);
@@ -471,8 +485,6 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
         }
 
         unsigned long long n_staged = 0;
-        const unsigned long long ts1 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
-        unsigned long long tmark = ts1;
 
         // does ANY query of the wave reach the box (m0..m5 = min xyz, max xyz; wave-uniform values)?
 #define MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)                                                                    \
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
            m2 <= qz[1] + reach[1] && m5 >= qz[1] - reach[1]))
 
         // one staged pass = two tiles (64 points); the NEXT pass's loads are issued before this pass computes
-        int pend_a = -1, pend_b = -1;  // tile ids (global) whose points sit in the registers below
+        int pend_a = -1, pend_b = -1;  // tile ids whose points sit in the registers below
         float px = 0.f, py = 0.f, pz = 0.f;
         int po = 0;
 #define MOLA_LOAD_PAIR(TA, TB)                                                                                    \
@@ -492,13 +504,15 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
         po = 0x7fffffff;                                                                                          \
         if (tt_ >= 0) {                                                                                           \
             const int j_ = tt_ * kTileG + (lane & 31);                                                            \
-            px = sx[j_]; py = sy[j_]; pz = sz[j_]; po = perm[j_];                                                 \
+            px = sx[j_]; py = sy[j_]; pz = sz[j_];                                                                \
+            if (EXACT) po = perm[j_];                                                                             \
         }                                                                                                         \
     }
 #define MOLA_COMPUTE_PENDING(NEXT_A, NEXT_B)                                                                      \
     {                                                                                                             \
         const int ca_ = pend_a, cb_ = pend_b;                                                                     \
-        sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz; sm[3][lane] = __int_as_float(po);                   \
+        sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz;                                                     \
+        if (EXACT) sm[3][lane] = __int_as_float(po);                                                              \
         pend_a = (NEXT_A); pend_b = (NEXT_B);                                                                     \
         if (pend_a >= 0) MOLA_LOAD_PAIR(pend_a, pend_b)                                                           \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                    \
@@ -510,37 +524,61 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
             const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);                                         \
             const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);                                         \
             const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);                                         \
-            const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);                                         \
             const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w}; \
-            const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),         \
-                                        __float_as_uint(O.w)};                                                    \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
+            if (EXACT) {                                                                                          \
+                const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);                                     \
+                const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),     \
+                                            __float_as_uint(O.w)};                                                \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
+                    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                               \
+                        const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);                          \
+                        const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];     \
+                        const bool better = ck < key[k];                                                          \
+                        key[k] = better ? ck : key[k];                                                            \
+                        bpos[k] = better ? ((m + u) < 32 ? jb0_ + m + u : jb1_ + m + u - 32) : bpos[k];           \
+                    }                                                                                             \
+                }                                                                                                 \
+            } else {                                                                                              \
+                const int cpos = m < 32 ? jb0_ + m : jb1_ + m - 32; /* sorted position of this chunk */           \
                 _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                   \
-                    const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);                              \
-                    const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];         \
-                    const bool better = ck < key[k];                                                              \
-                    key[k] = better ? ck : key[k];                                                                \
-                    bpos[k] = better ? ((m + u) < 32 ? jb0_ + m + u : jb1_ + m + u - 32) : bpos[k];               \
+                    const float d0 = dist2(qx[k], qy[k], qz[k], xs[0], ys[0], zs[0]);                             \
+                    const float d1 = dist2(qx[k], qy[k], qz[k], xs[1], ys[1], zs[1]);                             \
+                    const float d2 = dist2(qx[k], qy[k], qz[k], xs[2], ys[2], zs[2]);                             \
+                    const float d3 = dist2(qx[k], qy[k], qz[k], xs[3], ys[3], zs[3]);                             \
+                    const float m4 = fminf(fminf(d0, d1), fminf(d2, d3));                                         \
+                    const bool lt = m4 < best[k];                                                                 \
+                    tie[k] = lt ? false : (tie[k] || (m4 == best[k] && cpos != bpos[k]));                         \
+                    best[k] = lt ? m4 : best[k];                                                                  \
+                    bpos[k] = lt ? cpos : bpos[k];                                                                \
                 }                                                                                                 \
             }                                                                                                     \
         }                                                                                                         \
         __builtin_amdgcn_wave_barrier(); /* the staging area is rewritten by the next pass */                     \
     }
 
-        for (int sb = 0; sb < n_super; sb += 64) {
+        // three box levels: top (64 super-tiles = 131072 points) -> super-tile (64 tiles) -> tile (32 points);
+        // each level is one coalesced load per lane and one ballot, so the scan is ~3 dependent round trips
+        // whatever the map size
+        for (int ub = 0; ub < n_top; ub += 64) {
+          const int ui = ub + lane;
+          const bool uin = ui < n_top;
+          unsigned long long ucand =
+              __ballot(uin && ubox[ui] <= w.hi[0] && ubox[n_top + ui] <= w.hi[1] && ubox[2 * n_top + ui] <= w.hi[2] &&
+                       ubox[3 * n_top + ui] >= w.lo[0] && ubox[4 * n_top + ui] >= w.lo[1] && ubox[5 * n_top + ui] >= w.lo[2]);
+          while (ucand) {
+            const int sb = (ub + __builtin_ctzll(ucand)) * 64;  // first super-tile of this top box (n_super is padded)
+            ucand &= ucand - 1;
             const int si = sb + lane;
-            const bool sin = si < n_super;
-            const float c0 = sin ? sbox[si] : INFINITY, c1 = sin ? sbox[n_super + si] : INFINITY,
-                        c2 = sin ? sbox[2 * n_super + si] : INFINITY, c3 = sin ? sbox[3 * n_super + si] : -INFINITY,
-                        c4 = sin ? sbox[4 * n_super + si] : -INFINITY, c5 = sin ? sbox[5 * n_super + si] : -INFINITY;
+            const float c0 = sbox[si], c1 = sbox[n_super + si], c2 = sbox[2 * n_super + si], c3 = sbox[3 * n_super + si],
+                        c4 = sbox[4 * n_super + si], c5 = sbox[5 * n_super + si];
             unsigned long long scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] &&
                                                 c4 >= w.lo[1] && c5 >= w.lo[2]);
             while (scand) {
                 const int sl_ = __builtin_ctzll(scand);
                 scand &= scand - 1;
                 {   // super-tile vs the individual queries: a bimodal query group must not descend everywhere
-                    const float m0 = __shfl(c0, sl_), m1 = __shfl(c1, sl_), m2 = __shfl(c2, sl_), m3 = __shfl(c3, sl_),
-                                m4 = __shfl(c4, sl_), m5 = __shfl(c5, sl_);
+                    const float m0 = bcast_lane(c0, sl_), m1 = bcast_lane(c1, sl_), m2 = bcast_lane(c2, sl_),
+                                m3 = bcast_lane(c3, sl_), m4 = bcast_lane(c4, sl_), m5 = bcast_lane(c5, sl_);
                     if (!MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)) continue;
                 }
                 const int S = sb + sl_;
@@ -553,11 +591,10 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
                 while (cand) {
                     const int t = __builtin_ctzll(cand);
                     cand &= cand - 1;
-                    const float m0 = __shfl(b0, t), m1 = __shfl(b1, t), m2 = __shfl(b2, t), m3 = __shfl(b3, t),
-                                m4 = __shfl(b4, t), m5 = __shfl(b5, t);
+                    const float m0 = bcast_lane(b0, t), m1 = bcast_lane(b1, t), m2 = bcast_lane(b2, t),
+                                m3 = bcast_lane(b3, t), m4 = bcast_lane(b4, t), m5 = bcast_lane(b5, t);
                     if (MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)) tmask |= 1ull << t;
                 }
-                if (dbg_stats) { const unsigned long long n = __builtin_amdgcn_s_memtime(); tscan += n - tmark; tmark = n; }
                 while (tmask) {
                     const int t0 = S * kSuper + __builtin_ctzll(tmask);
                     tmask &= tmask - 1;
@@ -570,44 +607,69 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
                         MOLA_COMPUTE_PENDING(t0, t1)
                     }
                 }
-                if (dbg_stats) { const unsigned long long n = __builtin_amdgcn_s_memtime(); tcomp += n - tmark; tmark = n; }
             }
+          }
         }
         if (pend_a >= 0) MOLA_COMPUTE_PENDING(-1, -1)
 #undef MOLA_COMPUTE_PENDING
 #undef MOLA_LOAD_PAIR
 #undef MOLA_ANY_REACH
-        if (lane == 0) {
-            const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
-            if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
-            atomicAdd(staged_total, n_staged);  // executed work: staged points x 128 queries
-        }
-        if (dbg_stats && lane == 0) {
-            const unsigned long long te = __builtin_amdgcn_s_memtime();
-            tscan += te - tmark;
-            atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged);
-            atomicAdd(&dbg_stats[5], ts1 - ts0);   // prologue
-            atomicAdd(&dbg_stats[6], tscan);       // box scans
-            atomicAdd(&dbg_stats[7], tstage);      // tile loads + LDS staging
-            atomicAdd(&dbg_stats[8], tcomp);       // distance evaluation
-            atomicMax(&dbg_stats[9], te - ts0);    // longest item
-        }
 
+        bool any_tie = false;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = item * kQPW + k * 64 + lane;
             if (i < N) {  // coalesced: the pairing stays in sorted query order
-                const float d = __uint_as_float((unsigned int)(key[k] >> 32));
-                const bool ok = d < thr2;
-                pos_s[i] = ok ? bpos[k] : -1;
-                idx_s[i] = ok ? (int)(unsigned int)(key[k] & 0xffffffffu) : -1;
+                int pos = -1, oi = -1;
+                float d = thr2;
+                if (EXACT) {
+                    d = __uint_as_float((unsigned int)(key[k] >> 32));
+                    if (d < thr2) { pos = bpos[k]; oi = (int)(unsigned int)(key[k] & 0xffffffffu); }
+                } else if (bpos[k] >= 0) {
+                    // resolve inside the winning chunk: the point(s) with d2 == best, lowest original index first
+                    d = best[k];
+                    const float4 X = *reinterpret_cast<const float4*>(sx + bpos[k]);
+                    const float4 Y = *reinterpret_cast<const float4*>(sy + bpos[k]);
+                    const float4 Z = *reinterpret_cast<const float4*>(sz + bpos[k]);
+                    const int4 Pm = *reinterpret_cast<const int4*>(perm + bpos[k]);
+                    const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                    const int ps[4] = {Pm.x, Pm.y, Pm.z, Pm.w};
+                    unsigned int bo = 0xffffffffu;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float du = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
+                        if (du == d && (unsigned int)ps[u] < bo) { bo = (unsigned int)ps[u]; pos = bpos[k] + u; }
+                    }
+                    oi = (int)bo;
+                    if (pos < 0) tie[k] = true;  // cannot happen (same arithmetic); be safe: exact pass
+                }
+                pos_s[i] = pos;
+                idx_s[i] = pos >= 0 ? oi : -1;
                 d2_s[i] = d;
-                kept += ok;
+                any_tie |= tie[k];
             }
         }
+        if (!EXACT && __any(any_tie)) {
+            if (lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
+        }
+        if (lane == 0) {
+            if (!EXACT) {
+                const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
+                if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+            }
+            atomicAdd(staged_total, n_staged);  // executed work: staged points x 128 queries
+            if (dbg_stats) { atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged); }
+        }
     }
+}
+
+// number of kept pairs of a stored pairing (only when a caller asks for it)
+__global__ __launch_bounds__(256) void k_count_kept(const int* __restrict__ idx, int N, unsigned int* __restrict__ counter)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned int kept = (i < N && idx[i] >= 0) ? 1u : 0u;
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
-    if (lane == 0 && kept) atomicAdd(kept_counter, kept);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, kept);
 }
 
 // heavy-first work order for the next launch: counting sort of the items by the cycles they took in the
@@ -831,19 +893,20 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* _
     }
 }
 
-// sums the per-block rows in a fixed order: 8 interleaved slices per accumulator, then the slices in order
-__global__ __launch_bounds__(192) void k_reduce_partials(const double* __restrict__ partials, int nblocks,
-                                                         double* __restrict__ acc)
+// sums the per-block rows in a fixed order: 32 interleaved slices per accumulator, then the slices in order
+constexpr int kRedSlices = 32;
+__global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const double* __restrict__ partials, int nblocks,
+                                                                        double* __restrict__ acc)
 {
-    __shared__ double sm[8][kNAcc];
+    __shared__ double sm[kRedSlices][kNAcc];
     const int k = threadIdx.x % kNAcc, sl = threadIdx.x / kNAcc;
     double v = 0.0;
-    for (int b = sl; b < nblocks; b += 8) v += partials[(size_t)b * kNAcc + k];
+    for (int b = sl; b < nblocks; b += kRedSlices) v += partials[(size_t)b * kNAcc + k];
     sm[sl][k] = v;
     __syncthreads();
     if (threadIdx.x < kNAcc) {
         double t = 0.0;
-        for (int s = 0; s < 8; ++s) t += sm[s][threadIdx.x];
+        for (int s = 0; s < kRedSlices; ++s) t += sm[s][threadIdx.x];
         acc[threadIdx.x] = t;
     }
 }
@@ -876,8 +939,9 @@ HipWorkspace::~HipWorkspace()
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
-    sorted_.release(); perm_.release(); tbox_.release(); sbox_.release(); lsorted_.release(); qperm_.release();
-    ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); item_cost_.release(); item_order_.release();
+    sorted_.release(); perm_.release(); tbox_.release(); sbox_.release(); ubox_.release(); lsorted_.release();
+    qperm_.release();
+    ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
     sort_scratch_.release();
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
@@ -998,6 +1062,7 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     N_ = N;
     queries_valid_ = false;
     cost_valid_ = false;
+    order_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -1013,6 +1078,7 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     N_ = N;
     queries_valid_ = false;
     cost_valid_ = false;
+    order_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -1098,12 +1164,15 @@ int HipWorkspace::prepare_tiles()
     if ((rc = bbox_of(gx_, gy_, gz_, M_, bbox))) return rc;
     const size_t super_pts = (size_t)kTileG * kSuper;
     n_super_ = (int)((M_ + super_pts - 1) / super_pts);
+    n_super_ = (n_super_ + 63) / 64 * 64;  // whole top boxes (the padding tiles get empty boxes)
+    n_top_ = n_super_ / 64;
     n_tiles_p_ = n_super_ * kSuper;
     m_padded_ = (size_t)n_tiles_p_ * kTileG;
     if ((rc = sorted_.reserve(sizeof(float) * 3 * m_padded_))) return rc;
     if ((rc = perm_.reserve(sizeof(int) * m_padded_))) return rc;
     if ((rc = tbox_.reserve(sizeof(float) * 6 * (size_t)n_tiles_p_))) return rc;
     if ((rc = sbox_.reserve(sizeof(float) * 6 * (size_t)n_super_))) return rc;
+    if ((rc = ubox_.reserve(sizeof(float) * 6 * (size_t)n_top_))) return rc;
     if ((rc = morton_sort_points(stream_, gx_, gy_, gz_, M_, m_padded_, bbox, sort_scratch_, sorted_.as<float>(),
                                  perm_.as<int>())))
         return rc;
@@ -1113,6 +1182,9 @@ int HipWorkspace::prepare_tiles()
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((n_super_ + 255) / 256)), dim3(256), 0, stream_, tbox_.as<float>(),
                        n_tiles_p_, n_super_, sbox_.as<float>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((n_top_ + 255) / 256)), dim3(256), 0, stream_, sbox_.as<float>(),
+                       n_super_, n_top_, ubox_.as<float>());
     HIPCHK(hipGetLastError());
     tiles_valid_ = true;
     return MOLA_ICP_OK;
@@ -1138,8 +1210,8 @@ int HipWorkspace::prepare_queries()
 int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
 {
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
-    int per_cu = 4;
-    if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 4;  // tuning knob
+    int per_cu = 3;  // measured best at C3: 1 -> 0.45 ms, 2 -> 0.31, 3 -> 0.30, 4 -> 0.33, 5 -> 0.35
+    if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 3;  // tuning knob
     int grid = num_cus_ * per_cu;
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     int rc;
@@ -1147,9 +1219,15 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     if ((rc = item_order_.reserve(sizeof(int) * (size_t)n_items))) return rc;
     const int* order = nullptr;
     if (cost_valid_ && !std::getenv("MOLA_ICP_NO_LPT")) {
-        hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
-                           item_order_.as<int>());
-        HIPCHK(hipGetLastError());
+        // the cost profile drifts slowly with the pose: re-sort every 4th launch, reuse the order in between
+        if (!order_valid_ || (launches_since_order_ & 3) == 0) {
+            hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
+                               item_order_.as<int>());
+            HIPCHK(hipGetLastError());
+            order_valid_ = true;
+            launches_since_order_ = 0;
+        }
+        ++launches_since_order_;
         order = item_order_.as<int>();
     }
     if ((rc = ts_pos_.reserve(sizeof(int) * n_padded_))) return rc;
@@ -1157,11 +1235,23 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     if ((rc = ts_d2_.reserve(sizeof(float) * n_padded_))) return rc;
     const float* sl = lsorted_.as<float>();
     const float* sx = sorted_.as<float>();
-    hipLaunchKernelGGL(k_nn_tiled, dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_, (int)N_,
-                       (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(), tbox_.as<float>(), n_tiles_p_,
-                       sbox_.as<float>(), n_super_, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(),
-                       ts_d2_.as<float>(), order, item_cost_.as<unsigned int>(), counter + 1, counter,
-                       reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4), dbg_stats_);
+    if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
+    unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
+    // counter[1] = work queue (fast pass), counter[2] = redo count, counter[3] = work queue (exact pass)
+    hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,
+                       (int)N_, (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(), tbox_.as<float>(),
+                       n_tiles_p_, sbox_.as<float>(), n_super_, ubox_.as<float>(), n_top_, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),
+                       ts_idx_.as<int>(), ts_d2_.as<float>(), order, item_cost_.as<unsigned int>(), counter + 1,
+                       counter + 2, redo_list_.as<int>(), staged, dbg_stats_);
+    HIPCHK(hipGetLastError());
+    // exact ties (duplicate points, lattices): the queued items again with the full lexicographic key.
+    // Usually zero items: a few waves that read the count and leave.
+    hipLaunchKernelGGL((k_nn_tiled<true>), dim3(grid < 64 ? grid : 64), dim3(256), 0, stream_, sl, sl + n_padded_,
+                       sl + 2 * n_padded_, (int)N_, (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(),
+                       tbox_.as<float>(), n_tiles_p_, sbox_.as<float>(), n_super_, ubox_.as<float>(), n_top_, P, thr2,
+                       /*seed = fast pass's result*/ 1,
+                       ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr,
+                       (unsigned int*)nullptr, counter + 3, counter + 2, redo_list_.as<int>(), staged, dbg_stats_);
     cost_valid_ = true;
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
@@ -1317,6 +1407,12 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
     if (n_pairs) {
         unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
         unsigned int* hc = reinterpret_cast<unsigned int*>(acc_host_ + kNAcc);
+        if (pairing_sorted_) {  // the tiled kernels do not count: do it now
+            HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream_));
+            hipLaunchKernelGGL(k_count_kept, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, ts_idx_.as<int>(),
+                               (int)N_, counter);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipMemcpyAsync(hc, counter, sizeof(unsigned int), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         *n_pairs = *hc;
@@ -1370,7 +1466,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         for (int c = 0; c < 3; ++c) a.R[3 * r + c] = Tcur(r, c);
     hipLaunchKernelGGL(k_accumulate, dim3(nblocks), dim3(kAccThreads), 0, stream_, a, partials_.as<double>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(192), 0, stream_, partials_.as<double>(), nblocks,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kNAcc * kRedSlices), 0, stream_, partials_.as<double>(), nblocks,
                        acc_dev_.as<double>());
     HIPCHK(hipGetLastError());
     if (comm_) {  // query-sharded: the one collective of the path, in place on the device block (RCCL over xGMI)

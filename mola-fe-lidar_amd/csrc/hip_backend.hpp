@@ -97,13 +97,15 @@ class HipWorkspace final : public Stages {
     int num_cus_ = 256;
     // tiled matcher: Morton-sorted map (SoA, padded to whole super-tiles) + permutation + tile / super-tile boxes,
     // Morton-sorted local cloud + permutation
-    DevBuf sorted_, perm_, tbox_, sbox_, lsorted_, qperm_, sort_scratch_;
+    DevBuf sorted_, perm_, tbox_, sbox_, ubox_, lsorted_, qperm_, sort_scratch_;
     DevBuf ts_pos_, ts_idx_, ts_d2_;  // the tiled matcher's pairing, in SORTED query order
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
+    DevBuf redo_list_;                // work items with exact distance ties: redone with the full lexicographic key
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
-    bool cost_valid_ = false;
+    bool cost_valid_ = false, order_valid_ = false;
+    unsigned int launches_since_order_ = 0;
     bool tiles_valid_ = false, queries_valid_ = false;
-    int n_tiles_p_ = 0, n_super_ = 0;
+    int n_tiles_p_ = 0, n_super_ = 0, n_top_ = 0;
     size_t m_padded_ = 0, n_padded_ = 0;
     // pairing + scratch
     DevBuf idx_, d2_, seg_idx_, seg_d2_, outlier_, partials_, acc_dev_;

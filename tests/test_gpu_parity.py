@@ -262,20 +262,56 @@ def test_sequential_shards_equal_full(pkg, icp, synth):
         assert tot[16] == full[16]
 
 
-def test_resident_device_tensors(pkg, O, synth, small_scene):
-    torch = pytest.importorskip("torch")
+class _HipBuf:
+    """device buffer through the process's HIP runtime (ctypes), so the GPU suite needs no torch"""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes
+            cls._hip = ctypes.CDLL("libamdhip64.so.7")  # the instance the product library already uses (same SONAME)
+            cls._hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+            cls._hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            cls._hip.hipFree.argtypes = [ctypes.c_void_p]
+        return cls._hip
+
+    def __init__(self, host):
+        import ctypes
+        self.host = np.ascontiguousarray(host, dtype=np.float32)
+        self.ptr = ctypes.c_void_p()
+        assert self.hip().hipMalloc(ctypes.byref(self.ptr), self.host.nbytes) == 0
+        assert self.hip().hipMemcpy(self.ptr, self.host.ctypes.data, self.host.nbytes, 1) == 0  # hipMemcpyHostToDevice
+
+    def row(self, k):
+        return self.ptr.value + k * self.host.shape[1] * 4
+
+    def free(self):
+        self.hip().hipFree(self.ptr)
+
+
+def test_resident_device_pointers(pkg, O, synth, small_scene):
+    """clouds already in HBM (caller-owned device pointers): mola_icp_set_*_device + align_resident"""
+    import ctypes
     g, l, _ = synth.make_pair(8000, 6000, seed=31, scene=small_scene)
     icp = pkg.ICP(device=0)
-    tg, tl = torch.from_numpy(g).cuda(), torch.from_numpy(l).cuda()
-    icp.set_stream(torch.cuda.current_stream().cuda_stream)
-    icp.set_map(tg)
-    icp.set_local(tl)
+    dg, dl = _HipBuf(g), _HipBuf(l)
+    L = pkg._lib
+    L.check(L.lib().mola_icp_set_map_device(icp._h, dg.row(0), dg.row(1), dg.row(2), g.shape[1]))
+    L.check(L.lib().mola_icp_set_local_device(icp._h, dl.row(0), dl.row(1), dl.row(2), l.shape[1]))
     p = p2p_params(pkg, max_iterations=30)
-    r = icp.align_resident(np.eye(4), p)
-    ref = O.align(g, l, np.eye(4), O.params_from_product(p))
-    rot, trans = O.pose_error(r.optimal_tf, ref["T"])
-    assert r.nIterations == ref["n_iterations"] and rot < 1e-8 and trans < 1e-8
+    for kern in (pkg.NN_VALU, pkg.NN_MFMA, pkg.NN_TILED):
+        p.nn_kernel = kern
+        r = icp.align_resident(np.eye(4), p)
+        ref = O.align(g, l, np.eye(4), O.params_from_product(p))
+        rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+        assert r.nIterations == ref["n_iterations"] and rot < 1e-8 and trans < 1e-8
+        assert r.nn_kernel_used == kern
+    icp.set_stream(None)  # own stream again
+    assert icp.align_resident(np.eye(4), p).nIterations == ref["n_iterations"]
     icp.close()
+    dg.free()
+    dl.free()
 
 
 def test_loop_closure_montecarlo_multi_init(pkg, O, icp, synth, small_scene):
