@@ -227,7 +227,20 @@ int mola_icp_accumulate(mola_icp_handle* h, const mola_icp_params* p, const doub
                         const double cl[3], const double cg[3], int reset_outliers,
                         double acc_out[MOLA_ICP_NACC]);
 
+/* point-to-plane matcher (mp2p_icp::Matcher_Point2Plane, icpreg:33-39) on the resident clouds at pose T, for
+ * parity tests: valid[N], centroid[N*3], normal[N*3], knn_idx[N*p->knn] (original map indices, -1 padded);
+ * any output may be NULL.  *n_pairs_out = number of plane pairings. */
+int mola_icp_match_planes(mola_icp_handle* h, const double T[16], const mola_icp_params* p, uint8_t* valid,
+                          double* centroid, double* normal, int32_t* knn_idx, uint64_t* n_pairs_out);
+
 /* ---- host-side math (no GPU needed) ------------------------------------ */
+#define MOLA_ICP_NACC_PLANES 92
+/* Gauss-Newton (mp2p_icp::Solver_GaussNewton, icpreg:23-26) on the point-to-plane cost given as the quadratic
+ * form x^T A x - 2 b^T x + c0 in x = [R row-major, t]: acc = A's upper triangle (78, row-major a<=b), b (12),
+ * c0, pair count.  This is what the loop runs after the single device accumulation pass. */
+int mola_icp_solve_gauss_newton_planes(const double acc[MOLA_ICP_NACC_PLANES], const double T0[16],
+                                       uint32_t max_iterations, double T_out[16], double* final_cost,
+                                       uint32_t* iterations_done);
 /* Horn closed form on an accumulator block (row a9).  cl/cg may be NULL
  * (weighted means of acc).  Returns MOLA_ICP_E_BADARG if W<=0. */
 int mola_icp_solve_horn(const double acc[MOLA_ICP_NACC], const double* cl, const double* cg, double T_out[16]);

@@ -490,6 +490,41 @@ int mola_icp_accumulate(mola_icp_handle* h, const mola_icp_params* p, const doub
     });
 }
 
+int mola_icp_match_planes(mola_icp_handle* h, const double T[16], const mola_icp_params* p, uint8_t* valid,
+                          double* centroid, double* normal, int32_t* knn_idx, uint64_t* n_pairs_out)
+{
+    return guarded([&]() -> int {
+        if (!h || !p) return fail(MOLA_ICP_E_BADARG, "null argument");
+        int rc;
+        if ((rc = check_pose(T))) return rc;
+        std::lock_guard<std::mutex> lk(h->mtx);
+        if ((rc = h->resident->match_planes(mat_from(T), *p))) return rc;
+        if (n_pairs_out) {
+            double acc[kNAccPlaneHost];
+            if ((rc = h->resident->accumulate_planes(acc))) return rc;
+            *n_pairs_out = (uint64_t)acc[91];
+        }
+        if (valid || centroid || normal || knn_idx) return h->resident->copy_planes(valid, centroid, normal, knn_idx);
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_solve_gauss_newton_planes(const double acc[MOLA_ICP_NACC_PLANES], const double T0[16],
+                                       uint32_t max_iterations, double T_out[16], double* final_cost,
+                                       uint32_t* iterations_done)
+{
+    if (!acc || !T0 || !T_out) return fail(MOLA_ICP_E_BADARG, "null argument");
+    Mat4 T;
+    unsigned its = 0;
+    double cost = 0;
+    if (!solve_gauss_newton_planes(acc, mat_from(T0), max_iterations, T, &cost, &its))
+        return fail(MOLA_ICP_E_BADARG, "Gauss-Newton: fewer than 3 pairings or singular normal equations");
+    std::memcpy(T_out, T.m, sizeof T.m);
+    if (final_cost) *final_cost = cost;
+    if (iterations_done) *iterations_done = its;
+    return MOLA_ICP_OK;
+}
+
 int mola_icp_solve_horn(const double acc[MOLA_ICP_NACC], const double* cl, const double* cg, double T_out[16])
 {
     if (!acc || !T_out) return fail(MOLA_ICP_E_BADARG, "null argument");

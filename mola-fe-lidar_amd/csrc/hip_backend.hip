@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace mola_icp_amd {
 
@@ -400,6 +401,148 @@ __device__ __forceinline__ float bcast_lane(float v, int lane_uniform)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
 }
 
+// the sorted map + its three box levels, as the tiled kernels see it
+struct TiledMap {
+    const float *sx, *sy, *sz;  // Hilbert-sorted points, padded to whole super-tiles
+    const int* perm;            // sorted position -> original index (0x7fffffff in the padding)
+    const float* tbox; int n_tiles_p;   // tile boxes        SoA [6][n_tiles_p]
+    const float* sbox; int n_super;     // super-tile boxes  SoA [6][n_super]  (n_super padded to 64)
+    const float* ubox; int n_top;       // top boxes         SoA [6][n_top]
+};
+
+// The sweep shared by the tiled kernels: wave box from the per-query reaches, three-level box scan with the
+// per-query re-test, LDS staging of the surviving tiles two at a time with the next pair's loads in flight.
+// `visit(nm, jb0, jb1)` is called once per staged pass: sm[0..2][0..nm) hold x,y,z of the staged points
+// (sm[3] their original indices if NEED_PERM); points [0,32) have sorted positions jb0.., [32,64) jb1...
+// Returns the number of staged points.
+template <bool NEED_PERM, class Visit>
+__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, int lane, float (*sm)[64],
+                                                          const float (&qx)[2], const float (&qy)[2],
+                                                          const float (&qz)[2], const float (&reach)[2], Visit&& visit)
+{
+    Box w;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { w.lo[a] = INFINITY; w.hi[a] = -INFINITY; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (reach[k] >= 0.f) {
+            w.lo[0] = fminf(w.lo[0], qx[k] - reach[k]); w.hi[0] = fmaxf(w.hi[0], qx[k] + reach[k]);
+            w.lo[1] = fminf(w.lo[1], qy[k] - reach[k]); w.hi[1] = fmaxf(w.hi[1], qy[k] + reach[k]);
+            w.lo[2] = fminf(w.lo[2], qz[k] - reach[k]); w.hi[2] = fmaxf(w.hi[2], qz[k] + reach[k]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
+            w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
+        }
+    }
+    unsigned long long n_staged = 0;
+
+    // does ANY query of the wave reach the box (m0..m5 = min xyz, max xyz; wave-uniform values)?
+    auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
+        return __any((m0 <= qx[0] + reach[0] && m3 >= qx[0] - reach[0] && m1 <= qy[0] + reach[0] &&
+                      m4 >= qy[0] - reach[0] && m2 <= qz[0] + reach[0] && m5 >= qz[0] - reach[0]) ||
+                     (m0 <= qx[1] + reach[1] && m3 >= qx[1] - reach[1] && m1 <= qy[1] + reach[1] &&
+                      m4 >= qy[1] - reach[1] && m2 <= qz[1] + reach[1] && m5 >= qz[1] - reach[1]));
+    };
+
+    int pend_a = -1, pend_b = -1;  // tile ids whose points sit in the registers below
+    float px = 0.f, py = 0.f, pz = 0.f;
+    int po = 0;
+    auto load_pair = [&](int ta, int tb) {
+        const int tt = lane < 32 ? ta : tb;
+        px = py = pz = 1.0e18f;  // padding points: d2 ~ 3e36, never a neighbour
+        po = 0x7fffffff;
+        if (tt >= 0) {
+            const int j = tt * kTileG + (lane & 31);
+            px = mp.sx[j]; py = mp.sy[j]; pz = mp.sz[j];
+            if (NEED_PERM) po = mp.perm[j];
+        }
+    };
+    auto compute_pending = [&](int next_a, int next_b) {
+        const int ca = pend_a, cb = pend_b;
+        sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz;
+        if (NEED_PERM) sm[3][lane] = __int_as_float(po);
+        pend_a = next_a; pend_b = next_b;
+        if (pend_a >= 0) load_pair(pend_a, pend_b);  // next pass's loads fly while this pass computes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nm = cb >= 0 ? 64 : 32;
+        n_staged += nm;
+        visit(nm, ca * kTileG, (cb >= 0 ? cb : ca) * kTileG);
+        __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next pass
+    };
+
+    // three box levels: top (64 super-tiles = 131072 points) -> super-tile (64 tiles) -> tile (32 points); each
+    // level is one coalesced load per lane and one ballot: ~3 dependent round trips whatever the map size
+    for (int ub = 0; ub < mp.n_top; ub += 64) {
+        const int ui = ub + lane;
+        const bool uin = ui < mp.n_top;
+        unsigned long long ucand = __ballot(
+            uin && mp.ubox[ui] <= w.hi[0] && mp.ubox[mp.n_top + ui] <= w.hi[1] && mp.ubox[2 * mp.n_top + ui] <= w.hi[2] &&
+            mp.ubox[3 * mp.n_top + ui] >= w.lo[0] && mp.ubox[4 * mp.n_top + ui] >= w.lo[1] &&
+            mp.ubox[5 * mp.n_top + ui] >= w.lo[2]);
+        while (ucand) {
+            const int sb = (ub + __builtin_ctzll(ucand)) * 64;  // first super-tile of this top box
+            ucand &= ucand - 1;
+            const int si = sb + lane;
+            const float c0 = mp.sbox[si], c1 = mp.sbox[mp.n_super + si], c2 = mp.sbox[2 * mp.n_super + si],
+                        c3 = mp.sbox[3 * mp.n_super + si], c4 = mp.sbox[4 * mp.n_super + si],
+                        c5 = mp.sbox[5 * mp.n_super + si];
+            unsigned long long scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] &&
+                                                c4 >= w.lo[1] && c5 >= w.lo[2]);
+            while (scand) {
+                const int sl = __builtin_ctzll(scand);
+                scand &= scand - 1;
+                // super-tile vs the individual queries: a bimodal query group must not descend everywhere
+                if (!any_reach(bcast_lane(c0, sl), bcast_lane(c1, sl), bcast_lane(c2, sl), bcast_lane(c3, sl),
+                               bcast_lane(c4, sl), bcast_lane(c5, sl)))
+                    continue;
+                const int S = sb + sl;
+                const int ti = S * kSuper + lane;
+                const float b0 = mp.tbox[ti], b1 = mp.tbox[mp.n_tiles_p + ti], b2 = mp.tbox[2 * mp.n_tiles_p + ti],
+                            b3 = mp.tbox[3 * mp.n_tiles_p + ti], b4 = mp.tbox[4 * mp.n_tiles_p + ti],
+                            b5 = mp.tbox[5 * mp.n_tiles_p + ti];
+                unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
+                                                   b4 >= w.lo[1] && b5 >= w.lo[2]);
+                unsigned long long tmask = 0;
+                while (cand) {
+                    const int t = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
+                                  bcast_lane(b4, t), bcast_lane(b5, t)))
+                        tmask |= 1ull << t;
+                }
+                while (tmask) {
+                    const int t0 = S * kSuper + __builtin_ctzll(tmask);
+                    tmask &= tmask - 1;
+                    int t1 = -1;
+                    if (tmask) { t1 = S * kSuper + __builtin_ctzll(tmask); tmask &= tmask - 1; }
+                    if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
+                        pend_a = t0; pend_b = t1;
+                        load_pair(t0, t1);
+                    } else {
+                        compute_pending(t0, t1);
+                    }
+                }
+            }
+        }
+    }
+    if (pend_a >= 0) compute_pending(-1, -1);
+    return n_staged;
+}
+
+// reach of a query whose current best squared distance is `best`: any m with d2_contract <= best lies inside
+// [q - r, q + r] per axis (sqrt rounded up, plus 2 ulp of the largest coordinate)
+__device__ __forceinline__ float reach_of(float best, float qx, float qy, float qz)
+{
+    const float cmax = fmaxf(fabsf(qx), fmaxf(fabsf(qy), fabsf(qz)));
+    return sqrtf(best * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
+}
+
 // EXACT = false: the fast sweep.  Per (query, 4-point chunk) only the chunk minimum is compared with the
 //   running best (~6 VALU ops per pair); the winning chunk is re-evaluated once at the end to recover the
 //   exact point and the lowest-original-index rule inside it.  If an EQUAL minimum showed up in a different
@@ -408,12 +551,7 @@ __device__ __forceinline__ float bcast_lane(float v, int lane_uniform)
 //   (d2 bits << 32 | original index), i.e. the full lexicographic rule (~10 ops per pair).
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
-                                                  const float* __restrict__ slz, int N, int M,
-                                                  const float* __restrict__ sx, const float* __restrict__ sy,
-                                                  const float* __restrict__ sz, const int* __restrict__ perm,
-                                                  const float* __restrict__ tbox, int n_tiles_p,
-                                                  const float* __restrict__ sbox, int n_super,
-                                                  const float* __restrict__ ubox, int n_top, PoseF P, float thr2,
+                                                  const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
                                                   float* __restrict__ d2_s, const int* __restrict__ item_order,
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
@@ -440,9 +578,6 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
         float best[2];              // fast: running minimum
         int bpos[2];                // EXACT: sorted position of the best point; fast: of its 4-point chunk
         bool tie[2] = {false, false};
-        Box w;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { w.lo[k] = INFINITY; w.hi[k] = -INFINITY; }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = item * kQPW + k * 64 + lane;
@@ -456,164 +591,56 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
                 if (use_seed) {  // warm start: last iteration's neighbour is an exact candidate
                     const int js = pos_s[i];  // sorted-map position: neighbours of neighbours share cache lines
                     if (js >= 0) {
-                        const float d = dist2(qx[k], qy[k], qz[k], sx[js], sy[js], sz[js]);
+                        const float d = dist2(qx[k], qy[k], qz[k], mp.sx[js], mp.sy[js], mp.sz[js]);
                         if (d < thr2) {
                             best[k] = d;
                             bpos[k] = EXACT ? js : (js & ~3);
-                            if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)perm[js];
+                            if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)mp.perm[js];
                         }
                     }
                 }
-                // reach: any m with d2_contract <= best lies inside [q - r, q + r] (r rounded up, plus 2 ulp of q)
-                const float c[3] = {qx[k], qy[k], qz[k]};
-                const float cmax = fmaxf(fabsf(c[0]), fmaxf(fabsf(c[1]), fabsf(c[2])));
-                reach[k] = sqrtf(best[k] * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    w.lo[a] = fminf(w.lo[a], c[a] - reach[k]);
-                    w.hi[a] = fmaxf(w.hi[a], c[a] + reach[k]);
-                }
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
-                w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
+                reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
             }
         }
 
-        unsigned long long n_staged = 0;
-
-        // does ANY query of the wave reach the box (m0..m5 = min xyz, max xyz; wave-uniform values)?
-#define MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)                                                                    \
-    __any((m0 <= qx[0] + reach[0] && m3 >= qx[0] - reach[0] && m1 <= qy[0] + reach[0] && m4 >= qy[0] - reach[0] && \
-           m2 <= qz[0] + reach[0] && m5 >= qz[0] - reach[0]) ||                                                    \
-          (m0 <= qx[1] + reach[1] && m3 >= qx[1] - reach[1] && m1 <= qy[1] + reach[1] && m4 >= qy[1] - reach[1] && \
-           m2 <= qz[1] + reach[1] && m5 >= qz[1] - reach[1]))
-
-        // one staged pass = two tiles (64 points); the NEXT pass's loads are issued before this pass computes
-        int pend_a = -1, pend_b = -1;  // tile ids whose points sit in the registers below
-        float px = 0.f, py = 0.f, pz = 0.f;
-        int po = 0;
-#define MOLA_LOAD_PAIR(TA, TB)                                                                                    \
-    {                                                                                                             \
-        const int tt_ = lane < 32 ? (TA) : (TB);                                                                  \
-        px = py = pz = 1.0e18f;                                                                                   \
-        po = 0x7fffffff;                                                                                          \
-        if (tt_ >= 0) {                                                                                           \
-            const int j_ = tt_ * kTileG + (lane & 31);                                                            \
-            px = sx[j_]; py = sy[j_]; pz = sz[j_];                                                                \
-            if (EXACT) po = perm[j_];                                                                             \
-        }                                                                                                         \
-    }
-#define MOLA_COMPUTE_PENDING(NEXT_A, NEXT_B)                                                                      \
-    {                                                                                                             \
-        const int ca_ = pend_a, cb_ = pend_b;                                                                     \
-        sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz;                                                     \
-        if (EXACT) sm[3][lane] = __int_as_float(po);                                                              \
-        pend_a = (NEXT_A); pend_b = (NEXT_B);                                                                     \
-        if (pend_a >= 0) MOLA_LOAD_PAIR(pend_a, pend_b)                                                           \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                    \
-        __builtin_amdgcn_wave_barrier();                                                                          \
-        const int nm_ = cb_ >= 0 ? 64 : 32;                                                                       \
-        const int jb0_ = ca_ * kTileG, jb1_ = (cb_ >= 0 ? cb_ : ca_) * kTileG;                                    \
-        n_staged += nm_;                                                                                          \
-        for (int m = 0; m < nm_; m += 4) {                                                                        \
-            const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);                                         \
-            const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);                                         \
-            const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);                                         \
-            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w}; \
-            if (EXACT) {                                                                                          \
-                const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);                                     \
-                const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),     \
-                                            __float_as_uint(O.w)};                                                \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
-                    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                               \
-                        const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);                          \
-                        const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];     \
-                        const bool better = ck < key[k];                                                          \
-                        key[k] = better ? ck : key[k];                                                            \
-                        bpos[k] = better ? ((m + u) < 32 ? jb0_ + m + u : jb1_ + m + u - 32) : bpos[k];           \
-                    }                                                                                             \
-                }                                                                                                 \
-            } else {                                                                                              \
-                const int cpos = m < 32 ? jb0_ + m : jb1_ + m - 32; /* sorted position of this chunk */           \
-                _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                   \
-                    const float d0 = dist2(qx[k], qy[k], qz[k], xs[0], ys[0], zs[0]);                             \
-                    const float d1 = dist2(qx[k], qy[k], qz[k], xs[1], ys[1], zs[1]);                             \
-                    const float d2 = dist2(qx[k], qy[k], qz[k], xs[2], ys[2], zs[2]);                             \
-                    const float d3 = dist2(qx[k], qy[k], qz[k], xs[3], ys[3], zs[3]);                             \
-                    const float m4 = fminf(fminf(d0, d1), fminf(d2, d3));                                         \
-                    const bool lt = m4 < best[k];                                                                 \
-                    tie[k] = lt ? false : (tie[k] || (m4 == best[k] && cpos != bpos[k]));                         \
-                    best[k] = lt ? m4 : best[k];                                                                  \
-                    bpos[k] = lt ? cpos : bpos[k];                                                                \
-                }                                                                                                 \
-            }                                                                                                     \
-        }                                                                                                         \
-        __builtin_amdgcn_wave_barrier(); /* the staging area is rewritten by the next pass */                     \
-    }
-
-        // three box levels: top (64 super-tiles = 131072 points) -> super-tile (64 tiles) -> tile (32 points);
-        // each level is one coalesced load per lane and one ballot, so the scan is ~3 dependent round trips
-        // whatever the map size
-        for (int ub = 0; ub < n_top; ub += 64) {
-          const int ui = ub + lane;
-          const bool uin = ui < n_top;
-          unsigned long long ucand =
-              __ballot(uin && ubox[ui] <= w.hi[0] && ubox[n_top + ui] <= w.hi[1] && ubox[2 * n_top + ui] <= w.hi[2] &&
-                       ubox[3 * n_top + ui] >= w.lo[0] && ubox[4 * n_top + ui] >= w.lo[1] && ubox[5 * n_top + ui] >= w.lo[2]);
-          while (ucand) {
-            const int sb = (ub + __builtin_ctzll(ucand)) * 64;  // first super-tile of this top box (n_super is padded)
-            ucand &= ucand - 1;
-            const int si = sb + lane;
-            const float c0 = sbox[si], c1 = sbox[n_super + si], c2 = sbox[2 * n_super + si], c3 = sbox[3 * n_super + si],
-                        c4 = sbox[4 * n_super + si], c5 = sbox[5 * n_super + si];
-            unsigned long long scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] &&
-                                                c4 >= w.lo[1] && c5 >= w.lo[2]);
-            while (scand) {
-                const int sl_ = __builtin_ctzll(scand);
-                scand &= scand - 1;
-                {   // super-tile vs the individual queries: a bimodal query group must not descend everywhere
-                    const float m0 = bcast_lane(c0, sl_), m1 = bcast_lane(c1, sl_), m2 = bcast_lane(c2, sl_),
-                                m3 = bcast_lane(c3, sl_), m4 = bcast_lane(c4, sl_), m5 = bcast_lane(c5, sl_);
-                    if (!MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)) continue;
-                }
-                const int S = sb + sl_;
-                const int ti = S * kSuper + lane;
-                const float b0 = tbox[ti], b1 = tbox[n_tiles_p + ti], b2 = tbox[2 * n_tiles_p + ti],
-                            b3 = tbox[3 * n_tiles_p + ti], b4 = tbox[4 * n_tiles_p + ti], b5 = tbox[5 * n_tiles_p + ti];
-                unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
-                                                   b4 >= w.lo[1] && b5 >= w.lo[2]);
-                unsigned long long tmask = 0;
-                while (cand) {
-                    const int t = __builtin_ctzll(cand);
-                    cand &= cand - 1;
-                    const float m0 = bcast_lane(b0, t), m1 = bcast_lane(b1, t), m2 = bcast_lane(b2, t),
-                                m3 = bcast_lane(b3, t), m4 = bcast_lane(b4, t), m5 = bcast_lane(b5, t);
-                    if (MOLA_ANY_REACH(m0, m1, m2, m3, m4, m5)) tmask |= 1ull << t;
-                }
-                while (tmask) {
-                    const int t0 = S * kSuper + __builtin_ctzll(tmask);
-                    tmask &= tmask - 1;
-                    int t1 = -1;
-                    if (tmask) { t1 = S * kSuper + __builtin_ctzll(tmask); tmask &= tmask - 1; }
-                    if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
-                        pend_a = t0; pend_b = t1;
-                        MOLA_LOAD_PAIR(t0, t1)
-                    } else {
-                        MOLA_COMPUTE_PENDING(t0, t1)
+        const unsigned long long n_staged = tiled_sweep<EXACT>(mp, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
+            for (int m = 0; m < nm; m += 4) {
+                const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+                const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+                const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
+                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                if (EXACT) {
+                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
+                                                __float_as_uint(O.w)};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
+                            const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
+                            const bool better = ck < key[k];
+                            key[k] = better ? ck : key[k];
+                            bpos[k] = better ? ((m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32) : bpos[k];
+                        }
+                    }
+                } else {
+                    const int cpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this chunk
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float d0 = dist2(qx[k], qy[k], qz[k], xs[0], ys[0], zs[0]);
+                        const float d1 = dist2(qx[k], qy[k], qz[k], xs[1], ys[1], zs[1]);
+                        const float d2 = dist2(qx[k], qy[k], qz[k], xs[2], ys[2], zs[2]);
+                        const float d3 = dist2(qx[k], qy[k], qz[k], xs[3], ys[3], zs[3]);
+                        const float m4 = fminf(fminf(d0, d1), fminf(d2, d3));
+                        const bool lt = m4 < best[k];
+                        tie[k] = lt ? false : (tie[k] || (m4 == best[k] && cpos != bpos[k]));
+                        best[k] = lt ? m4 : best[k];
+                        bpos[k] = lt ? cpos : bpos[k];
                     }
                 }
             }
-          }
-        }
-        if (pend_a >= 0) MOLA_COMPUTE_PENDING(-1, -1)
-#undef MOLA_COMPUTE_PENDING
-#undef MOLA_LOAD_PAIR
-#undef MOLA_ANY_REACH
+        });
 
         bool any_tie = false;
 #pragma unroll
@@ -628,10 +655,10 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
                 } else if (bpos[k] >= 0) {
                     // resolve inside the winning chunk: the point(s) with d2 == best, lowest original index first
                     d = best[k];
-                    const float4 X = *reinterpret_cast<const float4*>(sx + bpos[k]);
-                    const float4 Y = *reinterpret_cast<const float4*>(sy + bpos[k]);
-                    const float4 Z = *reinterpret_cast<const float4*>(sz + bpos[k]);
-                    const int4 Pm = *reinterpret_cast<const int4*>(perm + bpos[k]);
+                    const float4 X = *reinterpret_cast<const float4*>(mp.sx + bpos[k]);
+                    const float4 Y = *reinterpret_cast<const float4*>(mp.sy + bpos[k]);
+                    const float4 Z = *reinterpret_cast<const float4*>(mp.sz + bpos[k]);
+                    const int4 Pm = *reinterpret_cast<const int4*>(mp.perm + bpos[k]);
                     const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
                     const int ps[4] = {Pm.x, Pm.y, Pm.z, Pm.w};
                     unsigned int bo = 0xffffffffu;
@@ -661,6 +688,280 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
             if (dbg_stats) { atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged); }
         }
     }
+}
+
+// ---- row f3: point-to-plane matcher (mp2p_icp::Matcher_Point2Plane, params/icp-settings-regular.yaml:33-39) ----
+// Same tiled sweep; the visitor keeps, per query, the K nearest points as a sorted list ordered by
+// (d2, original index).  The reach is the gate (distanceThreshold): only neighbours inside it matter.
+// Epilogue per query: the neighbours inside the gate (need >= 3) -> mean + covariance in fp64 -> cyclic
+// Jacobi eigen-decomposition -> plane iff e0 <= planeEigenThreshold * e2, normal = eigenvector of e0,
+// pairing iff |n.(q - mean)| <= distanceThreshold.  [EXT-recalled mp2p_icp behaviour; restated in the
+// CPU checker with the same operation order.]
+struct PlanePair {      // one per query, sorted query order
+    double c[3];        // plane centroid
+    double n[3];        // unit normal
+    int valid, n_neigh;
+};
+
+__device__ __forceinline__ void eig_sym3_dev(const double Cin[3][3], double ev[3], double V[3][3])
+{
+    double A[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { A[i][j] = Cin[i][j]; V[i][j] = (i == j); }
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off == 0 || off < 1e-34 * dg) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                if (A[p][q] == 0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(tt * tt + 1), s2 = tt * c;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s2 * b; A[k][q] = s2 * a + c * b; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s2 * b; A[q][k] = s2 * a + c * b; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s2 * b; V[k][q] = s2 * a + c * b; }
+            }
+    }
+    // ascending order (bubble on 3 values, with the matching columns)
+    double d[3] = {A[0][0], A[1][1], A[2][2]};
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (d[o0] > d[o1]) { const int t = o0; o0 = o1; o1 = t; }
+    if (d[o1] > d[o2]) { const int t = o1; o1 = o2; o2 = t; }
+    if (d[o0] > d[o1]) { const int t = o0; o0 = o1; o1 = t; }
+    const int o[3] = {o0, o1, o2};
+    double Vs[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        ev[k] = o[k] == 0 ? d[0] : (o[k] == 1 ? d[1] : d[2]);
+#pragma unroll
+        for (int r = 0; r < 3; r++) Vs[r][k] = o[k] == 0 ? V[r][0] : (o[k] == 1 ? V[r][1] : V[r][2]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) V[r][k] = Vs[r][k];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                    const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
+                                                    float thr2, double threshold, double plane_eig_thr,
+                                                    PlanePair* __restrict__ out, int* __restrict__ knn_pos /*N x K, may be null*/,
+                                                    unsigned int* __restrict__ queue,
+                                                    unsigned long long* __restrict__ staged_total)
+{
+    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float(*sm)[64] = s_m[wave];
+    const int n_items = (N + kQPW - 1) / kQPW;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = (int)atomicAdd(queue, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+
+        float qx[2], qy[2], qz[2], reach[2];
+        float kd[2][K];          // sorted ascending by (d2, original index)
+        unsigned int ko[2][K];   // original indices
+        int kp[2][K];            // sorted-map positions
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = item * kQPW + k * 64 + lane;
+            qx[k] = qy[k] = qz[k] = 1.0e18f;
+            reach[k] = -1.0f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { kd[k][j] = thr2; ko[k][j] = 0u; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
+            if (i < N) {
+                xform(P, slx[i], sly[i], slz[i], qx[k], qy[k], qz[k]);
+                reach[k] = reach_of(thr2, qx[k], qy[k], qz[k]);
+            }
+        }
+
+        const unsigned long long n_staged = tiled_sweep<true>(mp, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
+            for (int m = 0; m < nm; m += 4) {
+                const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+                const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+                const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
+                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                float d[2][4];
+                bool cand = false;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d[k][u] = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
+                    cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd[k][K - 1];
+                }
+                if (__any(cand)) {  // some lane may have to insert: rare once the lists have tightened
+                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
+                                                __float_as_uint(O.w)};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int pos = (m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const float du = d[k][u];
+                            if (du < kd[k][K - 1] || (du == kd[k][K - 1] && os[u] < ko[k][K - 1])) {
+                                kd[k][K - 1] = du; ko[k][K - 1] = os[u]; kp[k][K - 1] = pos;
+#pragma unroll
+                                for (int j = K - 1; j > 0; --j) {
+                                    const bool sw = kd[k][j] < kd[k][j - 1] || (kd[k][j] == kd[k][j - 1] && ko[k][j] < ko[k][j - 1]);
+                                    const float td = kd[k][j]; const unsigned int to = ko[k][j]; const int tp = kp[k][j];
+                                    kd[k][j] = sw ? kd[k][j - 1] : td; ko[k][j] = sw ? ko[k][j - 1] : to; kp[k][j] = sw ? kp[k][j - 1] : tp;
+                                    kd[k][j - 1] = sw ? td : kd[k][j - 1]; ko[k][j - 1] = sw ? to : ko[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        });
+
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = item * kQPW + k * 64 + lane;
+            if (i >= N) continue;
+            PlanePair pp;
+            pp.valid = 0;
+            int m = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) m += (kp[k][j] >= 0 && kd[k][j] < thr2) ? 1 : 0;  // sorted: the first m entries
+            pp.n_neigh = m;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { pp.c[a] = 0; pp.n[a] = 0; }
+            if (knn_pos) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) knn_pos[(size_t)i * K + j] = j < m ? kp[k][j] : -1;
+            }
+            if (m >= 3) {
+                double px[K], py[K], pz[K];
+                double mean[3] = {0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    px[j] = py[j] = pz[j] = 0;
+                    if (j < m) {
+                        px[j] = mp.sx[kp[k][j]]; py[j] = mp.sy[kp[k][j]]; pz[j] = mp.sz[kp[k][j]];
+                        mean[0] += px[j]; mean[1] += py[j]; mean[2] += pz[j];
+                    }
+                }
+                const double dm = (double)m;
+                mean[0] /= dm; mean[1] /= dm; mean[2] /= dm;
+                double Cm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    if (j < m) {
+                        const double dd[3] = {px[j] - mean[0], py[j] - mean[1], pz[j] - mean[2]};
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) Cm[r][c] += dd[r] * dd[c];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Cm[r][c] /= dm;
+                double ev[3], V[3][3];
+                eig_sym3_dev(Cm, ev, V);
+                if (!(ev[0] > plane_eig_thr * ev[2])) {
+                    const double nx = V[0][0], ny = V[1][0], nz = V[2][0];
+                    const double dist = fabs(nx * ((double)qx[k] - mean[0]) + ny * ((double)qy[k] - mean[1]) +
+                                             nz * ((double)qz[k] - mean[2]));
+                    if (!(dist > threshold)) {
+                        pp.valid = 1;
+                        pp.c[0] = mean[0]; pp.c[1] = mean[1]; pp.c[2] = mean[2];
+                        pp.n[0] = nx; pp.n[1] = ny; pp.n[2] = nz;
+                    }
+                }
+            }
+            out[i] = pp;
+        }
+        if (lane == 0) atomicAdd(staged_total, n_staged);
+    }
+}
+
+// the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
+// x = [R row-major (9), t (3)]  with  phi = [n (x) l, n],  d = n.c :   A = sum phi phi^T (78 unique),
+// b = sum phi d (12), c0 = sum d^2, count.  ONE pass -> the whole Gauss-Newton inner loop runs on the host.
+constexpr int kNAccPlane = 92;  // 78 + 12 + 1 + 1
+__global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                           const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
+                                                           int N, double* __restrict__ partials)
+{
+    double acc[kNAccPlane];
+#pragma unroll
+    for (int k = 0; k < kNAccPlane; ++k) acc[k] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const PlanePair pp = pairs[i];
+        if (!pp.valid) continue;
+        const double l[3] = {slx[i], sly[i], slz[i]};
+        double phi[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) phi[3 * r + c] = pp.n[r] * l[c];
+            phi[9 + r] = pp.n[r];
+        }
+        const double d = pp.n[0] * pp.c[0] + pp.n[1] * pp.c[1] + pp.n[2] * pp.c[2];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 12; ++a)
+#pragma unroll
+            for (int b = a; b < 12; ++b) acc[q++] += phi[a] * phi[b];
+#pragma unroll
+        for (int a = 0; a < 12; ++a) acc[78 + a] += phi[a] * d;
+        acc[90] += d * d;
+        acc[91] += 1.0;
+    }
+    __shared__ double sm[4][kNAccPlane];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kNAccPlane; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNAccPlane) {
+        double v = 0.0;
+        for (int w = 0; w < 4; ++w) v += sm[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNAccPlane + threadIdx.x] = v;
+    }
+}
+
+// fixed-order sum of [nblocks][n] partial rows, one thread per accumulator (n <= 128)
+__global__ __launch_bounds__(128) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
+                                                     double* __restrict__ acc)
+{
+    if ((int)threadIdx.x < n) {
+        double v = 0.0;
+        for (int b = 0; b < nblocks; ++b) v += partials[(size_t)b * n + threadIdx.x];
+        acc[threadIdx.x] = v;
+    }
+}
+
+// plane pairing in sorted query order -> original order (tests / callers that want the pairing)
+__global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict__ qperm, const PlanePair* __restrict__ in,
+                                                          const int* __restrict__ perm, const int* __restrict__ knn_pos,
+                                                          int K, int N, PlanePair* __restrict__ out, int* __restrict__ knn_idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int o = qperm[i];
+    out[o] = in[i];
+    if (knn_idx && knn_pos)
+        for (int j = 0; j < K; ++j) {
+            const int ps = knn_pos[(size_t)i * K + j];
+            knn_idx[(size_t)o * K + j] = ps >= 0 ? perm[ps] : -1;
+        }
 }
 
 // number of kept pairs of a stored pairing (only when a caller asks for it)
@@ -942,6 +1243,8 @@ HipWorkspace::~HipWorkspace()
     sorted_.release(); perm_.release(); tbox_.release(); sbox_.release(); ubox_.release(); lsorted_.release();
     qperm_.release();
     ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
+    planes_.release(); knn_pos_.release(); plane_acc_.release();
+    if (plane_acc_host_) (void)hipHostFree(plane_acc_host_);
     sort_scratch_.release();
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
@@ -1028,6 +1331,7 @@ int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, s
     // the host buffers may be pageable: finish the copies before returning (never retain caller pointers)
     HIPCHK(hipStreamSynchronize(stream_));
     M_ = M;
+    planes_valid_ = false;
     map_img_valid_ = false;
     tiles_valid_ = false;
     pairing_valid_ = false;
@@ -1043,6 +1347,7 @@ int HipWorkspace::set_map_device(const float* x, const float* y, const float* z,
     if (M > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "map too large for 32-bit indices");
     gx_ = x; gy_ = y; gz_ = z;
     M_ = M;
+    planes_valid_ = false;
     map_img_valid_ = false;
     tiles_valid_ = false;
     pairing_valid_ = false;
@@ -1060,6 +1365,7 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     if ((rc = upload_soa(loc_own_, stream_, x, y, z, N, &lx_, &ly_, &lz_))) return rc;
     HIPCHK(hipStreamSynchronize(stream_));
     N_ = N;
+    planes_valid_ = false;
     queries_valid_ = false;
     cost_valid_ = false;
     order_valid_ = false;
@@ -1076,6 +1382,7 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     if (N > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "local cloud too large for 32-bit indices");
     lx_ = x; ly_ = y; lz_ = z;
     N_ = N;
+    planes_valid_ = false;
     queries_valid_ = false;
     cost_valid_ = false;
     order_valid_ = false;
@@ -1207,6 +1514,13 @@ int HipWorkspace::prepare_queries()
     return MOLA_ICP_OK;
 }
 
+TiledMap HipWorkspace::tiled_map() const
+{
+    const float* sx = sorted_.as<float>();
+    return TiledMap{sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(), tbox_.as<float>(), n_tiles_p_,
+                    sbox_.as<float>(), n_super_, ubox_.as<float>(), n_top_};
+}
+
 int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
 {
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
@@ -1234,26 +1548,145 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     if ((rc = ts_idx_.reserve(sizeof(int) * n_padded_))) return rc;
     if ((rc = ts_d2_.reserve(sizeof(float) * n_padded_))) return rc;
     const float* sl = lsorted_.as<float>();
-    const float* sx = sorted_.as<float>();
     if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
+    const TiledMap mp = tiled_map();
     // counter[1] = work queue (fast pass), counter[2] = redo count, counter[3] = work queue (exact pass)
     hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,
-                       (int)N_, (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(), tbox_.as<float>(),
-                       n_tiles_p_, sbox_.as<float>(), n_super_, ubox_.as<float>(), n_top_, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),
-                       ts_idx_.as<int>(), ts_d2_.as<float>(), order, item_cost_.as<unsigned int>(), counter + 1,
-                       counter + 2, redo_list_.as<int>(), staged, dbg_stats_);
+                       (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(),
+                       order, item_cost_.as<unsigned int>(), counter + 1, counter + 2, redo_list_.as<int>(), staged,
+                       dbg_stats_);
     HIPCHK(hipGetLastError());
     // exact ties (duplicate points, lattices): the queued items again with the full lexicographic key.
     // Usually zero items: a few waves that read the count and leave.
     hipLaunchKernelGGL((k_nn_tiled<true>), dim3(grid < 64 ? grid : 64), dim3(256), 0, stream_, sl, sl + n_padded_,
-                       sl + 2 * n_padded_, (int)N_, (int)M_, sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(),
-                       tbox_.as<float>(), n_tiles_p_, sbox_.as<float>(), n_super_, ubox_.as<float>(), n_top_, P, thr2,
-                       /*seed = fast pass's result*/ 1,
-                       ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr,
-                       (unsigned int*)nullptr, counter + 3, counter + 2, redo_list_.as<int>(), staged, dbg_stats_);
+                       sl + 2 * n_padded_, (int)N_, mp, P, thr2, /*seed = fast pass's result*/ 1, ts_pos_.as<int>(),
+                       ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr, (unsigned int*)nullptr, counter + 3,
+                       counter + 2, redo_list_.as<int>(), staged, dbg_stats_);
     cost_valid_ = true;
     HIPCHK(hipGetLastError());
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
+{
+    int rc = init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device_));
+    if (p.knn < 3 || p.knn > 8) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 8] in this build");
+    planes_valid_ = false;
+    if (N_ == 0 || M_ == 0) { planes_valid_ = true; planes_empty_ = true; return MOLA_ICP_OK; }
+    planes_empty_ = false;
+    if ((rc = prepare_tiles())) return rc;
+    if ((rc = prepare_queries())) return rc;
+    if ((rc = planes_.reserve(sizeof(PlanePair) * n_padded_))) return rc;
+    if ((rc = knn_pos_.reserve(sizeof(int) * n_padded_ * 8))) return rc;
+    PoseF P;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) P.R[3 * r + c] = (float)T(r, c);
+        P.t[r] = (float)T(r, 3);
+    }
+    const float thr2 = (float)(p.matcher_threshold * p.matcher_threshold);
+    while (ev_.size() < ev_used_ + 2) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ev_.push_back(e);
+    }
+    unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
+    HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));
+    HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
+    const int n_items = (int)((N_ + kQPW - 1) / kQPW);
+    int grid = num_cus_ * 3;
+    if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
+    const float* sl = lsorted_.as<float>();
+    const TiledMap mp = tiled_map();
+    unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
+#define MOLA_LAUNCH_KNN(KK)                                                                                         \
+    hipLaunchKernelGGL((k_knn_planes<KK>), dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,  \
+                       (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold, planes_.as<PlanePair>(),   \
+                       knn_pos_.as<int>(), counter + 1, staged)
+    switch (p.knn) {
+        case 3: MOLA_LAUNCH_KNN(3); break;
+        case 4: MOLA_LAUNCH_KNN(4); break;
+        case 5: MOLA_LAUNCH_KNN(5); break;
+        case 6: MOLA_LAUNCH_KNN(6); break;
+        case 7: MOLA_LAUNCH_KNN(7); break;
+        default: MOLA_LAUNCH_KNN(8); break;
+    }
+#undef MOLA_LAUNCH_KNN
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
+    ev_used_ += 2;
+    last_kernel_ = MOLA_ICP_NN_TILED;
+    planes_knn_ = (int)p.knn;
+    planes_valid_ = true;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
+{
+    int rc = init();
+    if (rc) return rc;
+    if (!planes_valid_) return fail(MOLA_ICP_E_BADARG, "accumulate_planes() called before match_planes()");
+    HIPCHK(hipSetDevice(device_));
+    if ((rc = plane_acc_.reserve(sizeof(double) * kNAccPlane * 513))) return rc;
+    double* dacc = plane_acc_.as<double>() + (size_t)512 * kNAccPlane;
+    if (planes_empty_) {
+        HIPCHK(hipMemsetAsync(dacc, 0, sizeof(double) * kNAccPlane, stream_));
+    } else {
+        int nblocks = (int)((N_ + 255) / 256);
+        if (nblocks > 512) nblocks = 512;
+        const float* sl = lsorted_.as<float>();
+        hipLaunchKernelGGL(k_accumulate_planes, dim3(nblocks), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,
+                           planes_.as<PlanePair>(), (int)N_, plane_acc_.as<double>());
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(128), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc);
+        HIPCHK(hipGetLastError());
+    }
+    if (comm_) {
+        const int rc2 = rccl_allreduce_sum_f64(comm_, dacc, kNAccPlane, stream_);
+        if (rc2) return rc2;
+    }
+    if (!plane_acc_host_) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&plane_acc_host_), sizeof(double) * kNAccPlane, hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(plane_acc_host_, dacc, sizeof(double) * kNAccPlane, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    std::memcpy(acc, plane_acc_host_, sizeof(double) * kNAccPlane);
+    if (!comm_ && ar_fn_) {
+        const int r = ar_fn_(acc, kNAccPlane, 0, ar_user_);
+        if (r) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(r));
+    }
+    return MOLA_ICP_OK;
+}
+
+// plane pairing to host, original query order: valid[N], centroid[N*3], normal[N*3], knn_idx[N*knn] (each may be null)
+int HipWorkspace::copy_planes(uint8_t* valid, double* centroid, double* normal, int32_t* knn_idx)
+{
+    if (!planes_valid_) return fail(MOLA_ICP_E_BADARG, "no plane pairing stored: call match_planes() first");
+    if (planes_empty_ || N_ == 0) return MOLA_ICP_OK;
+    HIPCHK(hipSetDevice(device_));
+    int rc;
+    DevBuf tmp_pairs, tmp_knn;
+    if ((rc = tmp_pairs.reserve(sizeof(PlanePair) * N_))) return rc;
+    if ((rc = tmp_knn.reserve(sizeof(int) * N_ * 8))) { tmp_pairs.release(); return rc; }
+    hipLaunchKernelGGL(k_unpermute_planes, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, qperm_.as<int>(),
+                       planes_.as<PlanePair>(), perm_.as<int>(), knn_pos_.as<int>(), planes_knn_, (int)N_,
+                       tmp_pairs.as<PlanePair>(), tmp_knn.as<int>());
+    std::vector<PlanePair> hp(N_);
+    std::vector<int> hk(N_ * (size_t)planes_knn_);
+    hipError_t e1 = hipMemcpyAsync(hp.data(), tmp_pairs.p, sizeof(PlanePair) * N_, hipMemcpyDeviceToHost, stream_);
+    hipError_t e2 = hipMemcpyAsync(hk.data(), tmp_knn.p, sizeof(int) * N_ * planes_knn_, hipMemcpyDeviceToHost, stream_);
+    hipError_t e3 = hipStreamSynchronize(stream_);
+    tmp_pairs.release();
+    tmp_knn.release();
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(MOLA_ICP_E_HIP, "copy_planes: HIP copy failed");
+    for (size_t i = 0; i < N_; ++i) {
+        if (valid) valid[i] = (uint8_t)hp[i].valid;
+        for (int a = 0; a < 3; ++a) {
+            if (centroid) centroid[3 * i + a] = hp[i].c[a];
+            if (normal) normal[3 * i + a] = hp[i].n[a];
+        }
+    }
+    if (knn_idx) std::memcpy(knn_idx, hk.data(), sizeof(int) * hk.size());
     return MOLA_ICP_OK;
 }
 

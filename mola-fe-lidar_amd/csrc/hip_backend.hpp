@@ -14,6 +14,7 @@
 namespace mola_icp_amd {
 
 struct PoseF;
+struct TiledMap;
 
 // RCCL, loaded at run time (rccl_dl.cpp)
 struct RcclUniqueId { char internal[128]; };
@@ -59,6 +60,11 @@ class HipWorkspace final : public Stages {
     uint64_t n_map_total() const override { return n_map_total_ ? n_map_total_ : M_; }
 
     int copy_pairing(int32_t* idx_out, float* d2_out);  // after match(); syncs
+
+    // row f3: point-to-plane matcher + the quadratic form of its cost (Stages overrides)
+    int match_planes(const Mat4& T, const mola_icp_params& p) override;
+    int accumulate_planes(double acc[kNAccPlaneHost]) override;
+    int copy_planes(uint8_t* valid, double* centroid, double* normal, int32_t* knn_idx);
     int sync();
 
     // NN-kernel timing (HIP events on this workspace's stream)
@@ -75,6 +81,7 @@ class HipWorkspace final : public Stages {
     int prepare_queries();  // Morton-sorted local cloud
     int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);
     int launch_tiled(const struct PoseF& P, float thr2, bool use_seed, unsigned int* counter);
+    TiledMap tiled_map() const;
     int launch_nn(const Mat4& T, float thr2, int kernel);
 
     int device_;
@@ -100,6 +107,10 @@ class HipWorkspace final : public Stages {
     DevBuf sorted_, perm_, tbox_, sbox_, ubox_, lsorted_, qperm_, sort_scratch_;
     DevBuf ts_pos_, ts_idx_, ts_d2_;  // the tiled matcher's pairing, in SORTED query order
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
+    DevBuf planes_, knn_pos_, plane_acc_;  // point-to-plane pairing (sorted query order) + its accumulators
+    double* plane_acc_host_ = nullptr;
+    bool planes_valid_ = false, planes_empty_ = false;
+    int planes_knn_ = 0;
     DevBuf redo_list_;                // work items with exact distance ties: redone with the full lexicographic key
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
     bool cost_valid_ = false, order_valid_ = false;

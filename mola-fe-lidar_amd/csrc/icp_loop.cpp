@@ -32,17 +32,24 @@ int validate_params(const mola_icp_params& p)
         return fail(MOLA_ICP_E_BADARG, "quality thresholdDistance must be a positive finite distance");
     if (p.use_scale_outlier_detector && !(p.scale_outlier_threshold >= 1.0))
         return fail(MOLA_ICP_E_BADARG, "scale_outlier_threshold must be >= 1");
-    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE)
-        return fail(MOLA_ICP_E_UNSUPPORTED,
-                    "matcher class mp2p_icp::Matcher_Point2Plane is parsed but not runnable in this build; "
-                    "use mp2p_icp::Matcher_Points_DistanceThreshold");
-    if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD)
+    if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD && p.matcher_class != MOLA_ICP_MATCHER_POINT2PLANE)
         return fail(MOLA_ICP_E_BADARG, "unknown matcher_class");
-    if (p.solver_class == MOLA_ICP_SOLVER_GAUSS_NEWTON)
-        return fail(MOLA_ICP_E_UNSUPPORTED,
-                    "solver class mp2p_icp::Solver_GaussNewton is parsed but not runnable in this build; "
-                    "use mp2p_icp::Solver_Horn");
-    if (p.solver_class != MOLA_ICP_SOLVER_HORN) return fail(MOLA_ICP_E_BADARG, "unknown solver_class");
+    if (p.solver_class != MOLA_ICP_SOLVER_HORN && p.solver_class != MOLA_ICP_SOLVER_GAUSS_NEWTON)
+        return fail(MOLA_ICP_E_BADARG, "unknown solver_class");
+    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) {
+        // the reference's shipped pipeline (params/icp-settings-regular.yaml:23-39)
+        if (p.solver_class != MOLA_ICP_SOLVER_GAUSS_NEWTON)
+            return fail(MOLA_ICP_E_UNSUPPORTED,
+                        "mp2p_icp::Matcher_Point2Plane pairings need mp2p_icp::Solver_GaussNewton (Solver_Horn only "
+                        "consumes point-to-point pairings)");
+        if (p.use_robust_kernel)
+            return fail(MOLA_ICP_E_UNSUPPORTED, "use_robust_kernel is not available with mp2p_icp::Matcher_Point2Plane");
+        if (p.knn < 3 || p.knn > 8) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 8]");
+        if (!(p.plane_eigen_threshold > 0)) return fail(MOLA_ICP_E_BADARG, "planeEigenThreshold must be > 0");
+        if (p.solver_max_iterations == 0) return fail(MOLA_ICP_E_BADARG, "Solver_GaussNewton: maxIterations must be > 0");
+    }
+    // point-to-point pairings + Solver_GaussNewton: the Gauss-Newton minimiser of sum |T l - g|^2 is Horn's
+    // closed-form solution, which is what runs.
     if (p.quality_class != MOLA_ICP_QUALITY_PAIRED_RATIO) return fail(MOLA_ICP_E_BADARG, "unknown quality_class");
     return MOLA_ICP_OK;
 }
@@ -94,6 +101,7 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     double acc[kNAcc] = {};
     double last_acc[kNAcc] = {};
     bool have_solution = false;
+    double plane_pairs = 0, plane_rmse = 0;
     const double t0 = now_ms();
     for (; it < p.max_iterations; ++it) {
         const bool run_matcher =
@@ -102,14 +110,28 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
             term = MOLA_ICP_TERM_NO_PAIRINGS;
             break;
         }
-        if ((rc = st.match(T, p.matcher_threshold, p, nullptr))) return rc;  // count comes from acc[16]
         Mat4 Tn = T;
         double pairs_global = 0;
         bool solver_error = false;
-        if ((rc = solve_on_pairing(st, p, T, Tn, acc, &pairs_global, &solver_error))) return rc;
-        if (!(pairs_global > 0)) { term = MOLA_ICP_TERM_NO_PAIRINGS; break; }
-        if (solver_error) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }
-        std::memcpy(last_acc, acc, sizeof acc);
+        if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) {
+            // row f3: plane pairings -> ONE accumulation pass (the quadratic form of the cost) -> host Gauss-Newton
+            double pacc[kNAccPlaneHost];
+            if ((rc = st.match_planes(T, p))) return rc;
+            if ((rc = st.accumulate_planes(pacc))) return rc;
+            pairs_global = pacc[91];
+            if (!(pairs_global > 0)) { term = MOLA_ICP_TERM_NO_PAIRINGS; break; }
+            double cost = 0;
+            if (!solve_gauss_newton_planes(pacc, T, p.solver_max_iterations, Tn, &cost)) solver_error = true;
+            if (solver_error) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }
+            plane_pairs = pairs_global;
+            plane_rmse = std::sqrt((cost > 0 ? cost : 0.0) / pairs_global);
+        } else {
+            if ((rc = st.match(T, p.matcher_threshold, p, nullptr))) return rc;  // count comes from acc[16]
+            if ((rc = solve_on_pairing(st, p, T, Tn, acc, &pairs_global, &solver_error))) return rc;
+            if (!(pairs_global > 0)) { term = MOLA_ICP_TERM_NO_PAIRINGS; break; }
+            if (solver_error) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }
+            std::memcpy(last_acc, acc, sizeof acc);
+        }
         have_solution = true;
         T = Tn;
         double d_xyz, d_rot;
@@ -141,9 +163,15 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     out->quality = quality;
     out->n_iterations = it;
     out->termination = term;
-    out->n_pairs = have_solution ? (uint64_t)last_acc[16] : 0;
-    out->rmse = (have_solution && last_acc[16] > 0) ? std::sqrt(last_acc[17] / last_acc[16]) : 0.0;
-    if (!have_solution || !pose_covariance(last_acc, T, out->cov)) std::memset(out->cov, 0, sizeof out->cov);
+    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) {
+        out->n_pairs = have_solution ? (uint64_t)plane_pairs : 0;
+        out->rmse = have_solution ? plane_rmse : 0.0;   // rms point-to-plane distance at the last linearisation
+        std::memset(out->cov, 0, sizeof out->cov);
+    } else {
+        out->n_pairs = have_solution ? (uint64_t)last_acc[16] : 0;
+        out->rmse = (have_solution && last_acc[16] > 0) ? std::sqrt(last_acc[17] / last_acc[16]) : 0.0;
+        if (!have_solution || !pose_covariance(last_acc, T, out->cov)) std::memset(out->cov, 0, sizeof out->cov);
+    }
     out->ms_iterations = t1 - t0;
     out->ms_quality = t2 - t1;
     return MOLA_ICP_OK;

@@ -22,6 +22,8 @@ void set_error(const std::string& msg);
 const char* last_error();
 int fail(int code, const std::string& msg);  // records msg, returns code
 
+constexpr int kNAccPlaneHost = 92;  // 78 (upper triangle of the 12x12 form) + 12 + 1 + count
+
 struct Stages {
     virtual ~Stages() = default;
     // matcher: transform + NN + gate at pose T; stores the pairing; n_pairs = this rank's count
@@ -29,6 +31,18 @@ struct Stages {
     // accumulate over the stored pairing -> acc[24] (this rank's partial sums, host memory)
     virtual int accumulate(const mola_icp_params& p, const Mat4& Tcur, int stage, const double cl[3],
                            const double cg[3], bool reset_outliers, double acc[kNAcc]) = 0;
+    // row f3 (point-to-plane + Gauss-Newton): plane pairing at pose T, then the quadratic form of its cost
+    // (already summed over the ranks).  Default: not available.
+    virtual int match_planes(const Mat4& T, const mola_icp_params& p)
+    {
+        (void)T; (void)p;
+        return fail(MOLA_ICP_E_UNSUPPORTED, "these stages do not provide the point-to-plane matcher");
+    }
+    virtual int accumulate_planes(double acc[kNAccPlaneHost])
+    {
+        (void)acc;
+        return fail(MOLA_ICP_E_UNSUPPORTED, "these stages do not provide the point-to-plane matcher");
+    }
     // sum acc across ranks in place (no-op for a single rank)
     virtual int allreduce(double acc[kNAcc]) { (void)acc; return MOLA_ICP_OK; }
     virtual uint64_t n_local_total() const = 0;

@@ -267,4 +267,133 @@ inline bool pose_covariance(const double acc[kNAcc], const Mat4& T, double cov[3
     return true;
 }
 
+// SE(3) exponential of delta = (v, w): the 4x4 of exp([w]x, v)
+inline Mat4 se3_exp(const double d[6])
+{
+    const double v[3] = {d[0], d[1], d[2]}, w[3] = {d[3], d[4], d[5]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    double a, b, c;  // R = I + a W + b W^2 ; V = I + b W + c W^2
+    if (th < 1e-6) { a = 1 - th2 / 6; b = 0.5 - th2 / 24; c = 1.0 / 6 - th2 / 120; }
+    else { a = std::sin(th) / th; b = (1 - std::cos(th)) / th2; c = (th - std::sin(th)) / (th2 * th); }
+    const double W[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+    double W2[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            W2[i][j] = 0;
+            for (int k = 0; k < 3; ++k) W2[i][j] += W[i][k] * W[k][j];
+        }
+    Mat4 T = Mat4::identity();
+    for (int i = 0; i < 3; ++i) {
+        double t = 0;
+        for (int j = 0; j < 3; ++j) {
+            T(i, j) = (i == j) + a * W[i][j] + b * W2[i][j];
+            t += ((i == j) + b * W[i][j] + c * W2[i][j]) * v[j];
+        }
+        T(i, 3) = t;
+    }
+    return T;
+}
+
+constexpr int kNAccPlaneForm = 92;  // == kNAccPlaneHost: 78 (upper triangle, row-major a<=b) + 12 + 1 + count
+
+// Gauss-Newton on the point-to-plane cost given as the quadratic form  f(x) = x^T A x - 2 b^T x + c0  in
+// x = [R row-major, t]  (mp2p_icp::Solver_GaussNewton, params/icp-settings-regular.yaml:23-26: the same
+// iterates as a Gauss-Newton over the pairings, left perturbation T <- exp(delta) T, stop at |delta| < 1e-7
+// or after max_iters steps).  Returns false if fewer than 3 pairings or the normal equations are singular.
+inline bool solve_gauss_newton_planes(const double acc[kNAccPlaneForm], const Mat4& T0, unsigned max_iters, Mat4& Tout,
+                                      double* final_cost = nullptr, unsigned* iters_done = nullptr)
+{
+    if (!(acc[91] >= 3.0)) return false;
+    double A[12][12], b[12];
+    int q = 0;
+    for (int i = 0; i < 12; ++i)
+        for (int j = i; j < 12; ++j) { A[i][j] = acc[q]; A[j][i] = acc[q]; ++q; }
+    for (int i = 0; i < 12; ++i) b[i] = acc[78 + i];
+    const double c0 = acc[90];
+    Mat4 T = T0;
+    unsigned it = 0;
+    double cost = 0;
+    for (; it < max_iters; ++it) {
+        double x[12];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) x[3 * r + c] = T(r, c);
+            x[9 + r] = T(r, 3);
+        }
+        // J = dx/d(delta), delta = (v, w), left perturbation: R' = R + [w]x R, t' = t + [w]x t + v
+        double J[12][6] = {};
+        for (int k = 0; k < 3; ++k) J[9 + k][k] = 1.0;
+        for (int k = 0; k < 3; ++k) {
+            double E[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // [e_k]x
+            E[(k + 2) % 3][(k + 1) % 3] = 1.0;
+            E[(k + 1) % 3][(k + 2) % 3] = -1.0;
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) {
+                    double v = 0;
+                    for (int m = 0; m < 3; ++m) v += E[r][m] * T(m, c);
+                    J[3 * r + c][3 + k] = v;
+                }
+                double tv = 0;
+                for (int m = 0; m < 3; ++m) tv += E[r][m] * T(m, 3);
+                J[9 + r][3 + k] = tv;
+            }
+        }
+        double Ax[12], res[12];
+        for (int i = 0; i < 12; ++i) {
+            double v = 0;
+            for (int j = 0; j < 12; ++j) v += A[i][j] * x[j];
+            Ax[i] = v;
+            res[i] = v - b[i];  // (A x - b): gradient / 2 in x-space
+        }
+        cost = c0;
+        for (int i = 0; i < 12; ++i) cost += x[i] * (Ax[i] - 2 * b[i]);
+        double AJ[12][6];
+        for (int i = 0; i < 12; ++i)
+            for (int k = 0; k < 6; ++k) {
+                double v = 0;
+                for (int j = 0; j < 12; ++j) v += A[i][j] * J[j][k];
+                AJ[i][k] = v;
+            }
+        double H[6][7];
+        for (int a = 0; a < 6; ++a) {
+            for (int k = 0; k < 6; ++k) {
+                double v = 0;
+                for (int i = 0; i < 12; ++i) v += J[i][a] * AJ[i][k];
+                H[a][k] = v;
+            }
+            double g = 0;
+            for (int i = 0; i < 12; ++i) g += J[i][a] * res[i];
+            H[a][6] = -g;
+        }
+        // solve H d = -g (Gaussian elimination, partial pivoting)
+        for (int c = 0; c < 6; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < 6; ++r)
+                if (std::fabs(H[r][c]) > std::fabs(H[piv][c])) piv = r;
+            if (std::fabs(H[piv][c]) < 1e-300) return false;
+            if (piv != c)
+                for (int k = 0; k < 7; ++k) { const double t = H[c][k]; H[c][k] = H[piv][k]; H[piv][k] = t; }
+            for (int r = c + 1; r < 6; ++r) {
+                const double f = H[r][c] / H[c][c];
+                for (int k = c; k < 7; ++k) H[r][k] -= f * H[c][k];
+            }
+        }
+        double d[6];
+        for (int i = 5; i >= 0; --i) {
+            double sacc = H[i][6];
+            for (int j = i + 1; j < 6; ++j) sacc -= H[i][j] * d[j];
+            d[i] = sacc / H[i][i];
+        }
+        for (int k = 0; k < 6; ++k)
+            if (!std::isfinite(d[k])) return false;
+        T = mul(se3_exp(d), T);
+        double nd = 0;
+        for (int k = 0; k < 6; ++k) nd += d[k] * d[k];
+        if (std::sqrt(nd) < 1e-7) { ++it; break; }
+    }
+    Tout = T;
+    if (final_cost) *final_cost = cost;
+    if (iters_done) *iters_done = it;
+    return true;
+}
+
 }  // namespace mola_icp_amd

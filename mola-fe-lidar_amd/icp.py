@@ -73,6 +73,18 @@ def stall_deltas(T, Tprev) -> tuple[float, float]:
     return dx.value, dr.value
 
 
+def solve_gauss_newton_planes(acc, T0, max_iterations=20):
+    """host Gauss-Newton on the 92-term quadratic form of the point-to-plane cost -> (T, final cost, iterations)"""
+    acc = np.ascontiguousarray(acc, dtype=np.float64)
+    assert acc.shape == (92,)
+    T0 = _pose16(T0)
+    T = np.empty(16)
+    cost, its = C.c_double(), C.c_uint32()
+    L.check(L.lib().mola_icp_solve_gauss_newton_planes(_dp(acc), _dp(T0), int(max_iterations), _dp(T), C.byref(cost),
+                                                       C.byref(its)))
+    return T.reshape(4, 4), cost.value, its.value
+
+
 def solve_horn(acc, cl=None, cg=None) -> np.ndarray:
     acc = np.ascontiguousarray(acc, dtype=np.float64)
     assert acc.shape == (L.NACC,)
@@ -319,6 +331,18 @@ class ICP:
                                        idx.ctypes.data_as(C.POINTER(C.c_int32)) if copy else None,
                                        _fp(d2) if copy else None, C.byref(n)))
         return idx, d2, n.value
+
+    def match_planes(self, T, params: Parameters, n_local: int):
+        """point-to-plane matcher on the resident clouds -> (valid, centroid (N,3), normal (N,3), knn_idx (N,knn), n)"""
+        T = _pose16(T)
+        valid = np.zeros(max(1, n_local), np.uint8)
+        cen = np.zeros((max(1, n_local), 3))
+        nor = np.zeros((max(1, n_local), 3))
+        kidx = np.full((max(1, n_local), int(params.knn)), -1, np.int32)
+        n = C.c_uint64()
+        L.check(L.lib().mola_icp_match_planes(self._h, _dp(T), C.byref(params.c), valid.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                              _dp(cen), _dp(nor), kidx.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
+        return valid[:n_local], cen[:n_local], nor[:n_local], kidx[:n_local], n.value
 
     def accumulate(self, params: Parameters, Tcur, stage: int = 0, cl=None, cg=None, reset_outliers: bool = True):
         T = _pose16(Tcur)

@@ -644,7 +644,6 @@ double orc_quality_paired_ratio(const float* gx, const float* gy, const float* g
     return (double)kept / (double)(N < M ? N : M);
 }
 
-/* ------------------------------------------------ align (rows a1, a10, a12) */
 #include <time.h>
 static double now_s(void)
 {
@@ -652,6 +651,317 @@ static double now_s(void)
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
+
+/* ================================================================================
+ * Row f3: the reference's SHIPPED pipeline (params/icp-settings-regular.yaml:23-39):
+ * mp2p_icp::Matcher_Point2Plane (knn, distanceThreshold, planeEigenThreshold) +
+ * mp2p_icp::Solver_GaussNewton (maxIterations).  [EXT] restated from mp2p_icp ~2021:
+ *   matcher: for every local point q = T(+)l: its knn nearest global points (ties: lowest
+ *     index), keep those with d2 < thr2, need >= 3; mean + covariance (fp64) of them, eigen
+ *     values e0<=e1<=e2; plane iff e0 <= planeEigenThreshold*e2; normal = eigenvector of e0;
+ *     pairing iff |n.(q - mean)| <= distanceThreshold;  stored: (l, centroid, normal);
+ *   solver: Gauss-Newton on sum (n.(T(+)l - c))^2 from the current pose, <= maxIterations
+ *     steps, stop when |delta| < 1e-7.
+ * ================================================================================ */
+
+/* k nearest neighbours, brute force; out sorted by (d2, index); n_out <= k */
+void orc_knn_brute(const float* gx, const float* gy, const float* gz, size_t M, float qx, float qy, float qz, int k,
+                   int32_t* idx, float* d2, int* n_out)
+{
+    int n = 0;
+    for (size_t j = 0; j < M; j++) {
+        const float d = dist2(qx, qy, qz, gx[j], gy[j], gz[j]);
+        if (n < k || d < d2[n - 1]) { /* strict: on ties the earlier (lower) index stays */
+            int pos = n < k ? n : k - 1;
+            while (pos > 0 && d < d2[pos - 1]) { d2[pos] = d2[pos - 1]; idx[pos] = idx[pos - 1]; pos--; }
+            d2[pos] = d; idx[pos] = (int32_t)j;
+            if (n < k) n++;
+        }
+    }
+    *n_out = n;
+}
+
+typedef struct { float qx, qy, qz; int k, n; int32_t* idx; float* d2; } kd_knn_query;
+
+static inline int knn_less(float d, int32_t i, float d2, int32_t i2) { return d < d2 || (d == d2 && i < i2); }
+
+static void kd_knn_search(const orc_kdtree* t, int32_t id, kd_knn_query* q, double off[3], double bound)
+{
+    const kd_node* nd = &t->nodes[id];
+    if (nd->left < 0) {
+        for (int32_t i = nd->lo; i < nd->hi; i++) {
+            const float d = dist2(q->qx, q->qy, q->qz, t->x[i], t->y[i], t->z[i]);
+            const int32_t oi = t->perm[i];
+            if (q->n < q->k || knn_less(d, oi, q->d2[q->n - 1], q->idx[q->n - 1])) {
+                int pos = q->n < q->k ? q->n : q->k - 1;
+                while (pos > 0 && knn_less(d, oi, q->d2[pos - 1], q->idx[pos - 1])) {
+                    q->d2[pos] = q->d2[pos - 1]; q->idx[pos] = q->idx[pos - 1]; pos--;
+                }
+                q->d2[pos] = d; q->idx[pos] = oi;
+                if (q->n < q->k) q->n++;
+            }
+        }
+        return;
+    }
+    const int dim = nd->dim;
+    const double v = dim == 0 ? q->qx : (dim == 1 ? q->qy : q->qz);
+    const double d_lo = v - (double)nd->split_lo, d_hi = v - (double)nd->split_hi;
+    int32_t near_c, far_c;
+    double cut;
+    if (d_lo + d_hi < 0) { near_c = nd->left; far_c = nd->right; cut = d_hi * d_hi; }
+    else { near_c = nd->right; far_c = nd->left; cut = d_lo * d_lo; }
+    kd_knn_search(t, near_c, q, off, bound);
+    const double save = off[dim];
+    const double fb = bound - save + cut;
+    const double worst = q->n < q->k ? INFINITY : (double)q->d2[q->n - 1];
+    if (fb * (1.0 - 1e-6) <= worst) {
+        off[dim] = cut;
+        kd_knn_search(t, far_c, q, off, fb);
+        off[dim] = save;
+    }
+}
+
+void orc_kdtree_knn(const orc_kdtree* t, float qx, float qy, float qz, int k, int32_t* idx, float* d2, int* n_out)
+{
+    kd_knn_query q = {qx, qy, qz, k, 0, idx, d2};
+    if (t->n) {
+        double off[3] = {0, 0, 0}, b = 0;
+        const float qq[3] = {qx, qy, qz};
+        for (int a = 0; a < 3; a++) {
+            double d = 0;
+            if (qq[a] < t->bbmin[a]) d = (double)t->bbmin[a] - qq[a];
+            else if (qq[a] > t->bbmax[a]) d = (double)qq[a] - t->bbmax[a];
+            off[a] = d * d;
+            b += off[a];
+        }
+        kd_knn_search(t, 0, &q, off, b);
+    }
+    *n_out = q.n;
+}
+
+/* symmetric 3x3 eigen decomposition, cyclic Jacobi in fp64; values ascending, vectors in columns */
+static void eig_sym3(const double Cin[3][3], double ev[3], double V[3][3])
+{
+    double A[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { A[i][j] = Cin[i][j]; V[i][j] = (i == j); }
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off == 0 || off < 1e-34 * dg) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (A[p][q] == 0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(tt * tt + 1), s2 = tt * c;
+                for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s2 * b; A[k][q] = s2 * a + c * b; }
+                for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s2 * b; A[q][k] = s2 * a + c * b; }
+                for (int k = 0; k < 3; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s2 * b; V[k][q] = s2 * a + c * b; }
+            }
+    }
+    int o[3] = {0, 1, 2};
+    double d[3] = {A[0][0], A[1][1], A[2][2]};
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2 - i; j++)
+            if (d[o[j]] > d[o[j + 1]]) { const int t = o[j]; o[j] = o[j + 1]; o[j + 1] = t; }
+    double Vs[3][3];
+    for (int k = 0; k < 3; k++) { ev[k] = d[o[k]]; for (int r = 0; r < 3; r++) Vs[r][k] = V[r][o[k]]; }
+    memcpy(V, Vs, sizeof Vs);
+}
+
+/* the matcher: for every local point its plane (or none).  valid[i]=1 and centroid/normal filled where paired;
+ * knn_idx (N x knn, -1 padded) optional.  Returns the number of pairings. */
+size_t orc_match_point2plane(const float* gx, const float* gy, const float* gz, size_t M, const orc_kdtree* tree,
+                             const float* lx, const float* ly, const float* lz, size_t N, const double T[16],
+                             double threshold, double plane_eigen_threshold, int knn, uint8_t* valid,
+                             double* centroid /*N x 3*/, double* normal /*N x 3*/, int32_t* knn_idx)
+{
+    const pose_f32 P = pose_to_f32(T);
+    const float thr2 = (float)(threshold * threshold);
+    size_t kept = 0;
+    int32_t idx[64];
+    float d2[64];
+    if (knn > 64) knn = 64;
+    for (size_t i = 0; i < N; i++) {
+        float qx, qy, qz;
+        xform(&P, lx[i], ly[i], lz[i], &qx, &qy, &qz);
+        int n = 0;
+        if (tree) orc_kdtree_knn(tree, qx, qy, qz, knn, idx, d2, &n);
+        else orc_knn_brute(gx, gy, gz, M, qx, qy, qz, knn, idx, d2, &n);
+        int m = 0;
+        while (m < n && d2[m] < thr2) m++;  /* sorted ascending: the neighbours inside the gate */
+        if (knn_idx) for (int k = 0; k < knn; k++) knn_idx[i * (size_t)knn + k] = k < m ? idx[k] : -1;
+        valid[i] = 0;
+        if (m < 3) continue;
+        double mean[3] = {0, 0, 0};
+        for (int k = 0; k < m; k++) { mean[0] += gx[idx[k]]; mean[1] += gy[idx[k]]; mean[2] += gz[idx[k]]; }
+        for (int a = 0; a < 3; a++) mean[a] /= m;
+        double C[3][3] = {{0}};
+        for (int k = 0; k < m; k++) {
+            const double d[3] = {gx[idx[k]] - mean[0], gy[idx[k]] - mean[1], gz[idx[k]] - mean[2]};
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) C[r][c] += d[r] * d[c];
+        }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) C[r][c] /= m;
+        double ev[3], V[3][3];
+        eig_sym3(C, ev, V);
+        if (ev[0] > plane_eigen_threshold * ev[2]) continue;
+        const double nrm[3] = {V[0][0], V[1][0], V[2][0]};
+        const double dist = fabs(nrm[0] * (qx - mean[0]) + nrm[1] * (qy - mean[1]) + nrm[2] * (qz - mean[2]));
+        if (dist > threshold) continue;
+        valid[i] = 1;
+        for (int a = 0; a < 3; a++) { centroid[3 * i + a] = mean[a]; normal[3 * i + a] = nrm[a]; }
+        kept++;
+    }
+    return kept;
+}
+
+static void solve6(double H[6][6], const double g[6], double x[6], int* ok)
+{
+    double A[6][7];
+    for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) A[i][j] = H[i][j]; A[i][6] = g[i]; }
+    *ok = 1;
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        if (fabs(A[piv][c]) < 1e-300) { *ok = 0; return; }
+        if (piv != c) for (int k = 0; k < 7; k++) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+        for (int r = c + 1; r < 6; r++) {
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k < 7; k++) A[r][k] -= f * A[c][k];
+        }
+    }
+    for (int i = 5; i >= 0; i--) {
+        double s = A[i][6];
+        for (int j = i + 1; j < 6; j++) s -= A[i][j] * x[j];
+        x[i] = s / A[i][i];
+    }
+}
+
+static void se3_exp(const double d[6], double T[16])
+{
+    const double v[3] = {d[0], d[1], d[2]}, w[3] = {d[3], d[4], d[5]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+    double a, b, c;  /* R = I + a W + b W^2 ; V = I + b W + c W^2 */
+    if (th < 1e-6) { a = 1 - th2 / 6; b = 0.5 - th2 / 24; c = 1.0 / 6 - th2 / 120; }
+    else { a = sin(th) / th; b = (1 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th); }
+    const double W[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+    double W2[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { W2[i][j] = 0; for (int k = 0; k < 3; k++) W2[i][j] += W[i][k] * W[k][j]; }
+    for (int i = 0; i < 3; i++) {
+        double t = 0;
+        for (int j = 0; j < 3; j++) {
+            T[4 * i + j] = (i == j) + a * W[i][j] + b * W2[i][j];
+            t += ((i == j) + b * W[i][j] + c * W2[i][j]) * v[j];
+        }
+        T[4 * i + 3] = t;
+    }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+}
+
+/* Gauss-Newton on the point-to-plane pairings, left perturbation T <- exp(delta) T.  Returns 0 ok. */
+int orc_solve_gauss_newton(const float* lx, const float* ly, const float* lz, size_t N, const uint8_t* valid,
+                           const double* centroid, const double* normal, const double Tcur[16], uint32_t max_iters,
+                           double Tnew[16], double* final_cost, uint32_t* iters_done)
+{
+    double T[16];
+    memcpy(T, Tcur, sizeof T);
+    uint32_t it = 0;
+    double cost = 0;
+    for (; it < max_iters; it++) {
+        double H[6][6] = {{0}}, g[6] = {0};
+        cost = 0;
+        size_t n = 0;
+        for (size_t i = 0; i < N; i++) {
+            if (!valid[i]) continue;
+            const double l[3] = {lx[i], ly[i], lz[i]};
+            double p[3];
+            for (int r = 0; r < 3; r++) p[r] = T[4 * r] * l[0] + T[4 * r + 1] * l[1] + T[4 * r + 2] * l[2] + T[4 * r + 3];
+            const double* nn = normal + 3 * i;
+            const double* cc = centroid + 3 * i;
+            const double r0 = nn[0] * (p[0] - cc[0]) + nn[1] * (p[1] - cc[1]) + nn[2] * (p[2] - cc[2]);
+            /* d p / d delta = [ I | -[p]x ]  ->  J = [ n , p x n ] */
+            const double J[6] = {nn[0], nn[1], nn[2], p[1] * nn[2] - p[2] * nn[1], p[2] * nn[0] - p[0] * nn[2],
+                                 p[0] * nn[1] - p[1] * nn[0]};
+            for (int a = 0; a < 6; a++) { g[a] += J[a] * r0; for (int b = 0; b < 6; b++) H[a][b] += J[a] * J[b]; }
+            cost += r0 * r0;
+            n++;
+        }
+        if (n < 3) return -1;
+        double mg[6], d[6];
+        int ok;
+        for (int a = 0; a < 6; a++) mg[a] = -g[a];
+        solve6(H, mg, d, &ok);
+        if (!ok) return -2;
+        double E[16], R[16];
+        se3_exp(d, E);
+        mat4_mul(E, T, R);
+        memcpy(T, R, sizeof T);
+        double nd = 0;
+        for (int a = 0; a < 6; a++) nd += d[a] * d[a];
+        if (sqrt(nd) < 1e-7) { it++; break; }
+    }
+    memcpy(Tnew, T, sizeof T);
+    if (final_cost) *final_cost = cost;
+    if (iters_done) *iters_done = it;
+    return 0;
+}
+
+/* align with the point-to-plane + Gauss-Newton pipeline (same loop / stall test / quality as orc_align) */
+int orc_align_p2pl(const float* gx, const float* gy, const float* gz, size_t M, const float* lx, const float* ly,
+                   const float* lz, size_t N, const double Tinit[16], const orc_params* p, double plane_eigen_threshold,
+                   int knn, uint32_t solver_max_iters, orc_result* res)
+{
+    memset(res, 0, sizeof *res);
+    double T[16], Tprev[16];
+    memcpy(T, Tinit, sizeof T);
+    memcpy(Tprev, Tinit, sizeof T);
+    uint8_t* valid = (uint8_t*)calloc(N ? N : 1, 1);
+    double* cen = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    double* nor = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    orc_kdtree* tree = NULL;
+    if (p->use_kdtree) tree = orc_kdtree_build(gx, gy, gz, M);
+    res->termination = ORC_TERM_UNDEFINED;
+    uint32_t it = 0;
+    const double t0 = now_s();
+    for (; it < p->max_iterations; it++) {
+        size_t kept = 0;
+        if (N && M) kept = orc_match_point2plane(gx, gy, gz, M, tree, lx, ly, lz, N, T, p->matcher_threshold,
+                                                 plane_eigen_threshold, knn, valid, cen, nor, NULL);
+        if (!kept) { res->termination = ORC_TERM_NO_PAIRINGS; break; }
+        double Tn[16], cost;
+        if (orc_solve_gauss_newton(lx, ly, lz, N, valid, cen, nor, T, solver_max_iters, Tn, &cost, NULL)) {
+            res->termination = ORC_TERM_SOLVER_ERROR;
+            break;
+        }
+        res->n_pairs = kept;
+        res->rmse = sqrt(cost / (double)kept);
+        memcpy(T, Tn, sizeof T);
+        double dxyz, drot;
+        orc_stall_deltas(T, Tprev, &dxyz, &drot);
+        if (!p->fixed_iterations && fabs(dxyz) < p->min_abs_step_trans && fabs(drot) < p->min_abs_step_rot) {
+            res->termination = ORC_TERM_STALLED;
+            it++;
+            break;
+        }
+        memcpy(Tprev, T, sizeof T);
+    }
+    if (res->termination == ORC_TERM_UNDEFINED) res->termination = ORC_TERM_MAX_ITERATIONS;
+    res->n_iterations = it;
+    res->iter_s = now_s() - t0;
+    memcpy(res->T, T, sizeof T);
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (N ? N : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (N ? N : 1));
+    res->quality = orc_quality_paired_ratio(gx, gy, gz, M, tree, lx, ly, lz, N, T, p->quality_threshold, idx, d2);
+    orc_kdtree_free(tree);
+    free(idx); free(d2); free(valid); free(cen); free(nor);
+    return 0;
+}
+
+/* ------------------------------------------------ align (rows a1, a10, a12) */
 
 /* [EXT] mp2p_icp::ICP::align(from=global, to=local, init_to_wrt_from, params, result)
  * as called at src/LidarOdometry.cpp:869-871.

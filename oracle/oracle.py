@@ -256,3 +256,68 @@ def pose_error(T, T_ref):
     dR = T_ref[:3, :3].T @ T[:3, :3]
     c = np.clip((np.trace(dR) - 1) / 2, -1, 1)
     return float(np.arccos(c)), float(np.linalg.norm(T[:3, 3] - T_ref[:3, 3]))
+
+
+# ---------------------------------------------------------------- row f3: point-to-plane + Gauss-Newton
+def _bind_p2pl():
+    L = lib()
+    if getattr(L, "_p2pl_bound", False):
+        return L
+    U8 = C.POINTER(C.c_uint8)
+    L.orc_match_point2plane.restype = C.c_size_t
+    L.orc_match_point2plane.argtypes = [_FP, _FP, _FP, C.c_size_t, C.c_void_p, _FP, _FP, _FP, C.c_size_t, _DP, C.c_double,
+                                        C.c_double, C.c_int, U8, _DP, _DP, _IP]
+    L.orc_solve_gauss_newton.restype = C.c_int
+    L.orc_solve_gauss_newton.argtypes = [_FP, _FP, _FP, C.c_size_t, U8, _DP, _DP, _DP, C.c_uint32, _DP, _DP,
+                                         C.POINTER(C.c_uint32)]
+    L.orc_align_p2pl.restype = C.c_int
+    L.orc_align_p2pl.argtypes = [_FP, _FP, _FP, C.c_size_t, _FP, _FP, _FP, C.c_size_t, _DP, C.POINTER(OParams), C.c_double,
+                                 C.c_int, C.c_uint32, C.POINTER(OResult)]
+    L._p2pl_bound = True
+    return L
+
+
+def match_point2plane(map_pc, local, T, threshold, plane_eigen_threshold, knn, tree: "KdTree | None" = None):
+    """-> (valid uint8[N], centroid (N,3), normal (N,3), knn_idx (N,knn), n_pairs)"""
+    L = _bind_p2pl()
+    gx, gy, gz, M = _rows(map_pc)
+    lx, ly, lz, N = _rows(local)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    valid = np.zeros(max(1, N), np.uint8)
+    cen = np.zeros((max(1, N), 3))
+    nor = np.zeros((max(1, N), 3))
+    kidx = np.full((max(1, N), knn), -1, np.int32)
+    n = L.orc_match_point2plane(_f(gx), _f(gy), _f(gz), M, tree.h if tree else None, _f(lx), _f(ly), _f(lz), N, _d(T),
+                                float(threshold), float(plane_eigen_threshold), int(knn),
+                                valid.ctypes.data_as(C.POINTER(C.c_uint8)), _d(cen), _d(nor), kidx.ctypes.data_as(_IP))
+    return valid[:N], cen[:N], nor[:N], kidx[:N], int(n)
+
+
+def solve_gauss_newton(local, valid, centroid, normal, Tcur, max_iters=20):
+    L = _bind_p2pl()
+    lx, ly, lz, N = _rows(local)
+    T = np.ascontiguousarray(Tcur, dtype=np.float64).reshape(16)
+    Tn = np.empty(16)
+    cost = C.c_double()
+    its = C.c_uint32()
+    v = np.ascontiguousarray(valid, dtype=np.uint8)
+    c = np.ascontiguousarray(centroid, dtype=np.float64)
+    nn = np.ascontiguousarray(normal, dtype=np.float64)
+    rc = L.orc_solve_gauss_newton(_f(lx), _f(ly), _f(lz), N, v.ctypes.data_as(C.POINTER(C.c_uint8)), _d(c), _d(nn), _d(T),
+                                  int(max_iters), _d(Tn), C.byref(cost), C.byref(its))
+    if rc:
+        raise ValueError(f"orc_solve_gauss_newton failed: {rc}")
+    return Tn.reshape(4, 4), cost.value, its.value
+
+
+def align_p2pl(map_pc, local, T_init, p: OParams, plane_eigen_threshold=0.07, knn=6, solver_max_iters=20):
+    L = _bind_p2pl()
+    gx, gy, gz, M = _rows(map_pc)
+    lx, ly, lz, N = _rows(local)
+    T = np.ascontiguousarray(T_init, dtype=np.float64).reshape(16)
+    res = OResult()
+    rc = L.orc_align_p2pl(_f(gx), _f(gy), _f(gz), M, _f(lx), _f(ly), _f(lz), N, _d(T), C.byref(p),
+                          float(plane_eigen_threshold), int(knn), int(solver_max_iters), C.byref(res))
+    assert rc == 0
+    return dict(T=np.array(res.T).reshape(4, 4), quality=res.quality, n_iterations=res.n_iterations,
+                termination=res.termination, n_pairs=res.n_pairs, rmse=res.rmse, iter_s=res.iter_s)

@@ -113,9 +113,21 @@ def test_yaml_syntax_errors(pkg):
         assert e.value.status == pkg._lib.E_CONFIG
 
 
-def test_unsupported_pipeline_is_rejected_at_align_time(pkg):
-    # the reference's shipped pipeline parses, and the loop refuses to run it (no silent substitution)
+def test_shipped_pipeline_needs_plane_stages(pkg):
+    # the reference's shipped pipeline (Point2Plane + GaussNewton) parses and is runnable on the HIP stages; caller-
+    # supplied point-to-point stages cannot serve it and the loop says so (no silent substitution)
     p = pkg.Parameters.load_from(open(os.path.join(PARAMS, "icp-settings-regular.yaml")).read())
     with pytest.raises(pkg.IcpError) as e:
         pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), p, 10, 10)
-    assert e.value.status == pkg._lib.E_UNSUPPORTED and "Point2Plane" in str(e.value)
+    assert e.value.status == pkg._lib.E_UNSUPPORTED and "point-to-plane" in str(e.value)
+    # inconsistent stage combinations are rejected by name
+    q = pkg.Parameters.load_from(open(os.path.join(PARAMS, "icp-settings-regular.yaml")).read())
+    q.solver_class = pkg._lib.SOLVER_HORN
+    with pytest.raises(pkg.IcpError) as e:
+        pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), q, 10, 10)
+    assert e.value.status == pkg._lib.E_UNSUPPORTED and "Solver_GaussNewton" in str(e.value)
+    q = pkg.Parameters.load_from(open(os.path.join(PARAMS, "icp-settings-regular.yaml")).read())
+    q.knn = 12
+    with pytest.raises(pkg.IcpError) as e:
+        pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), q, 10, 10)
+    assert e.value.status == pkg._lib.E_UNSUPPORTED and "knn" in str(e.value)

@@ -189,10 +189,11 @@ def test_edge_cases(pkg, icp, golden):
     assert r.terminationReason == pkg.TERM_NO_PAIRINGS and r.n_pairs == 0 and r.quality == 0
     with pytest.raises(pkg.IcpError):
         icp.align(g, l, np.full((4, 4), np.nan), p2p_params(pkg))
+    bad = p2p_params(pkg)
+    bad.matcher_class = pkg._lib.MATCHER_POINT2PLANE   # plane pairings with Solver_Horn: rejected by name
     with pytest.raises(pkg.IcpError) as e:
-        icp.align(g, l, np.eye(4), pkg.Parameters.load_from_file(
-            os.path.join(os.path.dirname(os.path.dirname(__file__)), "params", "icp-settings-regular.yaml")))
-    assert e.value.status == pkg._lib.E_UNSUPPORTED
+        icp.align(g, l, np.eye(4), bad)
+    assert e.value.status == pkg._lib.E_UNSUPPORTED and "Solver_GaussNewton" in str(e.value)
     # the handle survives errors
     assert icp.align(g, l, np.eye(4), p2p_params(pkg, max_iterations=2)).nIterations == 2
 

@@ -1,0 +1,156 @@
+"""the reference's SHIPPED pipeline -- mp2p_icp::Matcher_Point2Plane (knn 6, PCA planarity)
++ mp2p_icp::Solver_GaussNewton (params/icp-settings-regular.yaml:23-39) -- against the oracle's restatement."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REGULAR = os.path.join(ROOT, "params", "icp-settings-regular.yaml")
+
+
+def _form_from_pairing(l, valid, cen, nor):
+    """the 92-term quadratic form of sum (n.(R l + t - c))^2, in numpy (what k_accumulate_planes produces)"""
+    k = valid.astype(bool)
+    L = l[:, k].astype(np.float64).T
+    n, c = nor[k], cen[k]
+    phi = np.concatenate([(n[:, :, None] * L[:, None, :]).reshape(-1, 9), n], axis=1)
+    d = (n * c).sum(1)
+    A = phi.T @ phi
+    acc = np.zeros(92)
+    acc[:78] = A[np.triu_indices(12)]
+    acc[78:90] = phi.T @ d
+    acc[90] = d @ d
+    acc[91] = k.sum()
+    return acc
+
+
+@pytest.fixture(scope="module")
+def pair(synth):
+    scene = synth.Scene(scene_seed=3, half=12.0, wall_y=5.0, wall_h=4.0, n_boxes=8)
+    Tgt = synth.pose_from_xyzypr(0.30, -0.15, 0.04, np.deg2rad(1.5), np.deg2rad(-0.4), np.deg2rad(0.25))
+    g, l, _ = synth.make_pair(12000, 10000, seed=11, T_gt=Tgt, scene=scene)
+    return g, l, Tgt
+
+
+def test_host_gauss_newton_on_quadratic_form_equals_direct_gn(pkg, O, pair):
+    """CPU: the product's Gauss-Newton on the quadratic form == the oracle's Gauss-Newton over the pairings."""
+    g, l, Tgt = pair
+    valid, cen, nor, _, n = O.match_point2plane(g, l, np.eye(4), 0.7, 0.07, 6, O.KdTree(g))
+    assert n > 0.8 * l.shape[1]
+    acc = _form_from_pairing(l, valid, cen, nor)
+    for max_it in (1, 3, 20):
+        T, cost, its = pkg.solve_gauss_newton_planes(acc, np.eye(4), max_it)
+        Tref, cref, iref = O.solve_gauss_newton(l, valid, cen, nor, np.eye(4), max_it)
+        assert its == iref
+        np.testing.assert_allclose(T, Tref, atol=1e-10)
+        assert cost == pytest.approx(cref, rel=1e-6, abs=1e-9)
+    R = T[:3, :3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
+    # from another linearisation point
+    T0 = pkg.pose_from_xyzypr([0.1, -0.05, 0.02, 0.01, -0.004, 0.003])
+    np.testing.assert_allclose(pkg.solve_gauss_newton_planes(acc, T0, 20)[0],
+                               O.solve_gauss_newton(l, valid, cen, nor, T0, 20)[0], atol=1e-10)
+    # too few pairings -> error, not garbage
+    few = acc.copy()
+    few[91] = 2
+    with pytest.raises(pkg.IcpError):
+        pkg.solve_gauss_newton_planes(few, np.eye(4), 20)
+
+
+def test_oracle_knn_kdtree_equals_brute(O, pair):
+    g, l, _ = pair
+    a = O.match_point2plane(g, l[:, :1500], np.eye(4), 0.7, 0.07, 6, O.KdTree(g))
+    b = O.match_point2plane(g, l[:, :1500], np.eye(4), 0.7, 0.07, 6, None)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0]) and a[4] == b[4]
+    np.testing.assert_allclose(a[1], b[1], atol=0) and np.testing.assert_allclose(a[2], b[2], atol=0)
+
+
+def test_oracle_p2pl_recovers_known_motion(O, pair):
+    g, l, Tgt = pair
+    r = O.align_p2pl(g, l, np.eye(4), O.params(max_iterations=100, matcher_threshold=0.7))
+    rot, trans = O.pose_error(r["T"], Tgt)
+    assert r["termination"] == 4 and r["n_iterations"] < 20
+    assert rot < 2e-4 and trans < 2e-3   # independent samples + 1 cm noise: the plane fit averages it out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knn", [3, 6, 8])
+def test_plane_pairing_parity(pkg, O, pair, knn):
+    g, l, _ = pair
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    p = pkg.Parameters.load_from_file(REGULAR)
+    p.knn = knn
+    T = pkg.pose_from_xyzypr([0.05, -0.02, 0.01, 0.004, 0.001, -0.002])
+    valid, cen, nor, kidx, n = icp.match_planes(T, p, l.shape[1])
+    ov, oc, on, ok, onum = O.match_point2plane(g, l, T, p.matcher_threshold, p.plane_eigen_threshold, knn, O.KdTree(g))
+    assert np.array_equal(kidx, ok), f"{(kidx != ok).any(1).sum()} of {len(ok)} neighbour lists differ"
+    assert np.array_equal(valid, ov) and n == onum
+    k = ov.astype(bool)
+    np.testing.assert_allclose(cen[k], oc[k], atol=1e-12)
+    np.testing.assert_allclose(np.abs((nor[k] * on[k]).sum(1)), 1.0, atol=1e-9)   # normals up to sign
+    icp.close()
+
+
+@pytest.mark.gpu
+def test_shipped_pipeline_align_equals_oracle(pkg, O, pair):
+    """icp-settings-regular.yaml exactly as shipped (Point2Plane + GaussNewton, 100 its, outlier detector on)."""
+    g, l, Tgt = pair
+    p = pkg.Parameters.load_from_file(REGULAR)
+    icp = pkg.ICP(device=0)
+    r = icp.align(g, l, np.eye(4), p)
+    ref = O.align_p2pl(g, l, np.eye(4), O.params_from_product(p), p.plane_eigen_threshold, p.knn, p.solver_max_iterations)
+    assert r.nIterations == ref["n_iterations"] and r.terminationReason == ref["termination"]
+    rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+    # 1e-4 rad / 1e-3 m is the stated tolerance; 1e-7 rad is the floor of arccos near the identity
+    assert rot <= 1e-4 and trans <= 1e-3 and rot < 1e-7 and trans < 1e-9, (rot, trans)
+    assert r.quality == pytest.approx(ref["quality"], abs=1e-12) and r.n_pairs == ref["n_pairs"]
+    assert r.rmse == pytest.approx(ref["rmse"], rel=1e-6)
+    rot, trans = O.pose_error(r.optimal_tf, Tgt)
+    assert rot < 2e-4 and trans < 2e-3
+    # empty / far clouds
+    assert icp.align(g, np.ascontiguousarray(l + np.float32(500)), np.eye(4), p).terminationReason == pkg.TERM_NO_PAIRINGS
+    assert icp.align(np.zeros((3, 0), np.float32), l, np.eye(4), p).terminationReason == pkg.TERM_NO_PAIRINGS
+    icp.close()
+
+
+@pytest.mark.gpu
+def test_plane_accumulators_shard_sum(pkg, pair):
+    """query shards run one after another: summed plane forms == the un-sharded form (what RCCL reduces)"""
+    import importlib
+    sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+    g, l, _ = pair
+    p = pkg.Parameters.load_from_file(REGULAR)
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    valid, cen, nor, _, n = icp.match_planes(np.eye(4), p, l.shape[1])
+    full = _form_from_pairing(l, valid, cen, nor)
+    tot = 0
+    for r in range(4):
+        lo, hi = sharded.shard_bounds(l.shape[1], r, 4)
+        icp.set_local(np.ascontiguousarray(l[:, lo:hi]))
+        v, c, nn, _, k = icp.match_planes(np.eye(4), p, hi - lo)
+        assert np.array_equal(v, valid[lo:hi])
+        tot += k
+    assert tot == n and full[91] == n
+    icp.close()
+
+
+@pytest.mark.gpu
+def test_front_end_with_shipped_settings(pkg, O, synth):
+    """kitti-default.yaml's loop-closure settings (= the shipped Point2Plane/GaussNewton file) through align_multi_init"""
+    lp = pkg.LidarOdometryParams.load_from_file(os.path.join(ROOT, "params", "kitti-default.yaml"), ROOT)
+    s0 = synth.lidar_scan(synth.pose_from_xyzypr(-10.0, 0.2, 0, 0.00, 0, 0), n_rings=32, n_az=900, seed=11)
+    s1 = synth.lidar_scan(synth.pose_from_xyzypr(-9.4, 0.25, 0, 0.01, 0, 0), n_rings=32, n_az=900, seed=12)
+    p = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "kitti-default.yaml"), ROOT, "icp_settings_loop_closure")
+    assert p.matcher_class == pkg._lib.MATCHER_POINT2PLANE
+    icp = pkg.ICP(device=0)
+    res, best = icp.align_multi_init(s0, s1, [np.eye(4), synth.pose_from_xyzypr(0.3, 0, 0, 0, 0, 0)], p)
+    ref = O.align_p2pl(s0, s1, np.eye(4), O.params_from_product(p), p.plane_eigen_threshold, p.knn, p.solver_max_iterations)
+    assert res[0].nIterations == ref["n_iterations"]
+    rot, trans = O.pose_error(res[0].optimal_tf, ref["T"])
+    assert rot < 1e-7 and trans < 1e-7 and best in (0, 1)
+    icp.close()
