@@ -247,6 +247,63 @@ def main():
     out["C_T"] = np.array([synth.pose_from_xyzypr(*p) for p in poses])
     out["C_log"] = np.array([se3_log(synth.pose_from_xyzypr(*p)) for p in poses])
 
+    # ---- case D: the shipped pipeline -- point-to-plane pairings (knn 6, PCA planarity) + Gauss-Newton
+    gD, lD = g[:, :2500], l[:, :2000]
+    qD = transform32(T0, lD)
+    thr, eig_thr, knn = 0.70, 0.07, 6
+    thr2 = f32(np.float64(thr) * np.float64(thr))
+    N = qD.shape[1]
+    kidx = np.full((N, knn), -1, np.int32)
+    valid = np.zeros(N, np.uint8)
+    cen = np.zeros((N, 3))
+    nor = np.zeros((N, 3))
+    for s0 in range(0, N, 256):
+        e = min(N, s0 + 256)
+        dx = sub32(qD[0, s0:e, None], gD[0][None, :])
+        dy = sub32(qD[1, s0:e, None], gD[1][None, :])
+        dz = sub32(qD[2, s0:e, None], gD[2][None, :])
+        d2 = fma32(dz, dz, fma32(dy, dy, mul32(dx, dx)))
+        order = np.argsort(d2, axis=1, kind="stable")[:, :knn]      # stable: lowest index first on ties
+        for r in range(e - s0):
+            nb = [j for j in order[r] if d2[r, j] < thr2]
+            kidx[s0 + r, :len(nb)] = nb
+            if len(nb) < 3:
+                continue
+            P3 = gD[:, nb].astype(np.float64).T
+            mean = P3.mean(0)
+            C3 = (P3 - mean).T @ (P3 - mean) / len(nb)
+            w3, V3 = np.linalg.eigh(C3)                                # ascending
+            if w3[0] > eig_thr * w3[2]:
+                continue
+            nrm = V3[:, 0]
+            if abs(nrm @ (qD[:, s0 + r].astype(np.float64) - mean)) > thr:
+                continue
+            valid[s0 + r], cen[s0 + r], nor[s0 + r] = 1, mean, nrm
+    # Gauss-Newton in numpy, RIGHT perturbation T <- T exp(delta) (the oracle/product use the left one):
+    # a different parametrisation must reach the same minimiser
+    def gn(T, iters):
+        k = valid.astype(bool)
+        Lk, ck, nk = lD[:, k].astype(np.float64).T, cen[k], nor[k]
+        for _ in range(iters):
+            R, t = T[:3, :3], T[:3, 3]
+            pw = Lk @ R.T + t
+            r = ((pw - ck) * nk).sum(1)
+            Rn = nk @ R                                    # R^T n  per pair
+            J = np.concatenate([Rn, np.cross(Lk, Rn)], axis=1)   # d r / d(v, w) for T exp(delta)
+            d = np.linalg.solve(J.T @ J, -J.T @ r)
+            X = np.zeros((4, 4))
+            X[:3, :3] = [[0, -d[5], d[4]], [d[5], 0, -d[3]], [-d[4], d[3], 0]]
+            X[:3, 3] = d[:3]
+            from scipy.linalg import expm
+            T = T @ expm(X)
+            if np.linalg.norm(d) < 1e-10:
+                break
+        return T
+    T_gn = gn(np.eye(4), 50)
+    out.update(D_map=gD, D_local=lD, D_knn_idx=kidx, D_valid=valid, D_centroid=cen, D_normal=nor, D_T_gn=T_gn,
+               D_params=np.array([thr, eig_thr, knn]))
+    print(f"case D: plane pairings={int(valid.sum())} of {N}")
+
     path = os.path.join(HERE, "icp_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

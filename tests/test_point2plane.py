@@ -154,3 +154,26 @@ def test_front_end_with_shipped_settings(pkg, O, synth):
     rot, trans = O.pose_error(res[0].optimal_tf, ref["T"])
     assert rot < 1e-7 and trans < 1e-7 and best in (0, 1)
     icp.close()
+
+
+def test_oracle_matches_independent_golden(O, golden):
+    """the oracle's point-to-plane matcher and Gauss-Newton against tests/golden/make_golden.py's numpy version
+    (fp32-emulated brute-force kNN, numpy eigh, Gauss-Newton with the RIGHT perturbation)"""
+    g, l = golden["D_map"], golden["D_local"]
+    thr, eig_thr, knn = golden["D_params"]
+    valid, cen, nor, kidx, n = O.match_point2plane(g, l, np.eye(4), thr, eig_thr, int(knn), O.KdTree(g))
+    assert np.array_equal(kidx, golden["D_knn_idx"])
+    assert np.array_equal(valid, golden["D_valid"]) and n == int(golden["D_valid"].sum())
+    k = valid.astype(bool)
+    np.testing.assert_allclose(cen[k], golden["D_centroid"][k], atol=1e-12)
+    np.testing.assert_allclose(np.abs((nor[k] * golden["D_normal"][k]).sum(1)), 1.0, atol=1e-9)
+    T, _, its = O.solve_gauss_newton(l, valid, cen, nor, np.eye(4), 50)
+    np.testing.assert_allclose(T, golden["D_T_gn"], atol=1e-9)
+
+
+def test_product_gn_matches_independent_golden(pkg, golden):
+    k = golden["D_valid"].astype(bool)
+    acc = _form_from_pairing(golden["D_local"], golden["D_valid"], golden["D_centroid"], golden["D_normal"])
+    T, _, _ = pkg.solve_gauss_newton_planes(acc, np.eye(4), 50)
+    np.testing.assert_allclose(T, golden["D_T_gn"], atol=1e-9)
+    assert k.sum() > 1000
