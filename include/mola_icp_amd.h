@@ -201,6 +201,19 @@ int mola_icp_align_multi_init(mola_icp_handle* h,
                               size_t n_init, const double* init_T, const mola_icp_params* p,
                               mola_icp_result* out, mola_icp_result* best, int* best_index);
 
+/* ---- device-resident cloud cache -------------------------------------------
+ * Keyframe / scan clouds stay in HBM keyed by a caller id (the reference keeps them in the world model and
+ * re-reads them for every nearby-KF / loop-closure ICP: src/LidarOdometry.cpp:384-388, 658-666; in odometry a
+ * scan is `to` once and `from` once: cpp:278-279).  A cached cloud is stored raw AND prepared (Hilbert order +
+ * tile boxes), so mola_icp_align_cached() does no upload and no sort.  put() with an existing id replaces it.
+ * Thread-safe; a cloud being used by a running align stays alive until that align returns. */
+int mola_icp_cloud_put(mola_icp_handle* h, uint64_t id, const float* x, const float* y, const float* z, size_t n);
+int mola_icp_cloud_drop(mola_icp_handle* h, uint64_t id);        /* MOLA_ICP_E_BADARG if the id is unknown */
+int mola_icp_cloud_count(mola_icp_handle* h, size_t* count_out, size_t* device_bytes_out);
+/* mola_icp_align() between two cached clouds (`from` = map, `to` = local) */
+int mola_icp_align_cached(mola_icp_handle* h, uint64_t from_id, uint64_t to_id, const double init_T[16],
+                          const mola_icp_params* p, mola_icp_result* out);
+
 /* ---- resident-cloud API (inputs already in HBM; bench + sharded path) ---
  * *_device take DEVICE pointers (fp32 SoA) that must stay valid until the
  * next set_* / destroy; *_host copy from host memory. */

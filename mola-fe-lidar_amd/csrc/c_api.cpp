@@ -1,6 +1,7 @@
 // c_api.cpp -- the extern "C" boundary declared in include/mola_icp_amd.h.
 // No exception, C++ type or HIP type crosses it.
 #include <atomic>
+#include <map>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -30,6 +31,8 @@ struct mola_icp_handle {
     mola_icp_allreduce_fn ar_fn = nullptr;
     void* ar_user = nullptr;
     void* comm = nullptr;  // RCCL communicator of the query-sharded path
+    std::mutex cache_mtx;  // guards the cloud cache (row f4)
+    std::map<uint64_t, std::shared_ptr<SortedCloud>> cache;
     ~mola_icp_handle()
     {
         if (resident) resident->sync();
@@ -413,6 +416,78 @@ int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* 
             }
         }
         return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_cloud_put(mola_icp_handle* h, uint64_t id, const float* x, const float* y, const float* z, size_t n)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        Lease lease(h);
+        if (lease.rc) return lease.rc;
+        auto sc = std::make_shared<SortedCloud>();
+        const int rc = lease.ws->build_cached(*sc, x, y, z, n);
+        if (rc) { lease.rc = rc; return rc; }
+        std::lock_guard<std::mutex> lk(h->cache_mtx);
+        h->cache[id] = std::move(sc);
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_cloud_drop(mola_icp_handle* h, uint64_t id)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->cache_mtx);
+        if (!h->cache.erase(id)) return fail(MOLA_ICP_E_BADARG, "no cached cloud with id " + std::to_string(id));
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_cloud_count(mola_icp_handle* h, size_t* count_out, size_t* device_bytes_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->cache_mtx);
+        size_t bytes = 0;
+        for (auto& kv : h->cache) {
+            const SortedCloud& c = *kv.second;
+            bytes += c.raw.cap + c.sorted.cap + c.perm.cap + c.tbox.cap + c.sbox.cap + c.ubox.cap;
+        }
+        if (count_out) *count_out = h->cache.size();
+        if (device_bytes_out) *device_bytes_out = bytes;
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_align_cached(mola_icp_handle* h, uint64_t from_id, uint64_t to_id, const double init_T[16],
+                          const mola_icp_params* p, mola_icp_result* out)
+{
+    return guarded([&]() -> int {
+        if (!h || !p || !out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        int rc;
+        if ((rc = check_pose(init_T))) return rc;
+        if ((rc = validate_params(*p))) return rc;
+        std::shared_ptr<SortedCloud> from, to;
+        {
+            std::lock_guard<std::mutex> lk(h->cache_mtx);
+            auto a = h->cache.find(from_id), b = h->cache.find(to_id);
+            if (a == h->cache.end()) return fail(MOLA_ICP_E_BADARG, "no cached cloud with id " + std::to_string(from_id));
+            if (b == h->cache.end()) return fail(MOLA_ICP_E_BADARG, "no cached cloud with id " + std::to_string(to_id));
+            from = a->second;
+            to = b->second;
+        }
+        Lease lease(h);
+        if (lease.rc) return lease.rc;
+        HipWorkspace& ws = *lease.ws;
+        std::memset(out, 0, sizeof *out);
+        ws.use_cached_map(from);
+        ws.use_cached_local(to);
+        ws.set_global_sizes(0, 0);
+        ws.set_allreduce(nullptr, nullptr);
+        rc = align_on(ws, init_T, p, out);
+        if (rc) lease.rc = rc;
+        return rc;
     });
 }
 

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -1231,7 +1232,10 @@ void DevBuf::release()
     cap = 0;
 }
 
-HipWorkspace::HipWorkspace(int device) : device_(device) {}
+HipWorkspace::HipWorkspace(int device)
+    : device_(device), map_sc_(std::make_shared<SortedCloud>()), loc_sc_(std::make_shared<SortedCloud>())
+{
+}
 
 HipWorkspace::~HipWorkspace()
 {
@@ -1240,8 +1244,8 @@ HipWorkspace::~HipWorkspace()
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
-    sorted_.release(); perm_.release(); tbox_.release(); sbox_.release(); ubox_.release(); lsorted_.release();
-    qperm_.release();
+    map_sc_.reset();
+    loc_sc_.reset();
     ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
     planes_.release(); knn_pos_.release(); plane_acc_.release();
     if (plane_acc_host_) (void)hipHostFree(plane_acc_host_);
@@ -1333,7 +1337,8 @@ int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, s
     M_ = M;
     planes_valid_ = false;
     map_img_valid_ = false;
-    tiles_valid_ = false;
+    if (map_sc_->cached) map_sc_ = std::make_shared<SortedCloud>();  // a cached cloud is immutable: use an own one
+    map_sc_->ready = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -1349,7 +1354,8 @@ int HipWorkspace::set_map_device(const float* x, const float* y, const float* z,
     M_ = M;
     planes_valid_ = false;
     map_img_valid_ = false;
-    tiles_valid_ = false;
+    if (map_sc_->cached) map_sc_ = std::make_shared<SortedCloud>();  // a cached cloud is immutable: use an own one
+    map_sc_->ready = false;
     pairing_valid_ = false;
     seed_valid_ = false;
     return MOLA_ICP_OK;
@@ -1366,7 +1372,8 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     HIPCHK(hipStreamSynchronize(stream_));
     N_ = N;
     planes_valid_ = false;
-    queries_valid_ = false;
+    if (loc_sc_->cached) loc_sc_ = std::make_shared<SortedCloud>();
+    loc_sc_->ready = false;
     cost_valid_ = false;
     order_valid_ = false;
     pairing_valid_ = false;
@@ -1383,7 +1390,8 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     lx_ = x; ly_ = y; lz_ = z;
     N_ = N;
     planes_valid_ = false;
-    queries_valid_ = false;
+    if (loc_sc_->cached) loc_sc_ = std::make_shared<SortedCloud>();
+    loc_sc_->ready = false;
     cost_valid_ = false;
     order_valid_ = false;
     pairing_valid_ = false;
@@ -1465,60 +1473,113 @@ int HipWorkspace::bbox_of(const float* x, const float* y, const float* z, size_t
 // Once per map: Morton order, tile boxes, super-tile boxes.
 int HipWorkspace::prepare_tiles()
 {
-    if (tiles_valid_) return MOLA_ICP_OK;
+    if (map_sc_->ready) return MOLA_ICP_OK;
     int rc;
     float bbox[6];
     if ((rc = bbox_of(gx_, gy_, gz_, M_, bbox))) return rc;
     const size_t super_pts = (size_t)kTileG * kSuper;
-    n_super_ = (int)((M_ + super_pts - 1) / super_pts);
-    n_super_ = (n_super_ + 63) / 64 * 64;  // whole top boxes (the padding tiles get empty boxes)
-    n_top_ = n_super_ / 64;
-    n_tiles_p_ = n_super_ * kSuper;
-    m_padded_ = (size_t)n_tiles_p_ * kTileG;
-    if ((rc = sorted_.reserve(sizeof(float) * 3 * m_padded_))) return rc;
-    if ((rc = perm_.reserve(sizeof(int) * m_padded_))) return rc;
-    if ((rc = tbox_.reserve(sizeof(float) * 6 * (size_t)n_tiles_p_))) return rc;
-    if ((rc = sbox_.reserve(sizeof(float) * 6 * (size_t)n_super_))) return rc;
-    if ((rc = ubox_.reserve(sizeof(float) * 6 * (size_t)n_top_))) return rc;
-    if ((rc = morton_sort_points(stream_, gx_, gy_, gz_, M_, m_padded_, bbox, sort_scratch_, sorted_.as<float>(),
-                                 perm_.as<int>())))
+    map_sc_->n_super = (int)((M_ + super_pts - 1) / super_pts);
+    map_sc_->n_super = (map_sc_->n_super + 63) / 64 * 64;  // whole top boxes (the padding tiles get empty boxes)
+    map_sc_->n_top = map_sc_->n_super / 64;
+    map_sc_->n_tiles_p = map_sc_->n_super * kSuper;
+    map_sc_->padded = (size_t)map_sc_->n_tiles_p * kTileG;
+    if ((rc = map_sc_->sorted.reserve(sizeof(float) * 3 * map_sc_->padded))) return rc;
+    if ((rc = map_sc_->perm.reserve(sizeof(int) * map_sc_->padded))) return rc;
+    if ((rc = map_sc_->tbox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_tiles_p))) return rc;
+    if ((rc = map_sc_->sbox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_super))) return rc;
+    if ((rc = map_sc_->ubox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_top))) return rc;
+    if ((rc = morton_sort_points(stream_, gx_, gy_, gz_, M_, map_sc_->padded, bbox, sort_scratch_, map_sc_->sorted.as<float>(),
+                                 map_sc_->perm.as<int>())))
         return rc;
-    const float* sx = sorted_.as<float>();
-    hipLaunchKernelGGL(k_tile_boxes, dim3((unsigned)((n_tiles_p_ + 255) / 256)), dim3(256), 0, stream_, sx, sx + m_padded_,
-                       sx + 2 * m_padded_, (int)M_, n_tiles_p_, tbox_.as<float>());
+    const float* sx = map_sc_->sorted.as<float>();
+    hipLaunchKernelGGL(k_tile_boxes, dim3((unsigned)((map_sc_->n_tiles_p + 255) / 256)), dim3(256), 0, stream_, sx, sx + map_sc_->padded,
+                       sx + 2 * map_sc_->padded, (int)M_, map_sc_->n_tiles_p, map_sc_->tbox.as<float>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((n_super_ + 255) / 256)), dim3(256), 0, stream_, tbox_.as<float>(),
-                       n_tiles_p_, n_super_, sbox_.as<float>());
+    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((map_sc_->n_super + 255) / 256)), dim3(256), 0, stream_, map_sc_->tbox.as<float>(),
+                       map_sc_->n_tiles_p, map_sc_->n_super, map_sc_->sbox.as<float>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((n_top_ + 255) / 256)), dim3(256), 0, stream_, sbox_.as<float>(),
-                       n_super_, n_top_, ubox_.as<float>());
+    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((map_sc_->n_top + 255) / 256)), dim3(256), 0, stream_, map_sc_->sbox.as<float>(),
+                       map_sc_->n_super, map_sc_->n_top, map_sc_->ubox.as<float>());
     HIPCHK(hipGetLastError());
-    tiles_valid_ = true;
+    map_sc_->ready = true;
     return MOLA_ICP_OK;
 }
 
 // Once per local cloud: Morton order of the queries (a rigid motion keeps them compact).
 int HipWorkspace::prepare_queries()
 {
-    if (queries_valid_) return MOLA_ICP_OK;
+    if (loc_sc_->ready) return MOLA_ICP_OK;
     int rc;
     float bbox[6];
     if ((rc = bbox_of(lx_, ly_, lz_, N_, bbox))) return rc;
-    n_padded_ = (N_ + kQPW - 1) / kQPW * kQPW;
-    if ((rc = lsorted_.reserve(sizeof(float) * 3 * n_padded_))) return rc;
-    if ((rc = qperm_.reserve(sizeof(int) * n_padded_))) return rc;
-    if ((rc = morton_sort_points(stream_, lx_, ly_, lz_, N_, n_padded_, bbox, sort_scratch_, lsorted_.as<float>(),
-                                 qperm_.as<int>())))
+    loc_sc_->padded = (N_ + kQPW - 1) / kQPW * kQPW;
+    if ((rc = loc_sc_->sorted.reserve(sizeof(float) * 3 * loc_sc_->padded))) return rc;
+    if ((rc = loc_sc_->perm.reserve(sizeof(int) * loc_sc_->padded))) return rc;
+    if ((rc = morton_sort_points(stream_, lx_, ly_, lz_, N_, loc_sc_->padded, bbox, sort_scratch_, loc_sc_->sorted.as<float>(),
+                                 loc_sc_->perm.as<int>())))
         return rc;
-    queries_valid_ = true;
+    loc_sc_->ready = true;
     return MOLA_ICP_OK;
+}
+
+// ---- row f4: device-resident cloud cache --------------------------------------------------------------
+// A cached cloud lives in HBM in raw AND Hilbert-sorted form with its tile boxes, so it can serve as the map
+// (`from`) or as the local cloud (`to`) of any later align without upload or sort: the reference keeps
+// keyframe clouds in the world model and re-reads them per nearby-KF / loop-closure ICP
+// (src/LidarOdometry.cpp:384-388, 658-666), and in odometry each scan is `to` once and `from` once (cpp:278-279).
+int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, const float* z, size_t n)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (n && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null cloud pointer");
+    if (n > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "cloud too large for 32-bit indices");
+    HIPCHK(hipSetDevice(device_));
+    if ((rc = upload_soa(sc.raw, stream_, x, y, z, n, &sc.x, &sc.y, &sc.z))) return rc;
+    sc.n = n;
+    sc.cached = true;
+    // build the sorted form through the map-role path of this workspace, then hand the buffers over
+    std::shared_ptr<SortedCloud> keep_sc = map_sc_;
+    const float *kx = gx_, *ky = gy_, *kz = gz_;
+    const size_t kM = M_;
+    std::shared_ptr<SortedCloud> tmp(&sc, [](SortedCloud*) {});
+    map_sc_ = tmp;
+    gx_ = sc.x; gy_ = sc.y; gz_ = sc.z; M_ = n;
+    sc.ready = false;
+    rc = n ? prepare_tiles() : MOLA_ICP_OK;
+    if (!rc) HIPCHK(hipStreamSynchronize(stream_));
+    map_sc_ = keep_sc;
+    gx_ = kx; gy_ = ky; gz_ = kz; M_ = kM;
+    return rc;
+}
+
+void HipWorkspace::use_cached_map(const std::shared_ptr<SortedCloud>& sc)
+{
+    map_sc_ = sc;
+    gx_ = sc->x; gy_ = sc->y; gz_ = sc->z;
+    M_ = sc->n;
+    planes_valid_ = false;
+    map_img_valid_ = false;
+    pairing_valid_ = false;
+    seed_valid_ = false;
+}
+
+void HipWorkspace::use_cached_local(const std::shared_ptr<SortedCloud>& sc)
+{
+    loc_sc_ = sc;
+    lx_ = sc->x; ly_ = sc->y; lz_ = sc->z;
+    N_ = sc->n;
+    planes_valid_ = false;
+    cost_valid_ = false;
+    order_valid_ = false;
+    pairing_valid_ = false;
+    seed_valid_ = false;
 }
 
 TiledMap HipWorkspace::tiled_map() const
 {
-    const float* sx = sorted_.as<float>();
-    return TiledMap{sx, sx + m_padded_, sx + 2 * m_padded_, perm_.as<int>(), tbox_.as<float>(), n_tiles_p_,
-                    sbox_.as<float>(), n_super_, ubox_.as<float>(), n_top_};
+    const float* sx = map_sc_->sorted.as<float>();
+    return TiledMap{sx, sx + map_sc_->padded, sx + 2 * map_sc_->padded, map_sc_->perm.as<int>(), map_sc_->tbox.as<float>(), map_sc_->n_tiles_p,
+                    map_sc_->sbox.as<float>(), map_sc_->n_super, map_sc_->ubox.as<float>(), map_sc_->n_top};
 }
 
 int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
@@ -1544,23 +1605,23 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
         ++launches_since_order_;
         order = item_order_.as<int>();
     }
-    if ((rc = ts_pos_.reserve(sizeof(int) * n_padded_))) return rc;
-    if ((rc = ts_idx_.reserve(sizeof(int) * n_padded_))) return rc;
-    if ((rc = ts_d2_.reserve(sizeof(float) * n_padded_))) return rc;
-    const float* sl = lsorted_.as<float>();
+    if ((rc = ts_pos_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
+    if ((rc = ts_idx_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
+    if ((rc = ts_d2_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
+    const float* sl = loc_sc_->sorted.as<float>();
     if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
     const TiledMap mp = tiled_map();
     // counter[1] = work queue (fast pass), counter[2] = redo count, counter[3] = work queue (exact pass)
-    hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,
+    hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
                        (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(),
                        order, item_cost_.as<unsigned int>(), counter + 1, counter + 2, redo_list_.as<int>(), staged,
                        dbg_stats_);
     HIPCHK(hipGetLastError());
     // exact ties (duplicate points, lattices): the queued items again with the full lexicographic key.
     // Usually zero items: a few waves that read the count and leave.
-    hipLaunchKernelGGL((k_nn_tiled<true>), dim3(grid < 64 ? grid : 64), dim3(256), 0, stream_, sl, sl + n_padded_,
-                       sl + 2 * n_padded_, (int)N_, mp, P, thr2, /*seed = fast pass's result*/ 1, ts_pos_.as<int>(),
+    hipLaunchKernelGGL((k_nn_tiled<true>), dim3(grid < 64 ? grid : 64), dim3(256), 0, stream_, sl, sl + loc_sc_->padded,
+                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, /*seed = fast pass's result*/ 1, ts_pos_.as<int>(),
                        ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr, (unsigned int*)nullptr, counter + 3,
                        counter + 2, redo_list_.as<int>(), staged, dbg_stats_);
     cost_valid_ = true;
@@ -1579,8 +1640,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     planes_empty_ = false;
     if ((rc = prepare_tiles())) return rc;
     if ((rc = prepare_queries())) return rc;
-    if ((rc = planes_.reserve(sizeof(PlanePair) * n_padded_))) return rc;
-    if ((rc = knn_pos_.reserve(sizeof(int) * n_padded_ * 8))) return rc;
+    if ((rc = planes_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
+    if ((rc = knn_pos_.reserve(sizeof(int) * loc_sc_->padded * 8))) return rc;
     PoseF P;
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) P.R[3 * r + c] = (float)T(r, c);
@@ -1598,11 +1659,11 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
     int grid = num_cus_ * 3;
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
-    const float* sl = lsorted_.as<float>();
+    const float* sl = loc_sc_->sorted.as<float>();
     const TiledMap mp = tiled_map();
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
 #define MOLA_LAUNCH_KNN(KK)                                                                                         \
-    hipLaunchKernelGGL((k_knn_planes<KK>), dim3(grid), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,  \
+    hipLaunchKernelGGL((k_knn_planes<KK>), dim3(grid), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,  \
                        (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold, planes_.as<PlanePair>(),   \
                        knn_pos_.as<int>(), counter + 1, staged)
     switch (p.knn) {
@@ -1636,8 +1697,8 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
     } else {
         int nblocks = (int)((N_ + 255) / 256);
         if (nblocks > 512) nblocks = 512;
-        const float* sl = lsorted_.as<float>();
-        hipLaunchKernelGGL(k_accumulate_planes, dim3(nblocks), dim3(256), 0, stream_, sl, sl + n_padded_, sl + 2 * n_padded_,
+        const float* sl = loc_sc_->sorted.as<float>();
+        hipLaunchKernelGGL(k_accumulate_planes, dim3(nblocks), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
                            planes_.as<PlanePair>(), (int)N_, plane_acc_.as<double>());
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(128), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc);
@@ -1668,8 +1729,8 @@ int HipWorkspace::copy_planes(uint8_t* valid, double* centroid, double* normal, 
     DevBuf tmp_pairs, tmp_knn;
     if ((rc = tmp_pairs.reserve(sizeof(PlanePair) * N_))) return rc;
     if ((rc = tmp_knn.reserve(sizeof(int) * N_ * 8))) { tmp_pairs.release(); return rc; }
-    hipLaunchKernelGGL(k_unpermute_planes, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, qperm_.as<int>(),
-                       planes_.as<PlanePair>(), perm_.as<int>(), knn_pos_.as<int>(), planes_knn_, (int)N_,
+    hipLaunchKernelGGL(k_unpermute_planes, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, loc_sc_->perm.as<int>(),
+                       planes_.as<PlanePair>(), map_sc_->perm.as<int>(), knn_pos_.as<int>(), planes_knn_, (int)N_,
                        tmp_pairs.as<PlanePair>(), tmp_knn.as<int>());
     std::vector<PlanePair> hp(N_);
     std::vector<int> hk(N_ * (size_t)planes_knn_);
@@ -1881,10 +1942,10 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     if ((rc = partials_.reserve(sizeof(double) * kNAcc * 512))) return rc;
     AccArgs a{};
     if (pairing_sorted_) {  // tiled matcher: sorted local cloud, neighbour = sorted-map position (local gathers)
-        const float* sl = lsorted_.as<float>();
-        const float* sm = sorted_.as<float>();
-        a.lx = sl; a.ly = sl + n_padded_; a.lz = sl + 2 * n_padded_;
-        a.gx = sm; a.gy = sm + m_padded_; a.gz = sm + 2 * m_padded_;
+        const float* sl = loc_sc_->sorted.as<float>();
+        const float* sm = map_sc_->sorted.as<float>();
+        a.lx = sl; a.ly = sl + loc_sc_->padded; a.lz = sl + 2 * loc_sc_->padded;
+        a.gx = sm; a.gy = sm + map_sc_->padded; a.gz = sm + 2 * map_sc_->padded;
         a.idx = ts_pos_.as<int>(); a.d2 = ts_d2_.as<float>();
     } else {
         a.lx = lx_; a.ly = ly_; a.lz = lz_; a.gx = gx_; a.gy = gy_; a.gz = gz_;
@@ -1927,7 +1988,7 @@ int HipWorkspace::copy_pairing(int32_t* idx_out, float* d2_out)
     HIPCHK(hipSetDevice(device_));
     if (N_ && pairing_sorted_) {
         hipLaunchKernelGGL(k_unpermute_pairing, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_,
-                           qperm_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(), (int)N_, idx_.as<int>(),
+                           loc_sc_->perm.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(), (int)N_, idx_.as<int>(),
                            d2_.as<float>());
         HIPCHK(hipGetLastError());
     }

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "icp_loop.hpp"
@@ -30,6 +31,19 @@ struct DevBuf {
     int reserve(size_t bytes);  // grows (never shrinks); contents are NOT preserved
     void release();
     template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// A cloud in Hilbert order with its three box levels (the tiled kernels' view of a map; its sorted coordinates and
+// permutation also serve the query role).  Owned by a workspace, or shared through the handle's cloud cache.
+struct SortedCloud {
+    DevBuf raw;                                     // cached clouds own their raw SoA too
+    const float *x = nullptr, *y = nullptr, *z = nullptr;
+    size_t n = 0;
+    DevBuf sorted, perm, tbox, sbox, ubox;
+    size_t padded = 0;
+    int n_tiles_p = 0, n_super = 0, n_top = 0;
+    bool ready = false, cached = false;
+    ~SortedCloud() { raw.release(); sorted.release(); perm.release(); tbox.release(); sbox.release(); ubox.release(); }
 };
 
 class HipWorkspace final : public Stages {
@@ -65,6 +79,11 @@ class HipWorkspace final : public Stages {
     int match_planes(const Mat4& T, const mola_icp_params& p) override;
     int accumulate_planes(double acc[kNAccPlaneHost]) override;
     int copy_planes(uint8_t* valid, double* centroid, double* normal, int32_t* knn_idx);
+
+    // row f4: device-resident cloud cache
+    int build_cached(SortedCloud& sc, const float* x, const float* y, const float* z, size_t n);  // host pointers
+    void use_cached_map(const std::shared_ptr<SortedCloud>& sc);
+    void use_cached_local(const std::shared_ptr<SortedCloud>& sc);
     int sync();
 
     // NN-kernel timing (HIP events on this workspace's stream)
@@ -102,9 +121,9 @@ class HipWorkspace final : public Stages {
     float map_radius_ = 0;
     int map_tiles_ = 0, map_segs_ = 0, map_seg_tiles_ = 0;
     int num_cus_ = 256;
-    // tiled matcher: Morton-sorted map (SoA, padded to whole super-tiles) + permutation + tile / super-tile boxes,
-    // Morton-sorted local cloud + permutation
-    DevBuf sorted_, perm_, tbox_, sbox_, ubox_, lsorted_, qperm_, sort_scratch_;
+    // tiled matcher: the map and the local cloud in Hilbert order (own, or borrowed from the handle's cache)
+    std::shared_ptr<SortedCloud> map_sc_, loc_sc_;
+    DevBuf sort_scratch_;
     DevBuf ts_pos_, ts_idx_, ts_d2_;  // the tiled matcher's pairing, in SORTED query order
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
     DevBuf planes_, knn_pos_, plane_acc_;  // point-to-plane pairing (sorted query order) + its accumulators
@@ -115,9 +134,6 @@ class HipWorkspace final : public Stages {
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
     bool cost_valid_ = false, order_valid_ = false;
     unsigned int launches_since_order_ = 0;
-    bool tiles_valid_ = false, queries_valid_ = false;
-    int n_tiles_p_ = 0, n_super_ = 0, n_top_ = 0;
-    size_t m_padded_ = 0, n_padded_ = 0;
     // pairing + scratch
     DevBuf idx_, d2_, seg_idx_, seg_d2_, outlier_, partials_, acc_dev_;
     double* acc_host_ = nullptr;  // pinned

@@ -237,6 +237,25 @@ class ICP:
                                                   _dp(Ts), C.byref(params.c), res, C.byref(best), C.byref(bi)))
         return [Results.from_c(res[k]) for k in range(n)], bi.value
 
+    # -- device-resident cloud cache (row f4): keyframe clouds stay prepared in HBM, keyed by id
+    def cloud_put(self, cloud_id: int, pc):
+        x, y, z, n = _soa(pc)
+        L.check(L.lib().mola_icp_cloud_put(self._h, int(cloud_id), _fp(x), _fp(y), _fp(z), n))
+
+    def cloud_drop(self, cloud_id: int):
+        L.check(L.lib().mola_icp_cloud_drop(self._h, int(cloud_id)))
+
+    def cloud_count(self) -> tuple[int, int]:
+        n, b = C.c_size_t(), C.c_size_t()
+        L.check(L.lib().mola_icp_cloud_count(self._h, C.byref(n), C.byref(b)))
+        return n.value, b.value
+
+    def align_cached(self, from_id: int, to_id: int, init_guess_to_wrt_from, params: Parameters) -> Results:
+        T = _pose16(init_guess_to_wrt_from)
+        r = L.CResult()
+        L.check(L.lib().mola_icp_align_cached(self._h, int(from_id), int(to_id), _dp(T), C.byref(params.c), C.byref(r)))
+        return Results.from_c(r)
+
     # -- resident clouds (already in HBM): bench + sharded path
     @staticmethod
     def _is_device_tensor(x) -> bool:

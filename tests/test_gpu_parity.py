@@ -339,3 +339,60 @@ def test_loop_closure_montecarlo_multi_init(pkg, O, icp, synth, small_scene):
     far = np.ascontiguousarray(l + np.float32(500))
     res, best = icp.align_multi_init(g, far, guesses[:2], p)
     assert best == -1 and all(r.quality == 0 for r in res)
+
+
+def test_cloud_cache_align_cached(pkg, O, synth, small_scene):
+    """row f4: clouds kept prepared in HBM by id; align between cached ids == align from host buffers, in every role"""
+    import threading
+    icp = pkg.ICP(device=0)
+    clouds = {}
+    for k in range(4):
+        g, l, _ = synth.make_pair(9000 + 500 * k, 9000 + 300 * k, seed=300 + k, scene=small_scene)
+        clouds[2 * k], clouds[2 * k + 1] = g, l
+        icp.cloud_put(2 * k, g)
+        icp.cloud_put(2 * k + 1, l)
+    n, nbytes = icp.cloud_count()
+    assert n == 8 and nbytes > 8 * 9000 * 28
+    p = p2p_params(pkg, max_iterations=30, matcher_threshold=0.6)
+    for kern in (pkg.NN_AUTO, pkg.NN_MFMA, pkg.NN_VALU):
+        p.nn_kernel = kern
+        for a, b in ((0, 1), (3, 2), (4, 5), (1, 0)):      # every cloud serves as map and as local cloud
+            r = icp.align_cached(a, b, np.eye(4), p)
+            s = icp.align(clouds[a], clouds[b], np.eye(4), p)
+            assert r.nIterations == s.nIterations and r.terminationReason == s.terminationReason
+            assert np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality
+            assert r.ms_upload == 0.0
+    # the shipped point-to-plane pipeline on cached clouds
+    pp = pkg.Parameters.load_from_file(os.path.join(os.path.dirname(os.path.dirname(__file__)), "params",
+                                                    "icp-settings-regular.yaml"))
+    r = icp.align_cached(0, 1, np.eye(4), pp)
+    s = icp.align(clouds[0], clouds[1], np.eye(4), pp)
+    assert r.nIterations == s.nIterations and np.array_equal(r.optimal_tf, s.optimal_tf)
+    # concurrent aligns on shared cached clouds (the reference's pool threads read the same KF clouds)
+    out = [None] * 6
+    p.nn_kernel = pkg.NN_AUTO
+
+    def run(i):
+        out[i] = icp.align_cached(2 * (i % 4), 2 * (i % 4) + 1, np.eye(4), p)
+    th = [threading.Thread(target=run, args=(i,)) for i in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i, r in enumerate(out):
+        ref = O.align(clouds[2 * (i % 4)], clouds[2 * (i % 4) + 1], np.eye(4), O.params_from_product(p))
+        assert r.nIterations == ref["n_iterations"]
+        rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+        assert rot < 1e-7 and trans < 1e-9
+    # replace, drop, errors
+    icp.cloud_put(1, clouds[3])
+    assert np.array_equal(icp.align_cached(0, 1, np.eye(4), p).optimal_tf, icp.align(clouds[0], clouds[3], np.eye(4), p).optimal_tf)
+    icp.cloud_drop(7)
+    assert icp.cloud_count()[0] == 7
+    for bad in (lambda: icp.cloud_drop(7), lambda: icp.align_cached(0, 7, np.eye(4), p), lambda: icp.align_cached(99, 1, np.eye(4), p)):
+        with pytest.raises(pkg.IcpError) as e:
+            bad()
+        assert e.value.status == pkg._lib.E_BADARG
+    # an empty cached cloud behaves like an empty host cloud
+    icp.cloud_put(50, np.zeros((3, 0), np.float32))
+    assert icp.align_cached(0, 50, np.eye(4), p).terminationReason == pkg.TERM_NO_PAIRINGS
+    assert icp.align_cached(50, 1, np.eye(4), p).terminationReason == pkg.TERM_NO_PAIRINGS
+    icp.close()
