@@ -214,6 +214,14 @@ int mola_icp_cloud_count(mola_icp_handle* h, size_t* count_out, size_t* device_b
 int mola_icp_align_cached(mola_icp_handle* h, uint64_t from_id, uint64_t to_id, const double init_T[16],
                           const mola_icp_params* p, mola_icp_result* out);
 
+/* Voxel-grid downsample on the GPU (the decimation step BEFORE the ICP: src/LidarOdometry.cpp:215-224,
+ * LidarOdometry.h:76-80, kitti-default.yaml:25-32): one centroid per occupied voxel of edge `voxel_size`, voxel
+ * grid anchored at the cloud's minimum corner, output ordered by (ix, iy, iz).  *n_out = number of voxels; at most
+ * `capacity` points are written (call with capacity = n to get them all). */
+int mola_icp_voxel_downsample(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t n,
+                              double voxel_size, float* out_x, float* out_y, float* out_z, size_t capacity,
+                              size_t* n_out);
+
 /* ---- resident-cloud API (inputs already in HBM; bench + sharded path) ---
  * *_device take DEVICE pointers (fp32 SoA) that must stay valid until the
  * next set_* / destroy; *_host copy from host memory. */

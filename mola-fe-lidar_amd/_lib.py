@@ -152,6 +152,8 @@ SIGNATURES = {
     "mola_icp_cloud_drop": (C.c_int, [_H, C.c_uint64]),
     "mola_icp_cloud_count": (C.c_int, [_H, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "mola_icp_align_cached": (C.c_int, [_H, C.c_uint64, C.c_uint64, _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_icp_voxel_downsample": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, C.c_double, _FP, _FP, _FP, C.c_size_t,
+                                            C.POINTER(C.c_size_t)]),
     "mola_icp_set_map_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t]),
     "mola_icp_set_map_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mola_icp_set_local_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t]),

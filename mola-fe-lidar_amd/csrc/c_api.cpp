@@ -491,6 +491,19 @@ int mola_icp_align_cached(mola_icp_handle* h, uint64_t from_id, uint64_t to_id, 
     });
 }
 
+int mola_icp_voxel_downsample(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t n,
+                              double voxel_size, float* out_x, float* out_y, float* out_z, size_t capacity, size_t* n_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        Lease lease(h);
+        if (lease.rc) return lease.rc;
+        const int rc = lease.ws->voxel_downsample(x, y, z, n, voxel_size, out_x, out_y, out_z, capacity, n_out);
+        if (rc) lease.rc = rc;
+        return rc;
+    });
+}
+
 #define RESIDENT_CALL(expr)                                             \
     return guarded([&]() -> int {                                       \
         if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");          \

@@ -1522,6 +1522,48 @@ int HipWorkspace::prepare_queries()
     return MOLA_ICP_OK;
 }
 
+int voxel_downsample_device(hipStream_t stream, const float* x, const float* y, const float* z, size_t n, const float bbox[6],
+                            float voxel, DevBuf& scratch, float* out_x, float* out_y, float* out_z, size_t capacity,
+                            size_t* n_out_host);
+
+// row f4: voxel-grid downsample of a host cloud -> host cloud (centroid per occupied voxel, ascending voxel key)
+int HipWorkspace::voxel_downsample(const float* x, const float* y, const float* z, size_t n, double voxel_size,
+                                   float* out_x, float* out_y, float* out_z, size_t capacity, size_t* n_out)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (!n_out) return fail(MOLA_ICP_E_BADARG, "null n_out");
+    *n_out = 0;
+    if (!(voxel_size > 0) || !std::isfinite(voxel_size)) return fail(MOLA_ICP_E_BADARG, "voxel size must be > 0");
+    if (n && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null cloud pointer");
+    if (n > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "cloud too large for 32-bit indices");
+    if (n == 0) return MOLA_ICP_OK;
+    HIPCHK(hipSetDevice(device_));
+    DevBuf in, out;
+    const float *dx, *dy, *dz;
+    if ((rc = upload_soa(in, stream_, x, y, z, n, &dx, &dy, &dz))) return rc;
+    float bbox[6];
+    if ((rc = bbox_of(dx, dy, dz, n, bbox))) { in.release(); return rc; }
+    if ((rc = out.reserve(sizeof(float) * 3 * n))) { in.release(); return rc; }
+    float* o = out.as<float>();
+    size_t nv = 0;
+    rc = voxel_downsample_device(stream_, dx, dy, dz, n, bbox, (float)voxel_size, sort_scratch_, o, o + n, o + 2 * n, n, &nv);
+    if (!rc) {
+        *n_out = nv;
+        const size_t m = nv < capacity ? nv : capacity;
+        if (m && out_x && out_y && out_z) {
+            hipError_t e = hipMemcpyAsync(out_x, o, sizeof(float) * m, hipMemcpyDeviceToHost, stream_);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_y, o + n, sizeof(float) * m, hipMemcpyDeviceToHost, stream_);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_z, o + 2 * n, sizeof(float) * m, hipMemcpyDeviceToHost, stream_);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+            if (e != hipSuccess) rc = fail(MOLA_ICP_E_HIP, std::string("voxel_downsample copy: ") + hipGetErrorString(e));
+        }
+    }
+    in.release();
+    out.release();
+    return rc;
+}
+
 // ---- row f4: device-resident cloud cache --------------------------------------------------------------
 // A cached cloud lives in HBM in raw AND Hilbert-sorted form with its tile boxes, so it can serve as the map
 // (`from`) or as the local cloud (`to`) of any later align without upload or sort: the reference keeps

@@ -84,6 +84,8 @@ class HipWorkspace final : public Stages {
     int build_cached(SortedCloud& sc, const float* x, const float* y, const float* z, size_t n);  // host pointers
     void use_cached_map(const std::shared_ptr<SortedCloud>& sc);
     void use_cached_local(const std::shared_ptr<SortedCloud>& sc);
+    int voxel_downsample(const float* x, const float* y, const float* z, size_t n, double voxel_size, float* out_x,
+                         float* out_y, float* out_z, size_t capacity, size_t* n_out);
     int sync();
 
     // NN-kernel timing (HIP events on this workspace's stream)

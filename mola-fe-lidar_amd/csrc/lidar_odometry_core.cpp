@@ -3,6 +3,7 @@
 // relative pose / keyframe decision (src/LidarOdometry.cpp:190-514), minus MOLA's back-end, world model and
 // GUI plumbing.  Pure host logic; the registration itself is the C-ABI's mola_icp_align (or an injected
 // function, which is how this logic is tested without a GPU).
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -34,6 +35,12 @@ struct mola_lo {
     Mat4 accum_since_last_kf = Mat4::identity();
     bool have_kf = false;
     uint64_t last_kf = 0, next_kf_id = 0;
+
+    // with a GPU ICP handle the scans live in its cloud cache (row f4): a scan is uploaded + sorted once, is the `to`
+    // cloud of this step and the `from` cloud of the next, then dropped.  Ids are taken from a reserved range.
+    uint64_t cache_base = 0, scan_no = 0;
+    bool have_cached_last = false;
+    uint64_t cached_last_id = 0;
 };
 
 namespace {
@@ -93,6 +100,8 @@ int mola_lo_create(mola_icp_handle* icp, mola_lo_align_fn align_cb, void* user, 
         lo->icp = icp;
         lo->align_cb = align_cb;
         lo->align_user = user;
+        static std::atomic<uint64_t> instance{0};
+        lo->cache_base = (0xF1ull << 56) | ((instance.fetch_add(1) & 0xFFFFFFull) << 32);
         *out = lo.release();
         return MOLA_ICP_OK;
     } catch (const std::exception& e) {
@@ -102,6 +111,7 @@ int mola_lo_create(mola_icp_handle* icp, mola_lo_align_fn align_cb, void* user, 
 
 int mola_lo_destroy(mola_lo* lo)
 {
+    if (lo && lo->icp && lo->have_cached_last) (void)mola_icp_cloud_drop(lo->icp, lo->cached_last_id);
     delete lo;
     return MOLA_ICP_OK;
 }
@@ -110,6 +120,8 @@ int mola_lo_destroy(mola_lo* lo)
 int mola_lo_reset(mola_lo* lo)
 {
     if (!lo) return fail(MOLA_ICP_E_BADARG, "null handle");
+    if (lo->icp && lo->have_cached_last) (void)mola_icp_cloud_drop(lo->icp, lo->cached_last_id);
+    lo->have_cached_last = false;
     lo->have_last_tim = false;
     lo->last_x.clear(); lo->last_y.clear(); lo->last_z.clear();
     lo->have_last_points = false;
@@ -146,8 +158,32 @@ int mola_lo_process_scan(mola_lo* lo, double timestamp, const float* x, const fl
         const bool had_points = lo->have_last_points && !px.empty();
         lo->last_obs_tim = timestamp;
         lo->have_last_tim = true;
-        lo->last_x.assign(x, x + n); lo->last_y.assign(y, y + n); lo->last_z.assign(z, z + n);
+        const bool use_cache = lo->icp && !lo->align_cb;
+        const bool had_cached = lo->have_cached_last;
+        const uint64_t prev_id = lo->cached_last_id;
+        uint64_t cur_id = 0;
+        if (use_cache) {
+            lo->last_x.assign(n ? 1 : 0, 0.f);  // the host copy is not needed: only "is there a last cloud"
+            lo->last_y.clear(); lo->last_z.clear();
+            lo->have_cached_last = false;
+            if (n) {
+                cur_id = lo->cache_base | (lo->scan_no++ & 0xFFFFFFFFull);
+                const int rc = mola_icp_cloud_put(lo->icp, cur_id, x, y, z, n);
+                if (rc) {
+                    if (had_cached) (void)mola_icp_cloud_drop(lo->icp, prev_id);
+                    return rc;
+                }
+                lo->have_cached_last = true;
+                lo->cached_last_id = cur_id;
+            }
+        } else {
+            lo->last_x.assign(x, x + n); lo->last_y.assign(y, y + n); lo->last_z.assign(z, z + n);
+        }
         lo->have_last_points = true;
+        struct DropPrev {  // the previous scan leaves the cache when this step is over, whatever path it takes
+            mola_icp_handle* h; bool on; uint64_t id;
+            ~DropPrev() { if (on) (void)mola_icp_cloud_drop(h, id); }
+        } drop_prev{lo->icp, use_cache && had_cached, prev_id};
 
         if (n == 0) {  // cpp:238-245: "could not be converted into a pointcloud. Doing nothing."
             out->status = MOLA_LO_EMPTY_CLOUD;
@@ -176,9 +212,8 @@ int mola_lo_process_scan(mola_lo* lo, double timestamp, const float* x, const fl
             if (lo->align_cb)
                 rc = lo->align_cb(lo->align_user, px.data(), py.data(), pz.data(), px.size(), x, y, z, n, guess.m, &ip,
                                   &out->icp);
-            else
-                rc = mola_icp_align(lo->icp, px.data(), py.data(), pz.data(), px.size(), x, y, z, n, guess.m, &ip,
-                                    &out->icp);
+            else  // both scans are already prepared in HBM
+                rc = mola_icp_align_cached(lo->icp, prev_id, cur_id, guess.m, &ip, &out->icp);
             if (rc) return rc < 0 ? rc : fail(MOLA_ICP_E_INTERNAL, "align function failed");
             Mat4 rel;
             std::memcpy(rel.m, out->icp.T, sizeof rel.m);  // out.found_pose_to_wrt_from = optimal_tf (cpp:879)

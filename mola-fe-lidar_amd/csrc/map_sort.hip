@@ -112,4 +112,96 @@ int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, con
     return MOLA_ICP_OK;
 }
 
+// ---- row f4: voxel-grid downsample (one centroid per occupied voxel) ------------------------------------
+// The reference decimates clouds before the ICP with mp2p_icp_filters (src/LidarOdometry.cpp:215-224; voxel
+// parameters include/mola-fe-lidar/LidarOdometry.h:76-80, params/kitti-default.yaml:25-32) [EXT: that library is
+// not in the tree; this is the plain voxel-centroid filter].  Key = (ix, iy, iz) of floor((p - min) * (1/size)) in
+// fp32, 21 bits per axis; stable radix sort by key; one thread per voxel head sums its run in fp64 (ascending
+// original index) -> centroid.  Output order = ascending key.
+__global__ __launch_bounds__(256) void k_voxel_keys(const float* __restrict__ x, const float* __restrict__ y,
+                                                    const float* __restrict__ z, int n, float ox, float oy, float oz,
+                                                    float inv, unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long ix = (unsigned long long)fminf(floorf((x[i] - ox) * inv), 2097151.f);
+    const unsigned long long iy = (unsigned long long)fminf(floorf((y[i] - oy) * inv), 2097151.f);
+    const unsigned long long iz = (unsigned long long)fminf(floorf((z[i] - oz) * inv), 2097151.f);
+    keys[i] = (ix << 42) | (iy << 21) | iz;
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_heads(const unsigned long long* __restrict__ keys, int n, int* __restrict__ head)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_centroids(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, const unsigned long long* __restrict__ keys,
+                                                         const int* __restrict__ order, const int* __restrict__ head,
+                                                         const int* __restrict__ slot, int n, int capacity,
+                                                         float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const int s = slot[i];
+    if (s >= capacity) return;
+    double sx = 0, sy = 0, sz = 0;
+    int c = 0;
+    for (int j = i; j < n && keys[j] == keys[i]; ++j) {
+        const int o = order[j];
+        sx += x[o]; sy += y[o]; sz += z[o];
+        ++c;
+    }
+    ox[s] = (float)(sx / c); oy[s] = (float)(sy / c); oz[s] = (float)(sz / c);
+}
+
+// device in (x,y,z,n) -> device out (capacity floats each); *n_out_host = number of voxels (may exceed capacity)
+int voxel_downsample_device(hipStream_t stream, const float* x, const float* y, const float* z, size_t n, const float bbox[6],
+                            float voxel, DevBuf& scratch, float* out_x, float* out_y, float* out_z, size_t capacity,
+                            size_t* n_out_host)
+{
+    *n_out_host = 0;
+    if (n == 0) return MOLA_ICP_OK;
+    const int ni = (int)n;
+    const float inv = 1.0f / voxel;
+    for (int k = 0; k < 3; ++k)
+        if (!((bbox[3 + k] - bbox[k]) * inv < 2097151.f))
+            return fail(MOLA_ICP_E_BADARG, "voxel size too small for the cloud extent (more than 2^21 voxels per axis)");
+    size_t sort_tmp = 0, scan_tmp = 0;
+    unsigned long long* nk = nullptr;
+    int* nv = nullptr;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, nk, nk, nv, nv, ni, 0, 63, stream));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, nv, nv, ni, stream));
+    const size_t a8 = (sizeof(unsigned long long) * n + 255) / 256 * 256, a4 = (sizeof(int) * n + 255) / 256 * 256;
+    const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+    int rc = scratch.reserve(2 * a8 + 4 * a4 + tmp_bytes + 512);
+    if (rc) return rc;
+    char* base = scratch.as<char>();
+    unsigned long long* k_in = reinterpret_cast<unsigned long long*>(base);
+    unsigned long long* k_out = reinterpret_cast<unsigned long long*>(base + a8);
+    int* v_in = reinterpret_cast<int*>(base + 2 * a8);
+    int* order = reinterpret_cast<int*>(base + 2 * a8 + a4);
+    int* head = reinterpret_cast<int*>(base + 2 * a8 + 2 * a4);
+    int* slot = reinterpret_cast<int*>(base + 2 * a8 + 3 * a4);
+    void* tmp = base + 2 * a8 + 4 * a4;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(256), 0, stream, x, y, z, ni, bbox[0], bbox[1], bbox[2], inv, k_in, v_in);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp, sort_tmp, k_in, k_out, v_in, order, ni, 0, 63, stream));
+    hipLaunchKernelGGL(k_voxel_heads, dim3(nb), dim3(256), 0, stream, k_out, ni, head);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, head, slot, ni, stream));
+    hipLaunchKernelGGL(k_voxel_centroids, dim3(nb), dim3(256), 0, stream, x, y, z, k_out, order, head, slot, ni, (int)capacity,
+                       out_x, out_y, out_z);
+    HIPCHK(hipGetLastError());
+    int last[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&last[0], slot + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(&last[1], head + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    *n_out_host = (size_t)last[0] + (size_t)last[1];
+    return MOLA_ICP_OK;
+}
+
 }  // namespace mola_icp_amd

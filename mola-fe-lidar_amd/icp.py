@@ -256,6 +256,15 @@ class ICP:
         L.check(L.lib().mola_icp_align_cached(self._h, int(from_id), int(to_id), _dp(T), C.byref(params.c), C.byref(r)))
         return Results.from_c(r)
 
+    def voxel_downsample(self, pc, voxel_size: float) -> np.ndarray:
+        """one centroid per occupied voxel (row f4; the decimation step before the ICP) -> (3, n_voxels) float32"""
+        x, y, z, n = _soa(pc)
+        out = np.empty((3, max(1, n)), dtype=np.float32)
+        nv = C.c_size_t()
+        L.check(L.lib().mola_icp_voxel_downsample(self._h, _fp(x), _fp(y), _fp(z), n, float(voxel_size), _fp(out[0]),
+                                                  _fp(out[1]), _fp(out[2]), n, C.byref(nv)))
+        return np.ascontiguousarray(out[:, :nv.value])
+
     # -- resident clouds (already in HBM): bench + sharded path
     @staticmethod
     def _is_device_tensor(x) -> bool:

@@ -396,3 +396,29 @@ def test_cloud_cache_align_cached(pkg, O, synth, small_scene):
     assert icp.align_cached(0, 50, np.eye(4), p).terminationReason == pkg.TERM_NO_PAIRINGS
     assert icp.align_cached(50, 1, np.eye(4), p).terminationReason == pkg.TERM_NO_PAIRINGS
     icp.close()
+
+
+def test_voxel_downsample(pkg, icp, synth, small_scene):
+    """row f4: centroid per occupied voxel vs a numpy restatement (same fp32 key arithmetic)"""
+    g, _, _ = synth.make_pair(10, 60000, seed=17, scene=small_scene)
+    for voxel in (0.25, 1.0, 7.5):
+        out = icp.voxel_downsample(g, voxel)
+        o = g.min(1)
+        inv = np.float32(1.0) / np.float32(voxel)
+        ijk = np.floor(((g - o[:, None]).astype(np.float32) * inv).astype(np.float32)).astype(np.int64)
+        key = (ijk[0] << 42) | (ijk[1] << 21) | ijk[2]
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        heads = np.nonzero(np.r_[True, ks[1:] != ks[:-1]])[0]
+        cnt = np.diff(np.r_[heads, len(ks)])
+        ref = np.stack([np.add.reduceat(g[a][order].astype(np.float64), heads) / cnt for a in range(3)]).astype(np.float32)
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+        assert out.shape[1] < g.shape[1]
+    assert icp.voxel_downsample(np.zeros((3, 0), np.float32), 1.0).shape == (3, 0)
+    one = icp.voxel_downsample(np.array([[1.0], [2.0], [3.0]], np.float32), 0.5)
+    assert np.array_equal(one, np.array([[1.0], [2.0], [3.0]], np.float32))
+    with pytest.raises(pkg.IcpError):
+        icp.voxel_downsample(g, 0.0)
+    with pytest.raises(pkg.IcpError):
+        icp.voxel_downsample(g, 1e-9)   # more than 2^21 voxels per axis
