@@ -1211,6 +1211,8 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const do
         for (int s = 0; s < kRedSlices; ++s) t += sm[s][threadIdx.x];
         acc[threadIdx.x] = t;
     }
+    // the matcher's work-queue / kept / redo counters sit right behind the block: leave them zero for its next launch
+    if (threadIdx.x == kNAcc) { acc[kNAcc] = 0.0; acc[kNAcc + 1] = 0.0; }
 }
 
 // ------------------------------------------------------------------ host code
@@ -1697,6 +1699,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     }
     unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
     HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));
+    counters_clean_ = false;
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
     int grid = num_cus_ * 3;
@@ -1869,7 +1872,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         if (rc) return rc;
     }
     unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
-    HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));  // [0] kept pairs [1] work queue [2] list count
+    if (!counters_clean_) HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));  // [0] kept [1] queue [2] redo [3] queue
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     if (kernel == MOLA_ICP_NN_TILED) {
         const bool use_seed = seed_valid_ && pairing_sorted_ && !std::getenv("MOLA_ICP_NO_WARM_START");
@@ -1877,6 +1880,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         if (rc) return rc;
         last_kernel_ = MOLA_ICP_NN_TILED;
         pairing_sorted_ = true;
+        counters_clean_ = false;
         HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
         ev_used_ += 2;
         return MOLA_ICP_OK;
@@ -1915,6 +1919,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
     HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
     ev_used_ += 2;
     pairing_sorted_ = false;
+    counters_clean_ = false;
     dense_pairs_ += (uint64_t)N_ * (uint64_t)M_;
     return MOLA_ICP_OK;
 }
@@ -1927,7 +1932,11 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
     if (!(threshold > 0)) return fail(MOLA_ICP_E_BADARG, "matcher threshold must be > 0");
     if ((rc = idx_.reserve(sizeof(int) * (N_ ? N_ : 1)))) return rc;
     if ((rc = d2_.reserve(sizeof(float) * (N_ ? N_ : 1)))) return rc;
-    if ((rc = outlier_.reserve(N_ ? N_ : 1))) return rc;
+    {
+        const void* before = outlier_.p;
+        if ((rc = outlier_.reserve(N_ ? N_ : 1))) return rc;
+        if (outlier_.p != before) outlier_cleared_for_ = 0;  // fresh allocation: contents undefined
+    }
     const float thr2 = (float)(threshold * threshold);
     if (N_ == 0 || M_ == 0) {
         if (N_) HIPCHK(hipMemsetAsync(idx_.p, 0xff, sizeof(int) * N_, stream_));
@@ -1978,7 +1987,12 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);
         return MOLA_ICP_OK;
     }
-    if (reset_outliers) HIPCHK(hipMemsetAsync(outlier_.p, 0, N_, stream_));
+    if (reset_outliers && (outliers_dirty_ || outlier_cleared_for_ != N_)) {  // nothing sets a flag unless stage 1 ran
+        HIPCHK(hipMemsetAsync(outlier_.p, 0, N_, stream_));
+        outliers_dirty_ = false;
+        outlier_cleared_for_ = N_;
+    }
+    if (stage == 1 && p.use_scale_outlier_detector) outliers_dirty_ = true;
     int nblocks = (int)((N_ + kAccThreads - 1) / kAccThreads);
     if (nblocks > 512) nblocks = 512;
     if ((rc = partials_.reserve(sizeof(double) * kNAcc * 512))) return rc;
@@ -2005,6 +2019,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kNAcc * kRedSlices), 0, stream_, partials_.as<double>(), nblocks,
                        acc_dev_.as<double>());
     HIPCHK(hipGetLastError());
+    counters_clean_ = true;
     if (comm_) {  // query-sharded: the one collective of the path, in place on the device block (RCCL over xGMI)
         const int rc2 = rccl_allreduce_sum_f64(comm_, acc_dev_.as<double>(), kNAcc, stream_);
         if (rc2) return rc2;

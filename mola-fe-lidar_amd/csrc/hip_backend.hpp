@@ -141,6 +141,9 @@ class HipWorkspace final : public Stages {
     double* acc_host_ = nullptr;  // pinned
     float* meta_host_ = nullptr;  // pinned
     bool pairing_valid_ = false;
+    bool counters_clean_ = false;      // the matcher's device counters are known to be zero
+    bool outliers_dirty_ = false;      // stage 1 may have flagged outliers since the last clear
+    size_t outlier_cleared_for_ = 0;   // the flag buffer is known to be all-zero for this many queries
     bool seed_valid_ = false;  // idx_ holds a pairing of the CURRENT clouds: usable as the next match's warm start
 
     mola_icp_allreduce_fn ar_fn_ = nullptr;

@@ -422,3 +422,37 @@ def test_voxel_downsample(pkg, icp, synth, small_scene):
         icp.voxel_downsample(g, 0.0)
     with pytest.raises(pkg.IcpError):
         icp.voxel_downsample(g, 1e-9)   # more than 2^21 voxels per axis
+
+
+def test_native_rccl_single_rank(pkg, icp, golden):
+    """the RCCL transport of the query-sharded path with a 1-rank communicator: ncclAllReduce runs in place on the
+    device accumulator block between k_reduce_partials and the read-back; results must equal the plain path."""
+    import ctypes
+    import importlib.util
+    L = pkg._lib
+    spec = importlib.util.find_spec("torch")
+    if spec is not None and spec.origin:   # the RCCL that matches the HIP runtime this process loaded
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+        if os.path.exists(cand):
+            L.check(L.lib().mola_icp_comm_set_library(cand.encode()))
+    g, l = golden["A_map"], golden["A_local"]
+    h = pkg.ICP(device=0)
+    h.set_map(g)
+    h.set_local(l)
+    p = p2p_params(pkg, max_iterations=30)
+    plain = h.align_resident(np.eye(4), p)
+    ident = (ctypes.c_uint8 * 128)()
+    L.check(L.lib().mola_icp_comm_unique_id(ident))
+    L.check(L.lib().mola_icp_comm_init(h._h, ident, 1, 0))
+    with pytest.raises(pkg.IcpError):      # a second communicator on the same handle is refused
+        L.check(L.lib().mola_icp_comm_init(h._h, ident, 1, 0))
+    r = h.align_resident(np.eye(4), p)
+    assert r.nIterations == plain.nIterations and np.array_equal(r.optimal_tf, plain.optimal_tf)
+    assert r.quality == plain.quality
+    pp = pkg.Parameters.load_from_file(os.path.join(os.path.dirname(os.path.dirname(__file__)), "params",
+                                                    "icp-settings-regular.yaml"))
+    a = h.align_resident(np.eye(4), pp)    # the 92-double plane form goes through the same collective
+    h.comm_destroy()
+    b = h.align_resident(np.eye(4), pp)
+    assert a.nIterations == b.nIterations and np.array_equal(a.optimal_tf, b.optimal_tf)
+    h.close()
