@@ -14,6 +14,7 @@
 #include "hip_backend.hpp"
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -386,6 +387,20 @@ __global__ __launch_bounds__(256) void k_nn_merge(const int* __restrict__ seg_id
 constexpr int kTileG = 32;     // map points per tile
 constexpr int kSuper = 64;     // tiles per super-tile
 constexpr int kQPW = 128;      // queries per wave
+#ifndef MOLA_VAR_GROUP
+#define MOLA_VAR_GROUP 8
+#endif
+constexpr int kGroup = MOLA_VAR_GROUP;      // fast sweep: points per bookkeeping group
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_f32;  // explicit LDS pointers: ds_read, never flat_load
+
+// dist2 for the two queries of a lane at once (v_pk_add/mul/fma_f32): each half is the same IEEE sequence as dist2
+__device__ __forceinline__ v2f dist2_pk(v2f qx, v2f qy, v2f qz, float mx, float my, float mz)
+{
+    const v2f dx = qx - mx, dy = qy - my, dz = qz - mz;
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
 
 struct Box { float lo[3], hi[3]; };
 
@@ -411,15 +426,40 @@ struct TiledMap {
     const float* ubox; int n_top;       // top boxes         SoA [6][n_top]
 };
 
-// The sweep shared by the tiled kernels: wave box from the per-query reaches, three-level box scan with the
-// per-query re-test, LDS staging of the surviving tiles two at a time with the next pair's loads in flight.
+#ifndef MOLA_VAR_LDSBOX_KB
+#define MOLA_VAR_LDSBOX_KB 40
+#endif
+constexpr size_t kMaxLdsBoxBytes = MOLA_VAR_LDSBOX_KB * 1024;  // upper box levels kept in LDS up to this size (~3.4M map points)
+constexpr size_t kDbgItems = 1u << 19;  // MOLA_ICP_DEBUG_STATS: per-item records for clouds up to 16M points
+constexpr int kQueues = 8, kQueueStride = 32;  // work-queue counters, one 128-byte line each
+constexpr int kMaxList = 64;   // super-tiles collected before their tiles are streamed
+
+// LDS copy of the two upper box levels (one per workgroup): [6][n_top] then [6][n_super] floats.  The upper
+// levels of the scan then cost LDS reads instead of dependent global round trips.
+__device__ __forceinline__ size_t lds_box_floats(int n_top, int n_super) { return 6u * ((size_t)n_top + (size_t)n_super); }
+__device__ __forceinline__ void load_boxes_to_lds(const TiledMap& mp, lds_f32* lbox)
+{
+    const int nu = 6 * mp.n_top, ns = 6 * mp.n_super;
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) lbox[i] = mp.ubox[i];
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) lbox[nu + i] = mp.sbox[i];
+    __syncthreads();
+}
+
+// The sweep shared by the tiled kernels: wave box from the per-query reaches; the two upper box levels select
+// the super-tiles some query reaches (from the LDS copy `lbox`, or from global memory if it is null) into the
+// per-wave list `slist`; the listed super-tiles are then streamed with the NEXT one's tile boxes already in
+// flight, their surviving tiles staged through LDS two at a time with the next pair's points in flight too.
 // `visit(nm, jb0, jb1)` is called once per staged pass: sm[0..2][0..nm) hold x,y,z of the staged points
 // (sm[3] their original indices if NEED_PERM); points [0,32) have sorted positions jb0.., [32,64) jb1...
 // Returns the number of staged points.
 template <bool NEED_PERM, class Visit>
-__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, int lane, float (*sm)[64],
-                                                          const float (&qx)[2], const float (&qy)[2],
-                                                          const float (&qz)[2], const float (&reach)[2], Visit&& visit)
+__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane,
+                                                          float (*sm)[64], const float (&qx)[2], const float (&qy)[2],
+                                                          const float (&qz)[2], const float (&reach)[2], Visit&& visit,
+                                                          bool prof, unsigned long long& p_stage,
+                                                          unsigned long long& p_visit, unsigned int& p_supers,
+                                                          unsigned int& p_entered, unsigned int& p_tiles,
+                                                          unsigned long long& p_boxwait, unsigned long long& p_tiletest)
 {
     Box w;
 #pragma unroll
@@ -465,6 +505,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, in
     };
     auto compute_pending = [&](int next_a, int next_b) {
         const int ca = pend_a, cb = pend_b;
+        const unsigned long long tp0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
         sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz;
         if (NEED_PERM) sm[3][lane] = __int_as_float(po);
         pend_a = next_a; pend_b = next_b;
@@ -473,64 +514,124 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, in
         __builtin_amdgcn_wave_barrier();
         const int nm = cb >= 0 ? 64 : 32;
         n_staged += nm;
+        const unsigned long long tp1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
         visit(nm, ca * kTileG, (cb >= 0 ? cb : ca) * kTileG);
         __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next pass
+        if (prof) { const unsigned long long tp2 = __builtin_amdgcn_s_memtime(); p_stage += tp1 - tp0; p_visit += tp2 - tp1; }
     };
 
-    // three box levels: top (64 super-tiles = 131072 points) -> super-tile (64 tiles) -> tile (32 points); each
-    // level is one coalesced load per lane and one ballot: ~3 dependent round trips whatever the map size
-    for (int ub = 0; ub < mp.n_top; ub += 64) {
-        const int ui = ub + lane;
-        const bool uin = ui < mp.n_top;
-        unsigned long long ucand = __ballot(
-            uin && mp.ubox[ui] <= w.hi[0] && mp.ubox[mp.n_top + ui] <= w.hi[1] && mp.ubox[2 * mp.n_top + ui] <= w.hi[2] &&
-            mp.ubox[3 * mp.n_top + ui] >= w.lo[0] && mp.ubox[4 * mp.n_top + ui] >= w.lo[1] &&
-            mp.ubox[5 * mp.n_top + ui] >= w.lo[2]);
-        while (ucand) {
-            const int sb = (ub + __builtin_ctzll(ucand)) * 64;  // first super-tile of this top box
-            ucand &= ucand - 1;
-            const int si = sb + lane;
-            const float c0 = mp.sbox[si], c1 = mp.sbox[mp.n_super + si], c2 = mp.sbox[2 * mp.n_super + si],
-                        c3 = mp.sbox[3 * mp.n_super + si], c4 = mp.sbox[4 * mp.n_super + si],
-                        c5 = mp.sbox[5 * mp.n_super + si];
-            unsigned long long scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] &&
-                                                c4 >= w.lo[1] && c5 >= w.lo[2]);
-            while (scand) {
-                const int sl = __builtin_ctzll(scand);
-                scand &= scand - 1;
-                // super-tile vs the individual queries: a bimodal query group must not descend everywhere
-                if (!any_reach(bcast_lane(c0, sl), bcast_lane(c1, sl), bcast_lane(c2, sl), bcast_lane(c3, sl),
-                               bcast_lane(c4, sl), bcast_lane(c5, sl)))
-                    continue;
-                const int S = sb + sl;
-                const int ti = S * kSuper + lane;
-                const float b0 = mp.tbox[ti], b1 = mp.tbox[mp.n_tiles_p + ti], b2 = mp.tbox[2 * mp.n_tiles_p + ti],
-                            b3 = mp.tbox[3 * mp.n_tiles_p + ti], b4 = mp.tbox[4 * mp.n_tiles_p + ti],
-                            b5 = mp.tbox[5 * mp.n_tiles_p + ti];
-                unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
-                                                   b4 >= w.lo[1] && b5 >= w.lo[2]);
-                unsigned long long tmask = 0;
-                while (cand) {
-                    const int t = __builtin_ctzll(cand);
-                    cand &= cand - 1;
-                    if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
-                                  bcast_lane(b4, t), bcast_lane(b5, t)))
-                        tmask |= 1ull << t;
-                }
-                while (tmask) {
-                    const int t0 = S * kSuper + __builtin_ctzll(tmask);
-                    tmask &= tmask - 1;
-                    int t1 = -1;
-                    if (tmask) { t1 = S * kSuper + __builtin_ctzll(tmask); tmask &= tmask - 1; }
-                    if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
-                        pend_a = t0; pend_b = t1;
-                        load_pair(t0, t1);
-                    } else {
-                        compute_pending(t0, t1);
-                    }
+    // ---- the listed super-tiles: tile boxes of entry e+1 in flight while entry e's tiles are processed ----
+    int n_list = 0;
+    auto process_list = [&]() {
+        if (n_list == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int S = __builtin_amdgcn_readfirstlane(slist[0]);
+        int ti = S * kSuper + lane;
+        float n0 = mp.tbox[ti], n1 = mp.tbox[mp.n_tiles_p + ti], n2 = mp.tbox[2 * mp.n_tiles_p + ti],
+              n3 = mp.tbox[3 * mp.n_tiles_p + ti], n4 = mp.tbox[4 * mp.n_tiles_p + ti], n5 = mp.tbox[5 * mp.n_tiles_p + ti];
+        for (int e = 0; e < n_list; ++e) {
+            const unsigned long long tb0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+            const float b0 = n0, b1 = n1, b2 = n2, b3 = n3, b4 = n4, b5 = n5;
+            const int Sc = S;
+            if (e + 1 < n_list) {
+                S = __builtin_amdgcn_readfirstlane(slist[e + 1]);
+                ti = S * kSuper + lane;
+                n0 = mp.tbox[ti]; n1 = mp.tbox[mp.n_tiles_p + ti]; n2 = mp.tbox[2 * mp.n_tiles_p + ti];
+                n3 = mp.tbox[3 * mp.n_tiles_p + ti]; n4 = mp.tbox[4 * mp.n_tiles_p + ti]; n5 = mp.tbox[5 * mp.n_tiles_p + ti];
+            }
+            unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
+                                               b4 >= w.lo[1] && b5 >= w.lo[2]);
+            unsigned long long tmask = 0;
+            const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+            while (cand) {
+                const int t = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                if (prof) p_tiles += 1;
+                if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
+                              bcast_lane(b4, t), bcast_lane(b5, t)))
+                    tmask |= 1ull << t;
+            }
+            if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); p_boxwait += tb1 - tb0; p_tiletest += tb2 - tb1; }
+            while (tmask) {
+                const int t0 = Sc * kSuper + __builtin_ctzll(tmask);
+                tmask &= tmask - 1;
+                int t1 = -1;
+                if (tmask) { t1 = Sc * kSuper + __builtin_ctzll(tmask); tmask &= tmask - 1; }
+                if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
+                    pend_a = t0; pend_b = t1;
+                    load_pair(t0, t1);
+                } else {
+                    compute_pending(t0, t1);
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();  // the list is rewritten from here on
+        n_list = 0;
+    };
+
+    // ---- upper levels: top boxes (64 super-tiles = 131072 points each) -> super-tile boxes ----
+    // Written as a resumable scan so that process_list() has ONE call site (its body holds the distance
+    // passes): collect up to kMaxList super-tiles, stream them, resume where the scan stopped.
+    const lds_f32* l_ubox = lbox;
+    const lds_f32* l_sbox = lbox + 6 * mp.n_top;
+    int ub = 0, sb = 0;
+    unsigned long long ucand = 0, scand = 0;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
+    bool c_valid = false;  // c0..c5 hold the super-tile boxes [sb, sb+64)
+    auto load_super_boxes = [&]() {
+        const int si = sb + lane;
+        if (use_lbox) {
+            c0 = l_sbox[si]; c1 = l_sbox[mp.n_super + si]; c2 = l_sbox[2 * mp.n_super + si];
+            c3 = l_sbox[3 * mp.n_super + si]; c4 = l_sbox[4 * mp.n_super + si]; c5 = l_sbox[5 * mp.n_super + si];
+        } else {
+            c0 = mp.sbox[si]; c1 = mp.sbox[mp.n_super + si]; c2 = mp.sbox[2 * mp.n_super + si];
+            c3 = mp.sbox[3 * mp.n_super + si]; c4 = mp.sbox[4 * mp.n_super + si]; c5 = mp.sbox[5 * mp.n_super + si];
+        }
+        c_valid = true;
+    };
+    for (;;) {
+        while (n_list < kMaxList) {
+            if (scand) {
+                if (!c_valid) load_super_boxes();  // resumed after a full list
+                const int sl = __builtin_ctzll(scand);
+                scand &= scand - 1;
+                if (prof) p_supers += 1;
+                // super-tile vs the individual queries: a bimodal query group must not descend everywhere
+                if (any_reach(bcast_lane(c0, sl), bcast_lane(c1, sl), bcast_lane(c2, sl), bcast_lane(c3, sl),
+                              bcast_lane(c4, sl), bcast_lane(c5, sl))) {
+                    if (prof) p_entered += 1;
+                    if (lane == 0) slist[n_list] = sb + sl;
+                    ++n_list;
+                }
+            } else if (ucand) {
+                sb = (ub - 64 + __builtin_ctzll(ucand)) * 64;  // first super-tile of this top box (ub already advanced)
+                ucand &= ucand - 1;
+                load_super_boxes();
+                scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] && c4 >= w.lo[1] &&
+                                 c5 >= w.lo[2]);
+            } else if (ub < mp.n_top) {
+                const int ui = ub + lane;
+                float u0 = INFINITY, u1 = INFINITY, u2 = INFINITY, u3 = -INFINITY, u4 = -INFINITY, u5 = -INFINITY;
+                if (ui < mp.n_top) {
+                    if (use_lbox) {
+                        u0 = l_ubox[ui]; u1 = l_ubox[mp.n_top + ui]; u2 = l_ubox[2 * mp.n_top + ui];
+                        u3 = l_ubox[3 * mp.n_top + ui]; u4 = l_ubox[4 * mp.n_top + ui]; u5 = l_ubox[5 * mp.n_top + ui];
+                    } else {
+                        u0 = mp.ubox[ui]; u1 = mp.ubox[mp.n_top + ui]; u2 = mp.ubox[2 * mp.n_top + ui];
+                        u3 = mp.ubox[3 * mp.n_top + ui]; u4 = mp.ubox[4 * mp.n_top + ui]; u5 = mp.ubox[5 * mp.n_top + ui];
+                    }
+                }
+                ucand = __ballot(u0 <= w.hi[0] && u1 <= w.hi[1] && u2 <= w.hi[2] && u3 >= w.lo[0] && u4 >= w.lo[1] &&
+                                 u5 >= w.lo[2]);
+                ub += 64;
+            } else {
+                break;
+            }
+        }
+        if (n_list == 0) break;
+        process_list();
+        c_valid = false;
     }
     if (pend_a >= 0) compute_pending(-1, -1);
     return n_staged;
@@ -544,6 +645,31 @@ __device__ __forceinline__ float reach_of(float best, float qx, float qy, float 
     return sqrtf(best * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
 }
 
+// Work queue of the persistent waves.  Same-address atomics serialise device-wide (measured: ~13 ns each; one
+// more atomic per item cost 20% of the kernel, the 3072-deep burst of first pops 40 us), so
+//  - the first entry of every wave is its own index: no atomics at kernel start;
+//  - the entries after those are dealt round-robin to kQueues counters on separate cache lines; a wave pops from
+//    the counter of its XCD (blockIdx & 7) and moves on to the next counter when that one runs dry.
+// Callers keep the next entry's pop in flight while the current item is processed.
+struct WaveQueue {
+    unsigned int* q;
+    int lane, n_waves, tried;
+    __device__ __forceinline__ WaveQueue(unsigned int* queue, int lane_) : q(queue), lane(lane_), n_waves((int)gridDim.x * 4), tried(0) {}
+    __device__ __forceinline__ int first() const { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
+    __device__ __forceinline__ int pop()  // the next entry (meaningful in lane 0), still in flight
+    {
+        const int c = ((int)blockIdx.x + tried) & (kQueues - 1);
+        int r = 0;
+        if (lane == 0) r = n_waves + c + kQueues * (int)atomicAdd(q + c * kQueueStride, 1u);
+        return r;
+    }
+    __device__ __forceinline__ int settle(int raw, int n_items)  // raw = readfirstlane(pop()): past the end -> other counters
+    {
+        while (raw >= n_items && ++tried < kQueues) raw = __builtin_amdgcn_readfirstlane(pop());
+        return raw;
+    }
+};
+
 // EXACT = false: the fast sweep.  Per (query, 4-point chunk) only the chunk minimum is compared with the
 //   running best (~6 VALU ops per pair); the winning chunk is re-evaluated once at the end to recover the
 //   exact point and the lowest-original-index rule inside it.  If an EQUAL minimum showed up in a different
@@ -551,67 +677,105 @@ __device__ __forceinline__ float reach_of(float best, float qx, float qy, float 
 // EXACT = true : the exact-key sweep over the queued items: per-pair argmin on the packed key
 //   (d2 bits << 32 | original index), i.e. the full lexicographic rule (~10 ops per pair).
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
+__global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
-                                                  float* __restrict__ d2_s, const int* __restrict__ item_order,
+                                                  float* __restrict__ d2_s, const int* __restrict__ item_plan,
+                                                  const unsigned int* __restrict__ n_plan, int uniform_shift, int uniform_stride,
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
                                                   unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
                                                   unsigned long long* __restrict__ staged_total,
-                                                  unsigned long long* __restrict__ dbg_stats)
+                                                  unsigned long long* __restrict__ dbg_stats, int lds_boxes)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
+    __shared__ int s_list[4][kMaxList];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float(*sm)[64] = s_m[wave];
-    const int n_items = EXACT ? (int)*redo_count : (N + kQPW - 1) / kQPW;
+    int* slist = s_list[wave];
+    const lds_f32* lbox = (const lds_f32*)s_dyn;
+    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
+    // A work item is a run of 32, 64 or 128 consecutive (sorted) queries, packed as (first / 32) << 3 | (count / 32).
+    // Items come from the plan of k_plan_items (heavy query groups split, heaviest first), or -- first launch
+    // on a cloud -- from a uniform split with 128 >> uniform_shift queries each.
+    const int ucount = kQPW >> uniform_shift;
+    const int n_items = EXACT ? (int)*redo_count : (item_plan ? (int)*n_plan : (N + ucount - 1) / ucount);
 
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = (int)atomicAdd(queue, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        if (EXACT) item = __builtin_amdgcn_readfirstlane(redo_list[item]);
-        else if (item_order) item = __builtin_amdgcn_readfirstlane(item_order[item]);  // heaviest items of the last launch first
+    WaveQueue wq(queue, lane);
+    auto lookup = [&](int raw) -> int {  // raw is wave-uniform
+        if (raw >= n_items) return -1;
+        if (EXACT) return redo_list[raw];
+        if (item_plan) return item_plan[raw];
+        const int it = uniform_stride > 1 ? (int)(((long long)raw * uniform_stride) % n_items) : raw;  // scatter neighbours over the CUs
+        return (((it * ucount) >> 5) << 3) | (ucount >> 5);
+    };
+    unsigned long long wave_staged = 0ull;
+    int item = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
+    while (item >= 0) {
+        const int next_raw_v = wq.pop();
         const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
+        const int i_first = (item >> 3) << 5, i_count = (item & 7) << 5;
 
         float qx[2], qy[2], qz[2], reach[2];
         unsigned long long key[2];  // EXACT: packed (d2, original index)
         float best[2];              // fast: running minimum
-        int bpos[2];                // EXACT: sorted position of the best point; fast: of its 4-point chunk
-        bool tie[2] = {false, false};
+        int bpos[2];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
+        int tie[2] = {0, 0};
+        // round trip 1: the two queries of the lane and their seeds (clamped indices: every load is unconditional)
+        int qi[2], js[2];
+        float lx[2], ly[2], lz[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int i = item * kQPW + k * 64 + lane;
-            qx[k] = qy[k] = qz[k] = 1.0e18f;
-            reach[k] = -1.0f;  // padding lane: reaches nothing
+            qi[k] = i_first + k * 64 + lane;
+            if (k * 64 + lane >= i_count || qi[k] >= N) qi[k] = N;  // not a query of this item: padding lane
+            const int ic = qi[k] < N ? qi[k] : N - 1;
+            lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
+            js[k] = use_seed ? pos_s[ic] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
+        // round trip 2: the seeds' coordinates, and the next item's id
+        const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items));
+        float gsx[2], gsy[2], gsz[2];
+        unsigned int gso[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int jc = js[k] >= 0 ? js[k] : 0;
+            gsx[k] = mp.sx[jc]; gsy[k] = mp.sy[jc]; gsz[k] = mp.sz[jc];
+            if (EXACT) gso[k] = (unsigned int)mp.perm[jc];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
             key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
             best[k] = thr2;
             bpos[k] = -1;
-            if (i < N) {
-                xform(P, slx[i], sly[i], slz[i], qx[k], qy[k], qz[k]);
-                if (use_seed) {  // warm start: last iteration's neighbour is an exact candidate
-                    const int js = pos_s[i];  // sorted-map position: neighbours of neighbours share cache lines
-                    if (js >= 0) {
-                        const float d = dist2(qx[k], qy[k], qz[k], mp.sx[js], mp.sy[js], mp.sz[js]);
-                        if (d < thr2) {
-                            best[k] = d;
-                            bpos[k] = EXACT ? js : (js & ~3);
-                            if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)mp.perm[js];
-                        }
-                    }
-                }
-                reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
+            const float d = dist2(qx[k], qy[k], qz[k], gsx[k], gsy[k], gsz[k]);
+            if (js[k] >= 0 && d < thr2) {  // warm start: last iteration's neighbour is an exact candidate
+                best[k] = d;
+                bpos[k] = EXACT ? js[k] : (js[k] & ~(kGroup - 1));
+                if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | gso[k];
+            }
+            reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
+            if (qi[k] >= N) {  // padding lane: reaches nothing, is never written
+                qx[k] = qy[k] = qz[k] = 1.0e18f;
+                reach[k] = -1.0f;
+                best[k] = thr2;
+                bpos[k] = -1;
             }
         }
 
-        const unsigned long long n_staged = tiled_sweep<EXACT>(mp, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
-            for (int m = 0; m < nm; m += 4) {
-                const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
-                const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
-                const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
-                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
-                if (EXACT) {
+        unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
+        unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
+        const unsigned long long t_sweep0 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
+        const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};  // both queries of the lane, packed
+        const unsigned long long n_staged = tiled_sweep<EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
+            if constexpr (EXACT) {
+                for (int m = 0; m < nm; m += 4) {
+                    const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+                    const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+                    const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
                     const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+                    const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
                     const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
                                                 __float_as_uint(O.w)};
 #pragma unroll
@@ -625,56 +789,102 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
                             bpos[k] = better ? ((m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32) : bpos[k];
                         }
                     }
-                } else {
-                    const int cpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this chunk
+                }
+            } else {
+                // per 16-point group: 16 x (3 packed sub, 1 packed mul, 2 packed fma) serve both queries, the group
+                // minimum is a chain of v_min3, and the (best, position, tie) bookkeeping runs once per group
+                for (int m = 0; m < nm; m += kGroup) {
+                    float g0 = INFINITY, g1 = INFINITY;
+#pragma unroll
+                    for (int h = 0; h < kGroup; h += 8) {
+                        const float4 X0 = *reinterpret_cast<const float4*>(&sm[0][m + h]);
+                        const float4 X1 = *reinterpret_cast<const float4*>(&sm[0][m + h + 4]);
+                        const float4 Y0 = *reinterpret_cast<const float4*>(&sm[1][m + h]);
+                        const float4 Y1 = *reinterpret_cast<const float4*>(&sm[1][m + h + 4]);
+                        const float4 Z0 = *reinterpret_cast<const float4*>(&sm[2][m + h]);
+                        const float4 Z1 = *reinterpret_cast<const float4*>(&sm[2][m + h + 4]);
+                        const float xs[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
+                        const float ys[8] = {Y0.x, Y0.y, Y0.z, Y0.w, Y1.x, Y1.y, Y1.z, Y1.w};
+                        const float zs[8] = {Z0.x, Z0.y, Z0.z, Z0.w, Z1.x, Z1.y, Z1.z, Z1.w};
+#pragma unroll
+                        for (int u = 0; u < 8; u += 2) {
+                            const v2f da = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                            const v2f db = dist2_pk(q2x, q2y, q2z, xs[u + 1], ys[u + 1], zs[u + 1]);
+                            g0 = fminf(fminf(g0, da.x), db.x);
+                            g1 = fminf(fminf(g1, da.y), db.y);
+                        }
+                    }
+                    const int gpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this group
+                    const float gm[2] = {g0, g1};
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const float d0 = dist2(qx[k], qy[k], qz[k], xs[0], ys[0], zs[0]);
-                        const float d1 = dist2(qx[k], qy[k], qz[k], xs[1], ys[1], zs[1]);
-                        const float d2 = dist2(qx[k], qy[k], qz[k], xs[2], ys[2], zs[2]);
-                        const float d3 = dist2(qx[k], qy[k], qz[k], xs[3], ys[3], zs[3]);
-                        const float m4 = fminf(fminf(d0, d1), fminf(d2, d3));
-                        const bool lt = m4 < best[k];
-                        tie[k] = lt ? false : (tie[k] || (m4 == best[k] && cpos != bpos[k]));
-                        best[k] = lt ? m4 : best[k];
-                        bpos[k] = lt ? cpos : bpos[k];
+                        const bool lt = gm[k] < best[k];
+                        const int eq = (int)(gm[k] == best[k]) & (int)(gpos != bpos[k]);
+                        tie[k] = lt ? 0 : (tie[k] | eq);
+                        best[k] = lt ? gm[k] : best[k];
+                        bpos[k] = lt ? gpos : bpos[k];
                     }
                 }
             }
-        });
+        }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
+        const unsigned long long t_sweep1 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
 
         bool any_tie = false;
+        int rpos[2] = {-1, -1}, roi[2] = {-1, -1};
+        float rd[2] = {thr2, thr2};
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = item * kQPW + k * 64 + lane;
-            if (i < N) {  // coalesced: the pairing stays in sorted query order
-                int pos = -1, oi = -1;
-                float d = thr2;
-                if (EXACT) {
-                    d = __uint_as_float((unsigned int)(key[k] >> 32));
-                    if (d < thr2) { pos = bpos[k]; oi = (int)(unsigned int)(key[k] & 0xffffffffu); }
-                } else if (bpos[k] >= 0) {
-                    // resolve inside the winning chunk: the point(s) with d2 == best, lowest original index first
-                    d = best[k];
-                    const float4 X = *reinterpret_cast<const float4*>(mp.sx + bpos[k]);
-                    const float4 Y = *reinterpret_cast<const float4*>(mp.sy + bpos[k]);
-                    const float4 Z = *reinterpret_cast<const float4*>(mp.sz + bpos[k]);
-                    const int4 Pm = *reinterpret_cast<const int4*>(mp.perm + bpos[k]);
-                    const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
-                    const int ps[4] = {Pm.x, Pm.y, Pm.z, Pm.w};
-                    unsigned int bo = 0xffffffffu;
+            for (int k = 0; k < 2; ++k) {
+                const float d = __uint_as_float((unsigned int)(key[k] >> 32));
+                if (d < thr2) { rd[k] = d; rpos[k] = bpos[k]; roi[k] = (int)(unsigned int)(key[k] & 0xffffffffu); }
+            }
+        } else {
+            // resolve inside the winning group: the point(s) with d2 == best, lowest original index first.
+            // One round trip: all loads of both queries are issued before the first use.
+            float4 RX[2][kGroup / 4], RY[2][kGroup / 4], RZ[2][kGroup / 4];
+            int4 RP[2][kGroup / 4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int bp = bpos[k] >= 0 ? bpos[k] : 0;
+#pragma unroll
+                for (int c = 0; c < kGroup / 4; ++c) {
+                    RX[k][c] = *reinterpret_cast<const float4*>(mp.sx + bp + 4 * c);
+                    RY[k][c] = *reinterpret_cast<const float4*>(mp.sy + bp + 4 * c);
+                    RZ[k][c] = *reinterpret_cast<const float4*>(mp.sz + bp + 4 * c);
+                    RP[k][c] = *reinterpret_cast<const int4*>(mp.perm + bp + 4 * c);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                unsigned int bo = 0xffffffffu;
+                int pos = -1;
+#pragma unroll
+                for (int c = 0; c < kGroup / 4; ++c) {
+                    const float xs[4] = {RX[k][c].x, RX[k][c].y, RX[k][c].z, RX[k][c].w};
+                    const float ys[4] = {RY[k][c].x, RY[k][c].y, RY[k][c].z, RY[k][c].w};
+                    const float zs[4] = {RZ[k][c].x, RZ[k][c].y, RZ[k][c].z, RZ[k][c].w};
+                    const int ps[4] = {RP[k][c].x, RP[k][c].y, RP[k][c].z, RP[k][c].w};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float du = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
-                        if (du == d && (unsigned int)ps[u] < bo) { bo = (unsigned int)ps[u]; pos = bpos[k] + u; }
+                        const bool take = du == best[k] && (unsigned int)ps[u] < bo;
+                        bo = take ? (unsigned int)ps[u] : bo;
+                        pos = take ? bpos[k] + 4 * c + u : pos;
                     }
-                    oi = (int)bo;
-                    if (pos < 0) tie[k] = true;  // cannot happen (same arithmetic); be safe: exact pass
                 }
-                pos_s[i] = pos;
-                idx_s[i] = pos >= 0 ? oi : -1;
-                d2_s[i] = d;
-                any_tie |= tie[k];
+                if (bpos[k] >= 0) {
+                    rd[k] = best[k]; rpos[k] = pos; roi[k] = (int)bo;
+                    if (pos < 0) tie[k] = 1;  // cannot happen (same arithmetic); be safe: exact pass
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (qi[k] < N) {  // coalesced: the pairing stays in sorted query order
+                pos_s[qi[k]] = rpos[k];
+                idx_s[qi[k]] = rpos[k] >= 0 ? roi[k] : -1;
+                d2_s[qi[k]] = rd[k];
+                any_tie |= tie[k] != 0;
             }
         }
         if (!EXACT && __any(any_tie)) {
@@ -683,12 +893,30 @@ __global__ __launch_bounds__(256) void k_nn_tiled(const float* __restrict__ slx,
         if (lane == 0) {
             if (!EXACT) {
                 const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
-                if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+                if (item_cost) item_cost[i_first >> 5] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;  // slot per 32 queries
             }
-            atomicAdd(staged_total, n_staged);  // executed work: staged points x 128 queries
-            if (dbg_stats) { atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged); }
+            wave_staged += n_staged;  // executed work: staged points x 128 queries (one atomic per wave, at exit)
+            if (dbg_stats) {
+                const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+                atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged);
+                atomicAdd(&dbg_stats[5], t_sweep0 - t_item0);                         // prologue
+                atomicAdd(&dbg_stats[6], (t_sweep1 - t_sweep0) - p_stage - p_visit);  // box scan
+                atomicAdd(&dbg_stats[7], p_stage);                                    // staging
+                atomicAdd(&dbg_stats[8], p_visit);                                    // distance passes
+                atomicAdd(&dbg_stats[10], t_end - t_sweep1);                          // epilogue
+                atomicMax(&dbg_stats[9], t_end - t_item0);
+                atomicAdd(&dbg_stats[11], (unsigned long long)p_supers); atomicAdd(&dbg_stats[12], (unsigned long long)p_entered);
+                atomicAdd(&dbg_stats[13], (unsigned long long)p_tiles);
+                atomicAdd(&dbg_stats[14], p_boxwait); atomicAdd(&dbg_stats[15], p_tiletest);
+                unsigned long long* rec = dbg_stats + 16 + 8 * (size_t)(i_first >> 5);  // per-item record
+                rec[0] = t_end - t_item0; rec[1] = n_staged; rec[2] = p_entered; rec[3] = p_tiles;
+                rec[4] = t_sweep0 - t_item0; rec[5] = (t_sweep1 - t_sweep0) - p_stage - p_visit; rec[6] = p_stage + p_visit;
+                rec[7] = t_end - t_sweep1;
+            }
         }
+        item = __builtin_amdgcn_readfirstlane(next_item_v);
     }
+    if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
 }
 
 // ---- row f3: point-to-plane matcher (mp2p_icp::Matcher_Point2Plane, params/icp-settings-regular.yaml:33-39) ----
@@ -757,17 +985,21 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
                                                     float thr2, double threshold, double plane_eig_thr,
                                                     PlanePair* __restrict__ out, int* __restrict__ knn_pos /*N x K, may be null*/,
                                                     unsigned int* __restrict__ queue,
-                                                    unsigned long long* __restrict__ staged_total)
+                                                    unsigned long long* __restrict__ staged_total, int lds_boxes)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
+    __shared__ int s_list[4][kMaxList];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float(*sm)[64] = s_m[wave];
+    int* slist = s_list[wave];
+    const lds_f32* lbox = (const lds_f32*)s_dyn;
+    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
     const int n_items = (N + kQPW - 1) / kQPW;
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = (int)atomicAdd(queue, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
+    unsigned long long wave_staged = 0ull;
+    WaveQueue wq(queue, lane);
+    for (int item = wq.first(); item < n_items;) {
+        const int next_raw_v = wq.pop();
 
         float qx[2], qy[2], qz[2], reach[2];
         float kd[2][K];          // sorted ascending by (d2, original index)
@@ -786,7 +1018,9 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
             }
         }
 
-        const unsigned long long n_staged = tiled_sweep<true>(mp, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
+        unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
+        unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
+        const unsigned long long n_staged = tiled_sweep<true>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
             for (int m = 0; m < nm; m += 4) {
                 const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
                 const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
@@ -824,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
                     }
                 }
             }
-        });
+         }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
 
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -885,8 +1119,10 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
             }
             out[i] = pp;
         }
-        if (lane == 0) atomicAdd(staged_total, n_staged);
+        wave_staged += n_staged;
+        item = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items);
     }
+    if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
 }
 
 // the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
@@ -974,34 +1210,70 @@ __global__ __launch_bounds__(256) void k_count_kept(const int* __restrict__ idx,
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, kept);
 }
 
-// heavy-first work order for the next launch: counting sort of the items by the cycles they took in the
-// last launch (32 buckets relative to the maximum), one 1024-thread block.  Longest-processing-time-first
-// keeps the persistent waves' tail short when a few query groups are much heavier than the rest.
-__global__ __launch_bounds__(1024) void k_order_items(const unsigned int* __restrict__ cost, int n_items,
-                                                      int* __restrict__ order)
+// The plan of the next launches, from the cycles the items took in the last one (slots of 32 queries; an item
+// writes the slot of its first query).  Per 128-query group: cost = sum of its 4 slots (then cleared);
+// groups dearer than `split2` are cut into 2 items of 64 queries, dearer than `split4` into 4 of 32 -- a few
+// query groups (range discontinuities, sparse far field) cost 4x the mean and would otherwise set the kernel
+// time by themselves.  The items are then ordered heaviest first (counting sort, 32 buckets of estimated cost):
+// longest-processing-time-first keeps the persistent waves' tail short.  One 1024-thread block.
+__global__ __launch_bounds__(1024) void k_plan_items(unsigned int* __restrict__ cost32, int N, int n_slots,
+                                                     float split2_rel, float split4_rel, int* __restrict__ plan,
+                                                     unsigned int* __restrict__ n_plan)
 {
     __shared__ unsigned int s_max, s_cnt[32], s_off[32];
-    if (threadIdx.x == 0) s_max = 1u;
+    __shared__ unsigned long long s_total;
+    const int n_base = (N + kQPW - 1) / kQPW, n32 = (N + 31) / 32;
+    if (threadIdx.x == 0) { s_max = 1u; s_total = 0ull; }
     if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
+    // pass 1: group costs (kept in slot 4i, the other three slots cleared), total
+    unsigned long long tot = 0;
+    for (int i = threadIdx.x; i < n_base; i += 1024) {
+        unsigned long long c = 0;
+        for (int q = 0; q < 4; ++q)
+            if (4 * i + q < n32) { c += cost32[4 * i + q]; cost32[4 * i + q] = 0u; }
+        c = c > 0xffffffffull ? 0xffffffffull : c;
+        cost32[4 * i] = (unsigned int)c;
+        tot += c;
+    }
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_total, tot);
+    __syncthreads();
+    // a perfectly balanced launch would take total / n_slots per persistent wave: keep every item well below that
+    const double balanced = (double)s_total / (double)(n_slots > 0 ? n_slots : 1);
+    const double split2 = (double)split2_rel * balanced, split4 = (double)split4_rel * balanced;
+    auto factor = [&](unsigned int c) -> int { return (double)c > split4 ? 4 : ((double)c > split2 ? 2 : 1); };
     unsigned int mx = 1u;
-    for (int i = threadIdx.x; i < n_items; i += 1024) mx = max(mx, cost[i]);
+    for (int i = threadIdx.x; i < n_base; i += 1024) { const unsigned int c = cost32[4 * i]; mx = max(mx, c / (unsigned int)factor(c)); }
     atomicMax(&s_max, mx);
     __syncthreads();
     const float scale = 32.0f / (float)s_max;
-    for (int i = threadIdx.x; i < n_items; i += 1024) {
-        const int b = 31 - min(31, (int)((float)cost[i] * scale));  // bucket 0 = heaviest
-        atomicAdd(&s_cnt[b], 1u);
+    auto pieces = [&](int i, int f) -> int {  // sub-items of group i that hold at least one query
+        const int cnt = kQPW / f, left = N - i * kQPW;
+        const int n = (left + cnt - 1) / cnt;
+        return n < f ? n : f;
+    };
+    for (int i = threadIdx.x; i < n_base; i += 1024) {
+        const unsigned int c = cost32[4 * i];
+        const int f = factor(c);
+        const int b = 31 - min(31, (int)((float)(c / (unsigned int)f) * scale));  // bucket 0 = heaviest
+        atomicAdd(&s_cnt[b], (unsigned int)pieces(i, f));
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int o = 0;
         for (int b = 0; b < 32; ++b) { s_off[b] = o; o += s_cnt[b]; }
+        *n_plan = o;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_items; i += 1024) {
-        const int b = 31 - min(31, (int)((float)cost[i] * scale));
-        order[atomicAdd(&s_off[b], 1u)] = i;
+    for (int i = threadIdx.x; i < n_base; i += 1024) {
+        const unsigned int c = cost32[4 * i];
+        const int f = factor(c);
+        const int b = 31 - min(31, (int)((float)(c / (unsigned int)f) * scale));
+        const int np = pieces(i, f), cnt = kQPW / f;
+        const unsigned int at = atomicAdd(&s_off[b], (unsigned int)np);
+        for (int q = 0; q < np; ++q) plan[at + q] = (((i * kQPW + q * cnt) >> 5) << 3) | (cnt >> 5);
+        cost32[4 * i] = 0u;
     }
 }
 
@@ -1213,6 +1485,8 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const do
     }
     // the matcher's work-queue / kept / redo counters sit right behind the block: leave them zero for its next launch
     if (threadIdx.x == kNAcc) { acc[kNAcc] = 0.0; acc[kNAcc + 1] = 0.0; }
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + 2 * kQueues)  // the tiled matcher's work-queue counters
+        reinterpret_cast<unsigned int*>(acc + kNAcc + 8)[(threadIdx.x - 32) * kQueueStride] = 0u;
 }
 
 // ------------------------------------------------------------------ host code
@@ -1281,10 +1555,10 @@ int HipWorkspace::init()
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * (kNAcc + 8), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocDefault));
     int rc;
-    if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8)))) return rc;
+    if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8) + sizeof(unsigned int) * 2 * kQueues * kQueueStride))) return rc;
     if (std::getenv("MOLA_ICP_DEBUG_STATS")) {  // diagnostic builds of a run, never on by default
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), 16 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(dbg_stats_, 0, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(dbg_stats_, 0, (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
     }
     inited_ = true;
     return MOLA_ICP_OK;
@@ -1628,46 +1902,76 @@ TiledMap HipWorkspace::tiled_map() const
 
 int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
 {
-    const int n_items = (int)((N_ + kQPW - 1) / kQPW);
+    const int n32 = (int)((N_ + 31) / 32);
     int per_cu = 3;  // measured best at C3: 1 -> 0.45 ms, 2 -> 0.31, 3 -> 0.30, 4 -> 0.33, 5 -> 0.35
     if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 3;  // tuning knob
+    const TiledMap mp = tiled_map();
+    const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
+    const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
+    const size_t dyn_lds = lds_boxes ? box_bytes : 0;
+    {   // persistent waves with a static first item: every block of the grid must be resident from the start
+        int fit = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false>, 256, dyn_lds));
+        if (fit >= 1 && per_cu > fit) per_cu = fit;
+    }
     int grid = num_cus_ * per_cu;
-    if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
+    if (grid > n32) grid = n32;  // never more waves than 32-query items
+    // first launch on a cloud (no cost profile yet): uniform items, small enough to occupy the persistent waves
+    const int slots = num_cus_ * per_cu * 4;
+    // Measured (1M and 100k clouds): the per-item cost is mostly fixed overhead (scan, staging, epilogue round
+    // trips), so smaller items raise the total and do not shorten the heaviest item: no splitting by default.
+    int uniform_shift = 0;
+    float split2_rel = 1e30f, split4_rel = 1e30f;  // thresholds relative to the balanced per-wave load
+    if (const char* e = std::getenv("MOLA_ICP_UNIFORM_SHIFT")) uniform_shift = std::atoi(e) & 3;
+    if (uniform_shift > 2) uniform_shift = 2;
+    // uniform order: consecutive queue entries far apart in the sorted cloud (a stride co-prime to the item count)
+    const int n_uniform = (int)((N_ + (size_t)(kQPW >> uniform_shift) - 1) / (size_t)(kQPW >> uniform_shift));
+    int uniform_stride = 1;
+    if (std::getenv("MOLA_ICP_STRIDE") && n_uniform > 8) {
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        uniform_stride = (int)(0.6180339887 * n_uniform) | 1;
+        while (gcd(uniform_stride, n_uniform) != 1) uniform_stride += 2;
+    }
+    if (const char* e = std::getenv("MOLA_ICP_SPLIT2")) split2_rel = (float)std::atof(e);
+    if (const char* e = std::getenv("MOLA_ICP_SPLIT4")) split4_rel = (float)std::atof(e);
     int rc;
-    if ((rc = item_cost_.reserve(sizeof(unsigned int) * (size_t)n_items))) return rc;
-    if ((rc = item_order_.reserve(sizeof(int) * (size_t)n_items))) return rc;
-    const int* order = nullptr;
+    if ((rc = item_cost_.reserve(sizeof(unsigned int) * (size_t)(n32 + 4)))) return rc;
+    if ((rc = item_order_.reserve(sizeof(int) * (size_t)(n32 + 4)))) return rc;
+    if (!cost_valid_) HIPCHK(hipMemsetAsync(item_cost_.p, 0, sizeof(unsigned int) * (size_t)(n32 + 4), stream_));  // no stale slots
+    const int* plan = nullptr;
+    unsigned int* n_plan = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 6);
     if (cost_valid_ && !std::getenv("MOLA_ICP_NO_LPT")) {
-        // the cost profile drifts slowly with the pose: re-sort every 4th launch, reuse the order in between
+        // the cost profile drifts slowly with the pose: re-plan every 4th launch, reuse the plan in between
         if (!order_valid_ || (launches_since_order_ & 3) == 0) {
-            hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
-                               item_order_.as<int>());
+            hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), (int)N_, slots,
+                               split2_rel, split4_rel, item_order_.as<int>(), n_plan);
             HIPCHK(hipGetLastError());
             order_valid_ = true;
             launches_since_order_ = 0;
         }
         ++launches_since_order_;
-        order = item_order_.as<int>();
+        plan = item_order_.as<int>();
     }
     if ((rc = ts_pos_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_idx_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_d2_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
     const float* sl = loc_sc_->sorted.as<float>();
-    if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
+    if ((rc = redo_list_.reserve(sizeof(int) * (size_t)(n32 + 4)))) return rc;
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
-    const TiledMap mp = tiled_map();
-    // counter[1] = work queue (fast pass), counter[2] = redo count, counter[3] = work queue (exact pass)
-    hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
+    // counter[2] = redo count; tq = the fast pass's queue counters, tq + kQueues * kQueueStride the exact pass's
+    unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
+    hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
                        (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(),
-                       order, item_cost_.as<unsigned int>(), counter + 1, counter + 2, redo_list_.as<int>(), staged,
-                       dbg_stats_);
+                       plan, n_plan, uniform_shift, uniform_stride, item_cost_.as<unsigned int>(), tq, counter + 2,
+                       redo_list_.as<int>(), staged, dbg_stats_, lds_boxes);
     HIPCHK(hipGetLastError());
     // exact ties (duplicate points, lattices): the queued items again with the full lexicographic key.
     // Usually zero items: a few waves that read the count and leave.
-    hipLaunchKernelGGL((k_nn_tiled<true>), dim3(grid < 64 ? grid : 64), dim3(256), 0, stream_, sl, sl + loc_sc_->padded,
+    hipLaunchKernelGGL((k_nn_tiled<true>), dim3(grid < 64 ? grid : 64), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, /*seed = fast pass's result*/ 1, ts_pos_.as<int>(),
-                       ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr, (unsigned int*)nullptr, counter + 3,
-                       counter + 2, redo_list_.as<int>(), staged, dbg_stats_);
+                       ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr, (const unsigned int*)nullptr, 0, 1,
+                       (unsigned int*)nullptr, tq + kQueues * kQueueStride,
+                       counter + 2, redo_list_.as<int>(), staged, dbg_stats_, lds_boxes);
     cost_valid_ = true;
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
@@ -1699,18 +2003,32 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     }
     unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
     HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));
+    HIPCHK(hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 8, 0, sizeof(unsigned int) * 2 * kQueues * kQueueStride, stream_));
     counters_clean_ = false;
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
-    int grid = num_cus_ * 3;
-    if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     const float* sl = loc_sc_->sorted.as<float>();
     const TiledMap mp = tiled_map();
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
+    const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
+    const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
+    const size_t dyn_lds = lds_boxes ? box_bytes : 0;
+    // persistent waves with a static first item: every block of the grid must be resident from the start
+    int fit = 0;
+    switch (p.knn) {
+        case 3: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<3>, 256, dyn_lds)); break;
+        case 4: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<4>, 256, dyn_lds)); break;
+        case 5: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<5>, 256, dyn_lds)); break;
+        case 6: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<6>, 256, dyn_lds)); break;
+        case 7: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<7>, 256, dyn_lds)); break;
+        default: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<8>, 256, dyn_lds)); break;
+    }
+    int grid = num_cus_ * (fit < 1 ? 1 : (fit > 3 ? 3 : fit));
+    if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
 #define MOLA_LAUNCH_KNN(KK)                                                                                         \
-    hipLaunchKernelGGL((k_knn_planes<KK>), dim3(grid), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,  \
+    hipLaunchKernelGGL((k_knn_planes<KK>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,  \
                        (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold, planes_.as<PlanePair>(),   \
-                       knn_pos_.as<int>(), counter + 1, staged)
+                       knn_pos_.as<int>(), reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8), staged, lds_boxes)
     switch (p.knn) {
         case 3: MOLA_LAUNCH_KNN(3); break;
         case 4: MOLA_LAUNCH_KNN(4); break;
@@ -1833,11 +2151,42 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
         HIPCHK(hipMemcpy(h, dbg_stats_, sizeof h, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[mola_icp debug] nn launches=%zu slow-path entries=%llu survivors=%llu (N=%zu M=%zu); "
                              "tiled: staged points per wave item=%.1f (items=%llu, max=%llu); cycles per item: prologue %.0f "
-                             "scan %.0f stage %.0f compute %.0f, longest item %llu\n",
+                             "scan %.0f stage %.0f compute %.0f epilogue %.0f, longest item %llu; per item: super tests %.1f, supers entered %.1f, tile tests %.1f; of scan: tile-box wait %.0f, tile tests %.0f\n",
                      ev_used_ / 2, h[0], h[1], N_, M_, h[3] ? (double)h[2] / (double)h[3] : 0.0, h[3], h[4],
                      h[3] ? (double)h[5] / h[3] : 0.0, h[3] ? (double)h[6] / h[3] : 0.0, h[3] ? (double)h[7] / h[3] : 0.0,
-                     h[3] ? (double)h[8] / h[3] : 0.0, h[9]);
+                     h[3] ? (double)h[8] / h[3] : 0.0, h[3] ? (double)h[10] / h[3] : 0.0, h[9],
+                     h[3] ? (double)h[11] / h[3] : 0.0, h[3] ? (double)h[12] / h[3] : 0.0, h[3] ? (double)h[13] / h[3] : 0.0,
+                     h[3] ? (double)h[14] / h[3] : 0.0, h[3] ? (double)h[15] / h[3] : 0.0);
         HIPCHK(hipMemset(dbg_stats_, 0, sizeof h));
+        if (cost_valid_ && N_ > 0 && (N_ + 31) / 32 <= kDbgItems) {  // the heaviest items of the last tiled launch
+            const size_t n32 = (N_ + 31) / 32;
+            std::vector<unsigned long long> rec(8 * n32);
+            HIPCHK(hipMemcpy(rec.data(), dbg_stats_ + 16, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::vector<size_t> ord;
+            for (size_t i = 0; i < n32; ++i) if (rec[8 * i]) ord.push_back(i);
+            std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return rec[8 * a] > rec[8 * b]; });
+            for (size_t r = 0; r < ord.size(); r = (r < 8 ? r + 1 : r * 2)) {
+                const unsigned long long* q = &rec[8 * ord[r]];
+                std::fprintf(stderr, "[mola_icp debug]   rank %zu item@%zu: cycles %llu staged %llu supers %llu tile tests %llu | prologue %llu scan %llu passes %llu epilogue %llu\n",
+                             r, ord[r] * 32, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]);
+            }
+            HIPCHK(hipMemset(dbg_stats_ + 16, 0, rec.size() * sizeof(unsigned long long)));
+        }
+        if (cost_valid_ && N_ > 0) {  // spread of the per-item cost of the last tiled launch
+            const size_t n32 = (N_ + 31) / 32;
+            std::vector<unsigned int> c32(n32);
+            HIPCHK(hipMemcpy(c32.data(), item_cost_.p, n32 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            std::vector<unsigned int> c;  // the items of the last launch (a slot is written by the item starting there)
+            for (unsigned int v : c32) if (v) c.push_back(v);
+            if (c.empty()) c.push_back(0u);
+            const size_t n_items = c.size();
+            std::sort(c.begin(), c.end());
+            double sum = 0;
+            for (unsigned int v : c) sum += v;
+            std::fprintf(stderr, "[mola_icp debug] item cost: n=%zu mean %.0f p50 %u p90 %u p99 %u p99.9 %u max %u; sum/3072 slots = %.0f\n",
+                         n_items, sum / n_items, c[n_items / 2], c[n_items * 9 / 10], c[n_items * 99 / 100],
+                         c[std::min(n_items - 1, n_items * 999 / 1000)], c[n_items - 1], sum / 3072.0);
+        }
     }
     if (ms_total) *ms_total = tot;
     if (launches) *launches = (uint32_t)(ev_used_ / 2);
@@ -1872,7 +2221,10 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         if (rc) return rc;
     }
     unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
-    if (!counters_clean_) HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));  // [0] kept [1] queue [2] redo [3] queue
+    if (!counters_clean_) {  // [0] kept [1] queue (dense kernels) [2] redo count; then the tiled kernels' queue counters
+        HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));
+        HIPCHK(hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 8, 0, sizeof(unsigned int) * 2 * kQueues * kQueueStride, stream_));
+    }
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     if (kernel == MOLA_ICP_NN_TILED) {
         const bool use_seed = seed_valid_ && pairing_sorted_ && !std::getenv("MOLA_ICP_NO_WARM_START");
