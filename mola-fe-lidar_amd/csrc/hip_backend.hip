@@ -980,11 +980,12 @@ __device__ __forceinline__ void eig_sym3_dev(const double Cin[3][3], double ev[3
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+__global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
                                                     const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
                                                     float thr2, double threshold, double plane_eig_thr,
-                                                    PlanePair* __restrict__ out, int* __restrict__ knn_pos /*N x K, may be null*/,
-                                                    unsigned int* __restrict__ queue,
+                                                    PlanePair* __restrict__ out,
+                                                    int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
+                                                    int use_seed, unsigned int* __restrict__ queue,
                                                     unsigned long long* __restrict__ staged_total, int lds_boxes)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
@@ -1005,19 +1006,61 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
         float kd[2][K];          // sorted ascending by (d2, original index)
         unsigned int ko[2][K];   // original indices
         int kp[2][K];            // sorted-map positions
+        // insert (du, o, pos) into the sorted list of query k (caller has checked that it belongs there)
+        auto insert = [&](int k, float du, unsigned int o, int pos) {
+            kd[k][K - 1] = du; ko[k][K - 1] = o; kp[k][K - 1] = pos;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                const bool sw = kd[k][j] < kd[k][j - 1] || (kd[k][j] == kd[k][j - 1] && ko[k][j] < ko[k][j - 1]);
+                const float td = kd[k][j]; const unsigned int to = ko[k][j]; const int tp = kp[k][j];
+                kd[k][j] = sw ? kd[k][j - 1] : td; ko[k][j] = sw ? ko[k][j - 1] : to; kp[k][j] = sw ? kp[k][j - 1] : tp;
+                kd[k][j - 1] = sw ? td : kd[k][j - 1]; ko[k][j - 1] = sw ? to : ko[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
+            }
+        };
+        int qi[2];
+        float lx[2], ly[2], lz[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int i = item * kQPW + k * 64 + lane;
-            qx[k] = qy[k] = qz[k] = 1.0e18f;
-            reach[k] = -1.0f;
+            qi[k] = item * kQPW + k * 64 + lane;
+            const int ic = qi[k] < N ? qi[k] : N - 1;
+            lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
 #pragma unroll
             for (int j = 0; j < K; ++j) { kd[k][j] = thr2; ko[k][j] = 0u; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
-            if (i < N) {
-                xform(P, slx[i], sly[i], slz[i], qx[k], qy[k], qz[k]);
-                reach[k] = reach_of(thr2, qx[k], qy[k], qz[k]);
+        }
+        if (use_seed) {
+            // warm start: the K neighbours of the last launch are exact candidates; with them in the list the
+            // reach is the K-th seed distance instead of the gate, and most tiles are never staged
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ic = qi[k] < N ? qi[k] : N - 1;
+                int js[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) js[j] = knn_pos[(size_t)ic * K + j];
+                float gx[K], gy[K], gz[K];
+                unsigned int go[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int jc = js[j] >= 0 ? js[j] : 0;
+                    gx[j] = mp.sx[jc]; gy[j] = mp.sy[jc]; gz[j] = mp.sz[jc]; go[j] = (unsigned int)mp.perm[jc];
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float du = dist2(qx[k], qy[k], qz[k], gx[j], gy[j], gz[j]);
+                    if (js[j] >= 0 && du < thr2) insert(k, du, go[j], js[j]);  // distinct positions: no duplicates among the seeds
+                }
             }
         }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            reach[k] = reach_of(kd[k][K - 1], qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
+            if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; }  // padding lane
+        }
 
+        const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
         unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
         unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
         const unsigned long long n_staged = tiled_sweep<true>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
@@ -1029,11 +1072,12 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
                 float d[2][4];
                 bool cand = false;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) d[k][u] = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
-                    cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd[k][K - 1];
+                for (int u = 0; u < 4; ++u) {  // both queries of the lane per packed instruction
+                    const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                    d[0][u] = dv.x; d[1][u] = dv.y;
                 }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd[k][K - 1];
                 if (__any(cand)) {  // some lane may have to insert: rare once the lists have tightened
                     const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
                     const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
@@ -1045,14 +1089,10 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
                         for (int k = 0; k < 2; ++k) {
                             const float du = d[k][u];
                             if (du < kd[k][K - 1] || (du == kd[k][K - 1] && os[u] < ko[k][K - 1])) {
-                                kd[k][K - 1] = du; ko[k][K - 1] = os[u]; kp[k][K - 1] = pos;
+                                bool dup = false;  // a seed met again by the sweep
 #pragma unroll
-                                for (int j = K - 1; j > 0; --j) {
-                                    const bool sw = kd[k][j] < kd[k][j - 1] || (kd[k][j] == kd[k][j - 1] && ko[k][j] < ko[k][j - 1]);
-                                    const float td = kd[k][j]; const unsigned int to = ko[k][j]; const int tp = kp[k][j];
-                                    kd[k][j] = sw ? kd[k][j - 1] : td; ko[k][j] = sw ? ko[k][j - 1] : to; kp[k][j] = sw ? kp[k][j - 1] : tp;
-                                    kd[k][j - 1] = sw ? td : kd[k][j - 1]; ko[k][j - 1] = sw ? to : ko[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
-                                }
+                                for (int j = 0; j < K; ++j) dup |= kp[k][j] == pos;
+                                if (!dup) insert(k, du, os[u], pos);
                             }
                         }
                     }
@@ -1062,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
 
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int i = item * kQPW + k * 64 + lane;
+            const int i = qi[k];
             if (i >= N) continue;
             PlanePair pp;
             pp.valid = 0;
@@ -1072,10 +1112,8 @@ __global__ __launch_bounds__(256) void k_knn_planes(const float* __restrict__ sl
             pp.n_neigh = m;
 #pragma unroll
             for (int a = 0; a < 3; ++a) { pp.c[a] = 0; pp.n[a] = 0; }
-            if (knn_pos) {
 #pragma unroll
-                for (int j = 0; j < K; ++j) knn_pos[(size_t)i * K + j] = j < m ? kp[k][j] : -1;
-            }
+            for (int j = 0; j < K; ++j) knn_pos[(size_t)i * K + j] = j < m ? kp[k][j] : -1;
             if (m >= 3) {
                 double px[K], py[K], pz[K];
                 double mean[3] = {0, 0, 0};
@@ -1617,6 +1655,7 @@ int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, s
     map_sc_->ready = false;
     pairing_valid_ = false;
     seed_valid_ = false;
+    knn_seed_valid_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -1634,6 +1673,7 @@ int HipWorkspace::set_map_device(const float* x, const float* y, const float* z,
     map_sc_->ready = false;
     pairing_valid_ = false;
     seed_valid_ = false;
+    knn_seed_valid_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -1652,8 +1692,10 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     loc_sc_->ready = false;
     cost_valid_ = false;
     order_valid_ = false;
+    knn_seed_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
+    knn_seed_valid_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -1670,8 +1712,10 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     loc_sc_->ready = false;
     cost_valid_ = false;
     order_valid_ = false;
+    knn_seed_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
+    knn_seed_valid_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -1879,6 +1923,7 @@ void HipWorkspace::use_cached_map(const std::shared_ptr<SortedCloud>& sc)
     map_img_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
+    knn_seed_valid_ = false;
 }
 
 void HipWorkspace::use_cached_local(const std::shared_ptr<SortedCloud>& sc)
@@ -1889,8 +1934,10 @@ void HipWorkspace::use_cached_local(const std::shared_ptr<SortedCloud>& sc)
     planes_valid_ = false;
     cost_valid_ = false;
     order_valid_ = false;
+    knn_seed_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
+    knn_seed_valid_ = false;
 }
 
 TiledMap HipWorkspace::tiled_map() const
@@ -2025,10 +2072,11 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     }
     int grid = num_cus_ * (fit < 1 ? 1 : (fit > 3 ? 3 : fit));
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
+    const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !std::getenv("MOLA_ICP_NO_KNN_SEED")) ? 1 : 0;
 #define MOLA_LAUNCH_KNN(KK)                                                                                         \
     hipLaunchKernelGGL((k_knn_planes<KK>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,  \
                        (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold, planes_.as<PlanePair>(),   \
-                       knn_pos_.as<int>(), reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8), staged, lds_boxes)
+                       knn_pos_.as<int>(), knn_seed, reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8), staged, lds_boxes)
     switch (p.knn) {
         case 3: MOLA_LAUNCH_KNN(3); break;
         case 4: MOLA_LAUNCH_KNN(4); break;
@@ -2044,6 +2092,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;
     planes_valid_ = true;
+    knn_seed_valid_ = true;
     return MOLA_ICP_OK;
 }
 
@@ -2294,6 +2343,7 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
         if (N_) HIPCHK(hipMemsetAsync(idx_.p, 0xff, sizeof(int) * N_, stream_));
         pairing_valid_ = true;
         seed_valid_ = false;
+    knn_seed_valid_ = false;
         pairing_sorted_ = false;
         if (n_pairs) *n_pairs = 0;
         return MOLA_ICP_OK;
