@@ -46,6 +46,10 @@ def main():
                     help="run the distributed code path (process group + RCCL communicator) even with one rank")
     ap.add_argument("--allreduce", choices=["rccl", "hook"], default="rccl",
                     help="rccl: native RCCL on the device block; hook: torch.distributed from the host hook")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing aid for 1-GPU boxes: ranks share the visible GPUs (rank %% device_count), the process "
+                         "group is gloo and the accumulator all-reduce goes through the host hook -- exercises the "
+                         "N>1 sharding path end to end without RCCL")
     ap.add_argument("--shipped-iters", type=int, default=10,
                     help="iterations of the shipped Point2Plane+GaussNewton pipeline measured beside the default path")
     ap.add_argument("--dense-iters", type=int, default=3, help="iterations of the dense MFMA kernel measured beside the default path (0 = skip)")
@@ -60,6 +64,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
+    if args.share_gpu:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        args.allreduce = "hook"
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -67,7 +74,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("mola-fe-lidar_amd")
     synth = importlib.import_module("mola-fe-lidar_amd.synth")
@@ -79,6 +89,7 @@ def main():
 
     # inputs resident in HBM before the timed region
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if args.share_gpu else dev   # where the bench's own small collectives live
     tg = torch.from_numpy(g).to(dev)
     tl = torch.from_numpy(np.ascontiguousarray(l[:, lo:hi])).to(dev)
     icp = pkg.ICP(device=local_rank)
@@ -96,7 +107,7 @@ def main():
                       file=sys.stderr, flush=True)
                 allreduce_used = "hook"
         # every rank must take the same path
-        flag = torch.tensor([1 if allreduce_used == "hook" else 0], device=dev)
+        flag = torch.tensor([1 if allreduce_used == "hook" else 0], device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) == 1:
             if allreduce_used == "rccl":
@@ -127,7 +138,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert res.nIterations == args.steps, (res.nIterations, args.steps)
@@ -160,7 +171,7 @@ def main():
     roof = roofline_of(res, hi - lo)
     roof["traffic"] = _recorded_traffic(roof["kernel"], N, M) if world == 1 else None
     if world > 1:
-        t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=dev)
+        t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)     # the slowest rank's kernel
         roof["achieved"] = float(t[0])
         roof["frac"] = roof["achieved"] / roof["peak"]

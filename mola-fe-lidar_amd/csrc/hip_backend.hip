@@ -430,7 +430,7 @@ struct TiledMap {
 #define MOLA_VAR_LDSBOX_KB 40
 #endif
 constexpr size_t kMaxLdsBoxBytes = MOLA_VAR_LDSBOX_KB * 1024;  // upper box levels kept in LDS up to this size (~3.4M map points)
-constexpr size_t kDbgItems = 1u << 19;  // MOLA_ICP_DEBUG_STATS: per-item records for clouds up to 16M points
+constexpr size_t kDbgItems = 1u << 17;  // MOLA_ICP_DEBUG_STATS: per-item records for clouds up to 16M points
 constexpr int kQueues = 8, kQueueStride = 32;  // work-queue counters, one 128-byte line each
 constexpr int kMaxList = 64;   // super-tiles collected before their tiles are streamed
 
@@ -680,8 +680,7 @@ template <bool EXACT>
 __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
-                                                  float* __restrict__ d2_s, const int* __restrict__ item_plan,
-                                                  const unsigned int* __restrict__ n_plan, int uniform_shift, int uniform_stride,
+                                                  float* __restrict__ d2_s, const int* __restrict__ item_order,
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
                                                   unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
                                                   unsigned long long* __restrict__ staged_total,
@@ -695,26 +694,19 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     int* slist = s_list[wave];
     const lds_f32* lbox = (const lds_f32*)s_dyn;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
-    // A work item is a run of 32, 64 or 128 consecutive (sorted) queries, packed as (first / 32) << 3 | (count / 32).
-    // Items come from the plan of k_plan_items (heavy query groups split, heaviest first), or -- first launch
-    // on a cloud -- from a uniform split with 128 >> uniform_shift queries each.
-    const int ucount = kQPW >> uniform_shift;
-    const int n_items = EXACT ? (int)*redo_count : (item_plan ? (int)*n_plan : (N + ucount - 1) / ucount);
+    const int n_items = EXACT ? (int)*redo_count : (N + kQPW - 1) / kQPW;  // an item = 128 consecutive sorted queries
 
     WaveQueue wq(queue, lane);
-    auto lookup = [&](int raw) -> int {  // raw is wave-uniform
+    auto lookup = [&](int raw) -> int {  // raw is wave-uniform; -1 = past the end
         if (raw >= n_items) return -1;
         if (EXACT) return redo_list[raw];
-        if (item_plan) return item_plan[raw];
-        const int it = uniform_stride > 1 ? (int)(((long long)raw * uniform_stride) % n_items) : raw;  // scatter neighbours over the CUs
-        return (((it * ucount) >> 5) << 3) | (ucount >> 5);
+        return item_order ? item_order[raw] : raw;  // heaviest items of the last launch first
     };
     unsigned long long wave_staged = 0ull;
     int item = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
     while (item >= 0) {
         const int next_raw_v = wq.pop();
         const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
-        const int i_first = (item >> 3) << 5, i_count = (item & 7) << 5;
 
         float qx[2], qy[2], qz[2], reach[2];
         unsigned long long key[2];  // EXACT: packed (d2, original index)
@@ -726,8 +718,8 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         float lx[2], ly[2], lz[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            qi[k] = i_first + k * 64 + lane;
-            if (k * 64 + lane >= i_count || qi[k] >= N) qi[k] = N;  // not a query of this item: padding lane
+            qi[k] = item * kQPW + k * 64 + lane;
+            if (qi[k] >= N) qi[k] = N;  // padding lane
             const int ic = qi[k] < N ? qi[k] : N - 1;
             lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
             js[k] = use_seed ? pos_s[ic] : -1;
@@ -893,7 +885,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         if (lane == 0) {
             if (!EXACT) {
                 const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
-                if (item_cost) item_cost[i_first >> 5] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;  // slot per 32 queries
+                if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
             }
             wave_staged += n_staged;  // executed work: staged points x 128 queries (one atomic per wave, at exit)
             if (dbg_stats) {
@@ -908,7 +900,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 atomicAdd(&dbg_stats[11], (unsigned long long)p_supers); atomicAdd(&dbg_stats[12], (unsigned long long)p_entered);
                 atomicAdd(&dbg_stats[13], (unsigned long long)p_tiles);
                 atomicAdd(&dbg_stats[14], p_boxwait); atomicAdd(&dbg_stats[15], p_tiletest);
-                unsigned long long* rec = dbg_stats + 16 + 8 * (size_t)(i_first >> 5);  // per-item record
+                unsigned long long* rec = dbg_stats + 16 + 8 * (size_t)item;  // per-item record
                 rec[0] = t_end - t_item0; rec[1] = n_staged; rec[2] = p_entered; rec[3] = p_tiles;
                 rec[4] = t_sweep0 - t_item0; rec[5] = (t_sweep1 - t_sweep0) - p_stage - p_visit; rec[6] = p_stage + p_visit;
                 rec[7] = t_end - t_sweep1;
@@ -1212,14 +1204,29 @@ __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restri
     }
 }
 
-// fixed-order sum of [nblocks][n] partial rows, one thread per accumulator (n <= 128)
-__global__ __launch_bounds__(128) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
-                                                     double* __restrict__ acc)
+// fixed-order sum of [nblocks][n] partial rows (n <= 128): 8 slices of rows per accumulator with the loads of a
+// slice independent of each other, then the 8 slice sums in order.  Deterministic for a given nblocks.
+__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
+                                                      double* __restrict__ acc)
 {
-    if ((int)threadIdx.x < n) {
-        double v = 0.0;
-        for (int b = 0; b < nblocks; ++b) v += partials[(size_t)b * n + threadIdx.x];
-        acc[threadIdx.x] = v;
+    __shared__ double sm[8][128];
+    const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    double v = 0.0;
+    if (k < n) {
+        int b = sl;
+        for (; b + 24 < nblocks; b += 32) {  // four rows in flight
+            const double a0 = partials[(size_t)b * n + k], a1 = partials[(size_t)(b + 8) * n + k];
+            const double a2 = partials[(size_t)(b + 16) * n + k], a3 = partials[(size_t)(b + 24) * n + k];
+            v += a0; v += a1; v += a2; v += a3;
+        }
+        for (; b < nblocks; b += 8) v += partials[(size_t)b * n + k];
+    }
+    sm[sl][k] = v;
+    __syncthreads();
+    if (sl == 0 && k < n) {
+        double t = 0.0;
+        for (int s2 = 0; s2 < 8; ++s2) t += sm[s2][k];
+        acc[k] = t;
     }
 }
 
@@ -1248,70 +1255,36 @@ __global__ __launch_bounds__(256) void k_count_kept(const int* __restrict__ idx,
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, kept);
 }
 
-// The plan of the next launches, from the cycles the items took in the last one (slots of 32 queries; an item
-// writes the slot of its first query).  Per 128-query group: cost = sum of its 4 slots (then cleared);
-// groups dearer than `split2` are cut into 2 items of 64 queries, dearer than `split4` into 4 of 32 -- a few
-// query groups (range discontinuities, sparse far field) cost 4x the mean and would otherwise set the kernel
-// time by themselves.  The items are then ordered heaviest first (counting sort, 32 buckets of estimated cost):
-// longest-processing-time-first keeps the persistent waves' tail short.  One 1024-thread block.
-__global__ __launch_bounds__(1024) void k_plan_items(unsigned int* __restrict__ cost32, int N, int n_slots,
-                                                     float split2_rel, float split4_rel, int* __restrict__ plan,
-                                                     unsigned int* __restrict__ n_plan)
+// heavy-first work order for the next launches: counting sort of the 128-query items by the cycles they took in
+// the last launch (32 buckets relative to the maximum), one 1024-thread block.  Longest-processing-time-first
+// keeps the persistent waves' tail short when a few query groups are much heavier than the rest.
+// (Cutting the heavy groups into smaller items was measured and dropped: an item's cost is mostly fixed
+// overhead -- box scan, staging and epilogue round trips -- so halves cost nearly as much as the whole.)
+__global__ __launch_bounds__(1024) void k_order_items(const unsigned int* __restrict__ cost, int n_items,
+                                                      int* __restrict__ order)
 {
     __shared__ unsigned int s_max, s_cnt[32], s_off[32];
-    __shared__ unsigned long long s_total;
-    const int n_base = (N + kQPW - 1) / kQPW, n32 = (N + 31) / 32;
-    if (threadIdx.x == 0) { s_max = 1u; s_total = 0ull; }
+    if (threadIdx.x == 0) s_max = 1u;
     if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    // pass 1: group costs (kept in slot 4i, the other three slots cleared), total
-    unsigned long long tot = 0;
-    for (int i = threadIdx.x; i < n_base; i += 1024) {
-        unsigned long long c = 0;
-        for (int q = 0; q < 4; ++q)
-            if (4 * i + q < n32) { c += cost32[4 * i + q]; cost32[4 * i + q] = 0u; }
-        c = c > 0xffffffffull ? 0xffffffffull : c;
-        cost32[4 * i] = (unsigned int)c;
-        tot += c;
-    }
-    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&s_total, tot);
-    __syncthreads();
-    // a perfectly balanced launch would take total / n_slots per persistent wave: keep every item well below that
-    const double balanced = (double)s_total / (double)(n_slots > 0 ? n_slots : 1);
-    const double split2 = (double)split2_rel * balanced, split4 = (double)split4_rel * balanced;
-    auto factor = [&](unsigned int c) -> int { return (double)c > split4 ? 4 : ((double)c > split2 ? 2 : 1); };
     unsigned int mx = 1u;
-    for (int i = threadIdx.x; i < n_base; i += 1024) { const unsigned int c = cost32[4 * i]; mx = max(mx, c / (unsigned int)factor(c)); }
+    for (int i = threadIdx.x; i < n_items; i += 1024) mx = max(mx, cost[i]);
     atomicMax(&s_max, mx);
     __syncthreads();
     const float scale = 32.0f / (float)s_max;
-    auto pieces = [&](int i, int f) -> int {  // sub-items of group i that hold at least one query
-        const int cnt = kQPW / f, left = N - i * kQPW;
-        const int n = (left + cnt - 1) / cnt;
-        return n < f ? n : f;
-    };
-    for (int i = threadIdx.x; i < n_base; i += 1024) {
-        const unsigned int c = cost32[4 * i];
-        const int f = factor(c);
-        const int b = 31 - min(31, (int)((float)(c / (unsigned int)f) * scale));  // bucket 0 = heaviest
-        atomicAdd(&s_cnt[b], (unsigned int)pieces(i, f));
+    for (int i = threadIdx.x; i < n_items; i += 1024) {
+        const int b = 31 - min(31, (int)((float)cost[i] * scale));  // bucket 0 = heaviest
+        atomicAdd(&s_cnt[b], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int o = 0;
         for (int b = 0; b < 32; ++b) { s_off[b] = o; o += s_cnt[b]; }
-        *n_plan = o;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_base; i += 1024) {
-        const unsigned int c = cost32[4 * i];
-        const int f = factor(c);
-        const int b = 31 - min(31, (int)((float)(c / (unsigned int)f) * scale));
-        const int np = pieces(i, f), cnt = kQPW / f;
-        const unsigned int at = atomicAdd(&s_off[b], (unsigned int)np);
-        for (int q = 0; q < np; ++q) plan[at + q] = (((i * kQPW + q * cnt) >> 5) << 3) | (cnt >> 5);
-        cost32[4 * i] = 0u;
+    for (int i = threadIdx.x; i < n_items; i += 1024) {
+        const int b = 31 - min(31, (int)((float)cost[i] * scale));
+        order[atomicAdd(&s_off[b], 1u)] = i;
     }
 }
 
@@ -1435,6 +1408,7 @@ struct AccArgs {
 };
 
 constexpr int kAccThreads = 256;
+constexpr int kAccMaxBlocks = 512;   // rows of partial sums (fixed for a given N: deterministic reduction)
 
 __global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* __restrict__ partials)
 {
@@ -1949,8 +1923,9 @@ TiledMap HipWorkspace::tiled_map() const
 
 int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
 {
-    const int n32 = (int)((N_ + 31) / 32);
-    int per_cu = 3;  // measured best at C3: 1 -> 0.45 ms, 2 -> 0.31, 3 -> 0.30, 4 -> 0.33, 5 -> 0.35
+    const int n_items = (int)((N_ + kQPW - 1) / kQPW);
+    // blocks per CU, measured at C3: 2 -> 0.190 ms, 3 -> 0.180, 4 -> 0.184
+    int per_cu = 3;
     if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 3;  // tuning knob
     const TiledMap mp = tiled_map();
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
@@ -1962,62 +1937,44 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
         if (fit >= 1 && per_cu > fit) per_cu = fit;
     }
     int grid = num_cus_ * per_cu;
-    if (grid > n32) grid = n32;  // never more waves than 32-query items
-    // first launch on a cloud (no cost profile yet): uniform items, small enough to occupy the persistent waves
-    const int slots = num_cus_ * per_cu * 4;
-    // Measured (1M and 100k clouds): the per-item cost is mostly fixed overhead (scan, staging, epilogue round
-    // trips), so smaller items raise the total and do not shorten the heaviest item: no splitting by default.
-    int uniform_shift = 0;
-    float split2_rel = 1e30f, split4_rel = 1e30f;  // thresholds relative to the balanced per-wave load
-    if (const char* e = std::getenv("MOLA_ICP_UNIFORM_SHIFT")) uniform_shift = std::atoi(e) & 3;
-    if (uniform_shift > 2) uniform_shift = 2;
-    // uniform order: consecutive queue entries far apart in the sorted cloud (a stride co-prime to the item count)
-    const int n_uniform = (int)((N_ + (size_t)(kQPW >> uniform_shift) - 1) / (size_t)(kQPW >> uniform_shift));
-    int uniform_stride = 1;
-    if (std::getenv("MOLA_ICP_STRIDE") && n_uniform > 8) {
-        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
-        uniform_stride = (int)(0.6180339887 * n_uniform) | 1;
-        while (gcd(uniform_stride, n_uniform) != 1) uniform_stride += 2;
-    }
-    if (const char* e = std::getenv("MOLA_ICP_SPLIT2")) split2_rel = (float)std::atof(e);
-    if (const char* e = std::getenv("MOLA_ICP_SPLIT4")) split4_rel = (float)std::atof(e);
+    if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     int rc;
-    if ((rc = item_cost_.reserve(sizeof(unsigned int) * (size_t)(n32 + 4)))) return rc;
-    if ((rc = item_order_.reserve(sizeof(int) * (size_t)(n32 + 4)))) return rc;
-    if (!cost_valid_) HIPCHK(hipMemsetAsync(item_cost_.p, 0, sizeof(unsigned int) * (size_t)(n32 + 4), stream_));  // no stale slots
-    const int* plan = nullptr;
-    unsigned int* n_plan = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 6);
+    if ((rc = item_cost_.reserve(sizeof(unsigned int) * (size_t)n_items))) return rc;
+    if ((rc = item_order_.reserve(sizeof(int) * (size_t)n_items))) return rc;
+    const int* order = nullptr;
     if (cost_valid_ && !std::getenv("MOLA_ICP_NO_LPT")) {
-        // the cost profile drifts slowly with the pose: re-plan every 4th launch, reuse the plan in between
-        if (!order_valid_ || (launches_since_order_ & 3) == 0) {
-            hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), (int)N_, slots,
-                               split2_rel, split4_rel, item_order_.as<int>(), n_plan);
+        // the cost profile drifts slowly with the pose: re-sort at launch 1, 2, 4, 8 after the clouds were set,
+        // then every 16th; the order is reused in between
+        if (!order_valid_ || launches_since_order_ >= plan_interval_) {
+            hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
+                               item_order_.as<int>());
             HIPCHK(hipGetLastError());
+            plan_interval_ = order_valid_ ? (plan_interval_ < 16 ? plan_interval_ * 2 : 16) : 1;
             order_valid_ = true;
             launches_since_order_ = 0;
         }
         ++launches_since_order_;
-        plan = item_order_.as<int>();
+        order = item_order_.as<int>();
     }
     if ((rc = ts_pos_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_idx_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_d2_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
     const float* sl = loc_sc_->sorted.as<float>();
-    if ((rc = redo_list_.reserve(sizeof(int) * (size_t)(n32 + 4)))) return rc;
+    if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
     // counter[2] = redo count; tq = the fast pass's queue counters, tq + kQueues * kQueueStride the exact pass's
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
     hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
                        (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(),
-                       plan, n_plan, uniform_shift, uniform_stride, item_cost_.as<unsigned int>(), tq, counter + 2,
+                       order, item_cost_.as<unsigned int>(), tq, counter + 2,
                        redo_list_.as<int>(), staged, dbg_stats_, lds_boxes);
     HIPCHK(hipGetLastError());
     // exact ties (duplicate points, lattices): the queued items again with the full lexicographic key.
     // Usually zero items: a few waves that read the count and leave.
     hipLaunchKernelGGL((k_nn_tiled<true>), dim3(grid < 64 ? grid : 64), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, /*seed = fast pass's result*/ 1, ts_pos_.as<int>(),
-                       ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr, (const unsigned int*)nullptr, 0, 1,
-                       (unsigned int*)nullptr, tq + kQueues * kQueueStride,
+                       ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr, (unsigned int*)nullptr,
+                       tq + kQueues * kQueueStride,
                        counter + 2, redo_list_.as<int>(), staged, dbg_stats_, lds_boxes);
     cost_valid_ = true;
     HIPCHK(hipGetLastError());
@@ -2113,7 +2070,7 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
         hipLaunchKernelGGL(k_accumulate_planes, dim3(nblocks), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
                            planes_.as<PlanePair>(), (int)N_, plane_acc_.as<double>());
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(128), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc);
+        hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc);
         HIPCHK(hipGetLastError());
     }
     if (comm_) {
@@ -2207,34 +2164,27 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
                      h[3] ? (double)h[11] / h[3] : 0.0, h[3] ? (double)h[12] / h[3] : 0.0, h[3] ? (double)h[13] / h[3] : 0.0,
                      h[3] ? (double)h[14] / h[3] : 0.0, h[3] ? (double)h[15] / h[3] : 0.0);
         HIPCHK(hipMemset(dbg_stats_, 0, sizeof h));
-        if (cost_valid_ && N_ > 0 && (N_ + 31) / 32 <= kDbgItems) {  // the heaviest items of the last tiled launch
-            const size_t n32 = (N_ + 31) / 32;
-            std::vector<unsigned long long> rec(8 * n32);
+        const size_t n_items = (N_ + kQPW - 1) / kQPW;
+        if (cost_valid_ && N_ > 0 && n_items <= kDbgItems) {  // the heaviest items of the last tiled launch
+            std::vector<unsigned long long> rec(8 * n_items);
             HIPCHK(hipMemcpy(rec.data(), dbg_stats_ + 16, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             std::vector<size_t> ord;
-            for (size_t i = 0; i < n32; ++i) if (rec[8 * i]) ord.push_back(i);
+            for (size_t i = 0; i < n_items; ++i) if (rec[8 * i]) ord.push_back(i);
             std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return rec[8 * a] > rec[8 * b]; });
-            for (size_t r = 0; r < ord.size(); r = (r < 8 ? r + 1 : r * 2)) {
+            for (size_t r = 0; r < ord.size(); r = (r < 4 ? r + 1 : r * 2)) {
                 const unsigned long long* q = &rec[8 * ord[r]];
-                std::fprintf(stderr, "[mola_icp debug]   rank %zu item@%zu: cycles %llu staged %llu supers %llu tile tests %llu | prologue %llu scan %llu passes %llu epilogue %llu\n",
-                             r, ord[r] * 32, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]);
+                std::fprintf(stderr, "[mola_icp debug]   rank %zu item %zu: cycles %llu staged %llu supers %llu tile tests %llu | prologue %llu scan %llu passes %llu epilogue %llu\n",
+                             r, ord[r], q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]);
             }
             HIPCHK(hipMemset(dbg_stats_ + 16, 0, rec.size() * sizeof(unsigned long long)));
-        }
-        if (cost_valid_ && N_ > 0) {  // spread of the per-item cost of the last tiled launch
-            const size_t n32 = (N_ + 31) / 32;
-            std::vector<unsigned int> c32(n32);
-            HIPCHK(hipMemcpy(c32.data(), item_cost_.p, n32 * sizeof(unsigned int), hipMemcpyDeviceToHost));
-            std::vector<unsigned int> c;  // the items of the last launch (a slot is written by the item starting there)
-            for (unsigned int v : c32) if (v) c.push_back(v);
-            if (c.empty()) c.push_back(0u);
-            const size_t n_items = c.size();
+            std::vector<unsigned int> c(n_items);
+            HIPCHK(hipMemcpy(c.data(), item_cost_.p, n_items * sizeof(unsigned int), hipMemcpyDeviceToHost));
             std::sort(c.begin(), c.end());
             double sum = 0;
             for (unsigned int v : c) sum += v;
-            std::fprintf(stderr, "[mola_icp debug] item cost: n=%zu mean %.0f p50 %u p90 %u p99 %u p99.9 %u max %u; sum/3072 slots = %.0f\n",
-                         n_items, sum / n_items, c[n_items / 2], c[n_items * 9 / 10], c[n_items * 99 / 100],
-                         c[std::min(n_items - 1, n_items * 999 / 1000)], c[n_items - 1], sum / 3072.0);
+            std::fprintf(stderr, "[mola_icp debug] item cost: n=%zu mean %.0f p50 %u p90 %u p99 %u max %u; sum/3072 slots = %.0f\n",
+                         n_items, sum / n_items, c[n_items / 2], c[n_items * 9 / 10], c[n_items * 99 / 100], c[n_items - 1],
+                         sum / 3072.0);
         }
     }
     if (ms_total) *ms_total = tot;
@@ -2396,8 +2346,8 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     }
     if (stage == 1 && p.use_scale_outlier_detector) outliers_dirty_ = true;
     int nblocks = (int)((N_ + kAccThreads - 1) / kAccThreads);
-    if (nblocks > 512) nblocks = 512;
-    if ((rc = partials_.reserve(sizeof(double) * kNAcc * 512))) return rc;
+    if (nblocks > kAccMaxBlocks) nblocks = kAccMaxBlocks;
+    if ((rc = partials_.reserve(sizeof(double) * kNAcc * kAccMaxBlocks))) return rc;
     AccArgs a{};
     if (pairing_sorted_) {  // tiled matcher: sorted local cloud, neighbour = sorted-map position (local gathers)
         const float* sl = loc_sc_->sorted.as<float>();

@@ -136,7 +136,7 @@ class HipWorkspace final : public Stages {
     DevBuf redo_list_;                // work items with exact distance ties: redone with the full lexicographic key
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
     bool cost_valid_ = false, order_valid_ = false;
-    unsigned int launches_since_order_ = 0;
+    unsigned int launches_since_order_ = 0, plan_interval_ = 1;
     // pairing + scratch
     DevBuf idx_, d2_, seg_idx_, seg_d2_, outlier_, partials_, acc_dev_;
     double* acc_host_ = nullptr;  // pinned
