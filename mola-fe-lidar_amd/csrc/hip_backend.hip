@@ -481,6 +481,12 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
         }
     }
     unsigned long long n_staged = 0;
+#ifdef MOLA_VAR_GUARD
+    int g_outer = 0, g_collect = 0, g_list = 0, g_cand = 0, g_tmask = 0;
+#define MOLA_GUARD(c, code) if (++(c) > 100000) { n_staged |= (1ull << (code)); break; }
+#else
+#define MOLA_GUARD(c, code)
+#endif
 
     // does ANY query of the wave reach the box (m0..m5 = min xyz, max xyz; wave-uniform values)?
     auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
@@ -531,6 +537,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
         float n0 = mp.tbox[ti], n1 = mp.tbox[mp.n_tiles_p + ti], n2 = mp.tbox[2 * mp.n_tiles_p + ti],
               n3 = mp.tbox[3 * mp.n_tiles_p + ti], n4 = mp.tbox[4 * mp.n_tiles_p + ti], n5 = mp.tbox[5 * mp.n_tiles_p + ti];
         for (int e = 0; e < n_list; ++e) {
+            MOLA_GUARD(g_list, 40)
             const unsigned long long tb0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
             const float b0 = n0, b1 = n1, b2 = n2, b3 = n3, b4 = n4, b5 = n5;
             const int Sc = S;
@@ -545,6 +552,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
             unsigned long long tmask = 0;
             const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
             while (cand) {
+                MOLA_GUARD(g_cand, 41)
                 const int t = __builtin_ctzll(cand);
                 cand &= cand - 1;
                 if (prof) p_tiles += 1;
@@ -554,6 +562,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
             }
             if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); p_boxwait += tb1 - tb0; p_tiletest += tb2 - tb1; }
             while (tmask) {
+                MOLA_GUARD(g_tmask, 42)
                 const int t0 = Sc * kSuper + __builtin_ctzll(tmask);
                 tmask &= tmask - 1;
                 int t1 = -1;
@@ -591,7 +600,9 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
         c_valid = true;
     };
     for (;;) {
+        MOLA_GUARD(g_outer, 43)
         while (n_list < kMaxList) {
+            MOLA_GUARD(g_collect, 44)
             if (scand) {
                 if (!c_valid) load_super_boxes();  // resumed after a full list
                 const int sl = __builtin_ctzll(scand);
@@ -990,8 +1001,14 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
     const int n_items = (N + kQPW - 1) / kQPW;
     unsigned long long wave_staged = 0ull;
+#ifdef MOLA_VAR_GUARD
+    int g_items = 0;
+#endif
     WaveQueue wq(queue, lane);
     for (int item = wq.first(); item < n_items;) {
+#ifdef MOLA_VAR_GUARD
+        if (++g_items > 20000) { wave_staged |= (1ull << 45); break; }
+#endif
         const int next_raw_v = wq.pop();
 
         float qx[2], qy[2], qz[2], reach[2];
@@ -1090,6 +1107,11 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                     }
                 }
             }
+#ifdef MOLA_VAR_DYNREACH
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (reach[k] >= 0.f) reach[k] = reach_of(kd[k][K - 1], qx[k], qy[k], qz[k]);
+#endif
          }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
 
 #pragma unroll

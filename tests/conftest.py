@@ -33,6 +33,9 @@ def pytest_collection_modifyitems(config, items):
     if HAS_GPU is None:
         HAS_GPU = _has_gpu()
     if HAS_GPU:
+        for it in items:  # a kernel that never finishes must fail the test, not stall the run
+            if "gpu" in it.keywords and not any(m.name == "timeout" for m in it.iter_markers()):
+                it.add_marker(pytest.mark.timeout(900))
         return
     skip = pytest.mark.skip(reason="no GPU in this container (GPU tests run on the MI355X box)")
     for it in items:

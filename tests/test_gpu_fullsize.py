@@ -75,6 +75,44 @@ def test_1m_x_1m_config3_run(pkg, O, big):
     icp.close()
 
 
+def test_1m_x_1m_shipped_point2plane(pkg, O, big):
+    """The shipped Point2Plane + Gauss-Newton pipeline at config-3 size (waves take several items each, the warm
+    start is active from the second iteration): the warm start must not change a single bit, and a sample of
+    the plane pairings equals the oracle's exact kd-tree kNN."""
+    import os
+    g, l, Tgt = big
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = pkg.Parameters.load_from_file(os.path.join(root, "params", "icp-settings-regular.yaml"))
+    p.fixed_iterations, p.skip_quality, p.max_iterations = 1, 1, 4
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    r = icp.align_resident(np.eye(4), p)
+    os.environ["MOLA_ICP_NO_KNN_SEED"] = "1"
+    try:
+        r0 = icp.align_resident(np.eye(4), p)
+        v0, c0, n0, k0, cnt0 = icp.match_planes(r.optimal_tf, p, l.shape[1])
+    finally:
+        del os.environ["MOLA_ICP_NO_KNN_SEED"]
+    assert r.nIterations == r0.nIterations == 4 and np.array_equal(r.optimal_tf, r0.optimal_tf)
+    rot, trans = O.pose_error(r.optimal_tf, Tgt)
+    rot_i, trans_i = O.pose_error(np.eye(4), Tgt)
+    assert rot < 0.1 * rot_i and trans < 0.1 * trans_i        # point-to-plane converges fast on this scene
+    # seeded (neighbours of the previous launch at another pose) == unseeded, bit for bit
+    icp.match_planes(np.eye(4), p, l.shape[1])
+    v1, c1, n1, k1, cnt1 = icp.match_planes(r.optimal_tf, p, l.shape[1])
+    assert cnt1 == cnt0 and np.array_equal(k1, k0) and np.array_equal(v1, v0)
+    assert np.array_equal(c1, c0) and np.array_equal(n1, n0)
+    # a 4k-query sample against the oracle
+    sel = np.arange(0, l.shape[1], 250)
+    ov, oc, on, ok, _ = O.match_point2plane(g, np.ascontiguousarray(l[:, sel]), r.optimal_tf, p.matcher_threshold,
+                                            p.plane_eigen_threshold, p.knn, O.KdTree(g))
+    assert np.array_equal(k1[sel], ok) and np.array_equal(v1[sel], ov)
+    kk = ov.astype(bool)
+    np.testing.assert_allclose(c1[sel][kk], oc[kk], atol=1e-12)
+    icp.close()
+
+
 def test_config1_kitti_like_pair_through_front_end(pkg, O, synth):
     """BASELINE configs[0]: params/kitti-default.yaml + one KITTI-like 64-ring scan pair (~120k points each; no
     real KITTI data exists in the image) through the front-end, GPU ICP vs the CPU oracle on the same pair."""

@@ -26,4 +26,4 @@ for its in (1, a.iters):
     t0 = time.perf_counter()
     r = icp.align_resident(np.eye(4), p)
     dt = time.perf_counter() - t0
-    print(f"n={a.n}: {its} iterations in {dt*1e3:.2f} ms = {dt*1e3/its:.3f} ms/iteration; kernel {r.ms_nn_kernel:.3f} ms total", flush=True)
+    print(f"n={a.n}: {its} iterations in {dt*1e3:.2f} ms = {dt*1e3/its:.3f} ms/iteration; kernel {r.ms_nn_kernel:.3f} ms total, pairs evaluated {r.nn_pairs_evaluated:#x}", flush=True)
