@@ -455,7 +455,8 @@ __device__ __forceinline__ void load_boxes_to_lds(const TiledMap& mp, lds_f32* l
 template <bool NEED_PERM, class Visit>
 __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane,
                                                           float (*sm)[64], const float (&qx)[2], const float (&qy)[2],
-                                                          const float (&qz)[2], const float (&reach)[2], Visit&& visit,
+                                                          const float (&qz)[2], const float (&reach)[2],
+                                                          const float (&bound2)[2], Visit&& visit,
                                                           bool prof, unsigned long long& p_stage,
                                                           unsigned long long& p_visit, unsigned int& p_supers,
                                                           unsigned int& p_entered, unsigned int& p_tiles,
@@ -488,12 +489,20 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
 #define MOLA_GUARD(c, code)
 #endif
 
-    // does ANY query of the wave reach the box (m0..m5 = min xyz, max xyz; wave-uniform values)?
+    // Can the box (m0..m5 = min xyz, max xyz; wave-uniform values) hold a point with d2 <= bound2 for ANY query of
+    // the wave?  Per query: squared distance to the box, computed with the contract's own operation sequence on
+    // the per-axis gaps.  Rounding is monotone, so for every point p inside the box gap_a <= |q_a - p_a| after
+    // rounding, hence box_d2 <= d2_contract(q, p) EXACTLY as computed -- no margin needed, and bound2 is read
+    // live: as a query's best shrinks during the sweep, later boxes are tested against the tighter value.
+    // Padding lanes carry bound2 < 0 and reach nothing; empty boxes (+inf, -inf) give inf.
+    const v2f s_qx = {qx[0], qx[1]}, s_qy = {qy[0], qy[1]}, s_qz = {qz[0], qz[1]};
     auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
-        return __any((m0 <= qx[0] + reach[0] && m3 >= qx[0] - reach[0] && m1 <= qy[0] + reach[0] &&
-                      m4 >= qy[0] - reach[0] && m2 <= qz[0] + reach[0] && m5 >= qz[0] - reach[0]) ||
-                     (m0 <= qx[1] + reach[1] && m3 >= qx[1] - reach[1] && m1 <= qy[1] + reach[1] &&
-                      m4 >= qy[1] - reach[1] && m2 <= qz[1] + reach[1] && m5 >= qz[1] - reach[1]));
+        const v2f zero = {0.f, 0.f};
+        const v2f ax = __builtin_elementwise_max(__builtin_elementwise_max(m0 - s_qx, s_qx - m3), zero);
+        const v2f ay = __builtin_elementwise_max(__builtin_elementwise_max(m1 - s_qy, s_qy - m4), zero);
+        const v2f az = __builtin_elementwise_max(__builtin_elementwise_max(m2 - s_qz, s_qz - m5), zero);
+        const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+        return __any(D.x <= bound2[0] || D.y <= bound2[1]);
     };
 
     int pend_a = -1, pend_b = -1;  // tile ids whose points sit in the registers below
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             if (qi[k] >= N) {  // padding lane: reaches nothing, is never written
                 qx[k] = qy[k] = qz[k] = 1.0e18f;
                 reach[k] = -1.0f;
-                best[k] = thr2;
+                best[k] = -1.0f;
                 bpos[k] = -1;
             }
         }
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
         const unsigned long long t_sweep0 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
         const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};  // both queries of the lane, packed
-        const unsigned long long n_staged = tiled_sweep<EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
+        const unsigned long long n_staged = tiled_sweep<EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
             if constexpr (EXACT) {
                 for (int m = 0; m < nm; m += 4) {
                     const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
@@ -789,6 +798,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                             const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
                             const bool better = ck < key[k];
                             key[k] = better ? ck : key[k];
+                            best[k] = better ? d : best[k];  // the sweep's box tests read it
                             bpos[k] = better ? ((m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32) : bpos[k];
                         }
                     }
@@ -1011,7 +1021,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
 #endif
         const int next_raw_v = wq.pop();
 
-        float qx[2], qy[2], qz[2], reach[2];
+        float qx[2], qy[2], qz[2], reach[2], kbound[2];
         float kd[2][K];          // sorted ascending by (d2, original index)
         unsigned int ko[2][K];   // original indices
         int kp[2][K];            // sorted-map positions
@@ -1066,13 +1076,14 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             reach[k] = reach_of(kd[k][K - 1], qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
-            if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; }  // padding lane
+            kbound[k] = kd[k][K - 1];  // (fixed during the sweep)
+            if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; kbound[k] = -1.0f; }  // padding lane
         }
 
         const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
         unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
         unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
-        const unsigned long long n_staged = tiled_sweep<true>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, [&](int nm, int jb0, int jb1) {
+        const unsigned long long n_staged = tiled_sweep<true>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
             for (int m = 0; m < nm; m += 4) {
                 const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
                 const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
