@@ -712,6 +712,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float(*sm)[64] = s_m[wave];
     int* slist = s_list[wave];
+    if (EXACT && *redo_count == 0u) return;  // the usual case: no exact ties in this launch (uniform: before any barrier)
     const lds_f32* lbox = (const lds_f32*)s_dyn;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
     const int n_items = EXACT ? (int)*redo_count : (N + kQPW - 1) / kQPW;  // an item = 128 consecutive sorted queries
@@ -1449,24 +1450,22 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* _
 #pragma unroll
     for (int k = 0; k < kNAcc; ++k) s[k] = 0.0;
     const int stride = gridDim.x * kAccThreads;
-    for (int i = blockIdx.x * kAccThreads + threadIdx.x; i < a.N; i += stride) {
-        const int j = a.idx[i];
-        if (j < 0) continue;
-        if (a.outlier[i]) continue;
-        const double l0 = a.lx[i], l1 = a.ly[i], l2 = a.lz[i];
-        const double g0 = a.gx[j], g1 = a.gy[j], g2 = a.gz[j];
+    // one pairing -> the 24 sums; elements are taken in ascending i per thread (fixed summation order)
+    auto element = [&](int i, int j, unsigned char out, double l0, double l1, double l2, double g0, double g1, double g2,
+                       float d2v) {
+        if (j < 0 || out) return;
         double w = 1.0;
         if (a.stage == 1) {
             double b0 = g0 - a.cg[0], b1 = g1 - a.cg[1], b2 = g2 - a.cg[2];
             double r0 = l0 - a.cl[0], r1 = l1 - a.cl[1], r2 = l2 - a.cl[2];
             const double bn = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
             const double rn = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-            if (bn < 1e-4 || rn < 1e-4) continue;
+            if (bn < 1e-4 || rn < 1e-4) return;
             if (a.use_scale) {
                 const double hi = bn > rn ? bn : rn, lo = bn > rn ? rn : bn;
                 if (hi / lo > a.scale_thr) {
                     a.outlier[i] = 1;
-                    continue;
+                    return;
                 }
             }
             if (a.use_robust) {
@@ -1491,9 +1490,25 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* _
         s[10] += w * l1 * g0; s[11] += w * l1 * g1; s[12] += w * l1 * g2;
         s[13] += w * l2 * g0; s[14] += w * l2 * g1; s[15] += w * l2 * g2;
         s[16] += 1.0;
-        s[17] += (double)a.d2[i];
+        s[17] += (double)d2v;
         s[18] += w * l0 * l0; s[19] += w * l0 * l1; s[20] += w * l0 * l2;
         s[21] += w * l1 * l1; s[22] += w * l1 * l2; s[23] += w * l2 * l2;
+    };
+    // two elements per trip with all their loads issued up front (the gather by neighbour position is a dependent
+    // load: this halves the exposed latency); they are summed in the same order as a one-by-one loop
+    for (int i = blockIdx.x * kAccThreads + threadIdx.x; i < a.N; i += 2 * stride) {
+        const int i2 = i + stride;
+        const bool in2 = i2 < a.N;
+        const int ic2 = in2 ? i2 : i;
+        const int jA = a.idx[i], jB = in2 ? a.idx[ic2] : -1;
+        const unsigned char oA = a.outlier[i], oB = a.outlier[ic2];
+        const float lA0 = a.lx[i], lA1 = a.ly[i], lA2 = a.lz[i], dA = a.d2[i];
+        const float lB0 = a.lx[ic2], lB1 = a.ly[ic2], lB2 = a.lz[ic2], dB = a.d2[ic2];
+        const int jcA = jA >= 0 ? jA : 0, jcB = jB >= 0 ? jB : 0;
+        const float gA0 = a.gx[jcA], gA1 = a.gy[jcA], gA2 = a.gz[jcA];
+        const float gB0 = a.gx[jcB], gB1 = a.gy[jcB], gB2 = a.gz[jcB];
+        element(i, jA, oA, lA0, lA1, lA2, gA0, gA1, gA2, dA);
+        element(i2, jB, oB, lB0, lB1, lB2, gB0, gB1, gB2, dB);
     }
     // fixed-order reduction: lanes (shuffle tree) -> waves (LDS, in wave order) -> one row per block
     __shared__ double sm[kAccThreads / 64][kNAcc];

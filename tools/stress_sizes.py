@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Both pipelines over a ladder of cloud sizes (several items per persistent wave above ~400k queries):
+prints ms/iteration; a size that never returns shows up as a missing line (run under `timeout`)."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("mola-fe-lidar_amd")
+synth = importlib.import_module("mola-fe-lidar_amd.synth")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pl = pkg.Parameters.load_from_file(os.path.join(root, "params", "icp-settings-regular.yaml"))
+pp = pkg.Parameters()
+pp.matcher_threshold = 1.0
+for p in (pl, pp):
+    p.fixed_iterations, p.skip_quality, p.max_iterations = 1, 1, 6
+icp = pkg.ICP(device=0)
+for n, m in ((9000, 9000), (50_000, 200_000), (393_216, 393_216), (500_000, 500_000), (777_777, 1_234_567),
+             (2_000_000, 1_000_000), (1_000_000, 4_000_000), (3_000_000, 3_000_000)):
+    g, l, _ = synth.make_pair(n, m, seed=n % 97)
+    icp.set_map(g)
+    icp.set_local(l)
+    for name, p in (("p2p", pp), ("p2pl", pl)):
+        t0 = time.perf_counter()
+        r = icp.align_resident(np.eye(4), p)
+        dt = time.perf_counter() - t0
+        print(f"N={n} M={m} {name}: {r.nIterations} its, {dt*1e3/6:.3f} ms/it (incl. preparation), kernel {r.ms_nn_kernel/max(1,r.n_nn_launches):.3f} ms/launch", flush=True)
