@@ -997,7 +997,7 @@ template <int K>
 __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
                                                     const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
                                                     float thr2, double threshold, double plane_eig_thr,
-                                                    PlanePair* __restrict__ out,
+                                                    PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
                                                     int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
                                                     int use_seed, unsigned int* __restrict__ queue,
                                                     unsigned long long* __restrict__ staged_total, int lds_boxes)
@@ -1119,69 +1119,85 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                     }
                 }
             }
-#ifdef MOLA_VAR_DYNREACH
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-                if (reach[k] >= 0.f) reach[k] = reach_of(kd[k][K - 1], qx[k], qy[k], qz[k]);
-#endif
          }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
 
+        // Epilogue.  The plane (centroid, normal, is-it-planar) depends only on the ordered neighbour list -- map
+        // points, fixed for the align -- so when a query's list equals the last launch's, the cached plane is reused
+        // bit for bit and the fp64 covariance + Jacobi eigen-solve (dearer than the search itself) is skipped.  Near
+        // convergence almost no list changes; a wave pays for the solve only if one of its lanes needs it.
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = qi[k];
-            if (i >= N) continue;
-            PlanePair pp;
-            pp.valid = 0;
+            const bool in = i < N;
+            const size_t ic = in ? (size_t)i : (size_t)(N - 1);
             int m = 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) m += (kp[k][j] >= 0 && kd[k][j] < thr2) ? 1 : 0;  // sorted: the first m entries
-            pp.n_neigh = m;
+            bool same = use_seed != 0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { pp.c[a] = 0; pp.n[a] = 0; }
-#pragma unroll
-            for (int j = 0; j < K; ++j) knn_pos[(size_t)i * K + j] = j < m ? kp[k][j] : -1;
-            if (m >= 3) {
-                double px[K], py[K], pz[K];
-                double mean[3] = {0, 0, 0};
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    px[j] = py[j] = pz[j] = 0;
-                    if (j < m) {
-                        px[j] = mp.sx[kp[k][j]]; py[j] = mp.sy[kp[k][j]]; pz[j] = mp.sz[kp[k][j]];
-                        mean[0] += px[j]; mean[1] += py[j]; mean[2] += pz[j];
-                    }
-                }
-                const double dm = (double)m;
-                mean[0] /= dm; mean[1] /= dm; mean[2] /= dm;
-                double Cm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    if (j < m) {
-                        const double dd[3] = {px[j] - mean[0], py[j] - mean[1], pz[j] - mean[2]};
-#pragma unroll
-                        for (int r = 0; r < 3; ++r)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) Cm[r][c] += dd[r] * dd[c];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) Cm[r][c] /= dm;
-                double ev[3], V[3][3];
-                eig_sym3_dev(Cm, ev, V);
-                if (!(ev[0] > plane_eig_thr * ev[2])) {
-                    const double nx = V[0][0], ny = V[1][0], nz = V[2][0];
-                    const double dist = fabs(nx * ((double)qx[k] - mean[0]) + ny * ((double)qy[k] - mean[1]) +
-                                             nz * ((double)qz[k] - mean[2]));
-                    if (!(dist > threshold)) {
-                        pp.valid = 1;
-                        pp.c[0] = mean[0]; pp.c[1] = mean[1]; pp.c[2] = mean[2];
-                        pp.n[0] = nx; pp.n[1] = ny; pp.n[2] = nz;
-                    }
-                }
+            for (int j = 0; j < K; ++j) {
+                const int now = j < m ? kp[k][j] : -1;
+                if (use_seed) same &= knn_pos[ic * K + j] == now;
+                if (in) knn_pos[ic * K + j] = now;
             }
-            out[i] = pp;
+            PlanePair pl;  // the plane of the list: valid = "is a plane" (before the query-distance test)
+            pl.valid = 0; pl.n_neigh = m;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { pl.c[a] = 0; pl.n[a] = 0; }
+            const bool solve = in && !same;
+            if (__any(solve)) {
+                if (solve && m >= 3) {
+                    double px[K], py[K], pz[K];
+                    double mean[3] = {0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        px[j] = py[j] = pz[j] = 0;
+                        if (j < m) {
+                            px[j] = mp.sx[kp[k][j]]; py[j] = mp.sy[kp[k][j]]; pz[j] = mp.sz[kp[k][j]];
+                            mean[0] += px[j]; mean[1] += py[j]; mean[2] += pz[j];
+                        }
+                    }
+                    const double dm = (double)m;
+                    mean[0] /= dm; mean[1] /= dm; mean[2] /= dm;
+                    double Cm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        if (j < m) {
+                            const double dd[3] = {px[j] - mean[0], py[j] - mean[1], pz[j] - mean[2]};
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) Cm[r][c] += dd[r] * dd[c];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) Cm[r][c] /= dm;
+                    double ev[3], V[3][3];
+                    eig_sym3_dev(Cm, ev, V);
+                    if (!(ev[0] > plane_eig_thr * ev[2])) {
+                        pl.valid = 1;
+                        pl.c[0] = mean[0]; pl.c[1] = mean[1]; pl.c[2] = mean[2];
+                        pl.n[0] = V[0][0]; pl.n[1] = V[1][0]; pl.n[2] = V[2][0];
+                    }
+                }
+                if (solve) cache[ic] = pl;
+            }
+            if (in && same) pl = cache[ic];
+            if (in) {
+                PlanePair pp = pl;
+                if (pl.valid) {
+                    const double dist = fabs(pl.n[0] * ((double)qx[k] - pl.c[0]) + pl.n[1] * ((double)qy[k] - pl.c[1]) +
+                                             pl.n[2] * ((double)qz[k] - pl.c[2]));
+                    if (dist > threshold) {
+                        pp.valid = 0;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) { pp.c[a] = 0; pp.n[a] = 0; }
+                    }
+                }
+                out[ic] = pp;
+            }
         }
         wave_staged += n_staged;
         item = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items);
@@ -1583,7 +1599,7 @@ HipWorkspace::~HipWorkspace()
     map_sc_.reset();
     loc_sc_.reset();
     ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
-    planes_.release(); knn_pos_.release(); plane_acc_.release();
+    planes_.release(); knn_pos_.release(); plane_acc_.release(); plane_cache_.release();
     if (plane_acc_host_) (void)hipHostFree(plane_acc_host_);
     sort_scratch_.release();
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
@@ -2042,6 +2058,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if ((rc = prepare_queries())) return rc;
     if ((rc = planes_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
     if ((rc = knn_pos_.reserve(sizeof(int) * loc_sc_->padded * 8))) return rc;
+    if ((rc = plane_cache_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
     PoseF P;
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) P.R[3 * r + c] = (float)T(r, c);
@@ -2081,6 +2098,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 #define MOLA_LAUNCH_KNN(KK)                                                                                         \
     hipLaunchKernelGGL((k_knn_planes<KK>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,  \
                        (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold, planes_.as<PlanePair>(),   \
+                       plane_cache_.as<PlanePair>(),                                                                 \
                        knn_pos_.as<int>(), knn_seed, reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8), staged, lds_boxes)
     switch (p.knn) {
         case 3: MOLA_LAUNCH_KNN(3); break;

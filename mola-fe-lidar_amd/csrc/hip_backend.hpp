@@ -128,7 +128,7 @@ class HipWorkspace final : public Stages {
     DevBuf sort_scratch_;
     DevBuf ts_pos_, ts_idx_, ts_d2_;  // the tiled matcher's pairing, in SORTED query order
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
-    DevBuf planes_, knn_pos_, plane_acc_;  // point-to-plane pairing (sorted query order) + its accumulators
+    DevBuf planes_, knn_pos_, plane_acc_, plane_cache_;  // point-to-plane pairing (sorted query order) + its accumulators
     double* plane_acc_host_ = nullptr;
     bool planes_valid_ = false, planes_empty_ = false;
     int planes_knn_ = 0;
