@@ -482,12 +482,6 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
         }
     }
     unsigned long long n_staged = 0;
-#ifdef MOLA_VAR_GUARD
-    int g_outer = 0, g_collect = 0, g_list = 0, g_cand = 0, g_tmask = 0;
-#define MOLA_GUARD(c, code) if (++(c) > 100000) { n_staged |= (1ull << (code)); break; }
-#else
-#define MOLA_GUARD(c, code)
-#endif
 
     // Can the box (m0..m5 = min xyz, max xyz; wave-uniform values) hold a point with d2 <= bound2 for ANY query of
     // the wave?  Per query: squared distance to the box, computed with the contract's own operation sequence on
@@ -546,7 +540,6 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
         float n0 = mp.tbox[ti], n1 = mp.tbox[mp.n_tiles_p + ti], n2 = mp.tbox[2 * mp.n_tiles_p + ti],
               n3 = mp.tbox[3 * mp.n_tiles_p + ti], n4 = mp.tbox[4 * mp.n_tiles_p + ti], n5 = mp.tbox[5 * mp.n_tiles_p + ti];
         for (int e = 0; e < n_list; ++e) {
-            MOLA_GUARD(g_list, 40)
             const unsigned long long tb0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
             const float b0 = n0, b1 = n1, b2 = n2, b3 = n3, b4 = n4, b5 = n5;
             const int Sc = S;
@@ -561,7 +554,6 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
             unsigned long long tmask = 0;
             const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
             while (cand) {
-                MOLA_GUARD(g_cand, 41)
                 const int t = __builtin_ctzll(cand);
                 cand &= cand - 1;
                 if (prof) p_tiles += 1;
@@ -571,7 +563,6 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
             }
             if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); p_boxwait += tb1 - tb0; p_tiletest += tb2 - tb1; }
             while (tmask) {
-                MOLA_GUARD(g_tmask, 42)
                 const int t0 = Sc * kSuper + __builtin_ctzll(tmask);
                 tmask &= tmask - 1;
                 int t1 = -1;
@@ -609,9 +600,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
         c_valid = true;
     };
     for (;;) {
-        MOLA_GUARD(g_outer, 43)
         while (n_list < kMaxList) {
-            MOLA_GUARD(g_collect, 44)
             if (scand) {
                 if (!c_valid) load_super_boxes();  // resumed after a full list
                 const int sl = __builtin_ctzll(scand);
@@ -993,13 +982,15 @@ __device__ __forceinline__ void eig_sym3_dev(const double Cin[3][3], double ev[3
         for (int k = 0; k < 3; k++) V[r][k] = Vs[r][k];
 }
 
-template <int K>
+template <int K, bool VERIFY>
 __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
                                                     const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
                                                     float thr2, double threshold, double plane_eig_thr,
                                                     PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
                                                     int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
                                                     int use_seed, unsigned int* __restrict__ queue,
+                                                    unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
+                                                    unsigned int* __restrict__ changed_items,
                                                     unsigned long long* __restrict__ staged_total, int lds_boxes)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
@@ -1008,19 +999,23 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float(*sm)[64] = s_m[wave];
     int* slist = s_list[wave];
+    // VERIFY = true (warm-started launches): all items; the sweep only COUNTS the points within each query's
+    //   K-th seed distance.  Count == number of seeds <=> the neighbour set is exactly the seeds (every seed lies
+    //   within that distance and is met once), so the sorted seed list IS the answer and no list is maintained
+    //   in the sweep.  Items with a lane whose count differs are queued in redo_list, untouched.
+    // VERIFY = false: the full sweep with sorted-list insertion -- over all items (first launch on a cloud pair:
+    //   redo_list == nullptr) or over the queued items only.
+    const bool from_list = !VERIFY && redo_list != nullptr;
+    if (from_list && *redo_count == 0u) return;  // nothing queued (uniform: before any barrier)
     const lds_f32* lbox = (const lds_f32*)s_dyn;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
-    const int n_items = (N + kQPW - 1) / kQPW;
+    const int n_items = from_list ? (int)*redo_count : (N + kQPW - 1) / kQPW;
     unsigned long long wave_staged = 0ull;
-#ifdef MOLA_VAR_GUARD
-    int g_items = 0;
-#endif
+    unsigned int wave_changed = 0u;  // items of this wave with a lane whose neighbour list differs from its seeds
     WaveQueue wq(queue, lane);
-    for (int item = wq.first(); item < n_items;) {
-#ifdef MOLA_VAR_GUARD
-        if (++g_items > 20000) { wave_staged |= (1ull << 45); break; }
-#endif
+    for (int raw = wq.first(); raw < n_items;) {
         const int next_raw_v = wq.pop();
+        const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : raw;
 
         float qx[2], qy[2], qz[2], reach[2], kbound[2];
         float kd[2][K];          // sorted ascending by (d2, original index)
@@ -1080,16 +1075,37 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
             kbound[k] = kd[k][K - 1];  // (fixed during the sweep)
             if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; kbound[k] = -1.0f; }  // padding lane
         }
+        // VERIFY: tau = K-th seed distance (list full), else the largest float below gate^2 ("d2 < gate^2" as "<=")
+        float tau[2];
+        int expect[2], cnt[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int sds = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) sds += kp[k][j] >= 0 ? 1 : 0;
+            expect[k] = sds;
+            tau[k] = sds == K ? kd[k][K - 1] : __uint_as_float(__float_as_uint(thr2) - 1u);
+            if (VERIFY && qi[k] < N) kbound[k] = tau[k];
+        }
 
         const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
         unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
         unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
-        const unsigned long long n_staged = tiled_sweep<true>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
+        const unsigned long long n_staged = tiled_sweep<!VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
             for (int m = 0; m < nm; m += 4) {
                 const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
                 const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
                 const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
                 const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                if constexpr (VERIFY) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                        cnt[0] += dv.x <= tau[0] ? 1 : 0;
+                        cnt[1] += dv.y <= tau[1] ? 1 : 0;
+                    }
+                    continue;
+                }
                 float d[2][4];
                 bool cand = false;
 #pragma unroll
@@ -1121,6 +1137,16 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
             }
          }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
 
+        bool redo = false;
+        if constexpr (VERIFY) {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) bad |= qi[k] < N && cnt[k] != expect[k];
+            redo = __any(bad);
+            if (redo && lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
+        }
+        bool item_changed = false;
+        if (!redo) {
         // Epilogue.  The plane (centroid, normal, is-it-planar) depends only on the ordered neighbour list -- map
         // points, fixed for the align -- so when a query's list equals the last launch's, the cached plane is reused
         // bit for bit and the fp64 covariance + Jacobi eigen-solve (dearer than the search itself) is skipped.  Near
@@ -1146,6 +1172,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
             for (int a = 0; a < 3; ++a) { pl.c[a] = 0; pl.n[a] = 0; }
             const bool solve = in && !same;
             if (__any(solve)) {
+                item_changed = true;
                 if (solve && m >= 3) {
                     double px[K], py[K], pz[K];
                     double mean[3] = {0, 0, 0};
@@ -1199,10 +1226,14 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                 out[ic] = pp;
             }
         }
+        }  // (epilogue)
+        wave_changed += item_changed ? 1u : 0u;
         wave_staged += n_staged;
-        item = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items);
+        raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items);
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
+    // (the verify flavour reports its queued items through redo_count; the queued-items launch must not count twice)
+    if (!VERIFY && !from_list && lane == 0 && wave_changed) atomicAdd(changed_items, wave_changed);
 }
 
 // the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
@@ -1257,8 +1288,11 @@ __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restri
 // fixed-order sum of [nblocks][n] partial rows (n <= 128): 8 slices of rows per accumulator with the loads of a
 // slice independent of each other, then the 8 slice sums in order.  Deterministic for a given nblocks.
 __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
-                                                      double* __restrict__ acc)
+                                                      double* __restrict__ acc, const unsigned int* __restrict__ counters)
 {
+    // acc[n] = items of the plane matcher whose neighbour lists changed in this iteration (its next launch picks
+    // the counting or the insertion flavour from it): counters[0] (insertion launch) + counters[2] (queued by verify)
+    if (counters && threadIdx.x == 0) acc[n] = (double)(counters[0] + counters[2]);
     __shared__ double sm[8][128];
     const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
     double v = 0.0;
@@ -2084,30 +2118,49 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     // persistent waves with a static first item: every block of the grid must be resident from the start
     int fit = 0;
-    switch (p.knn) {
-        case 3: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<3>, 256, dyn_lds)); break;
-        case 4: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<4>, 256, dyn_lds)); break;
-        case 5: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<5>, 256, dyn_lds)); break;
-        case 6: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<6>, 256, dyn_lds)); break;
-        case 7: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<7>, 256, dyn_lds)); break;
-        default: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<8>, 256, dyn_lds)); break;
+    switch (p.knn) {  // (the verify flavour needs fewer registers than the insertion flavour)
+        case 3: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<3, false>, 256, dyn_lds)); break;
+        case 4: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<4, false>, 256, dyn_lds)); break;
+        case 5: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<5, false>, 256, dyn_lds)); break;
+        case 6: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<6, false>, 256, dyn_lds)); break;
+        case 7: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<7, false>, 256, dyn_lds)); break;
+        default: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<8, false>, 256, dyn_lds)); break;
     }
     int grid = num_cus_ * (fit < 1 ? 1 : (fit > 3 ? 3 : fit));
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !std::getenv("MOLA_ICP_NO_KNN_SEED")) ? 1 : 0;
-#define MOLA_LAUNCH_KNN(KK)                                                                                         \
-    hipLaunchKernelGGL((k_knn_planes<KK>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,  \
-                       (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold, planes_.as<PlanePair>(),   \
-                       plane_cache_.as<PlanePair>(),                                                                 \
-                       knn_pos_.as<int>(), knn_seed, reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8), staged, lds_boxes)
+    // the counting flavour pays off when few items will need the insertion flavour afterwards: judged by the
+    // number of items whose lists changed in the previous iteration (read back with its accumulators)
+    const bool verify = knn_seed && knn_changed_items_ >= 0.0 && knn_changed_items_ < 0.3 * (double)n_items &&
+                        !std::getenv("MOLA_ICP_NO_KNN_VERIFY");
+    knn_changed_items_ = -1.0;  // consumed: only an accumulate_planes() after this launch renews it
+    if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
+    unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
+    // warm-started launches: the counting flavour over all items, then the insertion flavour over the items it
+    // queued (counter[2] = their number); first launch on a cloud pair: the insertion flavour over all items
+#define MOLA_LAUNCH_KNN(KK, VER, QUEUE, LIST)                                                                        \
+    hipLaunchKernelGGL((k_knn_planes<KK, VER>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
+                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold,   \
+                       planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, QUEUE,    \
+                       counter + 2, LIST, counter, staged, lds_boxes)
+#define MOLA_LAUNCH_KNN_ALL(KK)                                                                                      \
+    do {                                                                                                             \
+        if (verify) {                                                                                                \
+            MOLA_LAUNCH_KNN(KK, true, tq, redo_list_.as<int>());                                                     \
+            MOLA_LAUNCH_KNN(KK, false, tq + kQueues * kQueueStride, redo_list_.as<int>());                           \
+        } else {                                                                                                     \
+            MOLA_LAUNCH_KNN(KK, false, tq, (int*)nullptr);                                                           \
+        }                                                                                                            \
+    } while (0)
     switch (p.knn) {
-        case 3: MOLA_LAUNCH_KNN(3); break;
-        case 4: MOLA_LAUNCH_KNN(4); break;
-        case 5: MOLA_LAUNCH_KNN(5); break;
-        case 6: MOLA_LAUNCH_KNN(6); break;
-        case 7: MOLA_LAUNCH_KNN(7); break;
-        default: MOLA_LAUNCH_KNN(8); break;
+        case 3: MOLA_LAUNCH_KNN_ALL(3); break;
+        case 4: MOLA_LAUNCH_KNN_ALL(4); break;
+        case 5: MOLA_LAUNCH_KNN_ALL(5); break;
+        case 6: MOLA_LAUNCH_KNN_ALL(6); break;
+        case 7: MOLA_LAUNCH_KNN_ALL(7); break;
+        default: MOLA_LAUNCH_KNN_ALL(8); break;
     }
+#undef MOLA_LAUNCH_KNN_ALL
 #undef MOLA_LAUNCH_KNN
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
@@ -2125,10 +2178,10 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
     if (rc) return rc;
     if (!planes_valid_) return fail(MOLA_ICP_E_BADARG, "accumulate_planes() called before match_planes()");
     HIPCHK(hipSetDevice(device_));
-    if ((rc = plane_acc_.reserve(sizeof(double) * kNAccPlane * 513))) return rc;
+    if ((rc = plane_acc_.reserve(sizeof(double) * kNAccPlane * 514))) return rc;
     double* dacc = plane_acc_.as<double>() + (size_t)512 * kNAccPlane;
     if (planes_empty_) {
-        HIPCHK(hipMemsetAsync(dacc, 0, sizeof(double) * kNAccPlane, stream_));
+        HIPCHK(hipMemsetAsync(dacc, 0, sizeof(double) * (kNAccPlane + 1), stream_));
     } else {
         int nblocks = (int)((N_ + 255) / 256);
         if (nblocks > 512) nblocks = 512;
@@ -2136,17 +2189,19 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
         hipLaunchKernelGGL(k_accumulate_planes, dim3(nblocks), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
                            planes_.as<PlanePair>(), (int)N_, plane_acc_.as<double>());
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc);
+        hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc,
+                           reinterpret_cast<const unsigned int*>(acc_dev_.as<double>() + kNAcc));
         HIPCHK(hipGetLastError());
     }
     if (comm_) {
         const int rc2 = rccl_allreduce_sum_f64(comm_, dacc, kNAccPlane, stream_);
         if (rc2) return rc2;
     }
-    if (!plane_acc_host_) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&plane_acc_host_), sizeof(double) * kNAccPlane, hipHostMallocDefault));
-    HIPCHK(hipMemcpyAsync(plane_acc_host_, dacc, sizeof(double) * kNAccPlane, hipMemcpyDeviceToHost, stream_));
+    if (!plane_acc_host_) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&plane_acc_host_), sizeof(double) * (kNAccPlane + 1), hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(plane_acc_host_, dacc, sizeof(double) * (kNAccPlane + 1), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     std::memcpy(acc, plane_acc_host_, sizeof(double) * kNAccPlane);
+    knn_changed_items_ = planes_empty_ ? -1.0 : plane_acc_host_[kNAccPlane];
     if (!comm_ && ar_fn_) {
         const int r = ar_fn_(acc, kNAccPlane, 0, ar_user_);
         if (r) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(r));

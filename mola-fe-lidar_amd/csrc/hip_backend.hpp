@@ -132,6 +132,7 @@ class HipWorkspace final : public Stages {
     double* plane_acc_host_ = nullptr;
     bool planes_valid_ = false, planes_empty_ = false;
     int planes_knn_ = 0;
+    double knn_changed_items_ = -1.0;  // items whose neighbour lists changed in the last iteration (-1: unknown)
     bool knn_seed_valid_ = false;  // knn_pos_ holds the last launch's neighbours for the clouds in place
     DevBuf redo_list_;                // work items with exact distance ties: redone with the full lexicographic key
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
