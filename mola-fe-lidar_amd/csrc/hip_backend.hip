@@ -693,7 +693,8 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
                                                   unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
                                                   unsigned long long* __restrict__ staged_total,
-                                                  unsigned long long* __restrict__ dbg_stats, int lds_boxes)
+                                                  unsigned long long* __restrict__ dbg_stats, int lds_boxes,
+                                                  unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
     __shared__ int s_list[4][kMaxList];
@@ -713,8 +714,11 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         return item_order ? item_order[raw] : raw;  // heaviest items of the last launch first
     };
     unsigned long long wave_staged = 0ull;
+    const unsigned long long t_wave0 = wave_times ? wall_clock64() : 0ull;  // 100 MHz, the same on every XCD
+    unsigned int wave_items = 0u;
     int item = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
     while (item >= 0) {
+        ++wave_items;
         const int next_raw_v = wq.pop();
         const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
 
@@ -895,6 +899,8 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         }
         if (lane == 0) {
             if (!EXACT) {
+                // (a deterministic proxy -- staged points -- orders no better than the measured cycles; without any
+                // order the kernel is 6 % slower)
                 const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
                 if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
             }
@@ -920,6 +926,10 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         item = __builtin_amdgcn_readfirstlane(next_item_v);
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
+    if (wave_times && lane == 0) {  // [start, end, items] per wave
+        unsigned long long* w = wave_times + 3 * (size_t)wq.first();
+        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items;
+    }
 }
 
 // ---- row f3: point-to-plane matcher (mp2p_icp::Matcher_Point2Plane, params/icp-settings-regular.yaml:33-39) ----
@@ -1669,6 +1679,10 @@ int HipWorkspace::init()
     if (std::getenv("MOLA_ICP_DEBUG_STATS")) {  // diagnostic builds of a run, never on by default
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
         HIPCHK(hipMemset(dbg_stats_, 0, (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
+        if (std::atoi(std::getenv("MOLA_ICP_DEBUG_STATS")) == 2) {  // light mode: per-wave start/end of the tiled matcher only
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&wave_times_), 3 * 8192 * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(wave_times_, 0, 3 * 8192 * sizeof(unsigned long long)));
+        }
     }
     inited_ = true;
     return MOLA_ICP_OK;
@@ -2065,7 +2079,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
                        (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(),
                        order, item_cost_.as<unsigned int>(), tq, counter + 2,
-                       redo_list_.as<int>(), staged, dbg_stats_, lds_boxes);
+                       redo_list_.as<int>(), staged, dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr, lds_boxes, wave_times_);
     HIPCHK(hipGetLastError());
     // exact ties (duplicate points, lattices): the queued items again with the full lexicographic key.
     // Usually zero items: a few waves that read the count and leave.
@@ -2073,7 +2087,8 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, /*seed = fast pass's result*/ 1, ts_pos_.as<int>(),
                        ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr, (unsigned int*)nullptr,
                        tq + kQueues * kQueueStride,
-                       counter + 2, redo_list_.as<int>(), staged, dbg_stats_, lds_boxes);
+                       counter + 2, redo_list_.as<int>(), staged, dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr, lds_boxes,
+                       (unsigned long long*)nullptr);
     cost_valid_ = true;
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
@@ -2272,7 +2287,29 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
             tot += ms;
         }
     }
-    if (dbg_stats_) {
+    if (wave_times_) {
+        std::vector<unsigned long long> w(3 * 8192);
+        HIPCHK(hipStreamSynchronize(stream_));
+        HIPCHK(hipMemcpy(w.data(), wave_times_, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        std::vector<unsigned long long> ends;
+        for (size_t i = 0; i < 8192; ++i)
+            if (w[3 * i + 1]) { t0 = std::min(t0, w[3 * i]); t1 = std::max(t1, w[3 * i + 1]); ends.push_back(w[3 * i + 1]); }
+        if (!ends.empty()) {
+            std::sort(ends.begin(), ends.end());
+            const double span = (double)(t1 - t0);
+            double busy = 0;
+            for (unsigned long long e : ends) busy += (double)(e - t0);
+            std::fprintf(stderr, "[mola_icp debug] last tiled launch: %zu waves, span %.0f ticks; waves done at 10/25/50/75/90/99%%: "
+                                 "%.2f %.2f %.2f %.2f %.2f %.2f of the span; mean wave lifetime %.2f of the span\n",
+                         ends.size(), span, (ends[ends.size() / 10] - t0) / span, (ends[ends.size() / 4] - t0) / span,
+                         (ends[ends.size() / 2] - t0) / span, (ends[ends.size() * 3 / 4] - t0) / span,
+                         (ends[ends.size() * 9 / 10] - t0) / span, (ends[ends.size() * 99 / 100] - t0) / span,
+                         busy / ends.size() / span);
+        }
+        HIPCHK(hipMemset(wave_times_, 0, w.size() * sizeof(unsigned long long)));
+    }
+    if (dbg_stats_ && !wave_times_) {
         unsigned long long h[16] = {};
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipMemcpy(h, dbg_stats_, sizeof h, hipMemcpyDeviceToHost));

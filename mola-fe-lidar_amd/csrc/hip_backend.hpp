@@ -156,6 +156,7 @@ class HipWorkspace final : public Stages {
     size_t ev_used_ = 0;
     uint32_t last_kernel_ = 0;
     uint64_t dense_pairs_ = 0;
+    unsigned long long* wave_times_ = nullptr; // MOLA_ICP_DEBUG_STATS=2 only
     unsigned long long* dbg_stats_ = nullptr;  // MOLA_ICP_DEBUG_STATS=1 only
 };
 
