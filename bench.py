@@ -170,6 +170,8 @@ def main():
 
     roof = roofline_of(res, hi - lo)
     roof["traffic"] = _recorded_traffic(roof["kernel"], N, M) if world == 1 else None
+    if world == 1 and roof["kernel"] == "k_nn_tiled" and (N, M) == (1_000_000, 1_000_000):
+        roof["pmc"] = _recorded_pmc()   # committed counters of this kernel on this workload (VALU busy, waits, L2 latency)
     if world > 1:
         t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)     # the slowest rank's kernel
@@ -258,6 +260,19 @@ def _recorded_traffic(kernel, N, M):
             for e in json.load(open(f)):
                 if e.get("kernel") == kernel and e.get("n_local") == N and e.get("n_map") == M:
                     best = e.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    return best
+
+
+def _recorded_pmc():
+    """Derived counters of the tiled matcher from the committed rocprofv3 --pmc passes (profiles/*/tiled_pmc_summary.json,
+    written from tools/rocprof_lat.sh runs).  None if not recorded."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "tiled_pmc_summary.json"))):
+        try:
+            best = json.load(open(f)).get("derived")
         except Exception:
             pass
     return best
