@@ -50,7 +50,7 @@ def main():
                     help="testing aid for 1-GPU boxes: ranks share the visible GPUs (rank %% device_count), the process "
                          "group is gloo and the accumulator all-reduce goes through the host hook -- exercises the "
                          "N>1 sharding path end to end without RCCL")
-    ap.add_argument("--shipped-iters", type=int, default=10,
+    ap.add_argument("--shipped-iters", type=int, default=20,
                     help="iterations of the shipped Point2Plane+GaussNewton pipeline measured beside the default path")
     ap.add_argument("--dense-iters", type=int, default=3, help="iterations of the dense MFMA kernel measured beside the default path (0 = skip)")
     args = ap.parse_args()
@@ -91,7 +91,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if args.share_gpu else dev   # where the bench's own small collectives live
     tg = torch.from_numpy(g).to(dev)
-    tl = torch.from_numpy(np.ascontiguousarray(l[:, lo:hi])).to(dev)
+    # spatially compact shards (Z-order slices of the scan): a random 1/W subsample would be W times sparser than
+    # the map and every 128-query group would sweep W times more map tiles
+    shard = l[:, lo:hi] if world == 1 else l[:, sharded.spatial_order(l)[lo:hi]]
+    tl = torch.from_numpy(np.ascontiguousarray(shard)).to(dev)
     icp = pkg.ICP(device=local_rank)
     icp.set_map(tg)
     icp.set_local(tl)
