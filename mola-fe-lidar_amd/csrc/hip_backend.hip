@@ -402,6 +402,13 @@ __device__ __forceinline__ v2f dist2_pk(v2f qx, v2f qy, v2f qz, float mx, float 
     return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
 }
 
+// ... and for ONE query against two map points at once (same sequence per half)
+__device__ __forceinline__ v2f dist2_pk2(float qx, float qy, float qz, v2f mx, v2f my, v2f mz)
+{
+    const v2f dx = qx - mx, dy = qy - my, dz = qz - mz;
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
 struct Box { float lo[3], hi[3]; };
 
 __device__ __forceinline__ bool box_overlap(const float* __restrict__ b, int stride, int i, const Box& w)
@@ -452,11 +459,11 @@ __device__ __forceinline__ void load_boxes_to_lds(const TiledMap& mp, lds_f32* l
 // `visit(nm, jb0, jb1)` is called once per staged pass: sm[0..2][0..nm) hold x,y,z of the staged points
 // (sm[3] their original indices if NEED_PERM); points [0,32) have sorted positions jb0.., [32,64) jb1...
 // Returns the number of staged points.
-template <bool NEED_PERM, class Visit>
+template <int QPL, bool NEED_PERM, class Visit>
 __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane,
-                                                          float (*sm)[64], const float (&qx)[2], const float (&qy)[2],
-                                                          const float (&qz)[2], const float (&reach)[2],
-                                                          const float (&bound2)[2], Visit&& visit,
+                                                          float (*sm)[64], const float (&qx)[QPL], const float (&qy)[QPL],
+                                                          const float (&qz)[QPL], const float (&reach)[QPL],
+                                                          const float (&bound2)[QPL], Visit&& visit,
                                                           bool prof, unsigned long long& p_stage,
                                                           unsigned long long& p_visit, unsigned int& p_supers,
                                                           unsigned int& p_entered, unsigned int& p_tiles,
@@ -466,7 +473,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
 #pragma unroll
     for (int a = 0; a < 3; ++a) { w.lo[a] = INFINITY; w.hi[a] = -INFINITY; }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < QPL; ++k) {
         if (reach[k] >= 0.f) {
             w.lo[0] = fminf(w.lo[0], qx[k] - reach[k]); w.hi[0] = fmaxf(w.hi[0], qx[k] + reach[k]);
             w.lo[1] = fminf(w.lo[1], qy[k] - reach[k]); w.hi[1] = fmaxf(w.hi[1], qy[k] + reach[k]);
@@ -489,14 +496,21 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
     // rounding, hence box_d2 <= d2_contract(q, p) EXACTLY as computed -- no margin needed, and bound2 is read
     // live: as a query's best shrinks during the sweep, later boxes are tested against the tighter value.
     // Padding lanes carry bound2 < 0 and reach nothing; empty boxes (+inf, -inf) give inf.
-    const v2f s_qx = {qx[0], qx[1]}, s_qy = {qy[0], qy[1]}, s_qz = {qz[0], qz[1]};
     auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
-        const v2f zero = {0.f, 0.f};
-        const v2f ax = __builtin_elementwise_max(__builtin_elementwise_max(m0 - s_qx, s_qx - m3), zero);
-        const v2f ay = __builtin_elementwise_max(__builtin_elementwise_max(m1 - s_qy, s_qy - m4), zero);
-        const v2f az = __builtin_elementwise_max(__builtin_elementwise_max(m2 - s_qz, s_qz - m5), zero);
-        const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
-        return __any(D.x <= bound2[0] || D.y <= bound2[1]);
+        if constexpr (QPL == 2) {  // both queries of the lane per packed instruction
+            const v2f s_qx = {qx[0], qx[1]}, s_qy = {qy[0], qy[1]}, s_qz = {qz[0], qz[1]};
+            const v2f zero = {0.f, 0.f};
+            const v2f ax = __builtin_elementwise_max(__builtin_elementwise_max(m0 - s_qx, s_qx - m3), zero);
+            const v2f ay = __builtin_elementwise_max(__builtin_elementwise_max(m1 - s_qy, s_qy - m4), zero);
+            const v2f az = __builtin_elementwise_max(__builtin_elementwise_max(m2 - s_qz, s_qz - m5), zero);
+            const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+            return __any(D.x <= bound2[0] || D.y <= bound2[1]);
+        } else {
+            const float ax = fmaxf(fmaxf(m0 - qx[0], qx[0] - m3), 0.f);
+            const float ay = fmaxf(fmaxf(m1 - qy[0], qy[0] - m4), 0.f);
+            const float az = fmaxf(fmaxf(m2 - qz[0], qz[0] - m5), 0.f);
+            return __any(fmaf(az, az, fmaf(ay, ay, ax * ax)) <= bound2[0]);
+        }
     };
 
     int pend_a = -1, pend_b = -1;  // tile ids whose points sit in the registers below
@@ -685,7 +699,7 @@ struct WaveQueue {
 //   chunk (exact ties: duplicate points, lattices) the item is queued for the exact pass.
 // EXACT = true : the exact-key sweep over the queued items: per-pair argmin on the packed key
 //   (d2 bits << 32 | original index), i.e. the full lexicographic rule (~10 ops per pair).
-template <bool EXACT>
+template <bool EXACT, int QPL>
 __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
@@ -705,7 +719,8 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     if (EXACT && *redo_count == 0u) return;  // the usual case: no exact ties in this launch (uniform: before any barrier)
     const lds_f32* lbox = (const lds_f32*)s_dyn;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
-    const int n_items = EXACT ? (int)*redo_count : (N + kQPW - 1) / kQPW;  // an item = 128 consecutive sorted queries
+    constexpr int kQ = 64 * QPL;  // queries per item: QPL per lane (2 for large clouds, 1 when there are few items per wave)
+    const int n_items = EXACT ? (int)*redo_count : (N + kQ - 1) / kQ;
 
     WaveQueue wq(queue, lane);
     auto lookup = [&](int raw) -> int {  // raw is wave-uniform; -1 = past the end
@@ -722,36 +737,36 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         const int next_raw_v = wq.pop();
         const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
 
-        float qx[2], qy[2], qz[2], reach[2];
-        unsigned long long key[2];  // EXACT: packed (d2, original index)
-        float best[2];              // fast: running minimum
-        int bpos[2];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
-        int tie[2] = {0, 0};
+        float qx[QPL], qy[QPL], qz[QPL], reach[QPL];
+        unsigned long long key[QPL];  // EXACT: packed (d2, original index)
+        float best[QPL];              // fast: running minimum
+        int bpos[QPL];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
+        int tie[QPL] = {};
         // round trip 1: the two queries of the lane and their seeds (clamped indices: every load is unconditional)
-        int qi[2], js[2];
-        float lx[2], ly[2], lz[2];
+        int qi[QPL], js[QPL];
+        float lx[QPL], ly[QPL], lz[QPL];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            qi[k] = item * kQPW + k * 64 + lane;
+        for (int k = 0; k < QPL; ++k) {
+            qi[k] = item * kQ + k * 64 + lane;
             if (qi[k] >= N) qi[k] = N;  // padding lane
             const int ic = qi[k] < N ? qi[k] : N - 1;
             lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
             js[k] = use_seed ? pos_s[ic] : -1;
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
+        for (int k = 0; k < QPL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
         // round trip 2: the seeds' coordinates, and the next item's id
         const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items));
-        float gsx[2], gsy[2], gsz[2];
-        unsigned int gso[2] = {0u, 0u};
+        float gsx[QPL], gsy[QPL], gsz[QPL];
+        unsigned int gso[QPL] = {};
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < QPL; ++k) {
             const int jc = js[k] >= 0 ? js[k] : 0;
             gsx[k] = mp.sx[jc]; gsy[k] = mp.sy[jc]; gsz[k] = mp.sz[jc];
             if (EXACT) gso[k] = (unsigned int)mp.perm[jc];
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < QPL; ++k) {
             key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
             best[k] = thr2;
             bpos[k] = -1;
@@ -773,8 +788,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
         unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
         const unsigned long long t_sweep0 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
-        const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};  // both queries of the lane, packed
-        const unsigned long long n_staged = tiled_sweep<EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+        const unsigned long long n_staged = tiled_sweep<QPL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
             if constexpr (EXACT) {
                 for (int m = 0; m < nm; m += 4) {
                     const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
@@ -787,7 +801,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
+                        for (int k = 0; k < QPL; ++k) {
                             const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
                             const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
                             const bool better = ck < key[k];
@@ -798,10 +812,13 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                     }
                 }
             } else {
-                // per 16-point group: 16 x (3 packed sub, 1 packed mul, 2 packed fma) serve both queries, the group
+                // per kGroup-point group: packed sub/mul/fma (v_pk_*_f32) serve two (query, point) pairs per
+                // instruction -- the lane's two queries (QPL = 2) or two consecutive points (QPL = 1) -- the group
                 // minimum is a chain of v_min3, and the (best, position, tie) bookkeeping runs once per group
                 for (int m = 0; m < nm; m += kGroup) {
-                    float g0 = INFINITY, g1 = INFINITY;
+                    float gm[QPL];
+#pragma unroll
+                    for (int k = 0; k < QPL; ++k) gm[k] = INFINITY;
 #pragma unroll
                     for (int h = 0; h < kGroup; h += 8) {
                         const float4 X0 = *reinterpret_cast<const float4*>(&sm[0][m + h]);
@@ -813,18 +830,27 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                         const float xs[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
                         const float ys[8] = {Y0.x, Y0.y, Y0.z, Y0.w, Y1.x, Y1.y, Y1.z, Y1.w};
                         const float zs[8] = {Z0.x, Z0.y, Z0.z, Z0.w, Z1.x, Z1.y, Z1.z, Z1.w};
+                        if constexpr (QPL == 2) {
+                            const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
 #pragma unroll
-                        for (int u = 0; u < 8; u += 2) {
-                            const v2f da = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
-                            const v2f db = dist2_pk(q2x, q2y, q2z, xs[u + 1], ys[u + 1], zs[u + 1]);
-                            g0 = fminf(fminf(g0, da.x), db.x);
-                            g1 = fminf(fminf(g1, da.y), db.y);
+                            for (int u = 0; u < 8; u += 2) {
+                                const v2f da = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                                const v2f db = dist2_pk(q2x, q2y, q2z, xs[u + 1], ys[u + 1], zs[u + 1]);
+                                gm[0] = fminf(fminf(gm[0], da.x), db.x);
+                                gm[1] = fminf(fminf(gm[1], da.y), db.y);
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 8; u += 2) {
+                                const v2f mx = {xs[u], xs[u + 1]}, my = {ys[u], ys[u + 1]}, mz = {zs[u], zs[u + 1]};
+                                const v2f dd = dist2_pk2(qx[0], qy[0], qz[0], mx, my, mz);
+                                gm[0] = fminf(fminf(gm[0], dd.x), dd.y);
+                            }
                         }
                     }
                     const int gpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this group
-                    const float gm[2] = {g0, g1};
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
+                    for (int k = 0; k < QPL; ++k) {
                         const bool lt = gm[k] < best[k];
                         const int eq = (int)(gm[k] == best[k]) & (int)(gpos != bpos[k]);
                         tie[k] = lt ? 0 : (tie[k] | eq);
@@ -837,21 +863,23 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         const unsigned long long t_sweep1 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
 
         bool any_tie = false;
-        int rpos[2] = {-1, -1}, roi[2] = {-1, -1};
-        float rd[2] = {thr2, thr2};
+        int rpos[QPL], roi[QPL];
+        float rd[QPL];
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; }
         if constexpr (EXACT) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < QPL; ++k) {
                 const float d = __uint_as_float((unsigned int)(key[k] >> 32));
                 if (d < thr2) { rd[k] = d; rpos[k] = bpos[k]; roi[k] = (int)(unsigned int)(key[k] & 0xffffffffu); }
             }
         } else {
             // resolve inside the winning group: the point(s) with d2 == best, lowest original index first.
             // One round trip: all loads of both queries are issued before the first use.
-            float4 RX[2][kGroup / 4], RY[2][kGroup / 4], RZ[2][kGroup / 4];
-            int4 RP[2][kGroup / 4];
+            float4 RX[QPL][kGroup / 4], RY[QPL][kGroup / 4], RZ[QPL][kGroup / 4];
+            int4 RP[QPL][kGroup / 4];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < QPL; ++k) {
                 const int bp = bpos[k] >= 0 ? bpos[k] : 0;
 #pragma unroll
                 for (int c = 0; c < kGroup / 4; ++c) {
@@ -862,7 +890,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < QPL; ++k) {
                 unsigned int bo = 0xffffffffu;
                 int pos = -1;
 #pragma unroll
@@ -886,7 +914,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             }
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < QPL; ++k) {
             if (qi[k] < N) {  // coalesced: the pairing stays in sorted query order
                 pos_s[qi[k]] = rpos[k];
                 idx_s[qi[k]] = rpos[k] >= 0 ? roi[k] : -1;
@@ -904,7 +932,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
                 if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
             }
-            wave_staged += n_staged;  // executed work: staged points x 128 queries (one atomic per wave, at exit)
+            wave_staged += n_staged * QPL;  // executed work in units of 64 (query, point) pairs (one atomic per wave, at exit)
             if (dbg_stats) {
                 const unsigned long long t_end = __builtin_amdgcn_s_memtime();
                 atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged);
@@ -1101,7 +1129,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
         unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
         unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
-        const unsigned long long n_staged = tiled_sweep<!VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
+        const unsigned long long n_staged = tiled_sweep<2, !VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
             for (int m = 0; m < nm; m += 4) {
                 const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
                 const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
@@ -1238,7 +1266,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         }
         }  // (epilogue)
         wave_changed += item_changed ? 1u : 0u;
-        wave_staged += n_staged;
+        wave_staged += n_staged * 2;  // units of 64 (query, point) pairs
         raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items);
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
@@ -2035,17 +2063,26 @@ TiledMap HipWorkspace::tiled_map() const
 
 int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
 {
-    const int n_items = (int)((N_ + kQPW - 1) / kQPW);
-    // blocks per CU, measured at C3: 2 -> 0.190 ms, 3 -> 0.180, 4 -> 0.184
+    // blocks per CU, measured at C3: 2 -> 0.159 ms, 3 -> 0.150, 4 -> 0.156
     int per_cu = 3;
     if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 3;  // tuning knob
     const TiledMap mp = tiled_map();
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
+    // Queries per lane.  2 (items of 128 queries) amortises the per-item box scan best.  When 128-query items
+    // would give every persistent wave between one and two items -- the launch is then two items long for a
+    // work of one and a bit -- items of 64 queries (1 per lane; the packed math pairs map points instead) balance
+    // better: measured at 500k queries 0.128 -> 0.105 ms.  Below one item per wave the launch is one item long
+    // either way and the larger items do less total work (250k: 0.083 vs 0.091 ms).
+    const size_t n128 = (N_ + kQPW - 1) / kQPW, slots = (size_t)num_cus_ * per_cu * 4;
+    int qpl = (n128 >= slots && n128 < 2 * slots) ? 1 : 2;
+    if (const char* e = std::getenv("MOLA_ICP_QPL")) qpl = std::atoi(e) == 1 ? 1 : 2;  // tuning knob
+    const int n_items = (int)((N_ + (size_t)(64 * qpl) - 1) / (size_t)(64 * qpl));
     {   // persistent waves with a static first item: every block of the grid must be resident from the start
         int fit = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false>, 256, dyn_lds));
+        if (qpl == 2) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false, 2>, 256, dyn_lds));
+        else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false, 1>, 256, dyn_lds));
         if (fit >= 1 && per_cu > fit) per_cu = fit;
     }
     int grid = num_cus_ * per_cu;
@@ -2076,19 +2113,25 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
     // counter[2] = redo count; tq = the fast pass's queue counters, tq + kQueues * kQueueStride the exact pass's
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
-    hipLaunchKernelGGL((k_nn_tiled<false>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
-                       (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(),
-                       order, item_cost_.as<unsigned int>(), tq, counter + 2,
-                       redo_list_.as<int>(), staged, dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr, lds_boxes, wave_times_);
-    HIPCHK(hipGetLastError());
-    // exact ties (duplicate points, lattices): the queued items again with the full lexicographic key.
-    // Usually zero items: a few waves that read the count and leave.
-    hipLaunchKernelGGL((k_nn_tiled<true>), dim3(grid < 64 ? grid : 64), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,
-                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, /*seed = fast pass's result*/ 1, ts_pos_.as<int>(),
-                       ts_idx_.as<int>(), ts_d2_.as<float>(), (const int*)nullptr, (unsigned int*)nullptr,
-                       tq + kQueues * kQueueStride,
-                       counter + 2, redo_list_.as<int>(), staged, dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr, lds_boxes,
-                       (unsigned long long*)nullptr);
+    unsigned long long* dbg = dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr;
+    // fast pass, then the exact pass over the items it queued (exact ties: duplicate points, lattices; usually
+    // none: a few waves that read the count and leave)
+#define MOLA_LAUNCH_TILED(QPL)                                                                                        \
+    do {                                                                                                              \
+        hipLaunchKernelGGL((k_nn_tiled<false, QPL>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,  \
+                           sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),        \
+                           ts_idx_.as<int>(), ts_d2_.as<float>(), order, item_cost_.as<unsigned int>(), tq, counter + 2, \
+                           redo_list_.as<int>(), staged, dbg, lds_boxes, wave_times_);                                \
+        HIPCHK(hipGetLastError());                                                                                    \
+        hipLaunchKernelGGL((k_nn_tiled<true, QPL>), dim3(grid < 64 ? grid : 64), dim3(256), dyn_lds, stream_, sl,     \
+                           sl + loc_sc_->padded, sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2,                       \
+                           /*seed = fast pass's result*/ 1, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(), \
+                           (const int*)nullptr, (unsigned int*)nullptr, tq + kQueues * kQueueStride, counter + 2,     \
+                           redo_list_.as<int>(), staged, dbg, lds_boxes, (unsigned long long*)nullptr);               \
+    } while (0)
+    if (qpl == 2) MOLA_LAUNCH_TILED(2);
+    else MOLA_LAUNCH_TILED(1);
+#undef MOLA_LAUNCH_TILED
     cost_valid_ = true;
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
@@ -2275,7 +2318,7 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
             HIPCHK(hipStreamSynchronize(stream_));
             std::memcpy(&staged, acc_host_ + kNAcc + 4, sizeof staged);
         }
-        *pairs = dense_pairs_ + (uint64_t)staged * kQPW;
+        *pairs = dense_pairs_ + (uint64_t)staged * 64u;  // the tiled kernels count in units of 64 pairs
     }
     double tot = 0;
     if (ev_used_) {
@@ -2322,7 +2365,7 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
                      h[3] ? (double)h[11] / h[3] : 0.0, h[3] ? (double)h[12] / h[3] : 0.0, h[3] ? (double)h[13] / h[3] : 0.0,
                      h[3] ? (double)h[14] / h[3] : 0.0, h[3] ? (double)h[15] / h[3] : 0.0);
         HIPCHK(hipMemset(dbg_stats_, 0, sizeof h));
-        const size_t n_items = (N_ + kQPW - 1) / kQPW;
+        const size_t n_items = std::min((N_ + 63) / 64, item_cost_.cap / sizeof(unsigned int));  // upper bound (64-query items)
         if (cost_valid_ && N_ > 0 && n_items <= kDbgItems) {  // the heaviest items of the last tiled launch
             std::vector<unsigned long long> rec(8 * n_items);
             HIPCHK(hipMemcpy(rec.data(), dbg_stats_ + 16, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

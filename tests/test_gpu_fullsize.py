@@ -75,6 +75,26 @@ def test_1m_x_1m_config3_run(pkg, O, big):
     icp.close()
 
 
+def test_500k_queries_use_64_query_items(pkg, O, synth):
+    """~0.4-0.8M queries: the matcher runs with 64-query items (several per persistent wave).  Idempotence,
+    seeded == unseeded, and a sample against the oracle's kd-tree."""
+    g, l, _ = synth.make_pair(500_000, 700_000, seed=3)
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    T = synth.pose_from_xyzypr(0.05, 0.02, -0.01, 0.003, 0.0, 0.001)
+    idx0, d20, n0 = icp.match(T, 1.0, l.shape[1], pkg.NN_TILED)        # unseeded
+    icp.match(np.eye(4), 1.0, l.shape[1], pkg.NN_TILED)
+    idx1, d21, n1 = icp.match(T, 1.0, l.shape[1], pkg.NN_TILED)        # seeded from another pose
+    assert n0 == n1 and np.array_equal(idx0, idx1) and np.array_equal(d20, d21)
+    sel = np.arange(0, l.shape[1], 100)
+    oidx, od2, _ = O.match(g, np.ascontiguousarray(l[:, sel]), T, 1.0, O.KdTree(g))
+    assert np.array_equal(idx1[sel], oidx)
+    k = oidx >= 0
+    assert np.array_equal(d21[sel][k], od2[k])
+    icp.close()
+
+
 def test_1m_x_1m_shipped_point2plane(pkg, O, big):
     """The shipped Point2Plane + Gauss-Newton pipeline at config-3 size (waves take several items each, the warm
     start is active from the second iteration): the warm start must not change a single bit, and a sample of

@@ -81,6 +81,36 @@ def test_match_ties_lowest_index(pkg, O, icp, kern):
     assert (idx < 512).all() and (idx >= 0).all()
 
 
+@pytest.mark.parametrize("qpl", ["1", "2"])
+def test_tiled_both_item_sizes(pkg, O, synth, small_scene, qpl, monkeypatch):
+    """The tiled matcher picks 64- or 128-query items from the cloud size (64 only for ~0.4-0.8M queries); both
+    flavours forced here on ragged sizes, exact ties, a warm-started second launch and a full align."""
+    monkeypatch.setenv("MOLA_ICP_QPL", qpl)
+    icp = pkg.ICP(device=0)
+    T = synth.pose_from_xyzypr(0.1, -0.05, 0.02, 0.01, 0.002, -0.003)
+    for N, M in ((63, 5), (129, 4000), (9000, 9000), (30011, 20011)):
+        g, l, _ = synth.make_pair(N, M, seed=7 + N, scene=small_scene)
+        _check_match(pkg, O, icp, g, l, T, 0.7, pkg.NN_TILED)
+        idx, d2, n = icp.match(np.eye(4), 0.7, N, pkg.NN_TILED)          # seeded by the launch above
+        oidx, od2, on = O.match(g, l, np.eye(4), 0.7, O.KdTree(g))
+        assert n == on and np.array_equal(idx, oidx) and np.array_equal(d2[oidx >= 0], od2[oidx >= 0])
+    ax = np.arange(8, dtype=np.float32)
+    g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij")).reshape(3, -1)
+    g = np.ascontiguousarray(np.concatenate([g, g], axis=1))
+    l = np.ascontiguousarray((g[:, :512] + np.float32(0.5)).astype(np.float32))
+    idx, _ = _check_match(pkg, O, icp, g, l, np.eye(4), 2.0, pkg.NN_TILED)
+    assert (idx < 512).all() and (idx >= 0).all()
+    g, l, _ = synth.make_pair(20000, 20000, seed=5, scene=small_scene)
+    p = p2p_params(pkg, max_iterations=30)
+    p.nn_kernel = pkg.NN_TILED
+    r = icp.align(g, l, np.eye(4), p)
+    ref = O.align(g, l, np.eye(4), O.params_from_product(p))
+    assert r.nIterations == ref["n_iterations"] and r.n_pairs == ref["n_pairs"]
+    rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+    assert rot < 1e-7 and trans < 1e-9
+    icp.close()
+
+
 @pytest.mark.parametrize("kern", [1, 2, 3])
 def test_match_far_from_origin_and_gate_edges(pkg, O, icp, synth, small_scene, kern):
     # clouds 5 km from the origin (fp32 cancellation territory for an expanded-form distance)
