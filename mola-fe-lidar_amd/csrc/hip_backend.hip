@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1618,7 +1619,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* _
 // sums the per-block rows in a fixed order: 32 interleaved slices per accumulator, then the slices in order
 constexpr int kRedSlices = 32;
 __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const double* __restrict__ partials, int nblocks,
-                                                                        double* __restrict__ acc)
+                                                                        double* __restrict__ acc,
+                                                                        double* __restrict__ host_out /*pinned, may be null*/,
+                                                                        unsigned long long seq)
 {
     __shared__ double sm[kRedSlices][kNAcc];
     const int k = threadIdx.x % kNAcc, sl = threadIdx.x / kNAcc;
@@ -1630,6 +1633,15 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const do
         double t = 0.0;
         for (int s = 0; s < kRedSlices; ++s) t += sm[s][threadIdx.x];
         acc[threadIdx.x] = t;
+        if (host_out) host_out[threadIdx.x] = t;  // straight into the host's pinned block: no copy engine, no extra launch gap
+    }
+    if (host_out) {  // publish: data first, then the sequence number the host spins on
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            reinterpret_cast<volatile unsigned long long*>(host_out)[kNAcc + 6] = seq;  // (slots 24..29 serve other read-backs)
+            __threadfence_system();
+        }
     }
     // the matcher's work-queue / kept / redo counters sit right behind the block: leave them zero for its next launch
     if (threadIdx.x == kNAcc) { acc[kNAcc] = 0.0; acc[kNAcc + 1] = 0.0; }
@@ -1700,7 +1712,8 @@ int HipWorkspace::init()
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     own_stream_ = true;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * (kNAcc + 8), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * (kNAcc + 8), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(acc_host_, 0, sizeof(double) * (kNAcc + 8));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocDefault));
     int rc;
     if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8) + sizeof(unsigned int) * 2 * kQueues * kQueueStride))) return rc;
@@ -2569,10 +2582,31 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         for (int c = 0; c < 3; ++c) a.R[3 * r + c] = Tcur(r, c);
     hipLaunchKernelGGL(k_accumulate, dim3(nblocks), dim3(kAccThreads), 0, stream_, a, partials_.as<double>());
     HIPCHK(hipGetLastError());
+    // Single GPU: the reduction writes the 24 sums straight into the pinned host block and then a sequence number;
+    // the host spins on that number instead of a copy + stream synchronisation (both cost a launch gap and the
+    // driver's wake-up latency on a ~0.2 ms iteration).  Sharded over RCCL: the collective runs in between on the
+    // device block, then the block is copied.
+    const bool direct = !comm_ && !std::getenv("MOLA_ICP_NO_DIRECT_READBACK");
+    const unsigned long long seq = ++readback_seq_;
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kNAcc * kRedSlices), 0, stream_, partials_.as<double>(), nblocks,
-                       acc_dev_.as<double>());
+                       acc_dev_.as<double>(), direct ? acc_host_ : (double*)nullptr, seq);
     HIPCHK(hipGetLastError());
     counters_clean_ = true;
+    if (direct) {
+        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(acc_host_) + kNAcc + 6;
+        bool seen = false;
+        for (unsigned long long spins = 0; spins < 400000000ull; ++spins) {  // ~ seconds; then fall back to a real wait
+            if (*flag == seq) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!seen) {
+            HIPCHK(hipStreamSynchronize(stream_));
+            if (*flag != seq) return fail(MOLA_ICP_E_HIP, "accumulate(): the reduction kernel did not publish its result");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int k = 0; k < kNAcc; ++k) acc[k] = acc_host_[k];
+        return MOLA_ICP_OK;
+    }
     if (comm_) {  // query-sharded: the one collective of the path, in place on the device block (RCCL over xGMI)
         const int rc2 = rccl_allreduce_sum_f64(comm_, acc_dev_.as<double>(), kNAcc, stream_);
         if (rc2) return rc2;
