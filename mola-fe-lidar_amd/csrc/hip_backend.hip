@@ -816,6 +816,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 // per kGroup-point group: packed sub/mul/fma (v_pk_*_f32) serve two (query, point) pairs per
                 // instruction -- the lane's two queries (QPL = 2) or two consecutive points (QPL = 1) -- the group
                 // minimum is a chain of v_min3, and the (best, position, tie) bookkeeping runs once per group
+#pragma unroll 2
                 for (int m = 0; m < nm; m += kGroup) {
                     float gm[QPL];
 #pragma unroll
