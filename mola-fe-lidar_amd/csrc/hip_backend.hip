@@ -33,1622 +33,17 @@ namespace mola_icp_amd {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                                   \
     } while (0)
 
-// ------------------------------------------------------------------ device code
+}  // namespace mola_icp_amd
 
-struct PoseF {
-    float R[9];
-    float t[3];
-};
+// ------------------------------------------------------------------ device code (one translation unit)
+#include "kernels_common.hpp"
+#include "kernels_dense.hpp"
+#include "kernels_tiled.hpp"
+#include "kernels_planes.hpp"
+#include "kernels_prepare.hpp"
+#include "kernels_accumulate.hpp"
 
-__device__ __forceinline__ void xform(const PoseF& P, float lx, float ly, float lz, float& qx, float& qy, float& qz)
-{
-    float a;
-    a = fmaf(P.R[0], lx, P.t[0]); a = fmaf(P.R[1], ly, a); qx = fmaf(P.R[2], lz, a);
-    a = fmaf(P.R[3], lx, P.t[1]); a = fmaf(P.R[4], ly, a); qy = fmaf(P.R[5], lz, a);
-    a = fmaf(P.R[6], lx, P.t[2]); a = fmaf(P.R[7], ly, a); qz = fmaf(P.R[8], lz, a);
-}
-
-__device__ __forceinline__ float dist2(float qx, float qy, float qz, float gx, float gy, float gz)
-{
-    const float dx = qx - gx, dy = qy - gy, dz = qz - gz;
-    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-}
-
-// largest float <= x (HIP's __double2float_rd is not relied upon)
-__device__ __forceinline__ float down_f32(double x)
-{
-    float f = (float)x;
-    if ((double)f > x) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1u : (f < 0.f ? __float_as_uint(f) + 1u : 0x80000001u));
-    return f;
-}
-
-constexpr float kPadCoord = 1.0e18f;  // padding map points: d2 ~ 3e36, finite, never the minimum
-
-// ---- NN matcher, exact VALU form -------------------------------------------------
-// Block = 256 threads, each thread owns QPT queries in registers (coalesced SoA
-// loads).  The map streams HBM -> LDS in SoA tiles of TM points; every lane reads
-// the same LDS address (broadcast, conflict-free) as ds_read_b128 of 4 points.
-// Per pair: 3 sub + mul + 2 fma + ~1 min; the argmin is tracked per 8-point chunk
-// (first chunk that lowers the minimum) and resolved to the exact lowest index
-// after the sweep by re-evaluating that chunk -- bit-identical arithmetic.
-template <int QPT, int TM>
-__global__ __launch_bounds__(256) void k_nn_valu(const float* __restrict__ lx, const float* __restrict__ ly,
-                                                 const float* __restrict__ lz, int N, const float* __restrict__ gx,
-                                                 const float* __restrict__ gy, const float* __restrict__ gz, int M,
-                                                 PoseF P, float thr2, int* __restrict__ out_idx,
-                                                 float* __restrict__ out_d2, unsigned int* __restrict__ kept_counter)
-{
-    __shared__ __attribute__((aligned(16))) float sx[TM];
-    __shared__ __attribute__((aligned(16))) float sy[TM];
-    __shared__ __attribute__((aligned(16))) float sz[TM];
-    const int tid = threadIdx.x;
-    const int qbase = blockIdx.x * (256 * QPT);
-
-    float qx[QPT], qy[QPT], qz[QPT], best[QPT];
-    int bchunk[QPT];
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-        const int i = qbase + k * 256 + tid;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (i < N) { x = lx[i]; y = ly[i]; z = lz[i]; }
-        xform(P, x, y, z, qx[k], qy[k], qz[k]);
-        best[k] = thr2;  // gate: only d2 < thr2 can ever be kept
-        bchunk[k] = -1;
-    }
-
-    for (int tile0 = 0; tile0 < M; tile0 += TM) {
-        __syncthreads();
-#pragma unroll
-        for (int j = tid; j < TM; j += 256) {
-            const int gj = tile0 + j;
-            const bool in = gj < M;
-            sx[j] = in ? gx[gj] : kPadCoord;
-            sy[j] = in ? gy[gj] : kPadCoord;
-            sz[j] = in ? gz[gj] : kPadCoord;
-        }
-        __syncthreads();
-        const int lim = min(TM, M - tile0);
-        for (int c = 0; c < lim; c += 8) {
-            const float4 xa = *reinterpret_cast<const float4*>(&sx[c]);
-            const float4 xb = *reinterpret_cast<const float4*>(&sx[c + 4]);
-            const float4 ya = *reinterpret_cast<const float4*>(&sy[c]);
-            const float4 yb = *reinterpret_cast<const float4*>(&sy[c + 4]);
-            const float4 za = *reinterpret_cast<const float4*>(&sz[c]);
-            const float4 zb = *reinterpret_cast<const float4*>(&sz[c + 4]);
-#pragma unroll
-            for (int k = 0; k < QPT; ++k) {
-                const float d0 = dist2(qx[k], qy[k], qz[k], xa.x, ya.x, za.x);
-                const float d1 = dist2(qx[k], qy[k], qz[k], xa.y, ya.y, za.y);
-                const float d2 = dist2(qx[k], qy[k], qz[k], xa.z, ya.z, za.z);
-                const float d3 = dist2(qx[k], qy[k], qz[k], xa.w, ya.w, za.w);
-                const float d4 = dist2(qx[k], qy[k], qz[k], xb.x, yb.x, zb.x);
-                const float d5 = dist2(qx[k], qy[k], qz[k], xb.y, yb.y, zb.y);
-                const float d6 = dist2(qx[k], qy[k], qz[k], xb.z, yb.z, zb.z);
-                const float d7 = dist2(qx[k], qy[k], qz[k], xb.w, yb.w, zb.w);
-                const float m = fminf(fminf(fminf(d0, d1), fminf(d2, d3)), fminf(fminf(d4, d5), fminf(d6, d7)));
-                if (m < best[k]) { best[k] = m; bchunk[k] = tile0 + c; }
-            }
-        }
-    }
-
-    unsigned int kept = 0;
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-        const int i = qbase + k * 256 + tid;
-        int idx = -1;
-        if (bchunk[k] >= 0) {
-            for (int r = 7; r >= 0; --r) {  // descending: the lowest matching index wins
-                const int gj = bchunk[k] + r;
-                if (gj < M) {
-                    const float d = dist2(qx[k], qy[k], qz[k], gx[gj], gy[gj], gz[gj]);
-                    if (d == best[k]) idx = gj;
-                }
-            }
-        }
-        if (i < N) {
-            out_idx[i] = idx;
-            out_d2[i] = best[k];
-            kept += (idx >= 0);
-        }
-    }
-    // one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
-    if ((tid & 63) == 0 && kept) atomicAdd(kept_counter, kept);
-}
-
-// ---- NN matcher, MFMA filter + exact re-evaluation ------------------------------------
-// The N x M x 3 distance contraction in expanded form,
-//     e(q,m) = |m'|^2 - 2 q'.m'  = [ -2m'x, -2m'y, -2m'z, |m'|^2 ] . [ q'x, q'y, q'z, 1 ]      (K = 4)
-// (primes: coordinates relative to the map's bounding-box centre c) is exactly one
-// v_mfma_f32_16x16x4_f32 per 16 map points x 16 queries.  e + |q'|^2 approximates d2 only to
-// ~1e-2 m^2 at 100 m range (fp32 cancellation), so the MFMA is used as a FILTER with a
-// rigorous error bound (DESIGN.md "MFMA filter bound"):
-//     | (e_mfma + |q'|^2_fl) - d2_contract |  <=  u*(18.6|q'|^2 + 18.6|m'|^2 + 6.2 g^2),  u = 2^-24, g = gate
-// The |m'|^2 share is folded into the A operand (k=3 row holds |m'|^2 (1 - 20u)), the rest into
-// the accumulator input C = -(best - |q'|^2 + 20u|q'|^2 + 8u g^2), so an output <= 0 means
-// "d2 may be <= the query's current best".  Only those survivors (a handful per query over the
-// whole map) are re-evaluated with the exact direct-difference contract on the original
-// coordinates (staged in LDS beside the image) -- the result is bit-identical to k_nn_valu /
-// the CPU checker, including the lowest-index tie rule.  The best is warm-started from the
-// previous iteration's pairing (an exact candidate), which removes most survivors.
-//
-// Layout: A = map tile, lane l holds A[i = l&15][k = l>>4]; the map image in HBM/LDS is
-// [tile][k][16] so that is word (tile*64 + l): one conflict-free ds_read_b32 feeds QT MFMAs.
-// B = 16 queries, lane l holds B[k = l>>4][j = l&15] (register-resident for the whole sweep).
-// D: lane l, reg r = pair (map row (l>>4)*4 + r, query l&15): each lane tracks the best of
-// "its" rows for query l&15; the four lane groups are merged once at the end.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr float kMapPadNorm = 1.0e30f;          // |m'|^2 of padding rows: e = 1e30, never a survivor
-constexpr float kUnitRoundoff = 5.9604645e-8f;  // u = 2^-24
-constexpr float kFoldCoef = 20.0f * kUnitRoundoff;  // >= 18.6u + the rounding of the folding itself
-constexpr float kGateCoef = 8.0f * kUnitRoundoff;   // >= 6.2u
-
-// accumulator input for a query with squared norm qq (centred) and current best d2
-__device__ __forceinline__ float filter_c(float qq, float best, float gate2)
-{
-    // -(best - qq + eps_q), rounded towards "more survivors"
-    return (qq - best) - (kFoldCoef * qq + kGateCoef * gate2) * 1.0001f - 1e-30f;
-}
-
-struct MapFrame {
-    float cx, cy, cz;  // bounding-box centre of the map (fp32)
-    float radius;      // >= max |m - c| over the map
-};
-
-// Work decomposition: the sweep is cut into ITEMS = (group of QT*16 queries) x (map segment).
-// Persistent waves pull items from an atomic queue (segment-major, so the waves running at any
-// time read the same ~2 MiB slice of the map image: it stays in every XCD's L2).  Each wave is
-// autonomous -- no block barrier anywhere: it streams the A operand straight from L2 through a
-// 4-deep register prefetch ring (one coalesced 256-B load per 16 map points; ~4 B/clk/CU, far
-// below what L2 delivers) and keeps its queries, thresholds and running best in registers.
-// Per-segment results are merged by k_nn_merge (lexicographic (d2,index) minimum).
-template <int QT>
-__global__ __launch_bounds__(256, 2) void k_nn_mfma(const float* __restrict__ lx, const float* __restrict__ ly,
-                                                    const float* __restrict__ lz, int N,
-                                                    const float* __restrict__ gx, const float* __restrict__ gy,
-                                                    const float* __restrict__ gz, int M,
-                                                    const float* __restrict__ map_img, int n_tiles, int seg_tiles,
-                                                    int n_segs, int n_qgroups, MapFrame F, PoseF P, float thr2,
-                                                    const int* __restrict__ seed_idx, int* __restrict__ seg_idx,
-                                                    float* __restrict__ seg_d2, unsigned int* __restrict__ queue,
-                                                    unsigned long long* __restrict__ dbg_stats)
-{
-    __shared__ float4 s_q[4 * QT * 16];  // per wave: (qx,qy,qz,|q'|^2) of its queries, for the exact re-evaluation
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 15, grp = lane >> 4;
-    float4* my_q = s_q + wave * (QT * 16);
-    const int n_items = n_qgroups * n_segs;
-
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = (int)atomicAdd(queue, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const int seg = item / n_qgroups, qg = item - seg * n_qgroups;
-        const int q0 = qg * (QT * 16);
-        const int t_beg = seg * seg_tiles, t_end = min(t_beg + seg_tiles, n_tiles);  // multiples of 4 tiles
-
-        float B[QT], best[QT];
-        int bidx[QT];
-        f32x4 C[QT];
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const int i = q0 + t * 16 + col;
-            float qx = 0.f, qy = 0.f, qz = 0.f, cthr = kMapPadNorm;  // padding query: D = e + 1e30 > 0 always
-            float bx = 0.f, by = 0.f, bz = 0.f, qq = 0.f;
-            best[t] = thr2;  // gate: only d2 < thr2 can ever be kept
-            bidx[t] = -1;
-            if (i < N) {
-                xform(P, lx[i], ly[i], lz[i], qx, qy, qz);
-                bx = qx - F.cx; by = qy - F.cy; bz = qz - F.cz;
-                qq = fmaf(bz, bz, fmaf(by, by, bx * bx));
-                if (seed_idx) {  // warm start: last iteration's neighbour is an exact candidate
-                    const int j = seed_idx[i];
-                    if (j >= 0 && j < M) {
-                        const float d = dist2(qx, qy, qz, gx[j], gy[j], gz[j]);
-                        if (d < thr2) { best[t] = d; bidx[t] = j; }
-                    }
-                }
-                cthr = filter_c(qq, best[t], thr2);
-            }
-            B[t] = grp == 0 ? bx : (grp == 1 ? by : (grp == 2 ? bz : 1.0f));
-            C[t] = f32x4{cthr, cthr, cthr, cthr};
-            if (grp == 0) my_q[t * 16 + col] = make_float4(qx, qy, qz, qq);
-        }
-        // my_q is private to this wave: a wave-level fence is all the ordering it needs
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        const float* img = map_img + (size_t)t_beg * 64 + lane;  // word (tile*64 + lane) = A[lane&15][lane>>4]
-        // prefetch ring (the image carries 4 padding tiles past n_tiles, so these never run off the end)
-        float a0 = img[0], a1 = img[64], a2 = img[128], a3 = img[192];
-        f32x4 Dp[QT];
-#pragma unroll
-        for (int t = 0; t < QT; ++t) Dp[t] = f32x4{1.f, 1.f, 1.f, 1.f};  // nothing pending before the first step
-
-        // consume(): reduce/test the PREVIOUS step's accumulators while this step's MFMAs run
-#define MOLA_NN_CONSUME(TILE)                                                                                     \
-    {                                                                                                             \
-        int r = min(min(__float_as_int(Dp[0][0]), __float_as_int(Dp[0][1])),                                      \
-                    min(__float_as_int(Dp[0][2]), __float_as_int(Dp[0][3])));                                     \
-        _Pragma("unroll") for (int t = 1; t < QT; ++t) {                                                          \
-            r = min(min(r, __float_as_int(Dp[t][0])), __float_as_int(Dp[t][1]));                                  \
-            r = min(min(r, __float_as_int(Dp[t][2])), __float_as_int(Dp[t][3]));                                  \
-        }                                                                                                         \
-        if (__any(r <= 0)) {                                                                                      \
-            const int row0 = (TILE)*16 + grp * 4;                                                                 \
-            if (dbg_stats && lane == 0) atomicAdd(&dbg_stats[0], 1ull);                                           \
-            _Pragma("unroll") for (int t = 0; t < QT; ++t) {                                                      \
-                const int mt = min(min(__float_as_int(Dp[t][0]), __float_as_int(Dp[t][1])),                       \
-                                   min(__float_as_int(Dp[t][2]), __float_as_int(Dp[t][3])));                      \
-                if (__any(mt <= 0)) {                                                                             \
-                    const float4 q = my_q[t * 16 + col];                                                          \
-                    _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                            \
-                        if (Dp[t][rr] <= 0.0f) {                                                                  \
-                            if (dbg_stats) atomicAdd(&dbg_stats[1], 1ull);                                        \
-                            const int j = row0 + rr; /* < M: padding rows never survive */                        \
-                            const float d = dist2(q.x, q.y, q.z, gx[j], gy[j], gz[j]);                            \
-                            if (d < best[t] || (d == best[t] && j < bidx[t])) { best[t] = d; bidx[t] = j; }       \
-                        }                                                                                         \
-                    }                                                                                             \
-                    float nb = best[t];                                                                           \
-                    nb = fminf(nb, __shfl_xor(nb, 16));                                                           \
-                    nb = fminf(nb, __shfl_xor(nb, 32));                                                           \
-                    if (q0 + t * 16 + col < N) {                                                                  \
-                        const float cthr = filter_c(q.w, nb, thr2);                                               \
-                        C[t] = f32x4{cthr, cthr, cthr, cthr};                                                     \
-                    }                                                                                             \
-                }                                                                                                 \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-#define MOLA_NN_STEP(AREG, TILE, NEXT_OFF)                                                                        \
-    {                                                                                                             \
-        f32x4 Dn[QT];                                                                                             \
-        const float a_cur = AREG;                                                                                 \
-        AREG = img[(NEXT_OFF)];                                                                                   \
-        _Pragma("unroll") for (int t = 0; t < QT; ++t)                                                            \
-            Dn[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, B[t], C[t], 0, 0, 0);                             \
-        MOLA_NN_CONSUME((TILE)-1)                                                                                 \
-        _Pragma("unroll") for (int t = 0; t < QT; ++t) Dp[t] = Dn[t];                                             \
-    }
-        for (int tile = t_beg; tile < t_end; tile += 4) {
-            MOLA_NN_STEP(a0, tile, 4 * 64)
-            MOLA_NN_STEP(a1, tile + 1, 5 * 64)
-            MOLA_NN_STEP(a2, tile + 2, 6 * 64)
-            MOLA_NN_STEP(a3, tile + 3, 7 * 64)
-            img += 4 * 64;
-        }
-        MOLA_NN_CONSUME(t_end - 1)
-#undef MOLA_NN_STEP
-#undef MOLA_NN_CONSUME
-
-        // merge the four lane groups: lexicographic (d2, index) minimum -> lowest index on ties
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            float d = best[t];
-            int j = bidx[t] < 0 ? 0x7fffffff : bidx[t];
-#pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                const float od = __shfl_xor(d, off);
-                const int oj = __shfl_xor(j, off);
-                if (od < d || (od == d && oj < j)) { d = od; j = oj; }
-            }
-            const int i = q0 + t * 16 + col;
-            if (grp == 0 && i < N) {
-                seg_idx[(size_t)seg * N + i] = j == 0x7fffffff ? -1 : j;
-                seg_d2[(size_t)seg * N + i] = d;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // my_q is rewritten by the next item
-    }
-}
-
-// per-segment results -> the pairing: lexicographic (d2, index) minimum over the segments
-__global__ __launch_bounds__(256) void k_nn_merge(const int* __restrict__ seg_idx, const float* __restrict__ seg_d2,
-                                                  int n_segs, int N, int* __restrict__ out_idx,
-                                                  float* __restrict__ out_d2, unsigned int* __restrict__ kept_counter)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    unsigned int kept = 0;
-    if (i < N) {
-        float d = seg_d2[i];
-        int j = seg_idx[i] < 0 ? 0x7fffffff : seg_idx[i];
-        for (int s = 1; s < n_segs; ++s) {
-            const float od = seg_d2[(size_t)s * N + i];
-            const int oj = seg_idx[(size_t)s * N + i] < 0 ? 0x7fffffff : seg_idx[(size_t)s * N + i];
-            if (od < d || (od == d && oj < j)) { d = od; j = oj; }
-        }
-        const int idx = j == 0x7fffffff ? -1 : j;
-        out_idx[i] = idx;
-        out_d2[i] = d;
-        kept = idx >= 0;
-    }
-    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
-    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(kept_counter, kept);
-}
-
-// ---- tiled matcher: exact brute force over the map tiles a wave's queries can reach ---------
-// Both clouds are put in Morton order once (map: per map; local cloud: per cloud).  The map is cut
-// into TILES of 32 consecutive points with an axis-aligned box, 64 tiles form a super-tile.  A
-// wave owns 128 consecutive (hence spatially compact) queries, two per lane.  Per iteration:
-//   1. transform the queries, warm-start each best from the previous iteration's neighbour,
-//      give each query the box [q - r, q + r], r = sqrt(best) (rounded up), and reduce the
-//      boxes to one wave box;
-//   2. cull: lanes test 64 super-tile boxes at a time against the wave box (ballot), then the 64
-//      tiles of each hit super-tile.  A tile whose box misses the wave box cannot hold, for any of
-//      the wave's queries, a point with d2 <= best -- skipping it is exact;
-//   3. every surviving tile is staged in LDS (two tiles = 64 points per pass) and ALL 128 queries
-//      are evaluated against ALL its points with the exact contract: tiled brute force, per-lane
-//      argmin on the packed key (d2 bits << 32 | ORIGINAL map index), i.e. lexicographic
-//      (d2, lowest index) -- bit-identical to the untiled kernels.
-// No tree, no per-query traversal, no data-dependent recursion: two flat box scans and dense
-// 128 x 64 tiles.
-constexpr int kTileG = 32;     // map points per tile
-constexpr int kSuper = 64;     // tiles per super-tile
-constexpr int kQPW = 128;      // queries per wave
-#ifndef MOLA_VAR_GROUP
-#define MOLA_VAR_GROUP 8
-#endif
-constexpr int kGroup = MOLA_VAR_GROUP;      // fast sweep: points per bookkeeping group
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) float lds_f32;  // explicit LDS pointers: ds_read, never flat_load
-
-// dist2 for the two queries of a lane at once (v_pk_add/mul/fma_f32): each half is the same IEEE sequence as dist2
-__device__ __forceinline__ v2f dist2_pk(v2f qx, v2f qy, v2f qz, float mx, float my, float mz)
-{
-    const v2f dx = qx - mx, dy = qy - my, dz = qz - mz;
-    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-}
-
-// ... and for ONE query against two map points at once (same sequence per half)
-__device__ __forceinline__ v2f dist2_pk2(float qx, float qy, float qz, v2f mx, v2f my, v2f mz)
-{
-    const v2f dx = qx - mx, dy = qy - my, dz = qz - mz;
-    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-}
-
-struct Box { float lo[3], hi[3]; };
-
-__device__ __forceinline__ bool box_overlap(const float* __restrict__ b, int stride, int i, const Box& w)
-{
-    // b: SoA [6][stride] = minx,miny,minz,maxx,maxy,maxz ; empty boxes are (+inf,-inf)
-    return b[i] <= w.hi[0] && b[stride + i] <= w.hi[1] && b[2 * stride + i] <= w.hi[2] &&
-           b[3 * stride + i] >= w.lo[0] && b[4 * stride + i] >= w.lo[1] && b[5 * stride + i] >= w.lo[2];
-}
-
-__device__ __forceinline__ float bcast_lane(float v, int lane_uniform)
-{
-    // lane_uniform is wave-uniform (ctz of a ballot): a v_readlane, not an LDS round trip
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
-}
-
-// the sorted map + its three box levels, as the tiled kernels see it
-struct TiledMap {
-    const float *sx, *sy, *sz;  // Hilbert-sorted points, padded to whole super-tiles
-    const int* perm;            // sorted position -> original index (0x7fffffff in the padding)
-    const float* tbox; int n_tiles_p;   // tile boxes        SoA [6][n_tiles_p]
-    const float* sbox; int n_super;     // super-tile boxes  SoA [6][n_super]  (n_super padded to 64)
-    const float* ubox; int n_top;       // top boxes         SoA [6][n_top]
-};
-
-#ifndef MOLA_VAR_LDSBOX_KB
-#define MOLA_VAR_LDSBOX_KB 40
-#endif
-constexpr size_t kMaxLdsBoxBytes = MOLA_VAR_LDSBOX_KB * 1024;  // upper box levels kept in LDS up to this size (~3.4M map points)
-constexpr size_t kDbgItems = 1u << 17;  // MOLA_ICP_DEBUG_STATS: per-item records for clouds up to 16M points
-constexpr int kQueues = 8, kQueueStride = 32;  // work-queue counters, one 128-byte line each
-constexpr int kMaxList = 64;   // super-tiles collected before their tiles are streamed
-
-// LDS copy of the two upper box levels (one per workgroup): [6][n_top] then [6][n_super] floats.  The upper
-// levels of the scan then cost LDS reads instead of dependent global round trips.
-__device__ __forceinline__ size_t lds_box_floats(int n_top, int n_super) { return 6u * ((size_t)n_top + (size_t)n_super); }
-__device__ __forceinline__ void load_boxes_to_lds(const TiledMap& mp, lds_f32* lbox)
-{
-    const int nu = 6 * mp.n_top, ns = 6 * mp.n_super;
-    for (int i = threadIdx.x; i < nu; i += blockDim.x) lbox[i] = mp.ubox[i];
-    for (int i = threadIdx.x; i < ns; i += blockDim.x) lbox[nu + i] = mp.sbox[i];
-    __syncthreads();
-}
-
-// The sweep shared by the tiled kernels: wave box from the per-query reaches; the two upper box levels select
-// the super-tiles some query reaches (from the LDS copy `lbox`, or from global memory if it is null) into the
-// per-wave list `slist`; the listed super-tiles are then streamed with the NEXT one's tile boxes already in
-// flight, their surviving tiles staged through LDS two at a time with the next pair's points in flight too.
-// `visit(nm, jb0, jb1)` is called once per staged pass: sm[0..2][0..nm) hold x,y,z of the staged points
-// (sm[3] their original indices if NEED_PERM); points [0,32) have sorted positions jb0.., [32,64) jb1...
-// Returns the number of staged points.
-template <int QPL, bool NEED_PERM, class Visit>
-__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane,
-                                                          float (*sm)[64], const float (&qx)[QPL], const float (&qy)[QPL],
-                                                          const float (&qz)[QPL], const float (&reach)[QPL],
-                                                          const float (&bound2)[QPL], Visit&& visit,
-                                                          bool prof, unsigned long long& p_stage,
-                                                          unsigned long long& p_visit, unsigned int& p_supers,
-                                                          unsigned int& p_entered, unsigned int& p_tiles,
-                                                          unsigned long long& p_boxwait, unsigned long long& p_tiletest)
-{
-    Box w;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { w.lo[a] = INFINITY; w.hi[a] = -INFINITY; }
-#pragma unroll
-    for (int k = 0; k < QPL; ++k) {
-        if (reach[k] >= 0.f) {
-            w.lo[0] = fminf(w.lo[0], qx[k] - reach[k]); w.hi[0] = fmaxf(w.hi[0], qx[k] + reach[k]);
-            w.lo[1] = fminf(w.lo[1], qy[k] - reach[k]); w.hi[1] = fmaxf(w.hi[1], qy[k] + reach[k]);
-            w.lo[2] = fminf(w.lo[2], qz[k] - reach[k]); w.hi[2] = fmaxf(w.hi[2], qz[k] + reach[k]);
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
-            w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
-        }
-    }
-    unsigned long long n_staged = 0;
-
-    // Can the box (m0..m5 = min xyz, max xyz; wave-uniform values) hold a point with d2 <= bound2 for ANY query of
-    // the wave?  Per query: squared distance to the box, computed with the contract's own operation sequence on
-    // the per-axis gaps.  Rounding is monotone, so for every point p inside the box gap_a <= |q_a - p_a| after
-    // rounding, hence box_d2 <= d2_contract(q, p) EXACTLY as computed -- no margin needed, and bound2 is read
-    // live: as a query's best shrinks during the sweep, later boxes are tested against the tighter value.
-    // Padding lanes carry bound2 < 0 and reach nothing; empty boxes (+inf, -inf) give inf.
-    auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
-        if constexpr (QPL == 2) {  // both queries of the lane per packed instruction
-            const v2f s_qx = {qx[0], qx[1]}, s_qy = {qy[0], qy[1]}, s_qz = {qz[0], qz[1]};
-            const v2f zero = {0.f, 0.f};
-            const v2f ax = __builtin_elementwise_max(__builtin_elementwise_max(m0 - s_qx, s_qx - m3), zero);
-            const v2f ay = __builtin_elementwise_max(__builtin_elementwise_max(m1 - s_qy, s_qy - m4), zero);
-            const v2f az = __builtin_elementwise_max(__builtin_elementwise_max(m2 - s_qz, s_qz - m5), zero);
-            const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
-            return __any(D.x <= bound2[0] || D.y <= bound2[1]);
-        } else {
-            const float ax = fmaxf(fmaxf(m0 - qx[0], qx[0] - m3), 0.f);
-            const float ay = fmaxf(fmaxf(m1 - qy[0], qy[0] - m4), 0.f);
-            const float az = fmaxf(fmaxf(m2 - qz[0], qz[0] - m5), 0.f);
-            return __any(fmaf(az, az, fmaf(ay, ay, ax * ax)) <= bound2[0]);
-        }
-    };
-
-    int pend_a = -1, pend_b = -1;  // tile ids whose points sit in the registers below
-    float px = 0.f, py = 0.f, pz = 0.f;
-    int po = 0;
-    auto load_pair = [&](int ta, int tb) {
-        const int tt = lane < 32 ? ta : tb;
-        px = py = pz = 1.0e18f;  // padding points: d2 ~ 3e36, never a neighbour
-        po = 0x7fffffff;
-        if (tt >= 0) {
-            const int j = tt * kTileG + (lane & 31);
-            px = mp.sx[j]; py = mp.sy[j]; pz = mp.sz[j];
-            if (NEED_PERM) po = mp.perm[j];
-        }
-    };
-    auto compute_pending = [&](int next_a, int next_b) {
-        const int ca = pend_a, cb = pend_b;
-        const unsigned long long tp0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-        sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz;
-        if (NEED_PERM) sm[3][lane] = __int_as_float(po);
-        pend_a = next_a; pend_b = next_b;
-        if (pend_a >= 0) load_pair(pend_a, pend_b);  // next pass's loads fly while this pass computes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int nm = cb >= 0 ? 64 : 32;
-        n_staged += nm;
-        const unsigned long long tp1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-        visit(nm, ca * kTileG, (cb >= 0 ? cb : ca) * kTileG);
-        __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next pass
-        if (prof) { const unsigned long long tp2 = __builtin_amdgcn_s_memtime(); p_stage += tp1 - tp0; p_visit += tp2 - tp1; }
-    };
-
-    // ---- the listed super-tiles: tile boxes of entry e+1 in flight while entry e's tiles are processed ----
-    int n_list = 0;
-    auto process_list = [&]() {
-        if (n_list == 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        int S = __builtin_amdgcn_readfirstlane(slist[0]);
-        int ti = S * kSuper + lane;
-        float n0 = mp.tbox[ti], n1 = mp.tbox[mp.n_tiles_p + ti], n2 = mp.tbox[2 * mp.n_tiles_p + ti],
-              n3 = mp.tbox[3 * mp.n_tiles_p + ti], n4 = mp.tbox[4 * mp.n_tiles_p + ti], n5 = mp.tbox[5 * mp.n_tiles_p + ti];
-        for (int e = 0; e < n_list; ++e) {
-            const unsigned long long tb0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-            const float b0 = n0, b1 = n1, b2 = n2, b3 = n3, b4 = n4, b5 = n5;
-            const int Sc = S;
-            if (e + 1 < n_list) {
-                S = __builtin_amdgcn_readfirstlane(slist[e + 1]);
-                ti = S * kSuper + lane;
-                n0 = mp.tbox[ti]; n1 = mp.tbox[mp.n_tiles_p + ti]; n2 = mp.tbox[2 * mp.n_tiles_p + ti];
-                n3 = mp.tbox[3 * mp.n_tiles_p + ti]; n4 = mp.tbox[4 * mp.n_tiles_p + ti]; n5 = mp.tbox[5 * mp.n_tiles_p + ti];
-            }
-            unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
-                                               b4 >= w.lo[1] && b5 >= w.lo[2]);
-            unsigned long long tmask = 0;
-            const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-            while (cand) {
-                const int t = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                if (prof) p_tiles += 1;
-                if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
-                              bcast_lane(b4, t), bcast_lane(b5, t)))
-                    tmask |= 1ull << t;
-            }
-            if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); p_boxwait += tb1 - tb0; p_tiletest += tb2 - tb1; }
-            while (tmask) {
-                const int t0 = Sc * kSuper + __builtin_ctzll(tmask);
-                tmask &= tmask - 1;
-                int t1 = -1;
-                if (tmask) { t1 = Sc * kSuper + __builtin_ctzll(tmask); tmask &= tmask - 1; }
-                if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
-                    pend_a = t0; pend_b = t1;
-                    load_pair(t0, t1);
-                } else {
-                    compute_pending(t0, t1);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // the list is rewritten from here on
-        n_list = 0;
-    };
-
-    // ---- upper levels: top boxes (64 super-tiles = 131072 points each) -> super-tile boxes ----
-    // Written as a resumable scan so that process_list() has ONE call site (its body holds the distance
-    // passes): collect up to kMaxList super-tiles, stream them, resume where the scan stopped.
-    const lds_f32* l_ubox = lbox;
-    const lds_f32* l_sbox = lbox + 6 * mp.n_top;
-    int ub = 0, sb = 0;
-    unsigned long long ucand = 0, scand = 0;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
-    bool c_valid = false;  // c0..c5 hold the super-tile boxes [sb, sb+64)
-    auto load_super_boxes = [&]() {
-        const int si = sb + lane;
-        if (use_lbox) {
-            c0 = l_sbox[si]; c1 = l_sbox[mp.n_super + si]; c2 = l_sbox[2 * mp.n_super + si];
-            c3 = l_sbox[3 * mp.n_super + si]; c4 = l_sbox[4 * mp.n_super + si]; c5 = l_sbox[5 * mp.n_super + si];
-        } else {
-            c0 = mp.sbox[si]; c1 = mp.sbox[mp.n_super + si]; c2 = mp.sbox[2 * mp.n_super + si];
-            c3 = mp.sbox[3 * mp.n_super + si]; c4 = mp.sbox[4 * mp.n_super + si]; c5 = mp.sbox[5 * mp.n_super + si];
-        }
-        c_valid = true;
-    };
-    for (;;) {
-        while (n_list < kMaxList) {
-            if (scand) {
-                if (!c_valid) load_super_boxes();  // resumed after a full list
-                const int sl = __builtin_ctzll(scand);
-                scand &= scand - 1;
-                if (prof) p_supers += 1;
-                // super-tile vs the individual queries: a bimodal query group must not descend everywhere
-                if (any_reach(bcast_lane(c0, sl), bcast_lane(c1, sl), bcast_lane(c2, sl), bcast_lane(c3, sl),
-                              bcast_lane(c4, sl), bcast_lane(c5, sl))) {
-                    if (prof) p_entered += 1;
-                    if (lane == 0) slist[n_list] = sb + sl;
-                    ++n_list;
-                }
-            } else if (ucand) {
-                sb = (ub - 64 + __builtin_ctzll(ucand)) * 64;  // first super-tile of this top box (ub already advanced)
-                ucand &= ucand - 1;
-                load_super_boxes();
-                scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] && c4 >= w.lo[1] &&
-                                 c5 >= w.lo[2]);
-            } else if (ub < mp.n_top) {
-                const int ui = ub + lane;
-                float u0 = INFINITY, u1 = INFINITY, u2 = INFINITY, u3 = -INFINITY, u4 = -INFINITY, u5 = -INFINITY;
-                if (ui < mp.n_top) {
-                    if (use_lbox) {
-                        u0 = l_ubox[ui]; u1 = l_ubox[mp.n_top + ui]; u2 = l_ubox[2 * mp.n_top + ui];
-                        u3 = l_ubox[3 * mp.n_top + ui]; u4 = l_ubox[4 * mp.n_top + ui]; u5 = l_ubox[5 * mp.n_top + ui];
-                    } else {
-                        u0 = mp.ubox[ui]; u1 = mp.ubox[mp.n_top + ui]; u2 = mp.ubox[2 * mp.n_top + ui];
-                        u3 = mp.ubox[3 * mp.n_top + ui]; u4 = mp.ubox[4 * mp.n_top + ui]; u5 = mp.ubox[5 * mp.n_top + ui];
-                    }
-                }
-                ucand = __ballot(u0 <= w.hi[0] && u1 <= w.hi[1] && u2 <= w.hi[2] && u3 >= w.lo[0] && u4 >= w.lo[1] &&
-                                 u5 >= w.lo[2]);
-                ub += 64;
-            } else {
-                break;
-            }
-        }
-        if (n_list == 0) break;
-        process_list();
-        c_valid = false;
-    }
-    if (pend_a >= 0) compute_pending(-1, -1);
-    return n_staged;
-}
-
-// reach of a query whose current best squared distance is `best`: any m with d2_contract <= best lies inside
-// [q - r, q + r] per axis (sqrt rounded up, plus 2 ulp of the largest coordinate)
-__device__ __forceinline__ float reach_of(float best, float qx, float qy, float qz)
-{
-    const float cmax = fmaxf(fabsf(qx), fmaxf(fabsf(qy), fabsf(qz)));
-    return sqrtf(best * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
-}
-
-// Work queue of the persistent waves.  Same-address atomics serialise device-wide (measured: ~13 ns each; one
-// more atomic per item cost 20% of the kernel, the 3072-deep burst of first pops 40 us), so
-//  - the first entry of every wave is its own index: no atomics at kernel start;
-//  - the entries after those are dealt round-robin to kQueues counters on separate cache lines; a wave pops from
-//    the counter of its XCD (blockIdx & 7) and moves on to the next counter when that one runs dry.
-// Callers keep the next entry's pop in flight while the current item is processed.
-struct WaveQueue {
-    unsigned int* q;
-    int lane, n_waves, tried;
-    __device__ __forceinline__ WaveQueue(unsigned int* queue, int lane_) : q(queue), lane(lane_), n_waves((int)gridDim.x * 4), tried(0) {}
-    __device__ __forceinline__ int first() const { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
-    __device__ __forceinline__ int pop()  // the next entry (meaningful in lane 0), still in flight
-    {
-        const int c = ((int)blockIdx.x + tried) & (kQueues - 1);
-        int r = 0;
-        if (lane == 0) r = n_waves + c + kQueues * (int)atomicAdd(q + c * kQueueStride, 1u);
-        return r;
-    }
-    __device__ __forceinline__ int settle(int raw, int n_items)  // raw = readfirstlane(pop()): past the end -> other counters
-    {
-        while (raw >= n_items && ++tried < kQueues) raw = __builtin_amdgcn_readfirstlane(pop());
-        return raw;
-    }
-};
-
-// EXACT = false: the fast sweep.  Per (query, 4-point chunk) only the chunk minimum is compared with the
-//   running best (~6 VALU ops per pair); the winning chunk is re-evaluated once at the end to recover the
-//   exact point and the lowest-original-index rule inside it.  If an EQUAL minimum showed up in a different
-//   chunk (exact ties: duplicate points, lattices) the item is queued for the exact pass.
-// EXACT = true : the exact-key sweep over the queued items: per-pair argmin on the packed key
-//   (d2 bits << 32 | original index), i.e. the full lexicographic rule (~10 ops per pair).
-template <bool EXACT, int QPL>
-__global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
-                                                  const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
-                                                  int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
-                                                  float* __restrict__ d2_s, const int* __restrict__ item_order,
-                                                  unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
-                                                  unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
-                                                  unsigned long long* __restrict__ staged_total,
-                                                  unsigned long long* __restrict__ dbg_stats, int lds_boxes,
-                                                  unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
-{
-    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
-    __shared__ int s_list[4][kMaxList];
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float(*sm)[64] = s_m[wave];
-    int* slist = s_list[wave];
-    if (EXACT && *redo_count == 0u) return;  // the usual case: no exact ties in this launch (uniform: before any barrier)
-    const lds_f32* lbox = (const lds_f32*)s_dyn;
-    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
-    constexpr int kQ = 64 * QPL;  // queries per item: QPL per lane (2 for large clouds, 1 when there are few items per wave)
-    const int n_items = EXACT ? (int)*redo_count : (N + kQ - 1) / kQ;
-
-    WaveQueue wq(queue, lane);
-    auto lookup = [&](int raw) -> int {  // raw is wave-uniform; -1 = past the end
-        if (raw >= n_items) return -1;
-        if (EXACT) return redo_list[raw];
-        return item_order ? item_order[raw] : raw;  // heaviest items of the last launch first
-    };
-    unsigned long long wave_staged = 0ull;
-    const unsigned long long t_wave0 = wave_times ? wall_clock64() : 0ull;  // 100 MHz, the same on every XCD
-    unsigned int wave_items = 0u;
-    int item = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
-    while (item >= 0) {
-        ++wave_items;
-        const int next_raw_v = wq.pop();
-        const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
-
-        float qx[QPL], qy[QPL], qz[QPL], reach[QPL];
-        unsigned long long key[QPL];  // EXACT: packed (d2, original index)
-        float best[QPL];              // fast: running minimum
-        int bpos[QPL];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
-        int tie[QPL] = {};
-        // round trip 1: the two queries of the lane and their seeds (clamped indices: every load is unconditional)
-        int qi[QPL], js[QPL];
-        float lx[QPL], ly[QPL], lz[QPL];
-#pragma unroll
-        for (int k = 0; k < QPL; ++k) {
-            qi[k] = item * kQ + k * 64 + lane;
-            if (qi[k] >= N) qi[k] = N;  // padding lane
-            const int ic = qi[k] < N ? qi[k] : N - 1;
-            lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
-            js[k] = use_seed ? pos_s[ic] : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < QPL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
-        // round trip 2: the seeds' coordinates, and the next item's id
-        const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items));
-        float gsx[QPL], gsy[QPL], gsz[QPL];
-        unsigned int gso[QPL] = {};
-#pragma unroll
-        for (int k = 0; k < QPL; ++k) {
-            const int jc = js[k] >= 0 ? js[k] : 0;
-            gsx[k] = mp.sx[jc]; gsy[k] = mp.sy[jc]; gsz[k] = mp.sz[jc];
-            if (EXACT) gso[k] = (unsigned int)mp.perm[jc];
-        }
-#pragma unroll
-        for (int k = 0; k < QPL; ++k) {
-            key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
-            best[k] = thr2;
-            bpos[k] = -1;
-            const float d = dist2(qx[k], qy[k], qz[k], gsx[k], gsy[k], gsz[k]);
-            if (js[k] >= 0 && d < thr2) {  // warm start: last iteration's neighbour is an exact candidate
-                best[k] = d;
-                bpos[k] = EXACT ? js[k] : (js[k] & ~(kGroup - 1));
-                if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | gso[k];
-            }
-            reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
-            if (qi[k] >= N) {  // padding lane: reaches nothing, is never written
-                qx[k] = qy[k] = qz[k] = 1.0e18f;
-                reach[k] = -1.0f;
-                best[k] = -1.0f;
-                bpos[k] = -1;
-            }
-        }
-
-        unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
-        unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
-        const unsigned long long t_sweep0 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
-        const unsigned long long n_staged = tiled_sweep<QPL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
-            if constexpr (EXACT) {
-                for (int m = 0; m < nm; m += 4) {
-                    const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
-                    const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
-                    const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
-                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
-                    const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
-                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
-                                                __float_as_uint(O.w)};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                        for (int k = 0; k < QPL; ++k) {
-                            const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
-                            const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
-                            const bool better = ck < key[k];
-                            key[k] = better ? ck : key[k];
-                            best[k] = better ? d : best[k];  // the sweep's box tests read it
-                            bpos[k] = better ? ((m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32) : bpos[k];
-                        }
-                    }
-                }
-            } else {
-                // per kGroup-point group: packed sub/mul/fma (v_pk_*_f32) serve two (query, point) pairs per
-                // instruction -- the lane's two queries (QPL = 2) or two consecutive points (QPL = 1) -- the group
-                // minimum is a chain of v_min3, and the (best, position, tie) bookkeeping runs once per group
-#pragma unroll 2
-                for (int m = 0; m < nm; m += kGroup) {
-                    float gm[QPL];
-#pragma unroll
-                    for (int k = 0; k < QPL; ++k) gm[k] = INFINITY;
-#pragma unroll
-                    for (int h = 0; h < kGroup; h += 8) {
-                        const float4 X0 = *reinterpret_cast<const float4*>(&sm[0][m + h]);
-                        const float4 X1 = *reinterpret_cast<const float4*>(&sm[0][m + h + 4]);
-                        const float4 Y0 = *reinterpret_cast<const float4*>(&sm[1][m + h]);
-                        const float4 Y1 = *reinterpret_cast<const float4*>(&sm[1][m + h + 4]);
-                        const float4 Z0 = *reinterpret_cast<const float4*>(&sm[2][m + h]);
-                        const float4 Z1 = *reinterpret_cast<const float4*>(&sm[2][m + h + 4]);
-                        const float xs[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
-                        const float ys[8] = {Y0.x, Y0.y, Y0.z, Y0.w, Y1.x, Y1.y, Y1.z, Y1.w};
-                        const float zs[8] = {Z0.x, Z0.y, Z0.z, Z0.w, Z1.x, Z1.y, Z1.z, Z1.w};
-                        if constexpr (QPL == 2) {
-                            const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
-#pragma unroll
-                            for (int u = 0; u < 8; u += 2) {
-                                const v2f da = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
-                                const v2f db = dist2_pk(q2x, q2y, q2z, xs[u + 1], ys[u + 1], zs[u + 1]);
-                                gm[0] = fminf(fminf(gm[0], da.x), db.x);
-                                gm[1] = fminf(fminf(gm[1], da.y), db.y);
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < 8; u += 2) {
-                                const v2f mx = {xs[u], xs[u + 1]}, my = {ys[u], ys[u + 1]}, mz = {zs[u], zs[u + 1]};
-                                const v2f dd = dist2_pk2(qx[0], qy[0], qz[0], mx, my, mz);
-                                gm[0] = fminf(fminf(gm[0], dd.x), dd.y);
-                            }
-                        }
-                    }
-                    const int gpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this group
-#pragma unroll
-                    for (int k = 0; k < QPL; ++k) {
-                        const bool lt = gm[k] < best[k];
-                        const int eq = (int)(gm[k] == best[k]) & (int)(gpos != bpos[k]);
-                        tie[k] = lt ? 0 : (tie[k] | eq);
-                        best[k] = lt ? gm[k] : best[k];
-                        bpos[k] = lt ? gpos : bpos[k];
-                    }
-                }
-            }
-        }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
-        const unsigned long long t_sweep1 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
-
-        bool any_tie = false;
-        int rpos[QPL], roi[QPL];
-        float rd[QPL];
-#pragma unroll
-        for (int k = 0; k < QPL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; }
-        if constexpr (EXACT) {
-#pragma unroll
-            for (int k = 0; k < QPL; ++k) {
-                const float d = __uint_as_float((unsigned int)(key[k] >> 32));
-                if (d < thr2) { rd[k] = d; rpos[k] = bpos[k]; roi[k] = (int)(unsigned int)(key[k] & 0xffffffffu); }
-            }
-        } else {
-            // resolve inside the winning group: the point(s) with d2 == best, lowest original index first.
-            // One round trip: all loads of both queries are issued before the first use.
-            float4 RX[QPL][kGroup / 4], RY[QPL][kGroup / 4], RZ[QPL][kGroup / 4];
-            int4 RP[QPL][kGroup / 4];
-#pragma unroll
-            for (int k = 0; k < QPL; ++k) {
-                const int bp = bpos[k] >= 0 ? bpos[k] : 0;
-#pragma unroll
-                for (int c = 0; c < kGroup / 4; ++c) {
-                    RX[k][c] = *reinterpret_cast<const float4*>(mp.sx + bp + 4 * c);
-                    RY[k][c] = *reinterpret_cast<const float4*>(mp.sy + bp + 4 * c);
-                    RZ[k][c] = *reinterpret_cast<const float4*>(mp.sz + bp + 4 * c);
-                    RP[k][c] = *reinterpret_cast<const int4*>(mp.perm + bp + 4 * c);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < QPL; ++k) {
-                unsigned int bo = 0xffffffffu;
-                int pos = -1;
-#pragma unroll
-                for (int c = 0; c < kGroup / 4; ++c) {
-                    const float xs[4] = {RX[k][c].x, RX[k][c].y, RX[k][c].z, RX[k][c].w};
-                    const float ys[4] = {RY[k][c].x, RY[k][c].y, RY[k][c].z, RY[k][c].w};
-                    const float zs[4] = {RZ[k][c].x, RZ[k][c].y, RZ[k][c].z, RZ[k][c].w};
-                    const int ps[4] = {RP[k][c].x, RP[k][c].y, RP[k][c].z, RP[k][c].w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float du = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
-                        const bool take = du == best[k] && (unsigned int)ps[u] < bo;
-                        bo = take ? (unsigned int)ps[u] : bo;
-                        pos = take ? bpos[k] + 4 * c + u : pos;
-                    }
-                }
-                if (bpos[k] >= 0) {
-                    rd[k] = best[k]; rpos[k] = pos; roi[k] = (int)bo;
-                    if (pos < 0) tie[k] = 1;  // cannot happen (same arithmetic); be safe: exact pass
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < QPL; ++k) {
-            if (qi[k] < N) {  // coalesced: the pairing stays in sorted query order
-                pos_s[qi[k]] = rpos[k];
-                idx_s[qi[k]] = rpos[k] >= 0 ? roi[k] : -1;
-                d2_s[qi[k]] = rd[k];
-                any_tie |= tie[k] != 0;
-            }
-        }
-        if (!EXACT && __any(any_tie)) {
-            if (lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
-        }
-        if (lane == 0) {
-            if (!EXACT) {
-                // (a deterministic proxy -- staged points -- orders no better than the measured cycles; without any
-                // order the kernel is 6 % slower)
-                const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
-                if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
-            }
-            wave_staged += n_staged * QPL;  // executed work in units of 64 (query, point) pairs (one atomic per wave, at exit)
-            if (dbg_stats) {
-                const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-                atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged);
-                atomicAdd(&dbg_stats[5], t_sweep0 - t_item0);                         // prologue
-                atomicAdd(&dbg_stats[6], (t_sweep1 - t_sweep0) - p_stage - p_visit);  // box scan
-                atomicAdd(&dbg_stats[7], p_stage);                                    // staging
-                atomicAdd(&dbg_stats[8], p_visit);                                    // distance passes
-                atomicAdd(&dbg_stats[10], t_end - t_sweep1);                          // epilogue
-                atomicMax(&dbg_stats[9], t_end - t_item0);
-                atomicAdd(&dbg_stats[11], (unsigned long long)p_supers); atomicAdd(&dbg_stats[12], (unsigned long long)p_entered);
-                atomicAdd(&dbg_stats[13], (unsigned long long)p_tiles);
-                atomicAdd(&dbg_stats[14], p_boxwait); atomicAdd(&dbg_stats[15], p_tiletest);
-                unsigned long long* rec = dbg_stats + 16 + 8 * (size_t)item;  // per-item record
-                rec[0] = t_end - t_item0; rec[1] = n_staged; rec[2] = p_entered; rec[3] = p_tiles;
-                rec[4] = t_sweep0 - t_item0; rec[5] = (t_sweep1 - t_sweep0) - p_stage - p_visit; rec[6] = p_stage + p_visit;
-                rec[7] = t_end - t_sweep1;
-            }
-        }
-        item = __builtin_amdgcn_readfirstlane(next_item_v);
-    }
-    if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
-    if (wave_times && lane == 0) {  // [start, end, items] per wave
-        unsigned long long* w = wave_times + 3 * (size_t)wq.first();
-        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items;
-    }
-}
-
-// ---- row f3: point-to-plane matcher (mp2p_icp::Matcher_Point2Plane, params/icp-settings-regular.yaml:33-39) ----
-// Same tiled sweep; the visitor keeps, per query, the K nearest points as a sorted list ordered by
-// (d2, original index).  The reach is the gate (distanceThreshold): only neighbours inside it matter.
-// Epilogue per query: the neighbours inside the gate (need >= 3) -> mean + covariance in fp64 -> cyclic
-// Jacobi eigen-decomposition -> plane iff e0 <= planeEigenThreshold * e2, normal = eigenvector of e0,
-// pairing iff |n.(q - mean)| <= distanceThreshold.  [EXT-recalled mp2p_icp behaviour; restated in the
-// CPU checker with the same operation order.]
-struct PlanePair {      // one per query, sorted query order
-    double c[3];        // plane centroid
-    double n[3];        // unit normal
-    int valid, n_neigh;
-};
-
-__device__ __forceinline__ void eig_sym3_dev(const double Cin[3][3], double ev[3], double V[3][3])
-{
-    double A[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) { A[i][j] = Cin[i][j]; V[i][j] = (i == j); }
-    for (int sweep = 0; sweep < 32; sweep++) {
-        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
-        if (off == 0 || off < 1e-34 * dg) break;
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int q = p + 1; q < 3; q++) {
-                if (A[p][q] == 0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
-                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                const double c = 1 / sqrt(tt * tt + 1), s2 = tt * c;
-#pragma unroll
-                for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s2 * b; A[k][q] = s2 * a + c * b; }
-#pragma unroll
-                for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s2 * b; A[q][k] = s2 * a + c * b; }
-#pragma unroll
-                for (int k = 0; k < 3; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s2 * b; V[k][q] = s2 * a + c * b; }
-            }
-    }
-    // ascending order (bubble on 3 values, with the matching columns)
-    double d[3] = {A[0][0], A[1][1], A[2][2]};
-    int o0 = 0, o1 = 1, o2 = 2;
-    if (d[o0] > d[o1]) { const int t = o0; o0 = o1; o1 = t; }
-    if (d[o1] > d[o2]) { const int t = o1; o1 = o2; o2 = t; }
-    if (d[o0] > d[o1]) { const int t = o0; o0 = o1; o1 = t; }
-    const int o[3] = {o0, o1, o2};
-    double Vs[3][3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        ev[k] = o[k] == 0 ? d[0] : (o[k] == 1 ? d[1] : d[2]);
-#pragma unroll
-        for (int r = 0; r < 3; r++) Vs[r][k] = o[k] == 0 ? V[r][0] : (o[k] == 1 ? V[r][1] : V[r][2]);
-    }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) V[r][k] = Vs[r][k];
-}
-
-template <int K, bool VERIFY>
-__global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
-                                                    const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
-                                                    float thr2, double threshold, double plane_eig_thr,
-                                                    PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
-                                                    int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
-                                                    int use_seed, unsigned int* __restrict__ queue,
-                                                    unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
-                                                    unsigned int* __restrict__ changed_items,
-                                                    unsigned long long* __restrict__ staged_total, int lds_boxes)
-{
-    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
-    __shared__ int s_list[4][kMaxList];
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float(*sm)[64] = s_m[wave];
-    int* slist = s_list[wave];
-    // VERIFY = true (warm-started launches): all items; the sweep only COUNTS the points within each query's
-    //   K-th seed distance.  Count == number of seeds <=> the neighbour set is exactly the seeds (every seed lies
-    //   within that distance and is met once), so the sorted seed list IS the answer and no list is maintained
-    //   in the sweep.  Items with a lane whose count differs are queued in redo_list, untouched.
-    // VERIFY = false: the full sweep with sorted-list insertion -- over all items (first launch on a cloud pair:
-    //   redo_list == nullptr) or over the queued items only.
-    const bool from_list = !VERIFY && redo_list != nullptr;
-    if (from_list && *redo_count == 0u) return;  // nothing queued (uniform: before any barrier)
-    const lds_f32* lbox = (const lds_f32*)s_dyn;
-    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
-    const int n_items = from_list ? (int)*redo_count : (N + kQPW - 1) / kQPW;
-    unsigned long long wave_staged = 0ull;
-    unsigned int wave_changed = 0u;  // items of this wave with a lane whose neighbour list differs from its seeds
-    WaveQueue wq(queue, lane);
-    for (int raw = wq.first(); raw < n_items;) {
-        const int next_raw_v = wq.pop();
-        const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : raw;
-
-        float qx[2], qy[2], qz[2], reach[2], kbound[2];
-        float kd[2][K];          // sorted ascending by (d2, original index)
-        unsigned int ko[2][K];   // original indices
-        int kp[2][K];            // sorted-map positions
-        // insert (du, o, pos) into the sorted list of query k (caller has checked that it belongs there)
-        auto insert = [&](int k, float du, unsigned int o, int pos) {
-            kd[k][K - 1] = du; ko[k][K - 1] = o; kp[k][K - 1] = pos;
-#pragma unroll
-            for (int j = K - 1; j > 0; --j) {
-                const bool sw = kd[k][j] < kd[k][j - 1] || (kd[k][j] == kd[k][j - 1] && ko[k][j] < ko[k][j - 1]);
-                const float td = kd[k][j]; const unsigned int to = ko[k][j]; const int tp = kp[k][j];
-                kd[k][j] = sw ? kd[k][j - 1] : td; ko[k][j] = sw ? ko[k][j - 1] : to; kp[k][j] = sw ? kp[k][j - 1] : tp;
-                kd[k][j - 1] = sw ? td : kd[k][j - 1]; ko[k][j - 1] = sw ? to : ko[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
-            }
-        };
-        int qi[2];
-        float lx[2], ly[2], lz[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            qi[k] = item * kQPW + k * 64 + lane;
-            const int ic = qi[k] < N ? qi[k] : N - 1;
-            lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
-#pragma unroll
-            for (int j = 0; j < K; ++j) { kd[k][j] = thr2; ko[k][j] = 0u; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
-        }
-        if (use_seed) {
-            // warm start: the K neighbours of the last launch are exact candidates; with them in the list the
-            // reach is the K-th seed distance instead of the gate, and most tiles are never staged
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int ic = qi[k] < N ? qi[k] : N - 1;
-                int js[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) js[j] = knn_pos[(size_t)ic * K + j];
-                float gx[K], gy[K], gz[K];
-                unsigned int go[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int jc = js[j] >= 0 ? js[j] : 0;
-                    gx[j] = mp.sx[jc]; gy[j] = mp.sy[jc]; gz[j] = mp.sz[jc]; go[j] = (unsigned int)mp.perm[jc];
-                }
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float du = dist2(qx[k], qy[k], qz[k], gx[j], gy[j], gz[j]);
-                    if (js[j] >= 0 && du < thr2) insert(k, du, go[j], js[j]);  // distinct positions: no duplicates among the seeds
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            reach[k] = reach_of(kd[k][K - 1], qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
-            kbound[k] = kd[k][K - 1];  // (fixed during the sweep)
-            if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; kbound[k] = -1.0f; }  // padding lane
-        }
-        // VERIFY: tau = K-th seed distance (list full), else the largest float below gate^2 ("d2 < gate^2" as "<=")
-        float tau[2];
-        int expect[2], cnt[2] = {0, 0};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            int sds = 0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) sds += kp[k][j] >= 0 ? 1 : 0;
-            expect[k] = sds;
-            tau[k] = sds == K ? kd[k][K - 1] : __uint_as_float(__float_as_uint(thr2) - 1u);
-            if (VERIFY && qi[k] < N) kbound[k] = tau[k];
-        }
-
-        const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
-        unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
-        unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
-        const unsigned long long n_staged = tiled_sweep<2, !VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
-            for (int m = 0; m < nm; m += 4) {
-                const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
-                const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
-                const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
-                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
-                if constexpr (VERIFY) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
-                        cnt[0] += dv.x <= tau[0] ? 1 : 0;
-                        cnt[1] += dv.y <= tau[1] ? 1 : 0;
-                    }
-                    continue;
-                }
-                float d[2][4];
-                bool cand = false;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {  // both queries of the lane per packed instruction
-                    const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
-                    d[0][u] = dv.x; d[1][u] = dv.y;
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd[k][K - 1];
-                if (__any(cand)) {  // some lane may have to insert: rare once the lists have tightened
-                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
-                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
-                                                __float_as_uint(O.w)};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int pos = (m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32;
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const float du = d[k][u];
-                            if (du < kd[k][K - 1] || (du == kd[k][K - 1] && os[u] < ko[k][K - 1])) {
-                                bool dup = false;  // a seed met again by the sweep
-#pragma unroll
-                                for (int j = 0; j < K; ++j) dup |= kp[k][j] == pos;
-                                if (!dup) insert(k, du, os[u], pos);
-                            }
-                        }
-                    }
-                }
-            }
-         }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
-
-        bool redo = false;
-        if constexpr (VERIFY) {
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) bad |= qi[k] < N && cnt[k] != expect[k];
-            redo = __any(bad);
-            if (redo && lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
-        }
-        bool item_changed = false;
-        if (!redo) {
-        // Epilogue.  The plane (centroid, normal, is-it-planar) depends only on the ordered neighbour list -- map
-        // points, fixed for the align -- so when a query's list equals the last launch's, the cached plane is reused
-        // bit for bit and the fp64 covariance + Jacobi eigen-solve (dearer than the search itself) is skipped.  Near
-        // convergence almost no list changes; a wave pays for the solve only if one of its lanes needs it.
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = qi[k];
-            const bool in = i < N;
-            const size_t ic = in ? (size_t)i : (size_t)(N - 1);
-            int m = 0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) m += (kp[k][j] >= 0 && kd[k][j] < thr2) ? 1 : 0;  // sorted: the first m entries
-            bool same = use_seed != 0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const int now = j < m ? kp[k][j] : -1;
-                if (use_seed) same &= knn_pos[ic * K + j] == now;
-                if (in) knn_pos[ic * K + j] = now;
-            }
-            PlanePair pl;  // the plane of the list: valid = "is a plane" (before the query-distance test)
-            pl.valid = 0; pl.n_neigh = m;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { pl.c[a] = 0; pl.n[a] = 0; }
-            const bool solve = in && !same;
-            if (__any(solve)) {
-                item_changed = true;
-                if (solve && m >= 3) {
-                    double px[K], py[K], pz[K];
-                    double mean[3] = {0, 0, 0};
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        px[j] = py[j] = pz[j] = 0;
-                        if (j < m) {
-                            px[j] = mp.sx[kp[k][j]]; py[j] = mp.sy[kp[k][j]]; pz[j] = mp.sz[kp[k][j]];
-                            mean[0] += px[j]; mean[1] += py[j]; mean[2] += pz[j];
-                        }
-                    }
-                    const double dm = (double)m;
-                    mean[0] /= dm; mean[1] /= dm; mean[2] /= dm;
-                    double Cm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        if (j < m) {
-                            const double dd[3] = {px[j] - mean[0], py[j] - mean[1], pz[j] - mean[2]};
-#pragma unroll
-                            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                                for (int c = 0; c < 3; ++c) Cm[r][c] += dd[r] * dd[c];
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) Cm[r][c] /= dm;
-                    double ev[3], V[3][3];
-                    eig_sym3_dev(Cm, ev, V);
-                    if (!(ev[0] > plane_eig_thr * ev[2])) {
-                        pl.valid = 1;
-                        pl.c[0] = mean[0]; pl.c[1] = mean[1]; pl.c[2] = mean[2];
-                        pl.n[0] = V[0][0]; pl.n[1] = V[1][0]; pl.n[2] = V[2][0];
-                    }
-                }
-                if (solve) cache[ic] = pl;
-            }
-            if (in && same) pl = cache[ic];
-            if (in) {
-                PlanePair pp = pl;
-                if (pl.valid) {
-                    const double dist = fabs(pl.n[0] * ((double)qx[k] - pl.c[0]) + pl.n[1] * ((double)qy[k] - pl.c[1]) +
-                                             pl.n[2] * ((double)qz[k] - pl.c[2]));
-                    if (dist > threshold) {
-                        pp.valid = 0;
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) { pp.c[a] = 0; pp.n[a] = 0; }
-                    }
-                }
-                out[ic] = pp;
-            }
-        }
-        }  // (epilogue)
-        wave_changed += item_changed ? 1u : 0u;
-        wave_staged += n_staged * 2;  // units of 64 (query, point) pairs
-        raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items);
-    }
-    if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
-    // (the verify flavour reports its queued items through redo_count; the queued-items launch must not count twice)
-    if (!VERIFY && !from_list && lane == 0 && wave_changed) atomicAdd(changed_items, wave_changed);
-}
-
-// the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
-// x = [R row-major (9), t (3)]  with  phi = [n (x) l, n],  d = n.c :   A = sum phi phi^T (78 unique),
-// b = sum phi d (12), c0 = sum d^2, count.  ONE pass -> the whole Gauss-Newton inner loop runs on the host.
-constexpr int kNAccPlane = 92;  // 78 + 12 + 1 + 1
-__global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restrict__ slx, const float* __restrict__ sly,
-                                                           const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
-                                                           int N, double* __restrict__ partials)
-{
-    double acc[kNAccPlane];
-#pragma unroll
-    for (int k = 0; k < kNAccPlane; ++k) acc[k] = 0.0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
-        const PlanePair pp = pairs[i];
-        if (!pp.valid) continue;
-        const double l[3] = {slx[i], sly[i], slz[i]};
-        double phi[12];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) phi[3 * r + c] = pp.n[r] * l[c];
-            phi[9 + r] = pp.n[r];
-        }
-        const double d = pp.n[0] * pp.c[0] + pp.n[1] * pp.c[1] + pp.n[2] * pp.c[2];
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 12; ++a)
-#pragma unroll
-            for (int b = a; b < 12; ++b) acc[q++] += phi[a] * phi[b];
-#pragma unroll
-        for (int a = 0; a < 12; ++a) acc[78 + a] += phi[a] * d;
-        acc[90] += d * d;
-        acc[91] += 1.0;
-    }
-    __shared__ double sm[4][kNAccPlane];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kNAccPlane; ++k) {
-        double v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sm[wave][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNAccPlane) {
-        double v = 0.0;
-        for (int w = 0; w < 4; ++w) v += sm[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNAccPlane + threadIdx.x] = v;
-    }
-}
-
-// fixed-order sum of [nblocks][n] partial rows (n <= 128): 8 slices of rows per accumulator with the loads of a
-// slice independent of each other, then the 8 slice sums in order.  Deterministic for a given nblocks.
-__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
-                                                      double* __restrict__ acc, const unsigned int* __restrict__ counters)
-{
-    // acc[n] = items of the plane matcher whose neighbour lists changed in this iteration (its next launch picks
-    // the counting or the insertion flavour from it): counters[0] (insertion launch) + counters[2] (queued by verify)
-    if (counters && threadIdx.x == 0) acc[n] = (double)(counters[0] + counters[2]);
-    __shared__ double sm[8][128];
-    const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
-    double v = 0.0;
-    if (k < n) {
-        int b = sl;
-        for (; b + 24 < nblocks; b += 32) {  // four rows in flight
-            const double a0 = partials[(size_t)b * n + k], a1 = partials[(size_t)(b + 8) * n + k];
-            const double a2 = partials[(size_t)(b + 16) * n + k], a3 = partials[(size_t)(b + 24) * n + k];
-            v += a0; v += a1; v += a2; v += a3;
-        }
-        for (; b < nblocks; b += 8) v += partials[(size_t)b * n + k];
-    }
-    sm[sl][k] = v;
-    __syncthreads();
-    if (sl == 0 && k < n) {
-        double t = 0.0;
-        for (int s2 = 0; s2 < 8; ++s2) t += sm[s2][k];
-        acc[k] = t;
-    }
-}
-
-// plane pairing in sorted query order -> original order (tests / callers that want the pairing)
-__global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict__ qperm, const PlanePair* __restrict__ in,
-                                                          const int* __restrict__ perm, const int* __restrict__ knn_pos,
-                                                          int K, int N, PlanePair* __restrict__ out, int* __restrict__ knn_idx)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const int o = qperm[i];
-    out[o] = in[i];
-    if (knn_idx && knn_pos)
-        for (int j = 0; j < K; ++j) {
-            const int ps = knn_pos[(size_t)i * K + j];
-            knn_idx[(size_t)o * K + j] = ps >= 0 ? perm[ps] : -1;
-        }
-}
-
-// number of kept pairs of a stored pairing (only when a caller asks for it)
-__global__ __launch_bounds__(256) void k_count_kept(const int* __restrict__ idx, int N, unsigned int* __restrict__ counter)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    unsigned int kept = (i < N && idx[i] >= 0) ? 1u : 0u;
-    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
-    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, kept);
-}
-
-// heavy-first work order for the next launches: counting sort of the 128-query items by the cycles they took in
-// the last launch (32 buckets relative to the maximum), one 1024-thread block.  Longest-processing-time-first
-// keeps the persistent waves' tail short when a few query groups are much heavier than the rest.
-// (Cutting the heavy groups into smaller items was measured and dropped: an item's cost is mostly fixed
-// overhead -- box scan, staging and epilogue round trips -- so halves cost nearly as much as the whole.)
-__global__ __launch_bounds__(1024) void k_order_items(const unsigned int* __restrict__ cost, int n_items,
-                                                      int* __restrict__ order)
-{
-    __shared__ unsigned int s_max, s_cnt[32], s_off[32];
-    if (threadIdx.x == 0) s_max = 1u;
-    if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    unsigned int mx = 1u;
-    for (int i = threadIdx.x; i < n_items; i += 1024) mx = max(mx, cost[i]);
-    atomicMax(&s_max, mx);
-    __syncthreads();
-    const float scale = 32.0f / (float)s_max;
-    for (int i = threadIdx.x; i < n_items; i += 1024) {
-        const int b = 31 - min(31, (int)((float)cost[i] * scale));  // bucket 0 = heaviest
-        atomicAdd(&s_cnt[b], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int o = 0;
-        for (int b = 0; b < 32; ++b) { s_off[b] = o; o += s_cnt[b]; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_items; i += 1024) {
-        const int b = 31 - min(31, (int)((float)cost[i] * scale));
-        order[atomicAdd(&s_off[b], 1u)] = i;
-    }
-}
-
-// sorted-order pairing -> original query order (only when a caller asks for the pairing)
-__global__ __launch_bounds__(256) void k_unpermute_pairing(const int* __restrict__ qperm, const int* __restrict__ idx_s,
-                                                           const float* __restrict__ d2_s, int N,
-                                                           int* __restrict__ out_idx, float* __restrict__ out_d2)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const int o = qperm[i];
-    out_idx[o] = idx_s[i];
-    out_d2[o] = d2_s[i];
-}
-
-// boxes of the map tiles (one thread per tile) and super-tiles (one thread per super-tile); SoA [6][n]
-__global__ __launch_bounds__(256) void k_tile_boxes(const float* __restrict__ sx, const float* __restrict__ sy,
-                                                    const float* __restrict__ sz, int M, int n_tiles_p,
-                                                    float* __restrict__ tbox)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_tiles_p) return;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    const int j0 = t * kTileG, j1 = min(j0 + kTileG, M);
-    for (int j = j0; j < j1; ++j) {
-        mn[0] = fminf(mn[0], sx[j]); mx[0] = fmaxf(mx[0], sx[j]);
-        mn[1] = fminf(mn[1], sy[j]); mx[1] = fmaxf(mx[1], sy[j]);
-        mn[2] = fminf(mn[2], sz[j]); mx[2] = fmaxf(mx[2], sz[j]);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { tbox[k * n_tiles_p + t] = mn[k]; tbox[(3 + k) * n_tiles_p + t] = mx[k]; }
-}
-
-__global__ __launch_bounds__(256) void k_super_boxes(const float* __restrict__ tbox, int n_tiles_p, int n_super,
-                                                     float* __restrict__ sbox)
-{
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_super) return;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int t = s * kSuper; t < (s + 1) * kSuper; ++t) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            mn[k] = fminf(mn[k], tbox[k * n_tiles_p + t]);
-            mx[k] = fmaxf(mx[k], tbox[(3 + k) * n_tiles_p + t]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { sbox[k * n_super + s] = mn[k]; sbox[(3 + k) * n_super + s] = mx[k]; }
-}
-
-// ---- map preparation for the MFMA matcher (once per map) -------------------------------
-// bounding box: per-block partial min/max -> [nblocks][6]; second stage on one block
-__global__ __launch_bounds__(256) void k_bbox_partial(const float* __restrict__ gx, const float* __restrict__ gy,
-                                                      const float* __restrict__ gz, int M, float* __restrict__ part)
-{
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
-        const float v[3] = {gx[i], gy[i], gz[i]};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
-    }
-    __shared__ float sm[4][6];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        for (int off = 32; off > 0; off >>= 1) {
-            mn[k] = fminf(mn[k], __shfl_down(mn[k], off));
-            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off));
-        }
-        if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][k] = mn[k]; sm[threadIdx.x >> 6][3 + k] = mx[k]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        float v = sm[0][threadIdx.x];
-        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
-        part[blockIdx.x * 6 + threadIdx.x] = v;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_bbox_final(const float* __restrict__ part, int nblocks, float* __restrict__ out)
-{
-    if (threadIdx.x < 6) {
-        float v = part[threadIdx.x];
-        for (int b = 1; b < nblocks; ++b)
-            v = threadIdx.x < 3 ? fminf(v, part[b * 6 + threadIdx.x]) : fmaxf(v, part[b * 6 + threadIdx.x]);
-        out[threadIdx.x] = v;
-    }
-}
-
-// map image [tile][k][16]: k<3 -> -2*(m_k - c_k), k=3 -> |m - c|^2 (1 - 20u) (the map-point share of
-// the filter's error bound, folded in).  Rows >= M are padding.
-__global__ __launch_bounds__(256) void k_map_image(const float* __restrict__ gx, const float* __restrict__ gy,
-                                                   const float* __restrict__ gz, int M, int M_padded, MapFrame F,
-                                                   float* __restrict__ img)
-{
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= M_padded) return;
-    float ax = 0.f, ay = 0.f, az = 0.f, mm = kMapPadNorm;
-    if (p < M) {
-        const float x = gx[p] - F.cx, y = gy[p] - F.cy, z = gz[p] - F.cz;
-        const float n = fmaf(z, z, fmaf(y, y, x * x));
-        mm = n - kFoldCoef * n;
-        ax = -2.0f * x; ay = -2.0f * y; az = -2.0f * z;
-    }
-    float* t = img + (size_t)(p >> 4) * 64 + (p & 15);
-    t[0] = ax; t[16] = ay; t[32] = az; t[48] = mm;
-}
-
-// ---- accumulation (row a8) ---------------------------------------------------------
-struct AccArgs {
-    const float *lx, *ly, *lz, *gx, *gy, *gz;
-    const int* idx;
-    const float* d2;
-    unsigned char* outlier;
-    int N;
-    int stage;
-    int use_scale;
-    int use_robust;
-    double scale_thr, rk_param, rk_scale;
-    double cl[3], cg[3];
-    double R[9];
-};
-
-constexpr int kAccThreads = 256;
-constexpr int kAccMaxBlocks = 512;   // rows of partial sums (fixed for a given N: deterministic reduction)
-
-__global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* __restrict__ partials)
-{
-    double s[kNAcc];
-#pragma unroll
-    for (int k = 0; k < kNAcc; ++k) s[k] = 0.0;
-    const int stride = gridDim.x * kAccThreads;
-    // one pairing -> the 24 sums; elements are taken in ascending i per thread (fixed summation order)
-    auto element = [&](int i, int j, unsigned char out, double l0, double l1, double l2, double g0, double g1, double g2,
-                       float d2v) {
-        if (j < 0 || out) return;
-        double w = 1.0;
-        if (a.stage == 1) {
-            double b0 = g0 - a.cg[0], b1 = g1 - a.cg[1], b2 = g2 - a.cg[2];
-            double r0 = l0 - a.cl[0], r1 = l1 - a.cl[1], r2 = l2 - a.cl[2];
-            const double bn = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
-            const double rn = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-            if (bn < 1e-4 || rn < 1e-4) return;
-            if (a.use_scale) {
-                const double hi = bn > rn ? bn : rn, lo = bn > rn ? rn : bn;
-                if (hi / lo > a.scale_thr) {
-                    a.outlier[i] = 1;
-                    return;
-                }
-            }
-            if (a.use_robust) {
-                b0 /= bn; b1 /= bn; b2 /= bn;
-                r0 /= rn; r1 /= rn; r2 /= rn;
-                const double x = a.R[0] * r0 + a.R[1] * r1 + a.R[2] * r2;
-                const double y = a.R[3] * r0 + a.R[4] * r1 + a.R[5] * r2;
-                const double z = a.R[6] * r0 + a.R[7] * r1 + a.R[8] * r2;
-                double c = x * b0 + y * b1 + z * b2;
-                c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
-                const double ang = acos(c);
-                if (ang > a.rk_param) {
-                    const double e = ang - a.rk_param;
-                    w *= 1.0 / (1.0 + a.rk_scale * e * e);
-                }
-            }
-        }
-        s[0] += w;
-        s[1] += w * l0; s[2] += w * l1; s[3] += w * l2;
-        s[4] += w * g0; s[5] += w * g1; s[6] += w * g2;
-        s[7] += w * l0 * g0; s[8] += w * l0 * g1; s[9] += w * l0 * g2;
-        s[10] += w * l1 * g0; s[11] += w * l1 * g1; s[12] += w * l1 * g2;
-        s[13] += w * l2 * g0; s[14] += w * l2 * g1; s[15] += w * l2 * g2;
-        s[16] += 1.0;
-        s[17] += (double)d2v;
-        s[18] += w * l0 * l0; s[19] += w * l0 * l1; s[20] += w * l0 * l2;
-        s[21] += w * l1 * l1; s[22] += w * l1 * l2; s[23] += w * l2 * l2;
-    };
-    // two elements per trip with all their loads issued up front (the gather by neighbour position is a dependent
-    // load: this halves the exposed latency); they are summed in the same order as a one-by-one loop
-    for (int i = blockIdx.x * kAccThreads + threadIdx.x; i < a.N; i += 2 * stride) {
-        const int i2 = i + stride;
-        const bool in2 = i2 < a.N;
-        const int ic2 = in2 ? i2 : i;
-        const int jA = a.idx[i], jB = in2 ? a.idx[ic2] : -1;
-        const unsigned char oA = a.outlier[i], oB = a.outlier[ic2];
-        const float lA0 = a.lx[i], lA1 = a.ly[i], lA2 = a.lz[i], dA = a.d2[i];
-        const float lB0 = a.lx[ic2], lB1 = a.ly[ic2], lB2 = a.lz[ic2], dB = a.d2[ic2];
-        const int jcA = jA >= 0 ? jA : 0, jcB = jB >= 0 ? jB : 0;
-        const float gA0 = a.gx[jcA], gA1 = a.gy[jcA], gA2 = a.gz[jcA];
-        const float gB0 = a.gx[jcB], gB1 = a.gy[jcB], gB2 = a.gz[jcB];
-        element(i, jA, oA, lA0, lA1, lA2, gA0, gA1, gA2, dA);
-        element(i2, jB, oB, lB0, lB1, lB2, gB0, gB1, gB2, dB);
-    }
-    // fixed-order reduction: lanes (shuffle tree) -> waves (LDS, in wave order) -> one row per block
-    __shared__ double sm[kAccThreads / 64][kNAcc];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kNAcc; ++k) {
-        double v = s[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sm[wave][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNAcc) {
-        double v = 0.0;
-        for (int w = 0; w < kAccThreads / 64; ++w) v += sm[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNAcc + threadIdx.x] = v;
-    }
-}
-
-// sums the per-block rows in a fixed order: 32 interleaved slices per accumulator, then the slices in order
-constexpr int kRedSlices = 32;
-__global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const double* __restrict__ partials, int nblocks,
-                                                                        double* __restrict__ acc,
-                                                                        double* __restrict__ host_out /*pinned, may be null*/,
-                                                                        unsigned long long seq)
-{
-    __shared__ double sm[kRedSlices][kNAcc];
-    const int k = threadIdx.x % kNAcc, sl = threadIdx.x / kNAcc;
-    double v = 0.0;
-    for (int b = sl; b < nblocks; b += kRedSlices) v += partials[(size_t)b * kNAcc + k];
-    sm[sl][k] = v;
-    __syncthreads();
-    if (threadIdx.x < kNAcc) {
-        double t = 0.0;
-        for (int s = 0; s < kRedSlices; ++s) t += sm[s][threadIdx.x];
-        acc[threadIdx.x] = t;
-        if (host_out) host_out[threadIdx.x] = t;  // straight into the host's pinned block: no copy engine, no extra launch gap
-    }
-    if (host_out) {  // publish: data first, then the sequence number the host spins on
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            reinterpret_cast<volatile unsigned long long*>(host_out)[kNAcc + 6] = seq;  // (slots 24..29 serve other read-backs)
-            __threadfence_system();
-        }
-    }
-    // the matcher's work-queue / kept / redo counters sit right behind the block: leave them zero for its next launch
-    if (threadIdx.x == kNAcc) { acc[kNAcc] = 0.0; acc[kNAcc + 1] = 0.0; }
-    if (threadIdx.x >= 32 && threadIdx.x < 32 + 2 * kQueues)  // the tiled matcher's work-queue counters
-        reinterpret_cast<unsigned int*>(acc + kNAcc + 8)[(threadIdx.x - 32) * kQueueStride] = 0u;
-}
+namespace mola_icp_amd {
 
 // ------------------------------------------------------------------ host code
 

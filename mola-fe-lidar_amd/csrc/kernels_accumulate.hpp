@@ -1,0 +1,143 @@
+// kernels_accumulate.hpp -- row a8: weighted centroid / covariance accumulation and its fixed-order reduction
+// Device code of the ICP core for gfx950; included by hip_backend.hip only (one translation unit: the kernels are
+// launched from there).  Numeric contract and data layout: hip_backend.hip / DESIGN.md.
+#pragma once
+#include "kernels_tiled.hpp"
+
+namespace mola_icp_amd {
+
+// ---- accumulation (row a8) ---------------------------------------------------------
+struct AccArgs {
+    const float *lx, *ly, *lz, *gx, *gy, *gz;
+    const int* idx;
+    const float* d2;
+    unsigned char* outlier;
+    int N;
+    int stage;
+    int use_scale;
+    int use_robust;
+    double scale_thr, rk_param, rk_scale;
+    double cl[3], cg[3];
+    double R[9];
+};
+
+constexpr int kAccThreads = 256;
+constexpr int kAccMaxBlocks = 512;   // rows of partial sums (fixed for a given N: deterministic reduction)
+
+__global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* __restrict__ partials)
+{
+    double s[kNAcc];
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) s[k] = 0.0;
+    const int stride = gridDim.x * kAccThreads;
+    // one pairing -> the 24 sums; elements are taken in ascending i per thread (fixed summation order)
+    auto element = [&](int i, int j, unsigned char out, double l0, double l1, double l2, double g0, double g1, double g2,
+                       float d2v) {
+        if (j < 0 || out) return;
+        double w = 1.0;
+        if (a.stage == 1) {
+            double b0 = g0 - a.cg[0], b1 = g1 - a.cg[1], b2 = g2 - a.cg[2];
+            double r0 = l0 - a.cl[0], r1 = l1 - a.cl[1], r2 = l2 - a.cl[2];
+            const double bn = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+            const double rn = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+            if (bn < 1e-4 || rn < 1e-4) return;
+            if (a.use_scale) {
+                const double hi = bn > rn ? bn : rn, lo = bn > rn ? rn : bn;
+                if (hi / lo > a.scale_thr) {
+                    a.outlier[i] = 1;
+                    return;
+                }
+            }
+            if (a.use_robust) {
+                b0 /= bn; b1 /= bn; b2 /= bn;
+                r0 /= rn; r1 /= rn; r2 /= rn;
+                const double x = a.R[0] * r0 + a.R[1] * r1 + a.R[2] * r2;
+                const double y = a.R[3] * r0 + a.R[4] * r1 + a.R[5] * r2;
+                const double z = a.R[6] * r0 + a.R[7] * r1 + a.R[8] * r2;
+                double c = x * b0 + y * b1 + z * b2;
+                c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+                const double ang = acos(c);
+                if (ang > a.rk_param) {
+                    const double e = ang - a.rk_param;
+                    w *= 1.0 / (1.0 + a.rk_scale * e * e);
+                }
+            }
+        }
+        s[0] += w;
+        s[1] += w * l0; s[2] += w * l1; s[3] += w * l2;
+        s[4] += w * g0; s[5] += w * g1; s[6] += w * g2;
+        s[7] += w * l0 * g0; s[8] += w * l0 * g1; s[9] += w * l0 * g2;
+        s[10] += w * l1 * g0; s[11] += w * l1 * g1; s[12] += w * l1 * g2;
+        s[13] += w * l2 * g0; s[14] += w * l2 * g1; s[15] += w * l2 * g2;
+        s[16] += 1.0;
+        s[17] += (double)d2v;
+        s[18] += w * l0 * l0; s[19] += w * l0 * l1; s[20] += w * l0 * l2;
+        s[21] += w * l1 * l1; s[22] += w * l1 * l2; s[23] += w * l2 * l2;
+    };
+    // two elements per trip with all their loads issued up front (the gather by neighbour position is a dependent
+    // load: this halves the exposed latency); they are summed in the same order as a one-by-one loop
+    for (int i = blockIdx.x * kAccThreads + threadIdx.x; i < a.N; i += 2 * stride) {
+        const int i2 = i + stride;
+        const bool in2 = i2 < a.N;
+        const int ic2 = in2 ? i2 : i;
+        const int jA = a.idx[i], jB = in2 ? a.idx[ic2] : -1;
+        const unsigned char oA = a.outlier[i], oB = a.outlier[ic2];
+        const float lA0 = a.lx[i], lA1 = a.ly[i], lA2 = a.lz[i], dA = a.d2[i];
+        const float lB0 = a.lx[ic2], lB1 = a.ly[ic2], lB2 = a.lz[ic2], dB = a.d2[ic2];
+        const int jcA = jA >= 0 ? jA : 0, jcB = jB >= 0 ? jB : 0;
+        const float gA0 = a.gx[jcA], gA1 = a.gy[jcA], gA2 = a.gz[jcA];
+        const float gB0 = a.gx[jcB], gB1 = a.gy[jcB], gB2 = a.gz[jcB];
+        element(i, jA, oA, lA0, lA1, lA2, gA0, gA1, gA2, dA);
+        element(i2, jB, oB, lB0, lB1, lB2, gB0, gB1, gB2, dB);
+    }
+    // fixed-order reduction: lanes (shuffle tree) -> waves (LDS, in wave order) -> one row per block
+    __shared__ double sm[kAccThreads / 64][kNAcc];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) {
+        double v = s[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNAcc) {
+        double v = 0.0;
+        for (int w = 0; w < kAccThreads / 64; ++w) v += sm[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNAcc + threadIdx.x] = v;
+    }
+}
+
+// sums the per-block rows in a fixed order: 32 interleaved slices per accumulator, then the slices in order
+constexpr int kRedSlices = 32;
+__global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const double* __restrict__ partials, int nblocks,
+                                                                        double* __restrict__ acc,
+                                                                        double* __restrict__ host_out /*pinned, may be null*/,
+                                                                        unsigned long long seq)
+{
+    __shared__ double sm[kRedSlices][kNAcc];
+    const int k = threadIdx.x % kNAcc, sl = threadIdx.x / kNAcc;
+    double v = 0.0;
+    for (int b = sl; b < nblocks; b += kRedSlices) v += partials[(size_t)b * kNAcc + k];
+    sm[sl][k] = v;
+    __syncthreads();
+    if (threadIdx.x < kNAcc) {
+        double t = 0.0;
+        for (int s = 0; s < kRedSlices; ++s) t += sm[s][threadIdx.x];
+        acc[threadIdx.x] = t;
+        if (host_out) host_out[threadIdx.x] = t;  // straight into the host's pinned block: no copy engine, no extra launch gap
+    }
+    if (host_out) {  // publish: data first, then the sequence number the host spins on
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            reinterpret_cast<volatile unsigned long long*>(host_out)[kNAcc + 6] = seq;  // (slots 24..29 serve other read-backs)
+            __threadfence_system();
+        }
+    }
+    // the matcher's work-queue / kept / redo counters sit right behind the block: leave them zero for its next launch
+    if (threadIdx.x == kNAcc) { acc[kNAcc] = 0.0; acc[kNAcc + 1] = 0.0; }
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + 2 * kQueues)  // the tiled matcher's work-queue counters
+        reinterpret_cast<unsigned int*>(acc + kNAcc + 8)[(threadIdx.x - 32) * kQueueStride] = 0u;
+}
+
+}  // namespace mola_icp_amd

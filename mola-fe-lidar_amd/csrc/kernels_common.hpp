@@ -1,0 +1,41 @@
+// kernels_common.hpp -- pose transform and the distance contract shared by every matcher kernel
+// Device code of the ICP core for gfx950; included by hip_backend.hip only (one translation unit: the kernels are
+// launched from there).  Numeric contract and data layout: hip_backend.hip / DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hip_backend.hpp"
+
+namespace mola_icp_amd {
+
+
+struct PoseF {
+    float R[9];
+    float t[3];
+};
+
+__device__ __forceinline__ void xform(const PoseF& P, float lx, float ly, float lz, float& qx, float& qy, float& qz)
+{
+    float a;
+    a = fmaf(P.R[0], lx, P.t[0]); a = fmaf(P.R[1], ly, a); qx = fmaf(P.R[2], lz, a);
+    a = fmaf(P.R[3], lx, P.t[1]); a = fmaf(P.R[4], ly, a); qy = fmaf(P.R[5], lz, a);
+    a = fmaf(P.R[6], lx, P.t[2]); a = fmaf(P.R[7], ly, a); qz = fmaf(P.R[8], lz, a);
+}
+
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, float gx, float gy, float gz)
+{
+    const float dx = qx - gx, dy = qy - gy, dz = qz - gz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+// largest float <= x (HIP's __double2float_rd is not relied upon)
+__device__ __forceinline__ float down_f32(double x)
+{
+    float f = (float)x;
+    if ((double)f > x) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1u : (f < 0.f ? __float_as_uint(f) + 1u : 0x80000001u));
+    return f;
+}
+
+constexpr float kPadCoord = 1.0e18f;  // padding map points: d2 ~ 3e36, finite, never the minimum
+
+}  // namespace mola_icp_amd

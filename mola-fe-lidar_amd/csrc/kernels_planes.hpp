@@ -1,0 +1,417 @@
+// kernels_planes.hpp -- point-to-plane matcher k_knn_planes and its quadratic-form accumulation
+// Device code of the ICP core for gfx950; included by hip_backend.hip only (one translation unit: the kernels are
+// launched from there).  Numeric contract and data layout: hip_backend.hip / DESIGN.md.
+#pragma once
+#include "kernels_tiled.hpp"
+
+namespace mola_icp_amd {
+
+// ---- row f3: point-to-plane matcher (mp2p_icp::Matcher_Point2Plane, params/icp-settings-regular.yaml:33-39) ----
+// Same tiled sweep; the visitor keeps, per query, the K nearest points as a sorted list ordered by
+// (d2, original index).  The reach is the gate (distanceThreshold): only neighbours inside it matter.
+// Epilogue per query: the neighbours inside the gate (need >= 3) -> mean + covariance in fp64 -> cyclic
+// Jacobi eigen-decomposition -> plane iff e0 <= planeEigenThreshold * e2, normal = eigenvector of e0,
+// pairing iff |n.(q - mean)| <= distanceThreshold.  [EXT-recalled mp2p_icp behaviour; restated in the
+// CPU checker with the same operation order.]
+struct PlanePair {      // one per query, sorted query order
+    double c[3];        // plane centroid
+    double n[3];        // unit normal
+    int valid, n_neigh;
+};
+
+__device__ __forceinline__ void eig_sym3_dev(const double Cin[3][3], double ev[3], double V[3][3])
+{
+    double A[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { A[i][j] = Cin[i][j]; V[i][j] = (i == j); }
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off == 0 || off < 1e-34 * dg) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                if (A[p][q] == 0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(tt * tt + 1), s2 = tt * c;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s2 * b; A[k][q] = s2 * a + c * b; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s2 * b; A[q][k] = s2 * a + c * b; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s2 * b; V[k][q] = s2 * a + c * b; }
+            }
+    }
+    // ascending order (bubble on 3 values, with the matching columns)
+    double d[3] = {A[0][0], A[1][1], A[2][2]};
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (d[o0] > d[o1]) { const int t = o0; o0 = o1; o1 = t; }
+    if (d[o1] > d[o2]) { const int t = o1; o1 = o2; o2 = t; }
+    if (d[o0] > d[o1]) { const int t = o0; o0 = o1; o1 = t; }
+    const int o[3] = {o0, o1, o2};
+    double Vs[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        ev[k] = o[k] == 0 ? d[0] : (o[k] == 1 ? d[1] : d[2]);
+#pragma unroll
+        for (int r = 0; r < 3; r++) Vs[r][k] = o[k] == 0 ? V[r][0] : (o[k] == 1 ? V[r][1] : V[r][2]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) V[r][k] = Vs[r][k];
+}
+
+template <int K, bool VERIFY>
+__global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                    const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
+                                                    float thr2, double threshold, double plane_eig_thr,
+                                                    PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
+                                                    int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
+                                                    int use_seed, unsigned int* __restrict__ queue,
+                                                    unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
+                                                    unsigned int* __restrict__ changed_items,
+                                                    unsigned long long* __restrict__ staged_total, int lds_boxes)
+{
+    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
+    __shared__ int s_list[4][kMaxList];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float(*sm)[64] = s_m[wave];
+    int* slist = s_list[wave];
+    // VERIFY = true (warm-started launches): all items; the sweep only COUNTS the points within each query's
+    //   K-th seed distance.  Count == number of seeds <=> the neighbour set is exactly the seeds (every seed lies
+    //   within that distance and is met once), so the sorted seed list IS the answer and no list is maintained
+    //   in the sweep.  Items with a lane whose count differs are queued in redo_list, untouched.
+    // VERIFY = false: the full sweep with sorted-list insertion -- over all items (first launch on a cloud pair:
+    //   redo_list == nullptr) or over the queued items only.
+    const bool from_list = !VERIFY && redo_list != nullptr;
+    if (from_list && *redo_count == 0u) return;  // nothing queued (uniform: before any barrier)
+    const lds_f32* lbox = (const lds_f32*)s_dyn;
+    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
+    const int n_items = from_list ? (int)*redo_count : (N + kQPW - 1) / kQPW;
+    unsigned long long wave_staged = 0ull;
+    unsigned int wave_changed = 0u;  // items of this wave with a lane whose neighbour list differs from its seeds
+    WaveQueue wq(queue, lane);
+    for (int raw = wq.first(); raw < n_items;) {
+        const int next_raw_v = wq.pop();
+        const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : raw;
+
+        float qx[2], qy[2], qz[2], reach[2], kbound[2];
+        float kd[2][K];          // sorted ascending by (d2, original index)
+        unsigned int ko[2][K];   // original indices
+        int kp[2][K];            // sorted-map positions
+        // insert (du, o, pos) into the sorted list of query k (caller has checked that it belongs there)
+        auto insert = [&](int k, float du, unsigned int o, int pos) {
+            kd[k][K - 1] = du; ko[k][K - 1] = o; kp[k][K - 1] = pos;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                const bool sw = kd[k][j] < kd[k][j - 1] || (kd[k][j] == kd[k][j - 1] && ko[k][j] < ko[k][j - 1]);
+                const float td = kd[k][j]; const unsigned int to = ko[k][j]; const int tp = kp[k][j];
+                kd[k][j] = sw ? kd[k][j - 1] : td; ko[k][j] = sw ? ko[k][j - 1] : to; kp[k][j] = sw ? kp[k][j - 1] : tp;
+                kd[k][j - 1] = sw ? td : kd[k][j - 1]; ko[k][j - 1] = sw ? to : ko[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
+            }
+        };
+        int qi[2];
+        float lx[2], ly[2], lz[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            qi[k] = item * kQPW + k * 64 + lane;
+            const int ic = qi[k] < N ? qi[k] : N - 1;
+            lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) { kd[k][j] = thr2; ko[k][j] = 0u; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
+        }
+        if (use_seed) {
+            // warm start: the K neighbours of the last launch are exact candidates; with them in the list the
+            // reach is the K-th seed distance instead of the gate, and most tiles are never staged
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ic = qi[k] < N ? qi[k] : N - 1;
+                int js[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) js[j] = knn_pos[(size_t)ic * K + j];
+                float gx[K], gy[K], gz[K];
+                unsigned int go[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int jc = js[j] >= 0 ? js[j] : 0;
+                    gx[j] = mp.sx[jc]; gy[j] = mp.sy[jc]; gz[j] = mp.sz[jc]; go[j] = (unsigned int)mp.perm[jc];
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float du = dist2(qx[k], qy[k], qz[k], gx[j], gy[j], gz[j]);
+                    if (js[j] >= 0 && du < thr2) insert(k, du, go[j], js[j]);  // distinct positions: no duplicates among the seeds
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            reach[k] = reach_of(kd[k][K - 1], qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
+            kbound[k] = kd[k][K - 1];  // (fixed during the sweep)
+            if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; kbound[k] = -1.0f; }  // padding lane
+        }
+        // VERIFY: tau = K-th seed distance (list full), else the largest float below gate^2 ("d2 < gate^2" as "<=")
+        float tau[2];
+        int expect[2], cnt[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int sds = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) sds += kp[k][j] >= 0 ? 1 : 0;
+            expect[k] = sds;
+            tau[k] = sds == K ? kd[k][K - 1] : __uint_as_float(__float_as_uint(thr2) - 1u);
+            if (VERIFY && qi[k] < N) kbound[k] = tau[k];
+        }
+
+        const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
+        unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
+        unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
+        const unsigned long long n_staged = tiled_sweep<2, !VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
+            for (int m = 0; m < nm; m += 4) {
+                const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+                const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+                const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
+                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                if constexpr (VERIFY) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                        cnt[0] += dv.x <= tau[0] ? 1 : 0;
+                        cnt[1] += dv.y <= tau[1] ? 1 : 0;
+                    }
+                    continue;
+                }
+                float d[2][4];
+                bool cand = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // both queries of the lane per packed instruction
+                    const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                    d[0][u] = dv.x; d[1][u] = dv.y;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd[k][K - 1];
+                if (__any(cand)) {  // some lane may have to insert: rare once the lists have tightened
+                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
+                                                __float_as_uint(O.w)};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int pos = (m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const float du = d[k][u];
+                            if (du < kd[k][K - 1] || (du == kd[k][K - 1] && os[u] < ko[k][K - 1])) {
+                                bool dup = false;  // a seed met again by the sweep
+#pragma unroll
+                                for (int j = 0; j < K; ++j) dup |= kp[k][j] == pos;
+                                if (!dup) insert(k, du, os[u], pos);
+                            }
+                        }
+                    }
+                }
+            }
+         }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
+
+        bool redo = false;
+        if constexpr (VERIFY) {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) bad |= qi[k] < N && cnt[k] != expect[k];
+            redo = __any(bad);
+            if (redo && lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
+        }
+        bool item_changed = false;
+        if (!redo) {
+        // Epilogue.  The plane (centroid, normal, is-it-planar) depends only on the ordered neighbour list -- map
+        // points, fixed for the align -- so when a query's list equals the last launch's, the cached plane is reused
+        // bit for bit and the fp64 covariance + Jacobi eigen-solve (dearer than the search itself) is skipped.  Near
+        // convergence almost no list changes; a wave pays for the solve only if one of its lanes needs it.
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = qi[k];
+            const bool in = i < N;
+            const size_t ic = in ? (size_t)i : (size_t)(N - 1);
+            int m = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) m += (kp[k][j] >= 0 && kd[k][j] < thr2) ? 1 : 0;  // sorted: the first m entries
+            bool same = use_seed != 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int now = j < m ? kp[k][j] : -1;
+                if (use_seed) same &= knn_pos[ic * K + j] == now;
+                if (in) knn_pos[ic * K + j] = now;
+            }
+            PlanePair pl;  // the plane of the list: valid = "is a plane" (before the query-distance test)
+            pl.valid = 0; pl.n_neigh = m;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { pl.c[a] = 0; pl.n[a] = 0; }
+            const bool solve = in && !same;
+            if (__any(solve)) {
+                item_changed = true;
+                if (solve && m >= 3) {
+                    double px[K], py[K], pz[K];
+                    double mean[3] = {0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        px[j] = py[j] = pz[j] = 0;
+                        if (j < m) {
+                            px[j] = mp.sx[kp[k][j]]; py[j] = mp.sy[kp[k][j]]; pz[j] = mp.sz[kp[k][j]];
+                            mean[0] += px[j]; mean[1] += py[j]; mean[2] += pz[j];
+                        }
+                    }
+                    const double dm = (double)m;
+                    mean[0] /= dm; mean[1] /= dm; mean[2] /= dm;
+                    double Cm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        if (j < m) {
+                            const double dd[3] = {px[j] - mean[0], py[j] - mean[1], pz[j] - mean[2]};
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) Cm[r][c] += dd[r] * dd[c];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) Cm[r][c] /= dm;
+                    double ev[3], V[3][3];
+                    eig_sym3_dev(Cm, ev, V);
+                    if (!(ev[0] > plane_eig_thr * ev[2])) {
+                        pl.valid = 1;
+                        pl.c[0] = mean[0]; pl.c[1] = mean[1]; pl.c[2] = mean[2];
+                        pl.n[0] = V[0][0]; pl.n[1] = V[1][0]; pl.n[2] = V[2][0];
+                    }
+                }
+                if (solve) cache[ic] = pl;
+            }
+            if (in && same) pl = cache[ic];
+            if (in) {
+                PlanePair pp = pl;
+                if (pl.valid) {
+                    const double dist = fabs(pl.n[0] * ((double)qx[k] - pl.c[0]) + pl.n[1] * ((double)qy[k] - pl.c[1]) +
+                                             pl.n[2] * ((double)qz[k] - pl.c[2]));
+                    if (dist > threshold) {
+                        pp.valid = 0;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) { pp.c[a] = 0; pp.n[a] = 0; }
+                    }
+                }
+                out[ic] = pp;
+            }
+        }
+        }  // (epilogue)
+        wave_changed += item_changed ? 1u : 0u;
+        wave_staged += n_staged * 2;  // units of 64 (query, point) pairs
+        raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items);
+    }
+    if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
+    // (the verify flavour reports its queued items through redo_count; the queued-items launch must not count twice)
+    if (!VERIFY && !from_list && lane == 0 && wave_changed) atomicAdd(changed_items, wave_changed);
+}
+
+// the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
+// x = [R row-major (9), t (3)]  with  phi = [n (x) l, n],  d = n.c :   A = sum phi phi^T (78 unique),
+// b = sum phi d (12), c0 = sum d^2, count.  ONE pass -> the whole Gauss-Newton inner loop runs on the host.
+constexpr int kNAccPlane = 92;  // 78 + 12 + 1 + 1
+__global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                           const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
+                                                           int N, double* __restrict__ partials)
+{
+    double acc[kNAccPlane];
+#pragma unroll
+    for (int k = 0; k < kNAccPlane; ++k) acc[k] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const PlanePair pp = pairs[i];
+        if (!pp.valid) continue;
+        const double l[3] = {slx[i], sly[i], slz[i]};
+        double phi[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) phi[3 * r + c] = pp.n[r] * l[c];
+            phi[9 + r] = pp.n[r];
+        }
+        const double d = pp.n[0] * pp.c[0] + pp.n[1] * pp.c[1] + pp.n[2] * pp.c[2];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 12; ++a)
+#pragma unroll
+            for (int b = a; b < 12; ++b) acc[q++] += phi[a] * phi[b];
+#pragma unroll
+        for (int a = 0; a < 12; ++a) acc[78 + a] += phi[a] * d;
+        acc[90] += d * d;
+        acc[91] += 1.0;
+    }
+    __shared__ double sm[4][kNAccPlane];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kNAccPlane; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNAccPlane) {
+        double v = 0.0;
+        for (int w = 0; w < 4; ++w) v += sm[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNAccPlane + threadIdx.x] = v;
+    }
+}
+
+// fixed-order sum of [nblocks][n] partial rows (n <= 128): 8 slices of rows per accumulator with the loads of a
+// slice independent of each other, then the 8 slice sums in order.  Deterministic for a given nblocks.
+__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
+                                                      double* __restrict__ acc, const unsigned int* __restrict__ counters)
+{
+    // acc[n] = items of the plane matcher whose neighbour lists changed in this iteration (its next launch picks
+    // the counting or the insertion flavour from it): counters[0] (insertion launch) + counters[2] (queued by verify)
+    if (counters && threadIdx.x == 0) acc[n] = (double)(counters[0] + counters[2]);
+    __shared__ double sm[8][128];
+    const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    double v = 0.0;
+    if (k < n) {
+        int b = sl;
+        for (; b + 24 < nblocks; b += 32) {  // four rows in flight
+            const double a0 = partials[(size_t)b * n + k], a1 = partials[(size_t)(b + 8) * n + k];
+            const double a2 = partials[(size_t)(b + 16) * n + k], a3 = partials[(size_t)(b + 24) * n + k];
+            v += a0; v += a1; v += a2; v += a3;
+        }
+        for (; b < nblocks; b += 8) v += partials[(size_t)b * n + k];
+    }
+    sm[sl][k] = v;
+    __syncthreads();
+    if (sl == 0 && k < n) {
+        double t = 0.0;
+        for (int s2 = 0; s2 < 8; ++s2) t += sm[s2][k];
+        acc[k] = t;
+    }
+}
+
+// plane pairing in sorted query order -> original order (tests / callers that want the pairing)
+__global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict__ qperm, const PlanePair* __restrict__ in,
+                                                          const int* __restrict__ perm, const int* __restrict__ knn_pos,
+                                                          int K, int N, PlanePair* __restrict__ out, int* __restrict__ knn_idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int o = qperm[i];
+    out[o] = in[i];
+    if (knn_idx && knn_pos)
+        for (int j = 0; j < K; ++j) {
+            const int ps = knn_pos[(size_t)i * K + j];
+            knn_idx[(size_t)o * K + j] = ps >= 0 ? perm[ps] : -1;
+        }
+}
+
+}  // namespace mola_icp_amd

@@ -1,0 +1,155 @@
+// kernels_prepare.hpp -- small kernels around the matchers: pairing counters / order / un-permutation, box levels, bounding box, MFMA map image
+// Device code of the ICP core for gfx950; included by hip_backend.hip only (one translation unit: the kernels are
+// launched from there).  Numeric contract and data layout: hip_backend.hip / DESIGN.md.
+#pragma once
+#include "kernels_tiled.hpp"
+
+namespace mola_icp_amd {
+
+// number of kept pairs of a stored pairing (only when a caller asks for it)
+__global__ __launch_bounds__(256) void k_count_kept(const int* __restrict__ idx, int N, unsigned int* __restrict__ counter)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned int kept = (i < N && idx[i] >= 0) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, kept);
+}
+
+// heavy-first work order for the next launches: counting sort of the 128-query items by the cycles they took in
+// the last launch (32 buckets relative to the maximum), one 1024-thread block.  Longest-processing-time-first
+// keeps the persistent waves' tail short when a few query groups are much heavier than the rest.
+// (Cutting the heavy groups into smaller items was measured and dropped: an item's cost is mostly fixed
+// overhead -- box scan, staging and epilogue round trips -- so halves cost nearly as much as the whole.)
+__global__ __launch_bounds__(1024) void k_order_items(const unsigned int* __restrict__ cost, int n_items,
+                                                      int* __restrict__ order)
+{
+    __shared__ unsigned int s_max, s_cnt[32], s_off[32];
+    if (threadIdx.x == 0) s_max = 1u;
+    if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned int mx = 1u;
+    for (int i = threadIdx.x; i < n_items; i += 1024) mx = max(mx, cost[i]);
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    const float scale = 32.0f / (float)s_max;
+    for (int i = threadIdx.x; i < n_items; i += 1024) {
+        const int b = 31 - min(31, (int)((float)cost[i] * scale));  // bucket 0 = heaviest
+        atomicAdd(&s_cnt[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int o = 0;
+        for (int b = 0; b < 32; ++b) { s_off[b] = o; o += s_cnt[b]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_items; i += 1024) {
+        const int b = 31 - min(31, (int)((float)cost[i] * scale));
+        order[atomicAdd(&s_off[b], 1u)] = i;
+    }
+}
+
+// sorted-order pairing -> original query order (only when a caller asks for the pairing)
+__global__ __launch_bounds__(256) void k_unpermute_pairing(const int* __restrict__ qperm, const int* __restrict__ idx_s,
+                                                           const float* __restrict__ d2_s, int N,
+                                                           int* __restrict__ out_idx, float* __restrict__ out_d2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int o = qperm[i];
+    out_idx[o] = idx_s[i];
+    out_d2[o] = d2_s[i];
+}
+
+// boxes of the map tiles (one thread per tile) and super-tiles (one thread per super-tile); SoA [6][n]
+__global__ __launch_bounds__(256) void k_tile_boxes(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                    const float* __restrict__ sz, int M, int n_tiles_p,
+                                                    float* __restrict__ tbox)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles_p) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const int j0 = t * kTileG, j1 = min(j0 + kTileG, M);
+    for (int j = j0; j < j1; ++j) {
+        mn[0] = fminf(mn[0], sx[j]); mx[0] = fmaxf(mx[0], sx[j]);
+        mn[1] = fminf(mn[1], sy[j]); mx[1] = fmaxf(mx[1], sy[j]);
+        mn[2] = fminf(mn[2], sz[j]); mx[2] = fmaxf(mx[2], sz[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { tbox[k * n_tiles_p + t] = mn[k]; tbox[(3 + k) * n_tiles_p + t] = mx[k]; }
+}
+
+__global__ __launch_bounds__(256) void k_super_boxes(const float* __restrict__ tbox, int n_tiles_p, int n_super,
+                                                     float* __restrict__ sbox)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_super) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int t = s * kSuper; t < (s + 1) * kSuper; ++t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], tbox[k * n_tiles_p + t]);
+            mx[k] = fmaxf(mx[k], tbox[(3 + k) * n_tiles_p + t]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { sbox[k * n_super + s] = mn[k]; sbox[(3 + k) * n_super + s] = mx[k]; }
+}
+
+// ---- map preparation for the MFMA matcher (once per map) -------------------------------
+// bounding box: per-block partial min/max -> [nblocks][6]; second stage on one block
+__global__ __launch_bounds__(256) void k_bbox_partial(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                      const float* __restrict__ gz, int M, float* __restrict__ part)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
+        const float v[3] = {gx[i], gy[i], gz[i]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+    }
+    __shared__ float sm[4][6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], off));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off));
+        }
+        if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][k] = mn[k]; sm[threadIdx.x >> 6][3 + k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bbox_final(const float* __restrict__ part, int nblocks, float* __restrict__ out)
+{
+    if (threadIdx.x < 6) {
+        float v = part[threadIdx.x];
+        for (int b = 1; b < nblocks; ++b)
+            v = threadIdx.x < 3 ? fminf(v, part[b * 6 + threadIdx.x]) : fmaxf(v, part[b * 6 + threadIdx.x]);
+        out[threadIdx.x] = v;
+    }
+}
+
+// map image [tile][k][16]: k<3 -> -2*(m_k - c_k), k=3 -> |m - c|^2 (1 - 20u) (the map-point share of
+// the filter's error bound, folded in).  Rows >= M are padding.
+__global__ __launch_bounds__(256) void k_map_image(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                   const float* __restrict__ gz, int M, int M_padded, MapFrame F,
+                                                   float* __restrict__ img)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= M_padded) return;
+    float ax = 0.f, ay = 0.f, az = 0.f, mm = kMapPadNorm;
+    if (p < M) {
+        const float x = gx[p] - F.cx, y = gy[p] - F.cy, z = gz[p] - F.cz;
+        const float n = fmaf(z, z, fmaf(y, y, x * x));
+        mm = n - kFoldCoef * n;
+        ax = -2.0f * x; ay = -2.0f * y; az = -2.0f * z;
+    }
+    float* t = img + (size_t)(p >> 4) * 64 + (p & 15);
+    t[0] = ax; t[16] = ay; t[32] = az; t[48] = mm;
+}
+
+}  // namespace mola_icp_amd

@@ -1,0 +1,592 @@
+// kernels_tiled.hpp -- the tiled sweep (box levels, LDS staging), persistent-wave work queue, k_nn_tiled
+// Device code of the ICP core for gfx950; included by hip_backend.hip only (one translation unit: the kernels are
+// launched from there).  Numeric contract and data layout: hip_backend.hip / DESIGN.md.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace mola_icp_amd {
+
+// ---- tiled matcher: exact brute force over the map tiles a wave's queries can reach ---------
+// Both clouds are put in Hilbert order once (map: per map; local cloud: per cloud; map_sort.hip).  The map is
+// cut into TILES of 32 consecutive points with an axis-aligned box; 64 tiles form a super-tile, 64 super-tiles a
+// top box.  A wave owns 128 (or 64) consecutive -- hence spatially compact -- queries, two (one) per lane.  Per item:
+//   1. transform the queries, warm-start each best from the previous iteration's neighbour; the wave box is the
+//      union of the boxes [q - r, q + r], r = sqrt(best) rounded up;
+//   2. cull: lanes test 64 boxes of a level at a time against the wave box (ballot); a hit is re-tested against
+//      every query of the wave by its squared box distance vs the query's live best (exact, see tiled_sweep);
+//   3. every surviving tile is staged in LDS (two tiles = 64 points per pass) and all queries of the wave are
+//      evaluated against all its points with the exact contract; the winner is resolved with the lexicographic
+//      (d2, lowest ORIGINAL index) rule -- bit-identical to the dense kernels.
+// No tree, no per-query traversal, no data-dependent recursion: flat box scans and dense query x point tiles.
+constexpr int kTileG = 32;     // map points per tile
+constexpr int kSuper = 64;     // tiles per super-tile
+constexpr int kQPW = 128;      // queries per wave
+constexpr int kGroup = 8;      // fast sweep: points per bookkeeping group (16: epilogue too dear, 4: bookkeeping)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_f32;  // explicit LDS pointers: ds_read, never flat_load
+
+// dist2 for the two queries of a lane at once (v_pk_add/mul/fma_f32): each half is the same IEEE sequence as dist2
+__device__ __forceinline__ v2f dist2_pk(v2f qx, v2f qy, v2f qz, float mx, float my, float mz)
+{
+    const v2f dx = qx - mx, dy = qy - my, dz = qz - mz;
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
+// ... and for ONE query against two map points at once (same sequence per half)
+__device__ __forceinline__ v2f dist2_pk2(float qx, float qy, float qz, v2f mx, v2f my, v2f mz)
+{
+    const v2f dx = qx - mx, dy = qy - my, dz = qz - mz;
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
+struct Box { float lo[3], hi[3]; };
+
+__device__ __forceinline__ bool box_overlap(const float* __restrict__ b, int stride, int i, const Box& w)
+{
+    // b: SoA [6][stride] = minx,miny,minz,maxx,maxy,maxz ; empty boxes are (+inf,-inf)
+    return b[i] <= w.hi[0] && b[stride + i] <= w.hi[1] && b[2 * stride + i] <= w.hi[2] &&
+           b[3 * stride + i] >= w.lo[0] && b[4 * stride + i] >= w.lo[1] && b[5 * stride + i] >= w.lo[2];
+}
+
+__device__ __forceinline__ float bcast_lane(float v, int lane_uniform)
+{
+    // lane_uniform is wave-uniform (ctz of a ballot): a v_readlane, not an LDS round trip
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
+// the sorted map + its three box levels, as the tiled kernels see it
+struct TiledMap {
+    const float *sx, *sy, *sz;  // Hilbert-sorted points, padded to whole super-tiles
+    const int* perm;            // sorted position -> original index (0x7fffffff in the padding)
+    const float* tbox; int n_tiles_p;   // tile boxes        SoA [6][n_tiles_p]
+    const float* sbox; int n_super;     // super-tile boxes  SoA [6][n_super]  (n_super padded to 64)
+    const float* ubox; int n_top;       // top boxes         SoA [6][n_top]
+};
+
+constexpr size_t kMaxLdsBoxBytes = 40 * 1024;  // upper box levels kept in LDS up to this size (~3.4M map points)
+constexpr size_t kDbgItems = 1u << 17;  // MOLA_ICP_DEBUG_STATS: per-item records for clouds up to 16M points
+constexpr int kQueues = 8, kQueueStride = 32;  // work-queue counters, one 128-byte line each
+constexpr int kMaxList = 64;   // super-tiles collected before their tiles are streamed
+
+// LDS copy of the two upper box levels (one per workgroup): [6][n_top] then [6][n_super] floats.  The upper
+// levels of the scan then cost LDS reads instead of dependent global round trips.
+__device__ __forceinline__ size_t lds_box_floats(int n_top, int n_super) { return 6u * ((size_t)n_top + (size_t)n_super); }
+__device__ __forceinline__ void load_boxes_to_lds(const TiledMap& mp, lds_f32* lbox)
+{
+    const int nu = 6 * mp.n_top, ns = 6 * mp.n_super;
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) lbox[i] = mp.ubox[i];
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) lbox[nu + i] = mp.sbox[i];
+    __syncthreads();
+}
+
+// The sweep shared by the tiled kernels: wave box from the per-query reaches; the two upper box levels select
+// the super-tiles some query reaches (from the LDS copy `lbox`, or from global memory if it is null) into the
+// per-wave list `slist`; the listed super-tiles are then streamed with the NEXT one's tile boxes already in
+// flight, their surviving tiles staged through LDS two at a time with the next pair's points in flight too.
+// `visit(nm, jb0, jb1)` is called once per staged pass: sm[0..2][0..nm) hold x,y,z of the staged points
+// (sm[3] their original indices if NEED_PERM); points [0,32) have sorted positions jb0.., [32,64) jb1...
+// Returns the number of staged points.
+template <int QPL, bool NEED_PERM, class Visit>
+__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane,
+                                                          float (*sm)[64], const float (&qx)[QPL], const float (&qy)[QPL],
+                                                          const float (&qz)[QPL], const float (&reach)[QPL],
+                                                          const float (&bound2)[QPL], Visit&& visit,
+                                                          bool prof, unsigned long long& p_stage,
+                                                          unsigned long long& p_visit, unsigned int& p_supers,
+                                                          unsigned int& p_entered, unsigned int& p_tiles,
+                                                          unsigned long long& p_boxwait, unsigned long long& p_tiletest)
+{
+    Box w;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { w.lo[a] = INFINITY; w.hi[a] = -INFINITY; }
+#pragma unroll
+    for (int k = 0; k < QPL; ++k) {
+        if (reach[k] >= 0.f) {
+            w.lo[0] = fminf(w.lo[0], qx[k] - reach[k]); w.hi[0] = fmaxf(w.hi[0], qx[k] + reach[k]);
+            w.lo[1] = fminf(w.lo[1], qy[k] - reach[k]); w.hi[1] = fmaxf(w.hi[1], qy[k] + reach[k]);
+            w.lo[2] = fminf(w.lo[2], qz[k] - reach[k]); w.hi[2] = fmaxf(w.hi[2], qz[k] + reach[k]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
+            w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
+        }
+    }
+    unsigned long long n_staged = 0;
+
+    // Can the box (m0..m5 = min xyz, max xyz; wave-uniform values) hold a point with d2 <= bound2 for ANY query of
+    // the wave?  Per query: squared distance to the box, computed with the contract's own operation sequence on
+    // the per-axis gaps.  Rounding is monotone, so for every point p inside the box gap_a <= |q_a - p_a| after
+    // rounding, hence box_d2 <= d2_contract(q, p) EXACTLY as computed -- no margin needed, and bound2 is read
+    // live: as a query's best shrinks during the sweep, later boxes are tested against the tighter value.
+    // Padding lanes carry bound2 < 0 and reach nothing; empty boxes (+inf, -inf) give inf.
+    auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
+        if constexpr (QPL == 2) {  // both queries of the lane per packed instruction
+            const v2f s_qx = {qx[0], qx[1]}, s_qy = {qy[0], qy[1]}, s_qz = {qz[0], qz[1]};
+            const v2f zero = {0.f, 0.f};
+            const v2f ax = __builtin_elementwise_max(__builtin_elementwise_max(m0 - s_qx, s_qx - m3), zero);
+            const v2f ay = __builtin_elementwise_max(__builtin_elementwise_max(m1 - s_qy, s_qy - m4), zero);
+            const v2f az = __builtin_elementwise_max(__builtin_elementwise_max(m2 - s_qz, s_qz - m5), zero);
+            const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+            return __any(D.x <= bound2[0] || D.y <= bound2[1]);
+        } else {
+            const float ax = fmaxf(fmaxf(m0 - qx[0], qx[0] - m3), 0.f);
+            const float ay = fmaxf(fmaxf(m1 - qy[0], qy[0] - m4), 0.f);
+            const float az = fmaxf(fmaxf(m2 - qz[0], qz[0] - m5), 0.f);
+            return __any(fmaf(az, az, fmaf(ay, ay, ax * ax)) <= bound2[0]);
+        }
+    };
+
+    int pend_a = -1, pend_b = -1;  // tile ids whose points sit in the registers below
+    float px = 0.f, py = 0.f, pz = 0.f;
+    int po = 0;
+    auto load_pair = [&](int ta, int tb) {
+        const int tt = lane < 32 ? ta : tb;
+        px = py = pz = 1.0e18f;  // padding points: d2 ~ 3e36, never a neighbour
+        po = 0x7fffffff;
+        if (tt >= 0) {
+            const int j = tt * kTileG + (lane & 31);
+            px = mp.sx[j]; py = mp.sy[j]; pz = mp.sz[j];
+            if (NEED_PERM) po = mp.perm[j];
+        }
+    };
+    auto compute_pending = [&](int next_a, int next_b) {
+        const int ca = pend_a, cb = pend_b;
+        const unsigned long long tp0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz;
+        if (NEED_PERM) sm[3][lane] = __int_as_float(po);
+        pend_a = next_a; pend_b = next_b;
+        if (pend_a >= 0) load_pair(pend_a, pend_b);  // next pass's loads fly while this pass computes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nm = cb >= 0 ? 64 : 32;
+        n_staged += nm;
+        const unsigned long long tp1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        visit(nm, ca * kTileG, (cb >= 0 ? cb : ca) * kTileG);
+        __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next pass
+        if (prof) { const unsigned long long tp2 = __builtin_amdgcn_s_memtime(); p_stage += tp1 - tp0; p_visit += tp2 - tp1; }
+    };
+
+    // ---- the listed super-tiles: tile boxes of entry e+1 in flight while entry e's tiles are processed ----
+    int n_list = 0;
+    auto process_list = [&]() {
+        if (n_list == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int S = __builtin_amdgcn_readfirstlane(slist[0]);
+        int ti = S * kSuper + lane;
+        float n0 = mp.tbox[ti], n1 = mp.tbox[mp.n_tiles_p + ti], n2 = mp.tbox[2 * mp.n_tiles_p + ti],
+              n3 = mp.tbox[3 * mp.n_tiles_p + ti], n4 = mp.tbox[4 * mp.n_tiles_p + ti], n5 = mp.tbox[5 * mp.n_tiles_p + ti];
+        for (int e = 0; e < n_list; ++e) {
+            const unsigned long long tb0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+            const float b0 = n0, b1 = n1, b2 = n2, b3 = n3, b4 = n4, b5 = n5;
+            const int Sc = S;
+            if (e + 1 < n_list) {
+                S = __builtin_amdgcn_readfirstlane(slist[e + 1]);
+                ti = S * kSuper + lane;
+                n0 = mp.tbox[ti]; n1 = mp.tbox[mp.n_tiles_p + ti]; n2 = mp.tbox[2 * mp.n_tiles_p + ti];
+                n3 = mp.tbox[3 * mp.n_tiles_p + ti]; n4 = mp.tbox[4 * mp.n_tiles_p + ti]; n5 = mp.tbox[5 * mp.n_tiles_p + ti];
+            }
+            unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
+                                               b4 >= w.lo[1] && b5 >= w.lo[2]);
+            unsigned long long tmask = 0;
+            const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+            while (cand) {
+                const int t = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                if (prof) p_tiles += 1;
+                if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
+                              bcast_lane(b4, t), bcast_lane(b5, t)))
+                    tmask |= 1ull << t;
+            }
+            if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); p_boxwait += tb1 - tb0; p_tiletest += tb2 - tb1; }
+            while (tmask) {
+                const int t0 = Sc * kSuper + __builtin_ctzll(tmask);
+                tmask &= tmask - 1;
+                int t1 = -1;
+                if (tmask) { t1 = Sc * kSuper + __builtin_ctzll(tmask); tmask &= tmask - 1; }
+                if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
+                    pend_a = t0; pend_b = t1;
+                    load_pair(t0, t1);
+                } else {
+                    compute_pending(t0, t1);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the list is rewritten from here on
+        n_list = 0;
+    };
+
+    // ---- upper levels: top boxes (64 super-tiles = 131072 points each) -> super-tile boxes ----
+    // Written as a resumable scan so that process_list() has ONE call site (its body holds the distance
+    // passes): collect up to kMaxList super-tiles, stream them, resume where the scan stopped.
+    const lds_f32* l_ubox = lbox;
+    const lds_f32* l_sbox = lbox + 6 * mp.n_top;
+    int ub = 0, sb = 0;
+    unsigned long long ucand = 0, scand = 0;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
+    bool c_valid = false;  // c0..c5 hold the super-tile boxes [sb, sb+64)
+    auto load_super_boxes = [&]() {
+        const int si = sb + lane;
+        if (use_lbox) {
+            c0 = l_sbox[si]; c1 = l_sbox[mp.n_super + si]; c2 = l_sbox[2 * mp.n_super + si];
+            c3 = l_sbox[3 * mp.n_super + si]; c4 = l_sbox[4 * mp.n_super + si]; c5 = l_sbox[5 * mp.n_super + si];
+        } else {
+            c0 = mp.sbox[si]; c1 = mp.sbox[mp.n_super + si]; c2 = mp.sbox[2 * mp.n_super + si];
+            c3 = mp.sbox[3 * mp.n_super + si]; c4 = mp.sbox[4 * mp.n_super + si]; c5 = mp.sbox[5 * mp.n_super + si];
+        }
+        c_valid = true;
+    };
+    for (;;) {
+        while (n_list < kMaxList) {
+            if (scand) {
+                if (!c_valid) load_super_boxes();  // resumed after a full list
+                const int sl = __builtin_ctzll(scand);
+                scand &= scand - 1;
+                if (prof) p_supers += 1;
+                // super-tile vs the individual queries: a bimodal query group must not descend everywhere
+                if (any_reach(bcast_lane(c0, sl), bcast_lane(c1, sl), bcast_lane(c2, sl), bcast_lane(c3, sl),
+                              bcast_lane(c4, sl), bcast_lane(c5, sl))) {
+                    if (prof) p_entered += 1;
+                    if (lane == 0) slist[n_list] = sb + sl;
+                    ++n_list;
+                }
+            } else if (ucand) {
+                sb = (ub - 64 + __builtin_ctzll(ucand)) * 64;  // first super-tile of this top box (ub already advanced)
+                ucand &= ucand - 1;
+                load_super_boxes();
+                scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] && c4 >= w.lo[1] &&
+                                 c5 >= w.lo[2]);
+            } else if (ub < mp.n_top) {
+                const int ui = ub + lane;
+                float u0 = INFINITY, u1 = INFINITY, u2 = INFINITY, u3 = -INFINITY, u4 = -INFINITY, u5 = -INFINITY;
+                if (ui < mp.n_top) {
+                    if (use_lbox) {
+                        u0 = l_ubox[ui]; u1 = l_ubox[mp.n_top + ui]; u2 = l_ubox[2 * mp.n_top + ui];
+                        u3 = l_ubox[3 * mp.n_top + ui]; u4 = l_ubox[4 * mp.n_top + ui]; u5 = l_ubox[5 * mp.n_top + ui];
+                    } else {
+                        u0 = mp.ubox[ui]; u1 = mp.ubox[mp.n_top + ui]; u2 = mp.ubox[2 * mp.n_top + ui];
+                        u3 = mp.ubox[3 * mp.n_top + ui]; u4 = mp.ubox[4 * mp.n_top + ui]; u5 = mp.ubox[5 * mp.n_top + ui];
+                    }
+                }
+                ucand = __ballot(u0 <= w.hi[0] && u1 <= w.hi[1] && u2 <= w.hi[2] && u3 >= w.lo[0] && u4 >= w.lo[1] &&
+                                 u5 >= w.lo[2]);
+                ub += 64;
+            } else {
+                break;
+            }
+        }
+        if (n_list == 0) break;
+        process_list();
+        c_valid = false;
+    }
+    if (pend_a >= 0) compute_pending(-1, -1);
+    return n_staged;
+}
+
+// reach of a query whose current best squared distance is `best`: any m with d2_contract <= best lies inside
+// [q - r, q + r] per axis (sqrt rounded up, plus 2 ulp of the largest coordinate)
+__device__ __forceinline__ float reach_of(float best, float qx, float qy, float qz)
+{
+    const float cmax = fmaxf(fabsf(qx), fmaxf(fabsf(qy), fabsf(qz)));
+    return sqrtf(best * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
+}
+
+// Work queue of the persistent waves.  Same-address atomics serialise device-wide (measured: ~13 ns each; one
+// more atomic per item cost 20% of the kernel, the 3072-deep burst of first pops 40 us), so
+//  - the first entry of every wave is its own index: no atomics at kernel start;
+//  - the entries after those are dealt round-robin to kQueues counters on separate cache lines; a wave pops from
+//    the counter of its XCD (blockIdx & 7) and moves on to the next counter when that one runs dry.
+// Callers keep the next entry's pop in flight while the current item is processed.
+struct WaveQueue {
+    unsigned int* q;
+    int lane, n_waves, tried;
+    __device__ __forceinline__ WaveQueue(unsigned int* queue, int lane_) : q(queue), lane(lane_), n_waves((int)gridDim.x * 4), tried(0) {}
+    __device__ __forceinline__ int first() const { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
+    __device__ __forceinline__ int pop()  // the next entry (meaningful in lane 0), still in flight
+    {
+        const int c = ((int)blockIdx.x + tried) & (kQueues - 1);
+        int r = 0;
+        if (lane == 0) r = n_waves + c + kQueues * (int)atomicAdd(q + c * kQueueStride, 1u);
+        return r;
+    }
+    __device__ __forceinline__ int settle(int raw, int n_items)  // raw = readfirstlane(pop()): past the end -> other counters
+    {
+        while (raw >= n_items && ++tried < kQueues) raw = __builtin_amdgcn_readfirstlane(pop());
+        return raw;
+    }
+};
+
+// EXACT = false: the fast sweep.  Per (query, 4-point chunk) only the chunk minimum is compared with the
+//   running best (~6 VALU ops per pair); the winning chunk is re-evaluated once at the end to recover the
+//   exact point and the lowest-original-index rule inside it.  If an EQUAL minimum showed up in a different
+//   chunk (exact ties: duplicate points, lattices) the item is queued for the exact pass.
+// EXACT = true : the exact-key sweep over the queued items: per-pair argmin on the packed key
+//   (d2 bits << 32 | original index), i.e. the full lexicographic rule (~10 ops per pair).
+template <bool EXACT, int QPL>
+__global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                  const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
+                                                  int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
+                                                  float* __restrict__ d2_s, const int* __restrict__ item_order,
+                                                  unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
+                                                  unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
+                                                  unsigned long long* __restrict__ staged_total,
+                                                  unsigned long long* __restrict__ dbg_stats, int lds_boxes,
+                                                  unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
+{
+    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
+    __shared__ int s_list[4][kMaxList];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float(*sm)[64] = s_m[wave];
+    int* slist = s_list[wave];
+    if (EXACT && *redo_count == 0u) return;  // the usual case: no exact ties in this launch (uniform: before any barrier)
+    const lds_f32* lbox = (const lds_f32*)s_dyn;
+    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
+    constexpr int kQ = 64 * QPL;  // queries per item: QPL per lane (2 for large clouds, 1 when there are few items per wave)
+    const int n_items = EXACT ? (int)*redo_count : (N + kQ - 1) / kQ;
+
+    WaveQueue wq(queue, lane);
+    auto lookup = [&](int raw) -> int {  // raw is wave-uniform; -1 = past the end
+        if (raw >= n_items) return -1;
+        if (EXACT) return redo_list[raw];
+        return item_order ? item_order[raw] : raw;  // heaviest items of the last launch first
+    };
+    unsigned long long wave_staged = 0ull;
+    const unsigned long long t_wave0 = wave_times ? wall_clock64() : 0ull;  // 100 MHz, the same on every XCD
+    unsigned int wave_items = 0u;
+    int item = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
+    while (item >= 0) {
+        ++wave_items;
+        const int next_raw_v = wq.pop();
+        const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
+
+        float qx[QPL], qy[QPL], qz[QPL], reach[QPL];
+        unsigned long long key[QPL];  // EXACT: packed (d2, original index)
+        float best[QPL];              // fast: running minimum
+        int bpos[QPL];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
+        int tie[QPL] = {};
+        // round trip 1: the two queries of the lane and their seeds (clamped indices: every load is unconditional)
+        int qi[QPL], js[QPL];
+        float lx[QPL], ly[QPL], lz[QPL];
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) {
+            qi[k] = item * kQ + k * 64 + lane;
+            if (qi[k] >= N) qi[k] = N;  // padding lane
+            const int ic = qi[k] < N ? qi[k] : N - 1;
+            lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
+            js[k] = use_seed ? pos_s[ic] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
+        // round trip 2: the seeds' coordinates, and the next item's id
+        const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items));
+        float gsx[QPL], gsy[QPL], gsz[QPL];
+        unsigned int gso[QPL] = {};
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) {
+            const int jc = js[k] >= 0 ? js[k] : 0;
+            gsx[k] = mp.sx[jc]; gsy[k] = mp.sy[jc]; gsz[k] = mp.sz[jc];
+            if (EXACT) gso[k] = (unsigned int)mp.perm[jc];
+        }
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) {
+            key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
+            best[k] = thr2;
+            bpos[k] = -1;
+            const float d = dist2(qx[k], qy[k], qz[k], gsx[k], gsy[k], gsz[k]);
+            if (js[k] >= 0 && d < thr2) {  // warm start: last iteration's neighbour is an exact candidate
+                best[k] = d;
+                bpos[k] = EXACT ? js[k] : (js[k] & ~(kGroup - 1));
+                if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | gso[k];
+            }
+            reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
+            if (qi[k] >= N) {  // padding lane: reaches nothing, is never written
+                qx[k] = qy[k] = qz[k] = 1.0e18f;
+                reach[k] = -1.0f;
+                best[k] = -1.0f;
+                bpos[k] = -1;
+            }
+        }
+
+        unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
+        unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
+        const unsigned long long t_sweep0 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long n_staged = tiled_sweep<QPL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+            if constexpr (EXACT) {
+                for (int m = 0; m < nm; m += 4) {
+                    const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+                    const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+                    const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
+                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+                    const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
+                                                __float_as_uint(O.w)};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int k = 0; k < QPL; ++k) {
+                            const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
+                            const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
+                            const bool better = ck < key[k];
+                            key[k] = better ? ck : key[k];
+                            best[k] = better ? d : best[k];  // the sweep's box tests read it
+                            bpos[k] = better ? ((m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32) : bpos[k];
+                        }
+                    }
+                }
+            } else {
+                // per kGroup-point group: packed sub/mul/fma (v_pk_*_f32) serve two (query, point) pairs per
+                // instruction -- the lane's two queries (QPL = 2) or two consecutive points (QPL = 1) -- the group
+                // minimum is a chain of v_min3, and the (best, position, tie) bookkeeping runs once per group
+#pragma unroll 2
+                for (int m = 0; m < nm; m += kGroup) {
+                    float gm[QPL];
+#pragma unroll
+                    for (int k = 0; k < QPL; ++k) gm[k] = INFINITY;
+#pragma unroll
+                    for (int h = 0; h < kGroup; h += 8) {
+                        const float4 X0 = *reinterpret_cast<const float4*>(&sm[0][m + h]);
+                        const float4 X1 = *reinterpret_cast<const float4*>(&sm[0][m + h + 4]);
+                        const float4 Y0 = *reinterpret_cast<const float4*>(&sm[1][m + h]);
+                        const float4 Y1 = *reinterpret_cast<const float4*>(&sm[1][m + h + 4]);
+                        const float4 Z0 = *reinterpret_cast<const float4*>(&sm[2][m + h]);
+                        const float4 Z1 = *reinterpret_cast<const float4*>(&sm[2][m + h + 4]);
+                        const float xs[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
+                        const float ys[8] = {Y0.x, Y0.y, Y0.z, Y0.w, Y1.x, Y1.y, Y1.z, Y1.w};
+                        const float zs[8] = {Z0.x, Z0.y, Z0.z, Z0.w, Z1.x, Z1.y, Z1.z, Z1.w};
+                        if constexpr (QPL == 2) {
+                            const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
+#pragma unroll
+                            for (int u = 0; u < 8; u += 2) {
+                                const v2f da = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                                const v2f db = dist2_pk(q2x, q2y, q2z, xs[u + 1], ys[u + 1], zs[u + 1]);
+                                gm[0] = fminf(fminf(gm[0], da.x), db.x);
+                                gm[1] = fminf(fminf(gm[1], da.y), db.y);
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 8; u += 2) {
+                                const v2f mx = {xs[u], xs[u + 1]}, my = {ys[u], ys[u + 1]}, mz = {zs[u], zs[u + 1]};
+                                const v2f dd = dist2_pk2(qx[0], qy[0], qz[0], mx, my, mz);
+                                gm[0] = fminf(fminf(gm[0], dd.x), dd.y);
+                            }
+                        }
+                    }
+                    const int gpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this group
+#pragma unroll
+                    for (int k = 0; k < QPL; ++k) {
+                        const bool lt = gm[k] < best[k];
+                        const int eq = (int)(gm[k] == best[k]) & (int)(gpos != bpos[k]);
+                        tie[k] = lt ? 0 : (tie[k] | eq);
+                        best[k] = lt ? gm[k] : best[k];
+                        bpos[k] = lt ? gpos : bpos[k];
+                    }
+                }
+            }
+        }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
+        const unsigned long long t_sweep1 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
+
+        bool any_tie = false;
+        int rpos[QPL], roi[QPL];
+        float rd[QPL];
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; }
+        if constexpr (EXACT) {
+#pragma unroll
+            for (int k = 0; k < QPL; ++k) {
+                const float d = __uint_as_float((unsigned int)(key[k] >> 32));
+                if (d < thr2) { rd[k] = d; rpos[k] = bpos[k]; roi[k] = (int)(unsigned int)(key[k] & 0xffffffffu); }
+            }
+        } else {
+            // resolve inside the winning group: the point(s) with d2 == best, lowest original index first.
+            // One round trip: all loads of both queries are issued before the first use.
+            float4 RX[QPL][kGroup / 4], RY[QPL][kGroup / 4], RZ[QPL][kGroup / 4];
+            int4 RP[QPL][kGroup / 4];
+#pragma unroll
+            for (int k = 0; k < QPL; ++k) {
+                const int bp = bpos[k] >= 0 ? bpos[k] : 0;
+#pragma unroll
+                for (int c = 0; c < kGroup / 4; ++c) {
+                    RX[k][c] = *reinterpret_cast<const float4*>(mp.sx + bp + 4 * c);
+                    RY[k][c] = *reinterpret_cast<const float4*>(mp.sy + bp + 4 * c);
+                    RZ[k][c] = *reinterpret_cast<const float4*>(mp.sz + bp + 4 * c);
+                    RP[k][c] = *reinterpret_cast<const int4*>(mp.perm + bp + 4 * c);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < QPL; ++k) {
+                unsigned int bo = 0xffffffffu;
+                int pos = -1;
+#pragma unroll
+                for (int c = 0; c < kGroup / 4; ++c) {
+                    const float xs[4] = {RX[k][c].x, RX[k][c].y, RX[k][c].z, RX[k][c].w};
+                    const float ys[4] = {RY[k][c].x, RY[k][c].y, RY[k][c].z, RY[k][c].w};
+                    const float zs[4] = {RZ[k][c].x, RZ[k][c].y, RZ[k][c].z, RZ[k][c].w};
+                    const int ps[4] = {RP[k][c].x, RP[k][c].y, RP[k][c].z, RP[k][c].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float du = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
+                        const bool take = du == best[k] && (unsigned int)ps[u] < bo;
+                        bo = take ? (unsigned int)ps[u] : bo;
+                        pos = take ? bpos[k] + 4 * c + u : pos;
+                    }
+                }
+                if (bpos[k] >= 0) {
+                    rd[k] = best[k]; rpos[k] = pos; roi[k] = (int)bo;
+                    if (pos < 0) tie[k] = 1;  // cannot happen (same arithmetic); be safe: exact pass
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) {
+            if (qi[k] < N) {  // coalesced: the pairing stays in sorted query order
+                pos_s[qi[k]] = rpos[k];
+                idx_s[qi[k]] = rpos[k] >= 0 ? roi[k] : -1;
+                d2_s[qi[k]] = rd[k];
+                any_tie |= tie[k] != 0;
+            }
+        }
+        if (!EXACT && __any(any_tie)) {
+            if (lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
+        }
+        if (lane == 0) {
+            if (!EXACT) {
+                // (a deterministic proxy -- staged points -- orders no better than the measured cycles; without any
+                // order the kernel is 6 % slower)
+                const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
+                if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+            }
+            wave_staged += n_staged * QPL;  // executed work in units of 64 (query, point) pairs (one atomic per wave, at exit)
+            if (dbg_stats) {
+                const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+                atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged);
+                atomicAdd(&dbg_stats[5], t_sweep0 - t_item0);                         // prologue
+                atomicAdd(&dbg_stats[6], (t_sweep1 - t_sweep0) - p_stage - p_visit);  // box scan
+                atomicAdd(&dbg_stats[7], p_stage);                                    // staging
+                atomicAdd(&dbg_stats[8], p_visit);                                    // distance passes
+                atomicAdd(&dbg_stats[10], t_end - t_sweep1);                          // epilogue
+                atomicMax(&dbg_stats[9], t_end - t_item0);
+                atomicAdd(&dbg_stats[11], (unsigned long long)p_supers); atomicAdd(&dbg_stats[12], (unsigned long long)p_entered);
+                atomicAdd(&dbg_stats[13], (unsigned long long)p_tiles);
+                atomicAdd(&dbg_stats[14], p_boxwait); atomicAdd(&dbg_stats[15], p_tiletest);
+                unsigned long long* rec = dbg_stats + 16 + 8 * (size_t)item;  // per-item record
+                rec[0] = t_end - t_item0; rec[1] = n_staged; rec[2] = p_entered; rec[3] = p_tiles;
+                rec[4] = t_sweep0 - t_item0; rec[5] = (t_sweep1 - t_sweep0) - p_stage - p_visit; rec[6] = p_stage + p_visit;
+                rec[7] = t_end - t_sweep1;
+            }
+        }
+        item = __builtin_amdgcn_readfirstlane(next_item_v);
+    }
+    if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
+    if (wave_times && lane == 0) {  // [start, end, items] per wave
+        unsigned long long* w = wave_times + 3 * (size_t)wq.first();
+        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items;
+    }
+}
+
+}  // namespace mola_icp_amd
