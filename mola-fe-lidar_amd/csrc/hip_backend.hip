@@ -664,9 +664,20 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
         const int rc2 = rccl_allreduce_sum_f64(comm_, dacc, kNAccPlane, stream_);
         if (rc2) return rc2;
     }
-    if (!plane_acc_host_) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&plane_acc_host_), sizeof(double) * (kNAccPlane + 1), hipHostMallocDefault));
-    HIPCHK(hipMemcpyAsync(plane_acc_host_, dacc, sizeof(double) * (kNAccPlane + 1), hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
+    if (!plane_acc_host_) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&plane_acc_host_), sizeof(double) * (kNAccPlane + 4),
+                             hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(plane_acc_host_, 0, sizeof(double) * (kNAccPlane + 4));
+    }
+    if (std::getenv("MOLA_ICP_NO_DIRECT_READBACK")) {
+        HIPCHK(hipMemcpyAsync(plane_acc_host_, dacc, sizeof(double) * (kNAccPlane + 1), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+    } else {  // the form (+ the changed-lists count) into the pinned block, then the sequence number the host spins on
+        const unsigned long long seq = ++readback_seq_;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, stream_, dacc, kNAccPlane + 1, plane_acc_host_, kNAccPlane + 2, seq);
+        HIPCHK(hipGetLastError());
+        if ((rc = spin_for(reinterpret_cast<volatile unsigned long long*>(plane_acc_host_) + kNAccPlane + 2, seq))) return rc;
+    }
     std::memcpy(acc, plane_acc_host_, sizeof(double) * kNAccPlane);
     knn_changed_items_ = planes_empty_ ? -1.0 : plane_acc_host_[kNAccPlane];
     if (!comm_ && ar_fn_) {
@@ -927,6 +938,19 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
     return MOLA_ICP_OK;
 }
 
+// waits for `seq` in a pinned flag written by the device (k_reduce_partials / k_publish); a real stream wait as fallback
+int HipWorkspace::spin_for(volatile unsigned long long* flag, unsigned long long seq)
+{
+    for (unsigned long long spins = 0; spins < 400000000ull; ++spins) {  // ~ seconds
+        if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return MOLA_ICP_OK; }
+        __builtin_ia32_pause();
+    }
+    HIPCHK(hipStreamSynchronize(stream_));
+    if (*flag != seq) return fail(MOLA_ICP_E_HIP, "the device did not publish its result block");
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return MOLA_ICP_OK;
+}
+
 int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int stage, const double cl[3],
                              const double cg[3], bool reset_outliers, double acc[kNAcc])
 {
@@ -988,28 +1012,23 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
                        acc_dev_.as<double>(), direct ? acc_host_ : (double*)nullptr, seq);
     HIPCHK(hipGetLastError());
     counters_clean_ = true;
-    if (direct) {
-        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(acc_host_) + kNAcc + 6;
-        bool seen = false;
-        for (unsigned long long spins = 0; spins < 400000000ull; ++spins) {  // ~ seconds; then fall back to a real wait
-            if (*flag == seq) { seen = true; break; }
-            __builtin_ia32_pause();
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(acc_host_) + kNAcc + 6;
+    if (!direct) {
+        if (comm_) {  // query-sharded: the one collective of the path, in place on the device block (RCCL over xGMI)
+            const int rc2 = rccl_allreduce_sum_f64(comm_, acc_dev_.as<double>(), kNAcc, stream_);
+            if (rc2) return rc2;
         }
-        if (!seen) {
+        if (std::getenv("MOLA_ICP_NO_DIRECT_READBACK")) {
+            HIPCHK(hipMemcpyAsync(acc_host_, acc_dev_.p, sizeof(double) * kNAcc, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
-            if (*flag != seq) return fail(MOLA_ICP_E_HIP, "accumulate(): the reduction kernel did not publish its result");
+            std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);
+            return MOLA_ICP_OK;
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        for (int k = 0; k < kNAcc; ++k) acc[k] = acc_host_[k];
-        return MOLA_ICP_OK;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, stream_, acc_dev_.as<double>(), kNAcc, acc_host_, kNAcc + 6, seq);
+        HIPCHK(hipGetLastError());
     }
-    if (comm_) {  // query-sharded: the one collective of the path, in place on the device block (RCCL over xGMI)
-        const int rc2 = rccl_allreduce_sum_f64(comm_, acc_dev_.as<double>(), kNAcc, stream_);
-        if (rc2) return rc2;
-    }
-    HIPCHK(hipMemcpyAsync(acc_host_, acc_dev_.p, sizeof(double) * kNAcc, hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
-    std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);
+    if ((rc = spin_for(flag, seq))) return rc;
+    for (int k = 0; k < kNAcc; ++k) acc[k] = acc_host_[k];
     return MOLA_ICP_OK;
 }
 

@@ -103,6 +103,7 @@ class HipWorkspace final : public Stages {
     int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);
     int launch_tiled(const struct PoseF& P, float thr2, bool use_seed, unsigned int* counter);
     TiledMap tiled_map() const;
+    int spin_for(volatile unsigned long long* flag, unsigned long long seq);
     int launch_nn(const Mat4& T, float thr2, int kernel);
 
     int device_;

@@ -140,4 +140,18 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const do
         reinterpret_cast<unsigned int*>(acc + kNAcc + 8)[(threadIdx.x - 32) * kQueueStride] = 0u;
 }
 
+// hands a device block of n doubles to the host through its pinned block: data, then the sequence number the host
+// spins on (after an RCCL all-reduce on the device block, or for the plane form)
+__global__ __launch_bounds__(128) void k_publish(const double* __restrict__ src, int n, double* __restrict__ host_out,
+                                                 int flag_slot, unsigned long long seq)
+{
+    for (int k = threadIdx.x; k < n; k += 128) host_out[k] = src[k];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        reinterpret_cast<volatile unsigned long long*>(host_out)[flag_slot] = seq;
+        __threadfence_system();
+    }
+}
+
 }  // namespace mola_icp_amd
