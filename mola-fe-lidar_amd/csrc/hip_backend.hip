@@ -489,9 +489,14 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     if (const char* e = std::getenv("MOLA_ICP_QPL")) qpl = std::atoi(e) == 1 ? 1 : 2;  // tuning knob
     const int n_items = (int)((N_ + (size_t)(64 * qpl) - 1) / (size_t)(64 * qpl));
     {   // persistent waves with a static first item: every block of the grid must be resident from the start
-        int fit = 0;
-        if (qpl == 2) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false, 2>, 256, dyn_lds));
-        else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false, 1>, 256, dyn_lds));
+        // (the query is a runtime call of tens of microseconds on the launch path: once per kernel flavour and LDS size)
+        int& fit = fit_cache_[qpl == 2 ? 0 : 1];
+        size_t& fit_lds = fit_cache_lds_[qpl == 2 ? 0 : 1];
+        if (fit == 0 || fit_lds != dyn_lds) {
+            if (qpl == 2) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false, 2>, 256, dyn_lds));
+            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false, 1>, 256, dyn_lds));
+            fit_lds = dyn_lds;
+        }
         if (fit >= 1 && per_cu > fit) per_cu = fit;
     }
     int grid = num_cus_ * per_cu;
@@ -584,7 +589,9 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     // persistent waves with a static first item: every block of the grid must be resident from the start
-    int fit = 0;
+    int& fit = fit_cache_[p.knn < 3 ? 2 : (p.knn > 8 ? 7 : (int)p.knn - 1)];   // slots 2..7: knn 3..8
+    size_t& fit_lds = fit_cache_lds_[p.knn < 3 ? 2 : (p.knn > 8 ? 7 : (int)p.knn - 1)];
+    if (fit == 0 || fit_lds != dyn_lds)
     switch (p.knn) {  // (the verify flavour needs fewer registers than the insertion flavour)
         case 3: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<3, false>, 256, dyn_lds)); break;
         case 4: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<4, false>, 256, dyn_lds)); break;
@@ -593,6 +600,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         case 7: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<7, false>, 256, dyn_lds)); break;
         default: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<8, false>, 256, dyn_lds)); break;
     }
+    fit_lds = dyn_lds;
     int grid = num_cus_ * (fit < 1 ? 1 : (fit > 3 ? 3 : fit));
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !std::getenv("MOLA_ICP_NO_KNN_SEED")) ? 1 : 0;

@@ -139,6 +139,8 @@ class HipWorkspace final : public Stages {
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
     bool cost_valid_ = false, order_valid_ = false;
     unsigned int launches_since_order_ = 0, plan_interval_ = 1;
+    int fit_cache_[8] = {};            // resident blocks per CU of the tiled kernels (0 = not queried yet)
+    size_t fit_cache_lds_[8] = {};     // ... for this dynamic-LDS size
     unsigned long long readback_seq_ = 0;  // accumulate(): sequence number the reduction publishes next to its sums
     // pairing + scratch
     DevBuf idx_, d2_, seg_idx_, seg_d2_, outlier_, partials_, acc_dev_;
