@@ -86,3 +86,19 @@ def test_shard_bounds(pkg):
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_spatial_order_is_a_compact_permutation(pkg):
+    """Z-order used to cut query shards: a permutation, and contiguous slices are spatially compact (mean distance
+    to the shard's centroid well below that of an index-order shard of a shuffled cloud)."""
+    import importlib
+    sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-40, 40, size=(3, 20000)).astype(np.float32)
+    order = sharded.spatial_order(pts)
+    assert sorted(order.tolist()) == list(range(pts.shape[1]))
+    spread = lambda p: float(np.linalg.norm(p - p.mean(axis=1, keepdims=True), axis=0).mean())
+    for r in range(8):
+        lo, hi = sharded.shard_bounds(pts.shape[1], r, 8)
+        assert spread(pts[:, order[lo:hi]]) < 0.65 * spread(pts[:, lo:hi])
+    assert np.array_equal(order, sharded.spatial_order(pts))  # deterministic: every rank computes the same cut
