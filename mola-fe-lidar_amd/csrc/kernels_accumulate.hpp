@@ -90,21 +90,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* _
         element(i, jA, oA, lA0, lA1, lA2, gA0, gA1, gA2, dA);
         element(i2, jB, oB, lB0, lB1, lB2, gB0, gB1, gB2, dB);
     }
-    // fixed-order reduction: lanes (shuffle tree) -> waves (LDS, in wave order) -> one row per block
-    __shared__ double sm[kAccThreads / 64][kNAcc];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kNAcc; ++k) {
-        double v = s[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sm[wave][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNAcc) {
-        double v = 0.0;
-        for (int w = 0; w < kAccThreads / 64; ++w) v += sm[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNAcc + threadIdx.x] = v;
-    }
+    // fixed-order block sum -> one row per block
+    static_assert(kAccThreads == 256, "block_sum_256");
+    block_sum_256<kNAcc>(s, partials + (size_t)blockIdx.x * kNAcc);
 }
 
 // sums the per-block rows in a fixed order: 32 interleaved slices per accumulator, then the slices in order

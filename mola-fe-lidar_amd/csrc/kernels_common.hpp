@@ -38,4 +38,28 @@ __device__ __forceinline__ float down_f32(double x)
 
 constexpr float kPadCoord = 1.0e18f;  // padding map points: d2 ~ 3e36, finite, never the minimum
 
+// Sum of NV per-thread doubles over a 256-thread block, in a fixed order: eight values at a time are laid out in LDS
+// ([value][thread]), 32 threads per value add 8 entries each in index order, then a 32-wide shuffle tree.  ~3 LDS
+// operations per value and thread instead of the 12 of a 64-wide shuffle tree per value (ds_bpermute pairs for fp64),
+// which dominated the accumulation kernels.  out[v] is written by one thread per value; all threads must call.
+template <int NV>
+__device__ __forceinline__ void block_sum_256(const double (&v)[NV], double* __restrict__ out)
+{
+    __shared__ double s_bs[8][256];
+    const int tid = threadIdx.x, j = tid >> 5, l = tid & 31;
+#pragma unroll
+    for (int c = 0; c < NV; c += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_bs[q][tid] = c + q < NV ? v[c + q < NV ? c + q : 0] : 0.0;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_bs[j][l + 32 * r];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) t += __shfl_down(t, off, 32);
+        if (l == 0 && c + j < NV) out[c + j] = t;
+        __syncthreads();
+    }
+}
+
 }  // namespace mola_icp_amd

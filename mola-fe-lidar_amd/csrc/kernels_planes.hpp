@@ -353,20 +353,7 @@ __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restri
         acc[90] += d * d;
         acc[91] += 1.0;
     }
-    __shared__ double sm[4][kNAccPlane];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kNAccPlane; ++k) {
-        double v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) sm[wave][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNAccPlane) {
-        double v = 0.0;
-        for (int w = 0; w < 4; ++w) v += sm[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNAccPlane + threadIdx.x] = v;
-    }
+    block_sum_256<kNAccPlane>(acc, partials + (size_t)blockIdx.x * kNAccPlane);  // fixed order
 }
 
 // fixed-order sum of [nblocks][n] partial rows (n <= 128): 8 slices of rows per accumulator with the loads of a
