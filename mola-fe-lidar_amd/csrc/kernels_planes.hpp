@@ -102,18 +102,20 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : raw;
 
         float qx[2], qy[2], qz[2], reach[2], kbound[2];
-        float kd[2][K];          // sorted ascending by (d2, original index)
-        unsigned int ko[2][K];   // original indices
+        // the K best of each query, sorted ascending by the packed key (d2 bits << 32 | original index): d2 >= 0, so the
+        // unsigned order of the key IS the lexicographic (d2, index) order -- one 64-bit compare per list step
+        unsigned long long kk[2][K];
+        auto kd_of = [&](int k, int j) -> float { return __uint_as_float((unsigned int)(kk[k][j] >> 32)); };
         int kp[2][K];            // sorted-map positions
         // insert (du, o, pos) into the sorted list of query k (caller has checked that it belongs there)
         auto insert = [&](int k, float du, unsigned int o, int pos) {
-            kd[k][K - 1] = du; ko[k][K - 1] = o; kp[k][K - 1] = pos;
+            kk[k][K - 1] = ((unsigned long long)__float_as_uint(du) << 32) | o; kp[k][K - 1] = pos;
 #pragma unroll
             for (int j = K - 1; j > 0; --j) {
-                const bool sw = kd[k][j] < kd[k][j - 1] || (kd[k][j] == kd[k][j - 1] && ko[k][j] < ko[k][j - 1]);
-                const float td = kd[k][j]; const unsigned int to = ko[k][j]; const int tp = kp[k][j];
-                kd[k][j] = sw ? kd[k][j - 1] : td; ko[k][j] = sw ? ko[k][j - 1] : to; kp[k][j] = sw ? kp[k][j - 1] : tp;
-                kd[k][j - 1] = sw ? td : kd[k][j - 1]; ko[k][j - 1] = sw ? to : ko[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
+                const bool sw = kk[k][j] < kk[k][j - 1];
+                const unsigned long long tk = kk[k][j]; const int tp = kp[k][j];
+                kk[k][j] = sw ? kk[k][j - 1] : tk; kp[k][j] = sw ? kp[k][j - 1] : tp;
+                kk[k][j - 1] = sw ? tk : kk[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
             }
         };
         int qi[2];
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         for (int k = 0; k < 2; ++k) {
             xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
 #pragma unroll
-            for (int j = 0; j < K; ++j) { kd[k][j] = thr2; ko[k][j] = 0u; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
+            for (int j = 0; j < K; ++j) { kk[k][j] = (unsigned long long)__float_as_uint(thr2) << 32; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
         }
         if (use_seed) {
             // warm start: the K neighbours of the last launch are exact candidates; with them in the list the
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            reach[k] = reach_of(kd[k][K - 1], qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
-            kbound[k] = kd[k][K - 1];  // (fixed during the sweep)
+            reach[k] = reach_of(kd_of(k, K - 1), qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
+            kbound[k] = kd_of(k, K - 1);  // (fixed during the sweep)
             if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; kbound[k] = -1.0f; }  // padding lane
         }
         // VERIFY: tau = K-th seed distance (list full), else the largest float below gate^2 ("d2 < gate^2" as "<=")
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
 #pragma unroll
             for (int j = 0; j < K; ++j) sds += kp[k][j] >= 0 ? 1 : 0;
             expect[k] = sds;
-            tau[k] = sds == K ? kd[k][K - 1] : __uint_as_float(__float_as_uint(thr2) - 1u);
+            tau[k] = sds == K ? kd_of(k, K - 1) : __uint_as_float(__float_as_uint(thr2) - 1u);
             if (VERIFY && qi[k] < N) kbound[k] = tau[k];
         }
 
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                     d[0][u] = dv.x; d[1][u] = dv.y;
                 }
 #pragma unroll
-                for (int k = 0; k < 2; ++k) cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd[k][K - 1];
+                for (int k = 0; k < 2; ++k) cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd_of(k, K - 1);
                 if (__any(cand)) {  // some lane may have to insert: rare once the lists have tightened
                     const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
                     const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
                             const float du = d[k][u];
-                            if (du < kd[k][K - 1] || (du == kd[k][K - 1] && os[u] < ko[k][K - 1])) {
+                            if ((((unsigned long long)__float_as_uint(du) << 32) | os[u]) < kk[k][K - 1]) {
                                 bool dup = false;  // a seed met again by the sweep
 #pragma unroll
                                 for (int j = 0; j < K; ++j) dup |= kp[k][j] == pos;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
             const size_t ic = in ? (size_t)i : (size_t)(N - 1);
             int m = 0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) m += (kp[k][j] >= 0 && kd[k][j] < thr2) ? 1 : 0;  // sorted: the first m entries
+            for (int j = 0; j < K; ++j) m += (kp[k][j] >= 0 && kd_of(k, j) < thr2) ? 1 : 0;  // sorted: the first m entries
             bool same = use_seed != 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
