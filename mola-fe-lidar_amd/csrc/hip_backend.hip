@@ -577,8 +577,10 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         ev_.push_back(e);
     }
     unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
-    HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));
-    HIPCHK(hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 8, 0, sizeof(unsigned int) * 2 * kQueues * kQueueStride, stream_));
+    if (!counters_clean_) {  // (the reductions of both pipelines leave them zero: no memset inside an ICP loop)
+        HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));
+        HIPCHK(hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 8, 0, sizeof(unsigned int) * 2 * kQueues * kQueueStride, stream_));
+    }
     counters_clean_ = false;
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
@@ -667,6 +669,7 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
         hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc,
                            reinterpret_cast<const unsigned int*>(acc_dev_.as<double>() + kNAcc));
         HIPCHK(hipGetLastError());
+        counters_clean_ = true;
     }
     if (comm_) {
         const int rc2 = rccl_allreduce_sum_f64(comm_, dacc, kNAccPlane, stream_);

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
 #pragma unroll
             for (int j = K - 1; j > 0; --j) {
                 const bool sw = kk[k][j] < kk[k][j - 1];
+                if (!__any(sw)) break;  // every inserting lane has found its place (a new entry usually lands near the end)
                 const unsigned long long tk = kk[k][j]; const int tp = kp[k][j];
                 kk[k][j] = sw ? kk[k][j - 1] : tk; kp[k][j] = sw ? kp[k][j - 1] : tp;
                 kk[k][j - 1] = sw ? tk : kk[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
@@ -365,7 +366,14 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
 {
     // acc[n] = items of the plane matcher whose neighbour lists changed in this iteration (its next launch picks
     // the counting or the insertion flavour from it): counters[0] (insertion launch) + counters[2] (queued by verify)
-    if (counters && threadIdx.x == 0) acc[n] = (double)(counters[0] + counters[2]);
+    if (counters && threadIdx.x == 0) {
+        acc[n] = (double)(counters[0] + counters[2]);
+        // ... and leave the matcher's counters (kept / redo / ticket, then the work-queue counters) zero for its next launch
+        unsigned int* c = const_cast<unsigned int*>(counters);
+        c[0] = c[1] = c[2] = c[3] = 0u;
+    }
+    if (counters && threadIdx.x >= 32 && threadIdx.x < 32 + 2 * kQueues)
+        const_cast<unsigned int*>(counters)[16 + (threadIdx.x - 32) * kQueueStride] = 0u;  // (queues start 8 doubles on)
     __shared__ double sm[8][128];
     const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
     double v = 0.0;
