@@ -193,22 +193,25 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
             }
             unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
                                                b4 >= w.lo[1] && b5 >= w.lo[2]);
-            unsigned long long tmask = 0;
+            // Tiles are tested right before they are staged, not all up front: the per-query bound is live, so a
+            // tile tested after its neighbours were swept meets the tighter best (a first launch, or one after a
+            // large pose step, culls many of a super-tile's later tiles this way).
             const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-            while (cand) {
-                const int t = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                if (prof) p_tiles += 1;
-                if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
-                              bcast_lane(b4, t), bcast_lane(b5, t)))
-                    tmask |= 1ull << t;
-            }
-            if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); p_boxwait += tb1 - tb0; p_tiletest += tb2 - tb1; }
-            while (tmask) {
-                const int t0 = Sc * kSuper + __builtin_ctzll(tmask);
-                tmask &= tmask - 1;
-                int t1 = -1;
-                if (tmask) { t1 = Sc * kSuper + __builtin_ctzll(tmask); tmask &= tmask - 1; }
+            auto next_tile = [&]() -> int {  // next candidate some query still reaches, or -1
+                while (cand) {
+                    const int t = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    if (prof) p_tiles += 1;
+                    if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
+                                  bcast_lane(b4, t), bcast_lane(b5, t)))
+                        return Sc * kSuper + t;
+                }
+                return -1;
+            };
+            for (;;) {
+                const int t0 = next_tile();
+                if (t0 < 0) break;
+                const int t1 = next_tile();
                 if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
                     pend_a = t0; pend_b = t1;
                     load_pair(t0, t1);
@@ -216,6 +219,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
                     compute_pending(t0, t1);
                 }
             }
+            if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); p_boxwait += tb1 - tb0; p_tiletest += tb2 - tb1; }
         }
         __builtin_amdgcn_wave_barrier();  // the list is rewritten from here on
         n_list = 0;
