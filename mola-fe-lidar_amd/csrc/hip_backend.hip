@@ -503,7 +503,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     int rc;
     if ((rc = item_cost_.reserve(sizeof(unsigned int) * (size_t)n_items))) return rc;
-    if ((rc = item_order_.reserve(sizeof(int) * (size_t)n_items))) return rc;
+    if ((rc = item_order_.reserve(sizeof(int) * ((size_t)n_items + kQueues + 1)))) return rc;  // + the segment boundaries
     const int* order = nullptr;
     if (cost_valid_ && !std::getenv("MOLA_ICP_NO_LPT")) {
         // the cost profile drifts slowly with the pose: re-sort at launch 1, 2, 4, 8 after the clouds were set,

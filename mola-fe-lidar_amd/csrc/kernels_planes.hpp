@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
     const int n_items = from_list ? (int)*redo_count : (N + kQPW - 1) / kQPW;
     unsigned long long wave_staged = 0ull;
     unsigned int wave_changed = 0u;  // items of this wave with a lane whose neighbour list differs from its seeds
-    WaveQueue wq(queue, lane);
+    WaveQueue wq(queue, lane, n_items);
     for (int raw = wq.first(); raw < n_items;) {
         const int next_raw_v = wq.pop();
         const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : raw;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         }  // (epilogue)
         wave_changed += item_changed ? 1u : 0u;
         wave_staged += n_staged * 2;  // units of 64 (query, point) pairs
-        raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items);
+        raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v));
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
     // (the verify flavour reports its queued items through redo_count; the queued-items launch must not count twice)

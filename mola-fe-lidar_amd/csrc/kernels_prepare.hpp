@@ -15,36 +15,70 @@ __global__ __launch_bounds__(256) void k_count_kept(const int* __restrict__ idx,
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, kept);
 }
 
-// heavy-first work order for the next launches: counting sort of the 128-query items by the cycles they took in
-// the last launch (32 buckets relative to the maximum), one 1024-thread block.  Longest-processing-time-first
-// keeps the persistent waves' tail short when a few query groups are much heavier than the rest.
+// heavy-first work order for the next launches, per segment of the work queue (WaveQueue: kQueues contiguous
+// ranges of items, one per XCD).  The ranges are cut so that each holds an equal share of the COST (cycles of the
+// last launch) -- regions of the cloud differ in density -- and their boundaries are stored behind the order
+// (order[n_items .. n_items + kQueues]).  Inside a range: counting sort by cost (32 buckets relative to the
+// maximum): longest-processing-time-first keeps the persistent waves' tail short.  One 1024-thread block.
 // (Cutting the heavy groups into smaller items was measured and dropped: an item's cost is mostly fixed
 // overhead -- box scan, staging and epilogue round trips -- so halves cost nearly as much as the whole.)
 __global__ __launch_bounds__(1024) void k_order_items(const unsigned int* __restrict__ cost, int n_items,
                                                       int* __restrict__ order)
 {
-    __shared__ unsigned int s_max, s_cnt[32], s_off[32];
+    __shared__ unsigned int s_max, s_cnt[kQueues][32], s_off[kQueues][32];
+    __shared__ unsigned long long s_pre[1024];
+    __shared__ int s_seg[kQueues + 1];
     if (threadIdx.x == 0) s_max = 1u;
-    if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
+    if (threadIdx.x < kQueues * 32) (&s_cnt[0][0])[threadIdx.x] = 0u;
+    if (threadIdx.x <= kQueues) s_seg[threadIdx.x] = threadIdx.x == kQueues ? n_items : 0;
+    // prefix of the cost in item (= spatial) order: contiguous chunk per thread, Hillis-Steele over the chunk sums
+    const int chunk = (n_items + 1023) / 1024, i0 = min(n_items, (int)threadIdx.x * chunk), i1 = min(n_items, i0 + chunk);
+    unsigned long long mine = 0;
     unsigned int mx = 1u;
-    for (int i = threadIdx.x; i < n_items; i += 1024) mx = max(mx, cost[i]);
-    atomicMax(&s_max, mx);
+    for (int i = i0; i < i1; ++i) { mine += cost[i]; mx = max(mx, cost[i]); }
+    s_pre[threadIdx.x] = mine;
     __syncthreads();
+    atomicMax(&s_max, mx);
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned long long add = threadIdx.x >= (unsigned)off ? s_pre[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        s_pre[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const unsigned long long total = s_pre[1023];
+    unsigned long long run = s_pre[threadIdx.x] - mine;  // cost before my chunk
+    for (int i = i0; i < i1; ++i) {  // boundary c = first item whose preceding cost reaches c/kQueues of the total
+        for (int c = 1; c < kQueues; ++c) {
+            const unsigned long long want = total / kQueues * (unsigned long long)c;
+            if (run < want && run + cost[i] >= want) s_seg[c] = i + 1;
+        }
+        run += cost[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // degenerate profiles (all-zero cost): keep the boundaries monotone
+        for (int c = 1; c <= kQueues; ++c) if (s_seg[c] < s_seg[c - 1]) s_seg[c] = s_seg[c - 1];
+    }
+    __syncthreads();
+    if (threadIdx.x <= kQueues) order[n_items + threadIdx.x] = s_seg[threadIdx.x];
+    auto seg_of = [&](int i) -> int {
+        int c = 0;
+        while (c + 1 < kQueues && s_seg[c + 1] <= i) ++c;
+        return c;
+    };
     const float scale = 32.0f / (float)s_max;
     for (int i = threadIdx.x; i < n_items; i += 1024) {
         const int b = 31 - min(31, (int)((float)cost[i] * scale));  // bucket 0 = heaviest
-        atomicAdd(&s_cnt[b], 1u);
+        atomicAdd(&s_cnt[seg_of(i)][b], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int o = 0;
-        for (int b = 0; b < 32; ++b) { s_off[b] = o; o += s_cnt[b]; }
+    if (threadIdx.x < kQueues) {
+        unsigned int o = (unsigned int)s_seg[threadIdx.x];
+        for (int b = 0; b < 32; ++b) { s_off[threadIdx.x][b] = o; o += s_cnt[threadIdx.x][b]; }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_items; i += 1024) {
         const int b = 31 - min(31, (int)((float)cost[i] * scale));
-        order[atomicAdd(&s_off[b], 1u)] = i;
+        order[atomicAdd(&s_off[seg_of(i)][b], 1u)] = i;
     }
 }
 

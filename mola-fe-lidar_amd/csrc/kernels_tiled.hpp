@@ -300,28 +300,49 @@ __device__ __forceinline__ float reach_of(float best, float qx, float qy, float 
     return sqrtf(best * 1.000002f) * 1.00001f + cmax * 2.4e-7f + 1e-30f;
 }
 
-// Work queue of the persistent waves.  Same-address atomics serialise device-wide (measured: ~13 ns each; one
-// more atomic per item cost 20% of the kernel, the 3072-deep burst of first pops 40 us), so
-//  - the first entry of every wave is its own index: no atomics at kernel start;
-//  - the entries after those are dealt round-robin to kQueues counters on separate cache lines; a wave pops from
-//    the counter of its XCD (blockIdx & 7) and moves on to the next counter when that one runs dry.
+// Work queue of the persistent waves over the entries [0, n).  Same-address atomics serialise device-wide
+// (measured: ~13 ns each; one more atomic per item cost 20% of the kernel, the 3072-deep burst of first pops 40 us)
+// and every XCD has its own L2, so
+//  - the entries are cut into kQueues contiguous segments -- contiguous entries are neighbours in space and share
+//    map tiles -- and segment c belongs to XCD c (blocks are dealt to the XCDs round-robin: XCD = blockIdx & 7):
+//    the tiles a region needs are then fetched into ONE L2 instead of all eight;
+//  - the first entry of every wave is fixed (its rank among the waves of its XCD): no atomics at kernel start;
+//  - the rest of a segment is handed out by its own counter (separate cache lines); a wave whose segment has run
+//    dry steals from the next ones.
 // Callers keep the next entry's pop in flight while the current item is processed.
 struct WaveQueue {
     unsigned int* q;
-    int lane, n_waves, tried;
-    __device__ __forceinline__ WaveQueue(unsigned int* queue, int lane_) : q(queue), lane(lane_), n_waves((int)gridDim.x * 4), tried(0) {}
-    __device__ __forceinline__ int first() const { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
-    __device__ __forceinline__ int pop()  // the next entry (meaningful in lane 0), still in flight
+    const int* seg;  // kQueues + 1 segment boundaries (k_order_items: equal COST per segment), or null: equal counts
+    int lane, n, tried;
+    __device__ __forceinline__ WaveQueue(unsigned int* queue, int lane_, int n_entries, const int* seg_ = nullptr)
+        : q(queue), seg(seg_), lane(lane_), n(n_entries), tried(0) {}
+    __device__ __forceinline__ int seg_begin(int c) const { return seg ? seg[c] : (int)(((long long)c * n) / kQueues); }
+    __device__ __forceinline__ int n_static(int c) const  // waves of XCD c = fixed first entries of segment c
+    {
+        return (((int)gridDim.x + kQueues - 1 - c) / kQueues) * 4;
+    }
+    __device__ __forceinline__ int global_wave() const { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
+    __device__ __forceinline__ int pop()  // the next entry (meaningful in lane 0; >= n: none there), still in flight
     {
         const int c = ((int)blockIdx.x + tried) & (kQueues - 1);
         int r = 0;
-        if (lane == 0) r = n_waves + c + kQueues * (int)atomicAdd(q + c * kQueueStride, 1u);
+        if (lane == 0) {
+            const int e = seg_begin(c) + n_static(c) + (int)atomicAdd(q + c * kQueueStride, 1u);
+            r = e < seg_begin(c + 1) ? e : 0x7fffffff;
+        }
         return r;
     }
-    __device__ __forceinline__ int settle(int raw, int n_items)  // raw = readfirstlane(pop()): past the end -> other counters
+    __device__ __forceinline__ int settle(int raw)  // raw = readfirstlane(pop()): none there -> the other segments
     {
-        while (raw >= n_items && ++tried < kQueues) raw = __builtin_amdgcn_readfirstlane(pop());
+        while (raw >= n && ++tried < kQueues) raw = __builtin_amdgcn_readfirstlane(pop());
         return raw;
+    }
+    __device__ __forceinline__ int first()  // wave-uniform; >= n: nothing left anywhere
+    {
+        const int c = (int)blockIdx.x & (kQueues - 1);
+        const int e = seg_begin(c) + ((int)blockIdx.x / kQueues) * 4 + (int)(threadIdx.x >> 6);
+        if (e < seg_begin(c + 1)) return e;
+        return settle(__builtin_amdgcn_readfirstlane(pop()));  // more waves than entries in this segment
     }
 };
 
@@ -354,7 +375,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     constexpr int kQ = 64 * QPL;  // queries per item: QPL per lane (2 for large clouds, 1 when there are few items per wave)
     const int n_items = EXACT ? (int)*redo_count : (N + kQ - 1) / kQ;
 
-    WaveQueue wq(queue, lane);
+    WaveQueue wq(queue, lane, n_items, (!EXACT && item_order) ? item_order + n_items : nullptr);  // boundaries follow the order
     auto lookup = [&](int raw) -> int {  // raw is wave-uniform; -1 = past the end
         if (raw >= n_items) return -1;
         if (EXACT) return redo_list[raw];
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
 #pragma unroll
         for (int k = 0; k < QPL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
         // round trip 2: the seeds' coordinates, and the next item's id
-        const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v), n_items));
+        const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
         float gsx[QPL], gsy[QPL], gsz[QPL];
         unsigned int gso[QPL] = {};
 #pragma unroll
@@ -588,7 +609,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
     if (wave_times && lane == 0) {  // [start, end, items] per wave
-        unsigned long long* w = wave_times + 3 * (size_t)wq.first();
+        unsigned long long* w = wave_times + 3 * (size_t)wq.global_wave();
         w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items;
     }
 }
