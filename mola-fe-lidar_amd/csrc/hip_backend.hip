@@ -117,8 +117,8 @@ int HipWorkspace::init()
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
         HIPCHK(hipMemset(dbg_stats_, 0, (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
         if (std::atoi(std::getenv("MOLA_ICP_DEBUG_STATS")) == 2) {  // light mode: per-wave start/end of the tiled matcher only
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&wave_times_), 3 * 8192 * sizeof(unsigned long long)));
-            HIPCHK(hipMemset(wave_times_, 0, 3 * 8192 * sizeof(unsigned long long)));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&wave_times_), 8 * 8192 * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(wave_times_, 0, 8 * 8192 * sizeof(unsigned long long)));
         }
     }
     inited_ = true;
@@ -762,13 +762,16 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
         }
     }
     if (wave_times_) {
-        std::vector<unsigned long long> w(3 * 8192);
+        std::vector<unsigned long long> w(8 * 8192);
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipMemcpy(w.data(), wave_times_, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t1 = 0ull;
-        std::vector<unsigned long long> ends;
+        std::vector<unsigned long long> ends, pro, swp, epi, stg;
         for (size_t i = 0; i < 8192; ++i)
-            if (w[3 * i + 1]) { t0 = std::min(t0, w[3 * i]); t1 = std::max(t1, w[3 * i + 1]); ends.push_back(w[3 * i + 1]); }
+            if (w[8 * i + 1]) {
+                t0 = std::min(t0, w[8 * i]); t1 = std::max(t1, w[8 * i + 1]); ends.push_back(w[8 * i + 1]);
+                pro.push_back(w[8 * i + 3]); swp.push_back(w[8 * i + 4]); epi.push_back(w[8 * i + 5]); stg.push_back(w[8 * i + 6]);
+            }
         if (!ends.empty()) {
             std::sort(ends.begin(), ends.end());
             const double span = (double)(t1 - t0);
@@ -780,6 +783,10 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
                          (ends[ends.size() / 2] - t0) / span, (ends[ends.size() * 3 / 4] - t0) / span,
                          (ends[ends.size() * 9 / 10] - t0) / span, (ends[ends.size() * 99 / 100] - t0) / span,
                          busy / ends.size() / span);
+            auto med = [](std::vector<unsigned long long>& v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+            std::fprintf(stderr, "[mola_icp debug]   first item of a wave, shader cycles (median / p90): prologue %llu / %llu, sweep %llu / %llu, "
+                                 "epilogue %llu / %llu; staged points %llu / %llu\n",
+                         med(pro, 0.5), med(pro, 0.9), med(swp, 0.5), med(swp, 0.9), med(epi, 0.5), med(epi, 0.9), med(stg, 0.5), med(stg, 0.9));
         }
         HIPCHK(hipMemset(wave_times_, 0, w.size() * sizeof(unsigned long long)));
     }

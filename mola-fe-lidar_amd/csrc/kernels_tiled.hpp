@@ -384,10 +384,10 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     unsigned long long wave_staged = 0ull;
     const unsigned long long t_wave0 = wave_times ? wall_clock64() : 0ull;  // 100 MHz, the same on every XCD
     unsigned int wave_items = 0u;
+    unsigned long long ph0 = 0ull, ph1 = 0ull, ph2 = 0ull, ph3 = 0ull;
     int item = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
     while (item >= 0) {
         ++wave_items;
-        const int next_raw_v = wq.pop();
         const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
 
         float qx[QPL], qy[QPL], qz[QPL], reach[QPL];
@@ -406,10 +406,12 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
             js[k] = use_seed ? pos_s[ic] : -1;
         }
+        // the next entry's pop goes out BEHIND these loads: memory results return in order, and a device-scope atomic
+        // (slow, slower still in the burst at kernel start) ahead of them would sit on the prologue's critical path
+        const int next_raw_v = wq.pop();
 #pragma unroll
         for (int k = 0; k < QPL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
-        // round trip 2: the seeds' coordinates, and the next item's id
-        const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
+        // round trip 2: the seeds' coordinates
         float gsx[QPL], gsy[QPL], gsz[QPL];
         unsigned int gso[QPL] = {};
 #pragma unroll
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
 
         unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
         unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
-        const unsigned long long t_sweep0 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t_sweep0 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
         const unsigned long long n_staged = tiled_sweep<QPL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
             if constexpr (EXACT) {
                 for (int m = 0; m < nm; m += 4) {
@@ -514,7 +516,9 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 }
             }
         }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
-        const unsigned long long t_sweep1 = dbg_stats ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t_sweep1 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
+        // the popped entry has long arrived: its lookup (and a steal, if the segment is dry) overlaps the epilogue's loads
+        const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
 
         bool any_tie = false;
         int rpos[QPL], roi[QPL];
@@ -605,12 +609,16 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 rec[7] = t_end - t_sweep1;
             }
         }
+        if (wave_times && wave_items == 1u) {  // phases of the wave's first item (shader clock)
+            const unsigned long long t_end1 = __builtin_amdgcn_s_memtime();
+            ph0 = t_sweep0 - t_item0; ph1 = t_sweep1 - t_sweep0; ph2 = t_end1 - t_sweep1; ph3 = n_staged;
+        }
         item = __builtin_amdgcn_readfirstlane(next_item_v);
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
-    if (wave_times && lane == 0) {  // [start, end, items] per wave
-        unsigned long long* w = wave_times + 3 * (size_t)wq.global_wave();
-        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items;
+    if (wave_times && lane == 0) {  // [start, end, items, first item: prologue, sweep, epilogue cycles, staged points] per wave
+        unsigned long long* w = wave_times + 8 * (size_t)wq.global_wave();
+        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items; w[3] = ph0; w[4] = ph1; w[5] = ph2; w[6] = ph3;
     }
 }
 
