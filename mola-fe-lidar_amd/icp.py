@@ -329,15 +329,23 @@ class ICP:
         if os.path.exists(cand):  # the RCCL this process already uses
             L.check(L.lib().mola_icp_comm_set_library(cand.encode()))
         ident = (C.c_uint8 * 128)()
+        status, err = 0, None
         if rank == 0:
-            L.check(L.lib().mola_icp_comm_unique_id(ident))
+            try:  # a failure here must still reach the broadcast below, or the other ranks wait for ever
+                L.check(L.lib().mola_icp_comm_unique_id(ident))
+            except Exception as e:  # noqa: BLE001
+                status, err = 1, e
         on_gpu = dist.get_backend(group) == "nccl"
-        t = torch.tensor(list(ident), dtype=torch.uint8)
+        t = torch.tensor(list(ident) + [status], dtype=torch.uint8)
         if on_gpu:
             t = t.cuda()
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast(t, src=src, group=group)
-        ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        got = t.cpu().tolist()
+        if got[128] != 0:
+            raise err if err is not None else L.IcpError(L.E_COMM,
+                                                         "rank 0 could not create the RCCL unique id")
+        ident = (C.c_uint8 * 128)(*got[:128])
         L.check(L.lib().mola_icp_comm_init(self._h, ident, world, rank))
 
     def comm_destroy(self):
