@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOLA_ICP_ABI_VERSION 1
+#define MOLA_ICP_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -66,7 +66,7 @@ enum {
     MOLA_ICP_NN_AUTO  = 0,
     MOLA_ICP_NN_VALU  = 1,  /* exact VALU brute force (reference kernel)                            */
     MOLA_ICP_NN_MFMA  = 2,  /* dense N x M MFMA filter + exact re-evaluation of survivors           */
-    MOLA_ICP_NN_TILED = 3   /* dense N x M/32 MFMA test against Morton-sorted map tiles + exact refine */
+    MOLA_ICP_NN_TILED = 3   /* exact VALU brute force over the Hilbert-sorted map tiles a query group can reach */
 };
 
 /* ---- per-call parameters == mp2p_icp::Parameters + the per-object pipeline
@@ -149,6 +149,19 @@ int mola_icp_params_from_yaml(const char* yaml_text, mola_icp_params* p);
  * like params/kitti-default.yaml:43,46,50; `key` selects a sub-map
  * (e.g. "icp_settings_with_vel"), NULL/"" = the document root. */
 int mola_icp_params_from_yaml_file(const char* path, const char* mola_dir, const char* key, mola_icp_params* p);
+
+/* The reference keeps matchers / solvers / quality evaluators inside the ICP OBJECT (LidarOdometry.h:98,
+ * initialised once at src/LidarOdometry.cpp:80-87) and hands `mp2p_icp::Parameters` (cpp:77-78: maxIterations,
+ * minAbsStep_trans, minAbsStep_rot, pairingsWeightParameters{...}) to align() PER CALL -- and at cpp:287-290 it
+ * passes the NearbyAlign case's Parameters to the AlignKind::LidarOdometry object (cpp:869).  The flat
+ * mola_icp_params carries both halves; this composes them the way that call does:
+ *   *out = *object_settings  (solver_*, matcher_*, plane_eigen_threshold, knn, run_*_iteration, quality_*,
+ *                             nn_kernel, skip_quality)
+ *   with the mp2p_icp::Parameters fields of *call_parameters (max_iterations, min_abs_step_trans,
+ *   min_abs_step_rot, use_scale_outlier_detector, scale_outlier_threshold, use_robust_kernel, robust_kernel_param,
+ *   robust_kernel_scale; and fixed_iterations, which this implementation reads from the same `params:` block). */
+int mola_icp_params_compose(const mola_icp_params* object_settings, const mola_icp_params* call_parameters,
+                            mola_icp_params* out);
 
 /* ---- handle ----------------------------------------------------------- */
 /* device < 0: current HIP device.  Replaces mrpt::rtti::classFactory(icp_class)
@@ -298,8 +311,21 @@ typedef struct mola_lo_params {
     double min_dist_xyz_between_keyframes;  /* [m]   h:61,  kitti:8,  used cpp:336 */
     double min_rotation_between_keyframes;  /* [rad] h:66 (YAML in degrees, cpp:106), used cpp:337 */
     double min_icp_goodness;                /* h:70, kitti:12, used cpp:334 */
-    mola_icp_params icp_with_vel;           /* params_.icp[LidarOdometry].icpParameters, cpp:122-124, 288-289 */
-    mola_icp_params icp_without_vel;        /* params_.icp[NearbyAlign].icpParameters,   cpp:125-126, 290 */
+    /* the three ICP cases (LidarOdometry.h:96-102): each = {ICP object settings, default mp2p_icp::Parameters}.
+     * The odometry path ALWAYS runs the LidarOdometry object (icp_with_vel's matcher/solver/quality: cpp:869 with
+     * in.align_kind left at its default, h:118) and swaps only the mp2p_icp::Parameters half (cpp:287-290). */
+    mola_icp_params icp_with_vel;           /* params_.icp[LidarOdometry], cpp:122-124 */
+    mola_icp_params icp_without_vel;        /* params_.icp[NearbyAlign],   cpp:125-126 */
+    mola_icp_params icp_loop_closure;       /* params_.icp[LoopClosure],   cpp:127-128 */
+    /* nearby-KF / loop-closure policy (h:70-93, read at cpp:110-117) */
+    double   min_icp_goodness_lc;                     /* h:73,  kitti:14, used cpp:805-807 */
+    double   min_dist_to_matching;                    /* h:83,  kitti:35, used cpp:574 */
+    double   max_dist_to_matching;                    /* h:84,  kitti:36, used cpp:575-576, 592-594 */
+    double   max_dist_to_loop_closure;                /* h:85,  kitti:37, used cpp:575-576, 768 */
+    uint32_t loop_closure_montecarlo_samples;         /* h:86,  kitti:49, used cpp:774 */
+    uint32_t max_nearby_align_checks;                 /* h:87,  kitti:38, used cpp:706-708 */
+    uint32_t min_topo_dist_to_consider_loopclosure;   /* h:88,  kitti:39, used cpp:588-589 */
+    uint32_t max_kfs_local_graph;                     /* h:90,  used cpp:558 */
 } mola_lo_params;
 
 enum {

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmola_icp_amd.so")
 
 NACC = 24
+ABI_VERSION = 2   # MOLA_ICP_ABI_VERSION of include/mola_icp_amd.h
 
 OK = 0
 E_BADARG, E_CONFIG, E_HIP, E_OOM, E_NODEVICE, E_UNSUPPORTED, E_COMM, E_INTERNAL = -1, -2, -3, -4, -5, -6, -7, -8
@@ -74,6 +75,15 @@ class CLoParams(C.Structure):
         ("min_icp_goodness", C.c_double),
         ("icp_with_vel", CParams),
         ("icp_without_vel", CParams),
+        ("icp_loop_closure", CParams),
+        ("min_icp_goodness_lc", C.c_double),
+        ("min_dist_to_matching", C.c_double),
+        ("max_dist_to_matching", C.c_double),
+        ("max_dist_to_loop_closure", C.c_double),
+        ("loop_closure_montecarlo_samples", C.c_uint32),
+        ("max_nearby_align_checks", C.c_uint32),
+        ("min_topo_dist_to_consider_loopclosure", C.c_uint32),
+        ("max_kfs_local_graph", C.c_uint32),
     ]
 
 
@@ -132,6 +142,7 @@ SIGNATURES = {
     "mola_icp_params_default": (C.c_int, [C.POINTER(CParams)]),
     "mola_icp_params_from_yaml": (C.c_int, [C.c_char_p, C.POINTER(CParams)]),
     "mola_icp_params_from_yaml_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CParams)]),
+    "mola_icp_params_compose": (C.c_int, [C.POINTER(CParams), C.POINTER(CParams), C.POINTER(CParams)]),
     "mola_icp_create": (C.c_int, [C.c_int, C.POINTER(_H)]),
     "mola_icp_destroy": (C.c_int, [_H]),
     "mola_icp_set_stream": (C.c_int, [_H, C.c_void_p]),
@@ -230,7 +241,7 @@ def lib() -> C.CDLL:
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
-        if L.mola_icp_abi_version() != 1:
+        if L.mola_icp_abi_version() != ABI_VERSION:
             raise ImportError("libmola_icp_amd.so ABI version mismatch")
         _lib = L
     return _lib

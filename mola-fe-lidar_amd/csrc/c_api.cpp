@@ -19,6 +19,7 @@
 namespace mola_icp_amd {
 void params_default(mola_icp_params& p);
 void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p);
+void params_compose(const mola_icp_params& object_settings, const mola_icp_params& call_parameters, mola_icp_params& out);
 }  // namespace mola_icp_amd
 
 using namespace mola_icp_amd;
@@ -242,6 +243,14 @@ int mola_icp_params_from_yaml_file(const char* path, const char* mola_dir, const
     } catch (const std::exception& e) {
         return fail(MOLA_ICP_E_CONFIG, e.what());
     }
+}
+
+int mola_icp_params_compose(const mola_icp_params* object_settings, const mola_icp_params* call_parameters,
+                            mola_icp_params* out)
+{
+    if (!object_settings || !call_parameters || !out) return fail(MOLA_ICP_E_BADARG, "null argument");
+    params_compose(*object_settings, *call_parameters, *out);
+    return MOLA_ICP_OK;
 }
 
 int mola_icp_create(int device, mola_icp_handle** out)

@@ -39,6 +39,22 @@ void params_default(mola_icp_params& p)
     p.skip_quality = 0;
 }
 
+// mp2p_icp::Parameters (cpp:77-78) vs the ICP object's own pipelines (cpp:80-87): see mola_icp_params_compose()
+void params_compose(const mola_icp_params& object_settings, const mola_icp_params& call_parameters, mola_icp_params& out)
+{
+    mola_icp_params r = object_settings;
+    r.max_iterations = call_parameters.max_iterations;
+    r.min_abs_step_trans = call_parameters.min_abs_step_trans;
+    r.min_abs_step_rot = call_parameters.min_abs_step_rot;
+    r.use_scale_outlier_detector = call_parameters.use_scale_outlier_detector;
+    r.scale_outlier_threshold = call_parameters.scale_outlier_threshold;
+    r.use_robust_kernel = call_parameters.use_robust_kernel;
+    r.robust_kernel_param = call_parameters.robust_kernel_param;
+    r.robust_kernel_scale = call_parameters.robust_kernel_scale;
+    r.fixed_iterations = call_parameters.fixed_iterations;
+    out = r;
+}
+
 static const char* kKnownIcpClasses[] = {"mp2p_icp::ICP", "mola_icp_amd::ICP_MI355X"};
 
 static void require(const YamlNode& cfg, const char* key)

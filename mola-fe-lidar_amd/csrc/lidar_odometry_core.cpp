@@ -16,6 +16,7 @@
 
 namespace mola_icp_amd {
 void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p);
+void params_compose(const mola_icp_params& object_settings, const mola_icp_params& call_parameters, mola_icp_params& out);
 }
 using namespace mola_icp_amd;
 
@@ -59,6 +60,15 @@ int mola_lo_params_default(mola_lo_params* p)
     p->min_icp_goodness = 0.4;                             // h:70
     mola_icp_params_default(&p->icp_with_vel);
     mola_icp_params_default(&p->icp_without_vel);
+    mola_icp_params_default(&p->icp_loop_closure);
+    p->min_icp_goodness_lc = 0.6;                          // h:73
+    p->min_dist_to_matching = 6.0;                         // h:83
+    p->max_dist_to_matching = 12.0;                        // h:84
+    p->max_dist_to_loop_closure = 30.0;                    // h:85
+    p->loop_closure_montecarlo_samples = 10;               // h:86
+    p->max_nearby_align_checks = 2;                        // h:87
+    p->min_topo_dist_to_consider_loopclosure = 20;         // h:88
+    p->max_kfs_local_graph = 50000;                        // h:90
     return MOLA_ICP_OK;
 }
 
@@ -80,9 +90,21 @@ int mola_lo_params_from_yaml_file(const char* path, const char* mola_dir, mola_l
             p->min_rotation_between_keyframes = n->as_double() * M_PI / 180.0;                       // _OPT_DEG cpp:106
         if (auto* n = cfg->find("min_time_between_scans")) p->min_time_between_scans = n->as_double();
         if (auto* n = cfg->find("min_icp_goodness")) p->min_icp_goodness = n->as_double();
+        if (auto* n = cfg->find("min_icp_goodness_lc")) p->min_icp_goodness_lc = n->as_double();             // cpp:110
+        if (auto* n = cfg->find("min_dist_to_matching")) p->min_dist_to_matching = n->as_double();           // cpp:112
+        if (auto* n = cfg->find("max_dist_to_matching")) p->max_dist_to_matching = n->as_double();           // cpp:113
+        if (auto* n = cfg->find("max_dist_to_loop_closure")) p->max_dist_to_loop_closure = n->as_double();   // cpp:114
+        if (auto* n = cfg->find("max_nearby_align_checks")) p->max_nearby_align_checks = (uint32_t)n->as_int();  // cpp:115
+        if (auto* n = cfg->find("min_topo_dist_to_consider_loopclosure"))
+            p->min_topo_dist_to_consider_loopclosure = (uint32_t)n->as_int();                                // cpp:116
+        if (auto* n = cfg->find("loop_closure_montecarlo_samples"))
+            p->loop_closure_montecarlo_samples = (uint32_t)n->as_int();                                      // cpp:117
+        // (keys the reference's file carries but its code never reads -- decimate_to_point_count, pointcloud_filter_*,
+        //  debug_save_*: SURVEY.md §5 "stale-config warning" -- are accepted and ignored, as the reference does)
         if (!cfg->has("icp_settings_with_vel")) throw std::runtime_error("Missing YAML required entry `icp_settings_with_vel`");
         params_from_yaml_node(cfg->at("icp_settings_with_vel"), p->icp_with_vel);          // cpp:122-124
         params_from_yaml_node(cfg->at("icp_settings_without_vel"), p->icp_without_vel);    // cpp:125-126
+        params_from_yaml_node(cfg->at("icp_settings_loop_closure"), p->icp_loop_closure);  // cpp:127-128
         return MOLA_ICP_OK;
     } catch (const std::exception& e) {
         return fail(MOLA_ICP_E_CONFIG, e.what());
@@ -204,8 +226,12 @@ int mola_lo_process_scan(mola_lo* lo, double timestamp, const float* x, const fl
             // constant-velocity guess: (vx,vy,vz)*dt and yaw = wz*dt only (cpp:272-275, "do omega_xyz part!" TODO)
             const double guess6[6] = {lo->twist[0] * dt, lo->twist[1] * dt, lo->twist[2] * dt, lo->twist[3] * dt, 0, 0};
             const Mat4 guess = pose_from_xyzypr(guess6);
-            // larger threshold set when the twist is not trustworthy (cpp:287-290)
-            const mola_icp_params& ip = lo->twist_is_good ? lo->params.icp_with_vel : lo->params.icp_without_vel;
+            // Without a trustworthy twist the reference swaps ONLY icp_in.icp_params -- the mp2p_icp::Parameters half
+            // (maxIterations, minAbsStep_*, pairingsWeightParameters) -- for the NearbyAlign case's (cpp:287-290);
+            // the ICP object stays the AlignKind::LidarOdometry one (in.align_kind keeps its default, h:118; cpp:869),
+            // i.e. icp_with_vel's matcher / solver / quality settings run either way.
+            mola_icp_params ip = lo->params.icp_with_vel;
+            if (!lo->twist_is_good) params_compose(lo->params.icp_with_vel, lo->params.icp_without_vel, ip);
             out->used_with_vel_params = lo->twist_is_good ? 1 : 0;
             // run_one_icp: to = this scan, from = previous scan (cpp:278-279, 299, 869-871)
             int rc;

@@ -133,6 +133,18 @@ class Parameters:
         else:
             object.__setattr__(self, name, value)
 
+    #: the fields of `mp2p_icp::Parameters` proper (cpp:77-78; icpreg:10-21) -- what the reference passes per call
+    CALL_FIELDS = ("max_iterations", "min_abs_step_trans", "min_abs_step_rot", "use_scale_outlier_detector",
+                   "scale_outlier_threshold", "use_robust_kernel", "robust_kernel_param", "robust_kernel_scale")
+
+    @staticmethod
+    def compose(object_settings: "Parameters", call_parameters: "Parameters") -> "Parameters":
+        """the ICP object's matcher/solver/quality settings run with ANOTHER case's `mp2p_icp::Parameters`
+        (src/LidarOdometry.cpp:287-290 + 869): mola_icp_params_compose()"""
+        q = Parameters()
+        L.check(L.lib().mola_icp_params_compose(C.byref(object_settings.c), C.byref(call_parameters.c), C.byref(q.c)))
+        return q
+
     def copy(self) -> "Parameters":
         q = Parameters()
         C.memmove(C.byref(q.c), C.byref(self.c), C.sizeof(L.CParams))

@@ -43,20 +43,33 @@ class LidarOdometryParams:
                                                       C.byref(p.c)))
         return p
 
-    def set_icp(self, with_vel: Parameters, without_vel: Parameters | None = None):
+    _SCALARS = ("min_time_between_scans", "min_dist_xyz_between_keyframes", "min_rotation_between_keyframes",
+                "min_icp_goodness", "min_icp_goodness_lc", "min_dist_to_matching", "max_dist_to_matching",
+                "max_dist_to_loop_closure", "loop_closure_montecarlo_samples", "max_nearby_align_checks",
+                "min_topo_dist_to_consider_loopclosure", "max_kfs_local_graph")
+
+    def set_icp(self, with_vel: Parameters, without_vel: Parameters | None = None,
+                loop_closure: Parameters | None = None):
+        """the three ICP cases of `Parameters::icp` (LidarOdometry.h:96-102)"""
         C.memmove(C.byref(self.c.icp_with_vel), C.byref(with_vel.c), C.sizeof(L.CParams))
         C.memmove(C.byref(self.c.icp_without_vel), C.byref((without_vel or with_vel).c), C.sizeof(L.CParams))
+        C.memmove(C.byref(self.c.icp_loop_closure), C.byref((loop_closure or without_vel or with_vel).c),
+                  C.sizeof(L.CParams))
+
+    def icp_case(self, name: str) -> Parameters:
+        """a copy of one case: "with_vel" (AlignKind::LidarOdometry), "without_vel" (NearbyAlign), "loop_closure"""
+        p = Parameters()
+        C.memmove(C.byref(p.c), C.byref(getattr(self.c, "icp_" + name)), C.sizeof(L.CParams))
+        return p
 
     def __getattr__(self, name):
         c = object.__getattribute__(self, "c")
-        if name in ("min_time_between_scans", "min_dist_xyz_between_keyframes", "min_rotation_between_keyframes",
-                    "min_icp_goodness"):
+        if name in LidarOdometryParams._SCALARS:
             return getattr(c, name)
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
-        if name in ("min_time_between_scans", "min_dist_xyz_between_keyframes", "min_rotation_between_keyframes",
-                    "min_icp_goodness"):
+        if name in LidarOdometryParams._SCALARS:
             setattr(self.c, name, value)
         else:
             object.__setattr__(self, name, value)

@@ -47,6 +47,12 @@ class ReferenceFrontEnd:
     (src/LidarOdometry.cpp:190-514, without back-end / world model): what the product's
     csrc/lidar_odometry_core.cpp must reproduce step by step.  `align(from, to, T0, params)` -> (T, quality)."""
 
+    # mp2p_icp::Parameters proper (load_from(cfg["params"]) cpp:77-78; icpreg:10-21): the ONLY thing cpp:287-290 swaps.
+    # Matchers / solvers / quality belong to the ICP object (cpp:80-87), which is always the LidarOdometry one (cpp:869).
+    CALL_FIELDS = ("max_iterations", "min_abs_step_trans", "min_abs_step_rot", "use_scale_outlier_detector",
+                   "scale_outlier_threshold", "use_robust_kernel", "robust_kernel_param", "robust_kernel_scale",
+                   "fixed_iterations")
+
     def __init__(self, min_time, min_dist, min_rot, min_good, p_with, p_without, align, pose_from_xyzypr):
         self.min_time, self.min_dist, self.min_rot, self.min_good = min_time, min_dist, min_rot, min_good
         self.p_with, self.p_without, self.align, self.pose = p_with, p_without, align, pose_from_xyzypr
@@ -75,7 +81,10 @@ class ReferenceFrontEnd:
             out["status"] = 2
             dt = t - last_tim                                                      # cpp:268-269
             guess = self.pose(self.twist[0] * dt, self.twist[1] * dt, self.twist[2] * dt, self.twist[3] * dt, 0, 0)
-            p = self.p_with if self.twist_good else self.p_without                 # cpp:287-290
+            p = self.p_with.copy()                                                 # the LidarOdometry ICP object, cpp:869
+            if not self.twist_good:                                                # cpp:287-290: icpParameters only
+                for f in self.CALL_FIELDS:
+                    setattr(p, f, getattr(self.p_without, f))
             out["used_with"] = self.twist_good
             T, q = self.align(last_pts, pts, guess, p)                             # cpp:278-279, 299
             out["rel"], out["quality"], out["dt"] = T, q, dt

@@ -36,8 +36,10 @@ def test_include_and_mola_dir(pkg):
     f = os.path.join(PARAMS, "kitti-default.yaml")
     a = pkg.Parameters.load_from_file(f, mola_dir=ROOT, key="icp_settings_with_vel")
     b = pkg.Parameters.load_from_file(f, mola_dir=ROOT, key="icp_settings_loop_closure")
-    assert a.matcher_class == pkg._lib.MATCHER_POINTS_DISTANCE_THRESHOLD
+    assert a.matcher_class == pkg._lib.MATCHER_POINT2PLANE      # the reference's file: all three cases are its shipped pipeline
     assert b.matcher_class == pkg._lib.MATCHER_POINT2PLANE
+    c = pkg.Parameters.load_from_file(os.path.join(PARAMS, "kitti-p2p-horn.yaml"), mola_dir=ROOT, key="icp_settings_with_vel")
+    assert c.matcher_class == pkg._lib.MATCHER_POINTS_DISTANCE_THRESHOLD
     with pytest.raises(pkg.IcpError) as e:
         pkg.Parameters.load_from_file(f, mola_dir=None, key="icp_settings_with_vel")
     assert e.value.status == pkg._lib.E_CONFIG and "mola-dir" in str(e.value)

@@ -148,9 +148,9 @@ def test_config1_kitti_like_pair_through_front_end(pkg, O, synth):
     b = lo.on_new_observation(10.1, s1)
     assert a.status == pkg._lib.LO_FIRST_SCAN and a.keyframe_created
     assert b.status == pkg._lib.LO_ICP_RAN and not b.used_with_vel_params
-    p = pkg.Parameters()
-    import ctypes
-    ctypes.memmove(ctypes.byref(p.c), ctypes.byref(lp.c.icp_without_vel), ctypes.sizeof(pkg._lib.CParams))
+    # no twist yet: the LidarOdometry ICP object with the NearbyAlign case's mp2p_icp::Parameters (cpp:287-290, 869)
+    p = pkg.Parameters.compose(lp.icp_case("with_vel"), lp.icp_case("without_vel"))
+    assert p.matcher_class == pkg._lib.MATCHER_POINT2PLANE     # the reference's shipped pipeline (kitti-default.yaml:43,46)
     ref = O.align(s0, s1, np.eye(4), O.params_from_product(p))
     assert b.icp.nIterations == ref["n_iterations"] and b.icp.terminationReason == ref["termination"]
     rot, trans = O.pose_error(b.rel_pose, ref["T"])
