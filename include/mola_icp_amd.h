@@ -135,6 +135,9 @@ int         mola_icp_abi_version(void);
 const char* mola_icp_last_error(void);            /* thread-local, never NULL */
 const char* mola_icp_status_string(int status);
 int         mola_icp_device_count(int* count);    /* gfx950 devices visible   */
+/* The MOLA_ICP_* diagnostic / tuning environment variables are read once, when the library is loaded --
+ * never on a launch path.  Tests that toggle one on a live process call this to have them read again. */
+int         mola_icp_debug_reload_env(void);
 
 /* ---- parameters ------------------------------------------------------- */
 /* the defaults of mp2p_icp::Parameters + Points_DistanceThreshold/Horn/PairedRatio */
@@ -237,7 +240,12 @@ int mola_icp_voxel_downsample(mola_icp_handle* h, const float* x, const float* y
 
 /* ---- resident-cloud API (inputs already in HBM; bench + sharded path) ---
  * *_device take DEVICE pointers (fp32 SoA) that must stay valid until the
- * next set_* / destroy; *_host copy from host memory. */
+ * next set_* / destroy; *_host copy from host memory.
+ * ORDERING CONTRACT of *_device: the handle works on its own non-blocking HIP stream (or the one given to
+ * mola_icp_set_stream), which has NO implicit ordering against any other stream, the null stream included.  The
+ * buffers must be completely written -- the producing stream synchronised, or the producer run on the stream handed
+ * to mola_icp_set_stream() -- BEFORE the call that first uses them (the next match / align), and must not be
+ * rewritten while an align runs.  (The Python binding synchronises torch's current stream in set_map / set_local.) */
 int mola_icp_set_map_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M);
 int mola_icp_set_map_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t M);
 int mola_icp_set_local_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t N);

@@ -139,6 +139,7 @@ SIGNATURES = {
     "mola_icp_last_error": (C.c_char_p, []),
     "mola_icp_status_string": (C.c_char_p, [C.c_int]),
     "mola_icp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mola_icp_debug_reload_env": (C.c_int, []),
     "mola_icp_params_default": (C.c_int, [C.POINTER(CParams)]),
     "mola_icp_params_from_yaml": (C.c_int, [C.c_char_p, C.POINTER(CParams)]),
     "mola_icp_params_from_yaml_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CParams)]),

@@ -203,6 +203,12 @@ int mola_icp_device_count(int* count)
     });
 }
 
+int mola_icp_debug_reload_env(void)
+{
+    reload_env_knobs();
+    return MOLA_ICP_OK;
+}
+
 int mola_icp_params_default(mola_icp_params* p)
 {
     if (!p) return fail(MOLA_ICP_E_BADARG, "null params");

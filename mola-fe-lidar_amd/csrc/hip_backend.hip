@@ -47,6 +47,33 @@ namespace mola_icp_amd {
 
 // ------------------------------------------------------------------ host code
 
+// Diagnostic / tuning environment variables: read ONCE per process -- never on a launch path -- and again only
+// when a test asks for it through mola_icp_debug_reload_env().
+struct Knobs {
+    int blocks_per_cu = 0;     // MOLA_ICP_BLOCKS_PER_CU (0 = default)
+    int qpl = 0;               // MOLA_ICP_QPL (0 = by cloud size)
+    int coop = -1;             // MOLA_ICP_COOP (-1 = by cloud size, 0 = one item per wave, 1 = one item per block)
+    bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
+    int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
+};
+static Knobs read_knobs()
+{
+    Knobs k;
+    auto geti = [](const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : 0; };
+    k.blocks_per_cu = geti("MOLA_ICP_BLOCKS_PER_CU") > 0 ? geti("MOLA_ICP_BLOCKS_PER_CU") : 0;
+    k.qpl = std::getenv("MOLA_ICP_QPL") ? (geti("MOLA_ICP_QPL") == 1 ? 1 : 2) : 0;
+    k.coop = std::getenv("MOLA_ICP_COOP") ? (geti("MOLA_ICP_COOP") != 0 ? 1 : 0) : -1;
+    k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
+    k.no_knn_seed = std::getenv("MOLA_ICP_NO_KNN_SEED") != nullptr;
+    k.no_knn_verify = std::getenv("MOLA_ICP_NO_KNN_VERIFY") != nullptr;
+    k.no_direct_readback = std::getenv("MOLA_ICP_NO_DIRECT_READBACK") != nullptr;
+    k.no_warm_start = std::getenv("MOLA_ICP_NO_WARM_START") != nullptr;
+    k.debug_stats = geti("MOLA_ICP_DEBUG_STATS");
+    return k;
+}
+static Knobs g_knobs = read_knobs();
+void reload_env_knobs() { g_knobs = read_knobs(); }
+
 int DevBuf::reserve(size_t bytes)
 {
     if (bytes <= cap && p) return MOLA_ICP_OK;
@@ -113,10 +140,10 @@ int HipWorkspace::init()
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocDefault));
     int rc;
     if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8) + sizeof(unsigned int) * 2 * kQueues * kQueueStride))) return rc;
-    if (std::getenv("MOLA_ICP_DEBUG_STATS")) {  // diagnostic builds of a run, never on by default
+    if (g_knobs.debug_stats) {  // diagnostic builds of a run, never on by default
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
         HIPCHK(hipMemset(dbg_stats_, 0, (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
-        if (std::atoi(std::getenv("MOLA_ICP_DEBUG_STATS")) == 2) {  // light mode: per-wave start/end of the tiled matcher only
+        if (g_knobs.debug_stats == 2) {  // light mode: per-wave start/end of the tiled matcher only
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&wave_times_), 8 * 8192 * sizeof(unsigned long long)));
             HIPCHK(hipMemset(wave_times_, 0, 8 * 8192 * sizeof(unsigned long long)));
         }
@@ -473,8 +500,7 @@ TiledMap HipWorkspace::tiled_map() const
 int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
 {
     // blocks per CU, measured at C3: 2 -> 0.159 ms, 3 -> 0.150, 4 -> 0.156
-    int per_cu = 3;
-    if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 3;  // tuning knob
+    int per_cu = g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 3;  // tuning knob
     const TiledMap mp = tiled_map();
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
@@ -486,7 +512,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     // either way and the larger items do less total work (250k: 0.083 vs 0.091 ms).
     const size_t n128 = (N_ + kQPW - 1) / kQPW, slots = (size_t)num_cus_ * per_cu * 4;
     int qpl = (n128 >= slots && n128 < 2 * slots) ? 1 : 2;
-    if (const char* e = std::getenv("MOLA_ICP_QPL")) qpl = std::atoi(e) == 1 ? 1 : 2;  // tuning knob
+    if (g_knobs.qpl) qpl = g_knobs.qpl;  // tuning knob
     const int n_items = (int)((N_ + (size_t)(64 * qpl) - 1) / (size_t)(64 * qpl));
     {   // persistent waves with a static first item: every block of the grid must be resident from the start
         // (the query is a runtime call of tens of microseconds on the launch path: once per kernel flavour and LDS size)
@@ -505,7 +531,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     if ((rc = item_cost_.reserve(sizeof(unsigned int) * (size_t)n_items))) return rc;
     if ((rc = item_order_.reserve(sizeof(int) * ((size_t)n_items + kQueues + 1)))) return rc;  // + the segment boundaries
     const int* order = nullptr;
-    if (cost_valid_ && !std::getenv("MOLA_ICP_NO_LPT")) {
+    if (cost_valid_ && !g_knobs.no_lpt) {
         // the cost profile drifts slowly with the pose: re-sort at launch 1, 2, 4, 8 after the clouds were set,
         // then every 16th; the order is reused in between
         if (!order_valid_ || launches_since_order_ >= plan_interval_) {
@@ -605,11 +631,14 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     fit_lds = dyn_lds;
     int grid = num_cus_ * (fit < 1 ? 1 : (fit > 3 ? 3 : fit));
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
-    const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !std::getenv("MOLA_ICP_NO_KNN_SEED")) ? 1 : 0;
+    const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed) ? 1 : 0;
+    // the cached plane of an unchanged neighbour list carries the planar / non-planar decision of the launch that
+    // solved it: reusable only under the same planeEigenThreshold (the seeds themselves do not depend on it)
+    const int plane_cache_ok = (knn_seed && planes_eig_thr_ == p.plane_eigen_threshold) ? 1 : 0;
     // the counting flavour pays off when few items will need the insertion flavour afterwards: judged by the
     // number of items whose lists changed in the previous iteration (read back with its accumulators)
     const bool verify = knn_seed && knn_changed_items_ >= 0.0 && knn_changed_items_ < 0.3 * (double)n_items &&
-                        !std::getenv("MOLA_ICP_NO_KNN_VERIFY");
+                        !g_knobs.no_knn_verify;
     knn_changed_items_ = -1.0;  // consumed: only an accumulate_planes() after this launch renews it
     if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
@@ -618,7 +647,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 #define MOLA_LAUNCH_KNN(KK, VER, QUEUE, LIST)                                                                        \
     hipLaunchKernelGGL((k_knn_planes<KK, VER>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold,   \
-                       planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, QUEUE,    \
+                       planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
                        counter + 2, LIST, counter, staged, lds_boxes)
 #define MOLA_LAUNCH_KNN_ALL(KK)                                                                                      \
     do {                                                                                                             \
@@ -644,6 +673,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     ev_used_ += 2;
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;
+    planes_eig_thr_ = p.plane_eigen_threshold;
     planes_valid_ = true;
     knn_seed_valid_ = true;
     return MOLA_ICP_OK;
@@ -680,7 +710,7 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
                              hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(plane_acc_host_, 0, sizeof(double) * (kNAccPlane + 4));
     }
-    if (std::getenv("MOLA_ICP_NO_DIRECT_READBACK")) {
+    if (g_knobs.no_direct_readback) {
         HIPCHK(hipMemcpyAsync(plane_acc_host_, dacc, sizeof(double) * (kNAccPlane + 1), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
     } else {  // the form (+ the changed-lists count) into the pinned block, then the sequence number the host spins on
@@ -865,7 +895,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
     }
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     if (kernel == MOLA_ICP_NN_TILED) {
-        const bool use_seed = seed_valid_ && pairing_sorted_ && !std::getenv("MOLA_ICP_NO_WARM_START");
+        const bool use_seed = seed_valid_ && pairing_sorted_ && !g_knobs.no_warm_start;
         const int rc = launch_tiled(P, thr2, use_seed, counter);
         if (rc) return rc;
         last_kernel_ = MOLA_ICP_NN_TILED;
@@ -884,11 +914,10 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         if ((rc = seg_d2_.reserve(sizeof(float) * (size_t)map_segs_ * N_))) return rc;
         MapFrame F{map_center_[0], map_center_[1], map_center_[2], map_radius_};
         // warm start from the pairing this workspace computed last for the same clouds
-        const int* seed = (seed_valid_ && !pairing_sorted_ && !std::getenv("MOLA_ICP_NO_WARM_START")) ? idx_.as<int>()
+        const int* seed = (seed_valid_ && !pairing_sorted_ && !g_knobs.no_warm_start) ? idx_.as<int>()
                                                                                                         : nullptr;
         // persistent grid: every CU gets its resident blocks (2-3 per CU at this register count)
-        int per_cu = 3;
-        if (const char* e = std::getenv("MOLA_ICP_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 3;  // tuning knob
+        const int per_cu = g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 3;  // tuning knob
         int grid = num_cus_ * per_cu;
         if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
         hipLaunchKernelGGL((k_nn_mfma<kMfmaQT>), dim3(grid), dim3(256), 0, stream_, lx_, ly_, lz_, (int)N_, gx_, gy_,
@@ -1024,7 +1053,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     // the host spins on that number instead of a copy + stream synchronisation (both cost a launch gap and the
     // driver's wake-up latency on a ~0.2 ms iteration).  Sharded over RCCL: the collective runs in between on the
     // device block, then the block is copied.
-    const bool direct = !comm_ && !std::getenv("MOLA_ICP_NO_DIRECT_READBACK");
+    const bool direct = !comm_ && !g_knobs.no_direct_readback;
     const unsigned long long seq = ++readback_seq_;
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kNAcc * kRedSlices), 0, stream_, partials_.as<double>(), nblocks,
                        acc_dev_.as<double>(), direct ? acc_host_ : (double*)nullptr, seq);
@@ -1036,7 +1065,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
             const int rc2 = rccl_allreduce_sum_f64(comm_, acc_dev_.as<double>(), kNAcc, stream_);
             if (rc2) return rc2;
         }
-        if (std::getenv("MOLA_ICP_NO_DIRECT_READBACK")) {
+        if (g_knobs.no_direct_readback) {
             HIPCHK(hipMemcpyAsync(acc_host_, acc_dev_.p, sizeof(double) * kNAcc, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
             std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);

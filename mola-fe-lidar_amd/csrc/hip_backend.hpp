@@ -25,6 +25,8 @@ int rccl_comm_init(void** comm, int nranks, const RcclUniqueId& id, int rank);
 int rccl_allreduce_sum_f64(void* comm, double* dev_buf, size_t n, hipStream_t stream);
 int rccl_comm_destroy(void* comm);
 
+void reload_env_knobs();  // re-reads the MOLA_ICP_* diagnostic variables (tests); they are otherwise read once per process
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -133,6 +135,7 @@ class HipWorkspace final : public Stages {
     double* plane_acc_host_ = nullptr;
     bool planes_valid_ = false, planes_empty_ = false;
     int planes_knn_ = 0;
+    double planes_eig_thr_ = -1.0;  // planeEigenThreshold the planes in plane_cache_ were decided with
     double knn_changed_items_ = -1.0;  // items whose neighbour lists changed in the last iteration (-1: unknown)
     bool knn_seed_valid_ = false;  // knn_pos_ holds the last launch's neighbours for the clouds in place
     DevBuf redo_list_;                // work items with exact distance ties: redone with the full lexicographic key

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                                                     float thr2, double threshold, double plane_eig_thr,
                                                     PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
                                                     int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
-                                                    int use_seed, unsigned int* __restrict__ queue,
+                                                    int use_seed, int use_cache /*cached planes were decided with this launch's planeEigenThreshold*/,
+                                                    unsigned int* __restrict__ queue,
                                                     unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
                                                     unsigned int* __restrict__ changed_items,
                                                     unsigned long long* __restrict__ staged_total, int lds_boxes)
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
             int m = 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) m += (kp[k][j] >= 0 && kd_of(k, j) < thr2) ? 1 : 0;  // sorted: the first m entries
-            bool same = use_seed != 0;
+            bool same = use_seed != 0 && use_cache != 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int now = j < m ? kp[k][j] : -1;

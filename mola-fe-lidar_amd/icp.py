@@ -286,6 +286,9 @@ class ICP:
         if self._is_device_tensor(pc):
             import torch
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[0] == 3 and pc.is_contiguous()
+            # the handle's stream is non-blocking: no implicit ordering against torch's streams (ordering contract of
+            # mola_icp_set_*_device in include/mola_icp_amd.h) -- whatever produced `pc` must have finished
+            torch.cuda.current_stream(pc.device).synchronize()
             self._keep_map = pc
             L.check(L.lib().mola_icp_set_map_device(self._h, pc[0].data_ptr(), pc[1].data_ptr(), pc[2].data_ptr(),
                                                     pc.shape[1]))
@@ -297,6 +300,7 @@ class ICP:
         if self._is_device_tensor(pc):
             import torch
             assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[0] == 3 and pc.is_contiguous()
+            torch.cuda.current_stream(pc.device).synchronize()   # see set_map
             self._keep_local = pc
             L.check(L.lib().mola_icp_set_local_device(self._h, pc[0].data_ptr(), pc[1].data_ptr(), pc[2].data_ptr(),
                                                       pc.shape[1]))

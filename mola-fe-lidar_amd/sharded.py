@@ -50,13 +50,16 @@ def make_allreduce(group=None, device=None):
         return fn
 
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    stage = torch.zeros(32, dtype=torch.float64, device=dev)
+    stages = {}   # one staging tensor per block length: 24 doubles (point-to-point), 92 (the point-to-plane form)
 
     def fn(acc: np.ndarray) -> None:
         n = acc.shape[0]
-        stage[:n].copy_(torch.from_numpy(acc))
+        stage = stages.get(n)
+        if stage is None:
+            stage = stages[n] = torch.zeros(n, dtype=torch.float64, device=dev)
+        stage.copy_(torch.from_numpy(acc))
         dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=group)
-        acc[:] = stage[:n].cpu().numpy()
+        acc[:] = stage.cpu().numpy()
     return fn
 
 

@@ -109,11 +109,13 @@ def test_1m_x_1m_shipped_point2plane(pkg, O, big):
     icp.set_local(l)
     r = icp.align_resident(np.eye(4), p)
     os.environ["MOLA_ICP_NO_KNN_SEED"] = "1"
+    pkg._lib.lib().mola_icp_debug_reload_env()
     try:
         r0 = icp.align_resident(np.eye(4), p)
         v0, c0, n0, k0, cnt0 = icp.match_planes(r.optimal_tf, p, l.shape[1])
     finally:
         del os.environ["MOLA_ICP_NO_KNN_SEED"]
+        pkg._lib.lib().mola_icp_debug_reload_env()
     assert r.nIterations == r0.nIterations == 4 and np.array_equal(r.optimal_tf, r0.optimal_tf)
     rot, trans = O.pose_error(r.optimal_tf, Tgt)
     rot_i, trans_i = O.pose_error(np.eye(4), Tgt)

@@ -86,6 +86,7 @@ def test_tiled_both_item_sizes(pkg, O, synth, small_scene, qpl, monkeypatch):
     """The tiled matcher picks 64- or 128-query items from the cloud size (64 only for ~0.4-0.8M queries); both
     flavours forced here on ragged sizes, exact ties, a warm-started second launch and a full align."""
     monkeypatch.setenv("MOLA_ICP_QPL", qpl)
+    pkg._lib.lib().mola_icp_debug_reload_env()
     icp = pkg.ICP(device=0)
     T = synth.pose_from_xyzypr(0.1, -0.05, 0.02, 0.01, 0.002, -0.003)
     for N, M in ((63, 5), (129, 4000), (9000, 9000), (30011, 20011)):
@@ -109,6 +110,8 @@ def test_tiled_both_item_sizes(pkg, O, synth, small_scene, qpl, monkeypatch):
     rot, trans = O.pose_error(r.optimal_tf, ref["T"])
     assert rot < 1e-7 and trans < 1e-9
     icp.close()
+    monkeypatch.delenv("MOLA_ICP_QPL")
+    pkg._lib.lib().mola_icp_debug_reload_env()
 
 
 @pytest.mark.parametrize("kern", [1, 2, 3])

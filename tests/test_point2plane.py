@@ -117,6 +117,40 @@ def test_shipped_pipeline_align_equals_oracle(pkg, O, pair):
 
 
 @pytest.mark.gpu
+def test_plane_cache_follows_plane_eigen_threshold(pkg, O, pair):
+    """Resident clouds, two calls with DIFFERENT planeEigenThreshold: the plane cached for an unchanged neighbour list
+    carries the planar / non-planar decision of the threshold it was solved under, so a parameter change must not
+    reuse it (results independent of the handle's call history)."""
+    g, l, _ = pair
+    p_a = pkg.Parameters.load_from_file(REGULAR)
+    p_b = p_a.copy()
+    p_b.plane_eigen_threshold = 0.004      # much stricter: many 0.07-planar neighbourhoods are no planes any more
+    T = pkg.pose_from_xyzypr([0.05, -0.02, 0.01, 0.004, 0.001, -0.002])
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    va, *_ = icp.match_planes(T, p_a, l.shape[1])
+    vb, cb, nb, kb, cntb = icp.match_planes(T, p_b, l.shape[1])      # same pose: every list unchanged, seeds valid
+    fresh = pkg.ICP(device=0)
+    fresh.set_map(g)
+    fresh.set_local(l)
+    vf, cf, nf, kf, cntf = fresh.match_planes(T, p_b, l.shape[1])
+    assert va.sum() > vf.sum() > 0                                   # the thresholds really differ in effect
+    assert cntb == cntf and np.array_equal(vb, vf) and np.array_equal(kb, kf)
+    assert np.array_equal(cb, cf) and np.array_equal(nb, nf)
+    ov, *_ = O.match_point2plane(g, l, T, p_b.matcher_threshold, p_b.plane_eigen_threshold, p_b.knn, O.KdTree(g))
+    assert np.array_equal(vb, ov)
+    # and whole aligns: a-then-b on one handle == b on a fresh handle, bit for bit
+    r_a = icp.align_resident(np.eye(4), p_a)
+    r_b = icp.align_resident(np.eye(4), p_b)
+    r_f = fresh.align_resident(np.eye(4), p_b)
+    assert r_b.nIterations == r_f.nIterations and np.array_equal(r_b.optimal_tf, r_f.optimal_tf)
+    assert r_a.n_pairs != r_b.n_pairs
+    icp.close()
+    fresh.close()
+
+
+@pytest.mark.gpu
 def test_plane_accumulators_shard_sum(pkg, pair):
     """query shards run one after another: summed plane forms == the un-sharded form (what RCCL reduces)"""
     import importlib
