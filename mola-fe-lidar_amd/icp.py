@@ -192,8 +192,14 @@ class ICP:
         L.check(L.lib().mola_icp_create(device, C.byref(self._h)))
         self._keep = []       # device tensors / callbacks that must outlive the handle's use of them
         self._ar_cb = None
+        self._dependents = []  # weakrefs to objects holding this handle's raw pointer (LidarOdometry): closed first
 
     def close(self):
+        for ref in getattr(self, "_dependents", []):
+            d = ref()
+            if d is not None:
+                d.close()
+        self._dependents = []
         if getattr(self, "_h", None) and self._h.value:
             L.lib().mola_icp_destroy(self._h)
             self._h = L._H()

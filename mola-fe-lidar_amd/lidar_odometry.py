@@ -102,6 +102,9 @@ class LidarOdometry:
         self._h = L._H()
         L.check(L.lib().mola_lo_create(icp._h if icp is not None else None, self._cb or L.LO_ALIGN_FN(), None,
                                        C.byref(params.c), C.byref(self._h)))
+        if icp is not None:   # the front-end holds the ICP handle's raw pointer: it must be destroyed first
+            import weakref
+            icp._dependents.append(weakref.ref(self))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -79,6 +79,21 @@ typedef struct orc_result {
     double   iter_s;         /* seconds in the iteration loop */
 } orc_result;
 
+/* ---- alternative READINGS of the [EXT]-recalled mp2p_icp semantics ------------------------------------------
+ * Nothing in /root/reference pins these (the arithmetic lives in the absent mp2p_icp); the defaults (all 0) are the
+ * readings the product implements.  tests/test_readings.py switches each one and reports how far the final pose
+ * moves on the golden pairs, so the cost of a wrong reading is known.  Process-global: test
+ * infrastructure only. */
+typedef struct orc_readings {
+    int32_t stall_max_abs;        /* 0: |v| and |w| of log(Tprev^-1 T) (norms) vs minAbsStep_*   1: max |component|      */
+    int32_t quality_denominator;  /* 0: PairedRatio = pairings / min(N, M)                      1: pairings / N (local) */
+    int32_t outlier_single_pass;  /* 0: scale-outlier detector runs the weighted solve twice    1: once                 */
+    int32_t gn_right_perturbation;/* 0: Gauss-Newton update T <- exp(d) T (left)                1: T <- T exp(d)        */
+    int32_t p2pl_all_inside_gate; /* 0: plane from the >= 3 neighbours inside distanceThreshold 1: needs ALL knn inside  */
+} orc_readings;
+static orc_readings g_readings = {0, 0, 0, 0, 0};
+void orc_set_readings(const orc_readings* r) { if (r) g_readings = *r; else memset(&g_readings, 0, sizeof g_readings); }
+
 #define ORC_NACC 24
 /* accumulator block (fp64):
  *  [0] W=sum w  [1..3] sum w*l  [4..6] sum w*g  [7..15] sum w*l*g^T (row-major l_r*g_c)
@@ -190,6 +205,11 @@ void orc_stall_deltas(const double T[16], const double Tprev[16], double* d_xyz,
     se3_inv(Tprev, Ti);
     mat4_mul(Ti, T, D);
     orc_se3_log(D, lg);
+    if (g_readings.stall_max_abs) {  /* alternative reading: the largest component against the thresholds */
+        *d_xyz = fmax(fabs(lg[0]), fmax(fabs(lg[1]), fabs(lg[2])));
+        *d_rot = fmax(fabs(lg[3]), fmax(fabs(lg[4]), fabs(lg[5])));
+        return;
+    }
     *d_xyz = sqrt(lg[0] * lg[0] + lg[1] * lg[1] + lg[2] * lg[2]);
     *d_rot = sqrt(lg[3] * lg[3] + lg[4] * lg[4] + lg[5] * lg[5]);
 }
@@ -616,7 +636,7 @@ int orc_solve_pairs(const float* lx, const float* ly, const float* lz, const flo
     uint8_t* outl = (uint8_t*)calloc(N ? N : 1, 1);
     double cl[3], cg[3];
     int rc = 0;
-    const int passes = p->use_scale_outlier_detector ? 2 : 1;
+    const int passes = (p->use_scale_outlier_detector && !g_readings.outlier_single_pass) ? 2 : 1;
     for (int pass = 0; pass < passes; pass++) {
         orc_accumulate(lx, ly, lz, gx, gy, gz, idx, d2, N, p, Tcur, 0, NULL, NULL, outl, acc);
         if (!(acc[0] > 0)) { rc = -1; break; }
@@ -641,6 +661,7 @@ double orc_quality_paired_ratio(const float* gx, const float* gy, const float* g
 {
     if (!N || !M) return 0;
     const size_t kept = orc_match(gx, gy, gz, M, tree, lx, ly, lz, N, T, threshold, idx_tmp, d2_tmp);
+    if (g_readings.quality_denominator) return (double)kept / (double)N;
     return (double)kept / (double)(N < M ? N : M);
 }
 
@@ -793,6 +814,7 @@ size_t orc_match_point2plane(const float* gx, const float* gy, const float* gz, 
         while (m < n && d2[m] < thr2) m++;  /* sorted ascending: the neighbours inside the gate */
         if (knn_idx) for (int k = 0; k < knn; k++) knn_idx[i * (size_t)knn + k] = k < m ? idx[k] : -1;
         valid[i] = 0;
+        if (g_readings.p2pl_all_inside_gate && m < knn) continue;
         if (m < 3) continue;
         double mean[3] = {0, 0, 0};
         for (int k = 0; k < m; k++) { mean[0] += gx[idx[k]]; mean[1] += gy[idx[k]]; mean[2] += gz[idx[k]]; }
@@ -884,8 +906,14 @@ int orc_solve_gauss_newton(const float* lx, const float* ly, const float* lz, si
             const double* cc = centroid + 3 * i;
             const double r0 = nn[0] * (p[0] - cc[0]) + nn[1] * (p[1] - cc[1]) + nn[2] * (p[2] - cc[2]);
             /* d p / d delta = [ I | -[p]x ]  ->  J = [ n , p x n ] */
-            const double J[6] = {nn[0], nn[1], nn[2], p[1] * nn[2] - p[2] * nn[1], p[2] * nn[0] - p[0] * nn[2],
-                                 p[0] * nn[1] - p[1] * nn[0]};
+            double J[6] = {nn[0], nn[1], nn[2], p[1] * nn[2] - p[2] * nn[1], p[2] * nn[0] - p[0] * nn[2],
+                           p[0] * nn[1] - p[1] * nn[0]};
+            if (g_readings.gn_right_perturbation) {  /* T exp(d): p = R (l + w x l + v) + t  ->  J = [ R^T n , l x R^T n ] */
+                double m[3];
+                for (int c = 0; c < 3; c++) m[c] = T[c] * nn[0] + T[4 + c] * nn[1] + T[8 + c] * nn[2];
+                J[0] = m[0]; J[1] = m[1]; J[2] = m[2];
+                J[3] = l[1] * m[2] - l[2] * m[1]; J[4] = l[2] * m[0] - l[0] * m[2]; J[5] = l[0] * m[1] - l[1] * m[0];
+            }
             for (int a = 0; a < 6; a++) { g[a] += J[a] * r0; for (int b = 0; b < 6; b++) H[a][b] += J[a] * J[b]; }
             cost += r0 * r0;
             n++;
@@ -898,7 +926,8 @@ int orc_solve_gauss_newton(const float* lx, const float* ly, const float* lz, si
         if (!ok) return -2;
         double E[16], R[16];
         se3_exp(d, E);
-        mat4_mul(E, T, R);
+        if (g_readings.gn_right_perturbation) mat4_mul(T, E, R);
+        else mat4_mul(E, T, R);
         memcpy(T, R, sizeof T);
         double nd = 0;
         for (int a = 0; a < 6; a++) nd += d[a] * d[a];

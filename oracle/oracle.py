@@ -33,6 +33,20 @@ class OResult(C.Structure):
     ]
 
 
+class OReadings(C.Structure):
+    """alternative readings of the [EXT]-recalled mp2p_icp semantics (orc_readings in icp_oracle.c); all 0 = default"""
+    _fields_ = [("stall_max_abs", C.c_int32), ("quality_denominator", C.c_int32), ("outlier_single_pass", C.c_int32),
+                ("gn_right_perturbation", C.c_int32), ("p2pl_all_inside_gate", C.c_int32)]
+
+
+def set_readings(**kw):
+    """set_readings() restores the defaults; set_readings(stall_max_abs=1) switches one reading (process-global)."""
+    r = OReadings()
+    for k, v in kw.items():
+        setattr(r, k, int(v))
+    lib().orc_set_readings(C.byref(r))
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "icp_oracle.c")
     stale = (not os.path.exists(LIB_PATH)) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(LIB_PATH))

@@ -153,7 +153,7 @@ def test_config1_kitti_like_pair_through_front_end(pkg, O, synth):
     # no twist yet: the LidarOdometry ICP object with the NearbyAlign case's mp2p_icp::Parameters (cpp:287-290, 869)
     p = pkg.Parameters.compose(lp.icp_case("with_vel"), lp.icp_case("without_vel"))
     assert p.matcher_class == pkg._lib.MATCHER_POINT2PLANE     # the reference's shipped pipeline (kitti-default.yaml:43,46)
-    ref = O.align(s0, s1, np.eye(4), O.params_from_product(p))
+    ref = O.align_p2pl(s0, s1, np.eye(4), O.params_from_product(p), p.plane_eigen_threshold, p.knn, p.solver_max_iterations)
     assert b.icp.nIterations == ref["n_iterations"] and b.icp.terminationReason == ref["termination"]
     rot, trans = O.pose_error(b.rel_pose, ref["T"])
     assert rot <= 1e-4 and trans <= 1e-3 and rot < 1e-7 and trans < 1e-7, (rot, trans)
