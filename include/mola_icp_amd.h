@@ -207,6 +207,26 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs,
                          const size_t* N,
                          const double* init_T, const mola_icp_params* p, mola_icp_result* out);
 
+/* ---- device pool: the replica / task parallelism of the nearby-keyframe + loop-closure checks across the GPUs of one
+ * node (BASELINE config[3]: 64 independent pairs over 8 x MI355X, no collective).  The reference runs these checks on
+ * `worker_pool_past_KFs_`, max(2, hw/2) CPU threads (src/LidarOdometry.cpp:94-96, 704-741); here one handle per
+ * device, pair i goes to device i mod n (round-robin, as SURVEY.md section 8e states), and every device advances its
+ * share through mola_icp_align_batch on a host thread of its own.  Results are those of stand-alone aligns. */
+typedef struct mola_icp_pool mola_icp_pool;
+/* devices == NULL or n_devices == 0: every visible device.  A device index may repeat (two handles on one GPU). */
+int mola_icp_pool_create(const int* devices, int n_devices, mola_icp_pool** out);
+int mola_icp_pool_destroy(mola_icp_pool* pool);
+int mola_icp_pool_size(const mola_icp_pool* pool, int* n_handles);
+int mola_icp_pool_handle(mola_icp_pool* pool, int i, mola_icp_handle** h);   /* borrowed: owned by the pool */
+/* the dealing rule on its own (no GPU needed): device_of_pair[i] = i mod n_devices */
+int mola_icp_pool_assignment(size_t n_pairs, int n_devices, int* device_of_pair);
+int mola_icp_pool_align_batch(mola_icp_pool* pool, size_t n_pairs,
+                              const float* const* from_x, const float* const* from_y, const float* const* from_z,
+                              const size_t* M,
+                              const float* const* to_x, const float* const* to_y, const float* const* to_z,
+                              const size_t* N,
+                              const double* init_T, const mola_icp_params* p, mola_icp_result* out);
+
 /* Loop-closure Monte-Carlo (src/LidarOdometry.cpp:767-788): the SAME pair aligned from n_init initial
  * poses (init_T = n_init x 16), keeping the attempt with the highest goodness (strictly greater, i.e. the
  * first best, as `if (this_icp_out.goodness > icp_out.goodness)` cpp:785).  The clouds are uploaded and
@@ -308,6 +328,12 @@ typedef struct mola_icp_stage_callbacks {
 } mola_icp_stage_callbacks;
 int mola_icp_run_loop(const mola_icp_stage_callbacks* cb, const double init_T[16], const mola_icp_params* p,
                       mola_icp_result* out);
+/* The LOCKSTEP loop behind mola_icp_align_multi_init / mola_icp_align_batch (n_problems independent point-to-point
+ * problems, every stage issued for all problems still iterating) over caller-supplied stages: cb[k] serves problem k
+ * (its allreduce member is ignored), init_T = n_problems x 16, out = n_problems results.  Each result is bit-identical
+ * to mola_icp_run_loop(&cb[k], ...). */
+int mola_icp_run_loop_batch(const mola_icp_stage_callbacks* cb, size_t n_problems, const double* init_T,
+                            const mola_icp_params* p, mola_icp_result* out);
 
 /* ======================================================================================
  * Front-end logic around the ICP: LidarOdometry::doProcessNewObservation()

@@ -157,6 +157,14 @@ SIGNATURES = {
     "mola_icp_align_batch": (C.c_int, [_H, C.c_size_t, C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
                                        C.POINTER(C.c_size_t), C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
                                        C.POINTER(C.c_size_t), _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_icp_pool_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_H)]),
+    "mola_icp_pool_destroy": (C.c_int, [_H]),
+    "mola_icp_pool_size": (C.c_int, [_H, C.POINTER(C.c_int)]),
+    "mola_icp_pool_handle": (C.c_int, [_H, C.c_int, C.POINTER(_H)]),
+    "mola_icp_pool_assignment": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_int)]),
+    "mola_icp_pool_align_batch": (C.c_int, [_H, C.c_size_t, C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
+                                            C.POINTER(C.c_size_t), C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
+                                            C.POINTER(C.c_size_t), _DP, C.POINTER(CParams), C.POINTER(CResult)]),
     "mola_icp_align_multi_init": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, _FP, _FP, _FP, C.c_size_t, C.c_size_t, _DP,
                                             C.POINTER(CParams), C.POINTER(CResult), C.POINTER(CResult),
                                             C.POINTER(C.c_int)]),
@@ -183,6 +191,7 @@ SIGNATURES = {
     "mola_icp_pose_from_xyzypr": (C.c_int, [_DP, _DP]),
     "mola_icp_pose_to_xyzypr": (C.c_int, [_DP, _DP]),
     "mola_icp_run_loop": (C.c_int, [C.POINTER(CStageCallbacks), _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_icp_run_loop_batch": (C.c_int, [C.POINTER(CStageCallbacks), C.c_size_t, _DP, C.POINTER(CParams), C.POINTER(CResult)]),
     "mola_lo_params_default": (C.c_int, [C.POINTER(CLoParams)]),
     "mola_lo_params_from_yaml_file": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(CLoParams)]),
     "mola_lo_create": (C.c_int, [_H, LO_ALIGN_FN, C.c_void_p, C.POINTER(CLoParams), C.POINTER(_H)]),

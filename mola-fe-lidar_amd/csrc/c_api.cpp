@@ -1,6 +1,9 @@
 // c_api.cpp -- the extern "C" boundary declared in include/mola_icp_amd.h.
 // No exception, C++ type or HIP type crosses it.
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
 #include <chrono>
 #include <cstring>
@@ -34,14 +37,63 @@ struct mola_icp_handle {
     void* comm = nullptr;  // RCCL communicator of the query-sharded path
     std::mutex cache_mtx;  // guards the cloud cache (row f4)
     std::map<uint64_t, std::shared_ptr<SortedCloud>> cache;
+    // worker threads of mola_icp_align_batch (the analogue of worker_pool_past_KFs_, src/LidarOdometry.cpp:94-96):
+    // started on first use, kept for the handle's lifetime
+    std::mutex job_mtx;
+    std::condition_variable job_cv;
+    std::deque<std::function<void()>> jobs;
+    std::vector<std::thread> workers;
+    bool stopping = false;
+    void ensure_workers(size_t n)
+    {
+        std::lock_guard<std::mutex> lk(job_mtx);
+        while (workers.size() < n)
+            workers.emplace_back([this]() {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk2(job_mtx);
+                        job_cv.wait(lk2, [this]() { return stopping || !jobs.empty(); });
+                        if (jobs.empty()) return;  // stopping
+                        job = std::move(jobs.front());
+                        jobs.pop_front();
+                    }
+                    job();
+                }
+            });
+    }
+    void submit(std::function<void()> job)
+    {
+        {
+            std::lock_guard<std::mutex> lk(job_mtx);
+            jobs.push_back(std::move(job));
+        }
+        job_cv.notify_one();
+    }
     ~mola_icp_handle()
     {
+        {
+            std::lock_guard<std::mutex> lk(job_mtx);
+            stopping = true;
+        }
+        job_cv.notify_all();
+        for (auto& t : workers) t.join();
         if (resident) resident->sync();
         if (comm) (void)rccl_comm_destroy(comm);
     }
 };
 
+struct mola_icp_pool {
+    std::vector<mola_icp_handle*> handles;
+    ~mola_icp_pool()
+    {
+        for (mola_icp_handle* h : handles) delete h;
+    }
+};
+
 namespace {
+
+constexpr int kBatchChunk = 12;  // pairs advanced together by mola_icp_align_batch (= problems per batched launch)
 
 double now_ms()
 {
@@ -144,6 +196,40 @@ int align_host_clouds(mola_icp_handle* h, const float* fx, const float* fy, cons
     return rc;
 }
 
+// Would a stand-alone align of this problem run the tiled matcher (sorted pairing)?  Only then is the batched path
+// (k_nn_coop + batched accumulation) bit-identical to it: the dense kernels sum the pairing in another order.
+bool batch_eligible(const mola_icp_params& p, size_t N, size_t M)
+{
+    if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD || N == 0 || M == 0) return false;
+    if (p.nn_kernel == MOLA_ICP_NN_TILED) return true;
+    return p.nn_kernel == MOLA_ICP_NN_AUTO && N >= 8192 && M >= 8192;
+}
+
+// K prepared problems through the lockstep loop on one leased workspace; fills out[0..K)
+int run_batch_on(HipWorkspace& ws, std::vector<BatchProblem> probs, const double* init_T, const mola_icp_params* p,
+                 mola_icp_result* out)
+{
+    const size_t K = probs.size();
+    HipBatch batch(ws, std::move(probs));
+    int rc = batch.init();
+    if (rc) return rc;
+    std::vector<Mat4> inits(K);
+    for (size_t k = 0; k < K; ++k) inits[k] = mat_from(init_T + 16 * k);
+    for (size_t k = 0; k < K; ++k) std::memset(&out[k], 0, sizeof out[k]);
+    if ((rc = run_icp_loop_batch(batch, inits.data(), *p, out))) return rc;
+    double ms = 0;
+    uint32_t n = 0;
+    uint64_t pairs = 0;
+    if ((rc = batch.collect_stats(&ms, &n, &pairs))) return rc;
+    for (size_t k = 0; k < K; ++k) {  // the matcher launches served the whole batch: its totals, on every result
+        out[k].ms_nn_kernel = ms;
+        out[k].n_nn_launches = n;
+        out[k].nn_kernel_used = MOLA_ICP_NN_TILED;
+        out[k].nn_pairs_evaluated = pairs;
+    }
+    return MOLA_ICP_OK;
+}
+
 struct CallbackStages final : Stages {
     const mola_icp_stage_callbacks* cb;
     explicit CallbackStages(const mola_icp_stage_callbacks* c) : cb(c) {}
@@ -167,6 +253,36 @@ struct CallbackStages final : Stages {
     }
     uint64_t n_local_total() const override { return cb->n_local_total; }
     uint64_t n_map_total() const override { return cb->n_map_total; }
+};
+
+struct CallbackBatchStages final : BatchStages {
+    const mola_icp_stage_callbacks* cb;
+    size_t K;
+    CallbackBatchStages(const mola_icp_stage_callbacks* c, size_t k) : cb(c), K(k) {}
+    int size() const override { return (int)K; }
+    int match(const uint8_t* active, const Mat4* T, double thr, const mola_icp_params&) override
+    {
+        for (size_t k = 0; k < K; ++k) {
+            if (!active[k]) continue;
+            uint64_t n = 0;
+            const int rc = cb[k].match(cb[k].user, T[k].m, thr, &n);
+            if (rc) return fail(rc < 0 ? rc : MOLA_ICP_E_INTERNAL, "match callback failed");
+        }
+        return MOLA_ICP_OK;
+    }
+    int accumulate(const uint8_t* active, const mola_icp_params& p, const Mat4* Tcur, int stage, const double (*cl)[3],
+                   const double (*cg)[3], bool reset, double (*acc)[kNAcc]) override
+    {
+        for (size_t k = 0; k < K; ++k) {
+            if (!active[k]) continue;
+            const int rc = cb[k].accumulate(cb[k].user, &p, Tcur[k].m, stage, cl ? cl[k] : nullptr, cg ? cg[k] : nullptr,
+                                            reset ? 1 : 0, acc[k]);
+            if (rc) return fail(rc < 0 ? rc : MOLA_ICP_E_INTERNAL, "accumulate callback failed");
+        }
+        return MOLA_ICP_OK;
+    }
+    uint64_t n_local_total(int k) const override { return cb[k].n_local_total; }
+    uint64_t n_map_total(int k) const override { return cb[k].n_map_total; }
 };
 
 }  // namespace
@@ -364,34 +480,182 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const*
         if (!h || !p || !out || !init_T) return fail(MOLA_ICP_E_BADARG, "null argument");
         if (n_pairs && (!fx || !fy || !fz || !M || !tx || !ty || !tz || !N))
             return fail(MOLA_ICP_E_BADARG, "null batch array");
-        // stream-per-pair: a few host threads, each driving its own workspace/stream
-        // (the analogue of worker_pool_past_KFs_, src/LidarOdometry.cpp:94-96)
-        const size_t n_threads = n_pairs < 8 ? n_pairs : 8;
-        std::atomic<size_t> next{0};
+        int rc;
+        if ((rc = validate_params(*p))) return rc;
+        for (size_t i = 0; i < n_pairs; ++i)
+            if ((rc = check_pose(init_T + 16 * i))) return rc;
+        // Pairs whose stand-alone align would run the tiled matcher advance TOGETHER, kCoopMaxBatch at a time: every
+        // stage is one launch over the pairs still iterating (blockIdx.y = pair), so a launch that is "one item long"
+        // for a 100k-point cloud serves a dozen of them.  The others (tiny clouds, the point-to-plane pipeline) go to
+        // the handle's worker threads, stream-per-pair (worker_pool_past_KFs_, src/LidarOdometry.cpp:94-96).
+        std::vector<size_t> together, apart;
+        for (size_t i = 0; i < n_pairs; ++i) (batch_eligible(*p, N[i], M[i]) ? together : apart).push_back(i);
+        if (together.size() == 1) { apart.push_back(together[0]); together.clear(); }
         std::atomic<int> first_err{MOLA_ICP_OK};
         std::string err_msg;
         std::mutex err_mtx;
-        auto worker = [&]() {
-            for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= n_pairs) break;
-                const int rc = guarded([&]() -> int {
-                    return align_host_clouds(h, fx[i], fy[i], fz[i], M[i], tx[i], ty[i], tz[i], N[i], init_T + 16 * i,
-                                             p, &out[i]);
-                });
-                if (rc) {
-                    std::lock_guard<std::mutex> lk(err_mtx);
-                    if (first_err.load() == MOLA_ICP_OK) {
-                        first_err = rc;
-                        err_msg = "pair " + std::to_string(i) + ": " + last_error();
-                    }
-                }
+        auto record = [&](int rc2, size_t i) {
+            std::lock_guard<std::mutex> lk(err_mtx);
+            if (first_err.load() == MOLA_ICP_OK) {
+                first_err = rc2;
+                err_msg = "pair " + std::to_string(i) + ": " + last_error();
             }
         };
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < n_threads; ++t) th.emplace_back(worker);
-        for (auto& t : th) t.join();
+        // the stream-per-pair jobs run on the pool while this thread drives the lockstep chunks
+        std::mutex done_mtx;
+        std::condition_variable done_cv;
+        size_t pending = apart.size();
+        if (!apart.empty()) {
+            h->ensure_workers(apart.size() < 8 ? apart.size() : 8);
+            for (size_t i : apart)
+                h->submit([&, i]() {
+                    const int rc2 = guarded([&]() -> int {
+                        return align_host_clouds(h, fx[i], fy[i], fz[i], M[i], tx[i], ty[i], tz[i], N[i], init_T + 16 * i, p,
+                                                 &out[i]);
+                    });
+                    if (rc2) record(rc2, i);
+                    {
+                        std::lock_guard<std::mutex> lk(done_mtx);
+                        --pending;
+                    }
+                    done_cv.notify_all();
+                });
+        }
+        for (size_t c0 = 0; c0 < together.size() && first_err.load() == MOLA_ICP_OK; c0 += kBatchChunk) {
+            const size_t K = std::min((size_t)kBatchChunk, together.size() - c0);
+            const int rc2 = guarded([&]() -> int {
+                Lease lease(h);
+                if (lease.rc) return lease.rc;
+                const double t0 = now_ms();
+                std::vector<BatchProblem> probs(K);
+                std::vector<double> inits(16 * K);
+                int rc3;
+                for (size_t k = 0; k < K; ++k) {
+                    const size_t i = together[c0 + k];
+                    probs[k].map = std::make_shared<SortedCloud>();
+                    probs[k].loc = std::make_shared<SortedCloud>();
+                    if ((rc3 = lease.ws->build_cached(*probs[k].map, fx[i], fy[i], fz[i], M[i]))) { lease.rc = rc3; return rc3; }
+                    if ((rc3 = lease.ws->build_cached(*probs[k].loc, tx[i], ty[i], tz[i], N[i]))) { lease.rc = rc3; return rc3; }
+                    std::memcpy(&inits[16 * k], init_T + 16 * i, sizeof(double) * 16);
+                }
+                const double upload_ms = now_ms() - t0;
+                std::vector<mola_icp_result> res(K);
+                if ((rc3 = run_batch_on(*lease.ws, std::move(probs), inits.data(), p, res.data()))) { lease.rc = rc3; return rc3; }
+                for (size_t k = 0; k < K; ++k) {
+                    res[k].ms_upload = upload_ms;  // the chunk's uploads + preparation
+                    out[together[c0 + k]] = res[k];
+                }
+                return MOLA_ICP_OK;
+            });
+            if (rc2) record(rc2, together[c0]);
+        }
+        {
+            std::unique_lock<std::mutex> lk(done_mtx);
+            done_cv.wait(lk, [&]() { return pending == 0; });
+        }
         if (first_err.load()) return fail(first_err.load(), err_msg);
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_pool_assignment(size_t n_pairs, int n_devices, int* device_of_pair)
+{
+    if (n_devices < 1 || (n_pairs && !device_of_pair)) return fail(MOLA_ICP_E_BADARG, "bad pool assignment arguments");
+    for (size_t i = 0; i < n_pairs; ++i) device_of_pair[i] = (int)(i % (size_t)n_devices);  // round-robin
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_pool_create(const int* devices, int n_devices, mola_icp_pool** out)
+{
+    return guarded([&]() -> int {
+        if (!out) return fail(MOLA_ICP_E_BADARG, "null out");
+        *out = nullptr;
+        std::vector<int> devs;
+        if (!devices || n_devices <= 0) {
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+                return fail(MOLA_ICP_E_NODEVICE, "no HIP device available; this library has no CPU fallback");
+            for (int d = 0; d < n; ++d) devs.push_back(d);
+        } else {
+            devs.assign(devices, devices + n_devices);
+        }
+        std::unique_ptr<mola_icp_pool> pool(new mola_icp_pool);
+        for (int d : devs) {
+            if (d < 0) return fail(MOLA_ICP_E_BADARG, "negative device index in a pool");
+            mola_icp_handle* h = nullptr;
+            const int rc = mola_icp_create(d, &h);
+            if (rc) return rc;
+            pool->handles.push_back(h);
+        }
+        *out = pool.release();
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_pool_destroy(mola_icp_pool* pool)
+{
+    return guarded([&]() -> int {
+        delete pool;
+        return MOLA_ICP_OK;
+    });
+}
+
+int mola_icp_pool_size(const mola_icp_pool* pool, int* n_handles)
+{
+    if (!pool || !n_handles) return fail(MOLA_ICP_E_BADARG, "null argument");
+    *n_handles = (int)pool->handles.size();
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_pool_handle(mola_icp_pool* pool, int i, mola_icp_handle** h)
+{
+    if (!pool || !h || i < 0 || i >= (int)pool->handles.size()) return fail(MOLA_ICP_E_BADARG, "bad pool handle index");
+    *h = pool->handles[(size_t)i];
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_pool_align_batch(mola_icp_pool* pool, size_t n_pairs, const float* const* fx, const float* const* fy,
+                              const float* const* fz, const size_t* M, const float* const* tx, const float* const* ty,
+                              const float* const* tz, const size_t* N, const double* init_T, const mola_icp_params* p,
+                              mola_icp_result* out)
+{
+    return guarded([&]() -> int {
+        if (!pool || pool->handles.empty() || !p || !out || !init_T) return fail(MOLA_ICP_E_BADARG, "null argument");
+        if (n_pairs && (!fx || !fy || !fz || !M || !tx || !ty || !tz || !N))
+            return fail(MOLA_ICP_E_BADARG, "null batch array");
+        const int nd = (int)pool->handles.size();
+        std::vector<int> dev(n_pairs);
+        int rc = mola_icp_pool_assignment(n_pairs, nd, dev.data());
+        if (rc) return rc;
+        // one host thread per device, each driving its share through its own handle (no collective, no shared state)
+        std::vector<int> rcs((size_t)nd, MOLA_ICP_OK);
+        std::vector<std::string> msgs((size_t)nd);
+        std::vector<std::thread> th;
+        for (int d = 0; d < nd; ++d)
+            th.emplace_back([&, d]() {
+                std::vector<size_t> mine;
+                for (size_t i = 0; i < n_pairs; ++i)
+                    if (dev[i] == d) mine.push_back(i);
+                if (mine.empty()) return;
+                const size_t n = mine.size();
+                std::vector<const float*> a(n), b(n), c(n), e(n), f(n), g(n);
+                std::vector<size_t> Ms(n), Ns(n);
+                std::vector<double> Ts(16 * n);
+                std::vector<mola_icp_result> res(n);
+                for (size_t k = 0; k < n; ++k) {
+                    const size_t i = mine[k];
+                    a[k] = fx[i]; b[k] = fy[i]; c[k] = fz[i]; e[k] = tx[i]; f[k] = ty[i]; g[k] = tz[i];
+                    Ms[k] = M[i]; Ns[k] = N[i];
+                    std::memcpy(&Ts[16 * k], init_T + 16 * i, sizeof(double) * 16);
+                }
+                rcs[(size_t)d] = mola_icp_align_batch(pool->handles[(size_t)d], n, a.data(), b.data(), c.data(), Ms.data(), e.data(),
+                                                      f.data(), g.data(), Ns.data(), Ts.data(), p, res.data());
+                if (rcs[(size_t)d]) { msgs[(size_t)d] = last_error(); return; }
+                for (size_t k = 0; k < n; ++k) out[mine[k]] = res[k];
+            });
+        for (auto& t : th) t.join();
+        for (int d = 0; d < nd; ++d)
+            if (rcs[(size_t)d]) return fail(rcs[(size_t)d], "device slot " + std::to_string(d) + ": " + msgs[(size_t)d]);
         return MOLA_ICP_OK;
     });
 }
@@ -411,12 +675,35 @@ int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* 
         if (lease.rc) return lease.rc;
         HipWorkspace& ws = *lease.ws;
         const double t0 = now_ms();
+        *best_index = -1;
+        if (n_init >= 2 && batch_eligible(*p, N, M)) {
+            // the K guesses as a batch dimension on the device: the pair is uploaded and prepared once, every stage of
+            // every iteration is ONE launch over the guesses still iterating (blockIdx.y = guess)
+            auto map = std::make_shared<SortedCloud>(), loc = std::make_shared<SortedCloud>();
+            if ((rc = ws.build_cached(*map, fx, fy, fz, M))) { lease.rc = rc; return rc; }
+            if ((rc = ws.build_cached(*loc, tx, ty, tz, N))) { lease.rc = rc; return rc; }
+            const double upload_ms = now_ms() - t0;
+            std::vector<BatchProblem> probs(n_init);
+            for (auto& pr : probs) { pr.map = map; pr.loc = loc; }
+            std::vector<mola_icp_result> res(n_init);
+            if ((rc = run_batch_on(ws, std::move(probs), init_T, p, res.data()))) { lease.rc = rc; return rc; }
+            double best_q = 0.0;  // ICP_Output::goodness starts at .0 (LidarOdometry.h:130); strictly greater wins (cpp:785)
+            for (size_t k = 0; k < n_init; ++k) {
+                res[k].ms_upload = k == 0 ? upload_ms : 0.0;
+                if (out) out[k] = res[k];
+                if (res[k].quality > best_q) {
+                    best_q = res[k].quality;
+                    *best_index = (int)k;
+                    if (best) *best = res[k];
+                }
+            }
+            return MOLA_ICP_OK;
+        }
         if ((rc = ws.set_map_host(fx, fy, fz, M))) { lease.rc = rc; return rc; }
         if ((rc = ws.set_local_host(tx, ty, tz, N))) { lease.rc = rc; return rc; }
         ws.set_global_sizes(0, 0);
         ws.set_allreduce(nullptr, nullptr);
         const double upload_ms = now_ms() - t0;
-        *best_index = -1;
         double best_q = 0.0;  // ICP_Output::goodness starts at .0 (LidarOdometry.h:130)
         for (size_t k = 0; k < n_init; ++k) {
             mola_icp_result r;
@@ -676,6 +963,24 @@ int mola_icp_run_loop(const mola_icp_stage_callbacks* cb, const double init_T[16
         std::memset(out, 0, sizeof *out);
         CallbackStages st(cb);
         return run_icp_loop(st, mat_from(init_T), *p, out);
+    });
+}
+
+int mola_icp_run_loop_batch(const mola_icp_stage_callbacks* cb, size_t n_problems, const double* init_T,
+                            const mola_icp_params* p, mola_icp_result* out)
+{
+    return guarded([&]() -> int {
+        if (!p || (n_problems && (!cb || !init_T || !out))) return fail(MOLA_ICP_E_BADARG, "null argument");
+        int rc;
+        std::vector<Mat4> inits(n_problems);
+        for (size_t k = 0; k < n_problems; ++k) {
+            if (!cb[k].match || !cb[k].accumulate) return fail(MOLA_ICP_E_BADARG, "null stage callback");
+            if ((rc = check_pose(init_T + 16 * k))) return rc;
+            inits[k] = mat_from(init_T + 16 * k);
+            std::memset(&out[k], 0, sizeof out[k]);
+        }
+        CallbackBatchStages st(cb, n_problems);
+        return run_icp_loop_batch(st, inits.data(), *p, out);
     });
 }
 

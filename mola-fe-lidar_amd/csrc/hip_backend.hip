@@ -39,6 +39,7 @@ namespace mola_icp_amd {
 #include "kernels_common.hpp"
 #include "kernels_dense.hpp"
 #include "kernels_tiled.hpp"
+#include "kernels_coop.hpp"
 #include "kernels_planes.hpp"
 #include "kernels_prepare.hpp"
 #include "kernels_accumulate.hpp"
@@ -112,6 +113,8 @@ HipWorkspace::~HipWorkspace()
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
     if (meta_host_) (void)hipHostFree(meta_host_);
+    if (stats_host_) (void)hipHostFree(stats_host_);
+    stats_.release();
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -140,6 +143,9 @@ int HipWorkspace::init()
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocDefault));
     int rc;
     if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8) + sizeof(unsigned int) * 2 * kQueues * kQueueStride))) return rc;
+    if ((rc = stats_.reserve(sizeof(unsigned long long) * kStatSlots * kStatStride))) return rc;
+    HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, stream_));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&stats_host_), sizeof(unsigned long long) * kStatSlots * kStatStride, hipHostMallocDefault));
     if (g_knobs.debug_stats) {  // diagnostic builds of a run, never on by default
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&dbg_stats_), (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
         HIPCHK(hipMemset(dbg_stats_, 0, (16 + 8 * kDbgItems) * sizeof(unsigned long long)));
@@ -577,6 +583,50 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     return MOLA_ICP_OK;
 }
 
+// One NN problem of a cooperative / batched launch on this workspace's clouds and pairing buffers.
+int HipWorkspace::fill_nn_problem(const PoseF& P, float thr2, bool use_seed, NnProblem& pb)
+{
+    int rc;
+    if ((rc = ts_pos_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
+    if ((rc = ts_idx_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
+    if ((rc = ts_d2_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
+    const size_t n_items = (N_ + kQPW - 1) / kQPW;
+    if ((rc = redo_list_.reserve(sizeof(int) * n_items))) return rc;
+    const float* sl = loc_sc_->sorted.as<float>();
+    unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
+    pb.slx = sl; pb.sly = sl + loc_sc_->padded; pb.slz = sl + 2 * loc_sc_->padded;
+    pb.N = (int)N_;
+    pb.mp = tiled_map();
+    pb.P = P;
+    pb.thr2 = thr2;
+    pb.use_seed = use_seed ? 1 : 0;
+    pb.pos_s = ts_pos_.as<int>(); pb.idx_s = ts_idx_.as<int>(); pb.d2_s = ts_d2_.as<float>();
+    pb.redo_count = counter + 2;
+    pb.redo_list = redo_list_.as<int>();
+    pb.staged = stats_.as<unsigned long long>();
+    return MOLA_ICP_OK;
+}
+
+// Small clouds: one workgroup per 128-query item (k_nn_coop), fast flavour then the exact flavour over the items it queued.
+int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
+{
+    NnBatch<1> b;
+    int rc;
+    if ((rc = fill_nn_problem(P, thr2, use_seed, b.p[0]))) return rc;
+    const TiledMap& mp = b.p[0].mp;
+    const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
+    const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
+    const size_t dyn_lds = lds_boxes ? box_bytes : 0;
+    const int n_items = (int)((N_ + kQPW - 1) / kQPW);
+    hipLaunchKernelGGL((k_nn_coop<false, 1>), dim3(n_items), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
+    HIPCHK(hipGetLastError());
+    wave_times_coop_ = true;
+    hipLaunchKernelGGL((k_nn_coop<true, 1>), dim3(n_items < 16 ? n_items : 16), dim3(256), dyn_lds, stream_, b, lds_boxes,
+                       (unsigned long long*)nullptr);
+    HIPCHK(hipGetLastError());
+    return MOLA_ICP_OK;
+}
+
 int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 {
     int rc = init();
@@ -765,7 +815,10 @@ void HipWorkspace::reset_stats()
     ev_used_ = 0;
     last_kernel_ = 0;
     dense_pairs_ = 0;
-    if (inited_) (void)hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 4, 0, sizeof(unsigned long long), stream_);
+    if (inited_) {
+        (void)hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 4, 0, sizeof(unsigned long long), stream_);
+        (void)hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, stream_);
+    }
 }
 
 int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used, uint64_t* pairs)
@@ -776,8 +829,11 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
             HIPCHK(hipSetDevice(device_));
             HIPCHK(hipMemcpyAsync(acc_host_ + kNAcc + 4, acc_dev_.as<double>() + kNAcc + 4, sizeof staged,
                                   hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipMemcpyAsync(stats_host_, stats_.p, sizeof(unsigned long long) * kStatSlots * kStatStride,
+                                  hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
             std::memcpy(&staged, acc_host_ + kNAcc + 4, sizeof staged);
+            for (int k = 0; k < kStatSlots; ++k) staged += stats_host_[(size_t)k * kStatStride];  // the cooperative kernel's slotted counters
         }
         *pairs = dense_pairs_ + (uint64_t)staged * 64u;  // the tiled kernels count in units of 64 pairs
     }
@@ -796,11 +852,17 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipMemcpy(w.data(), wave_times_, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t1 = 0ull;
-        std::vector<unsigned long long> ends, pro, swp, epi, stg;
+        std::vector<unsigned long long> ends, pro, swp, epi, stg, setup, mwait, starts;
         for (size_t i = 0; i < 8192; ++i)
             if (w[8 * i + 1]) {
                 t0 = std::min(t0, w[8 * i]); t1 = std::max(t1, w[8 * i + 1]); ends.push_back(w[8 * i + 1]);
-                pro.push_back(w[8 * i + 3]); swp.push_back(w[8 * i + 4]); epi.push_back(w[8 * i + 5]); stg.push_back(w[8 * i + 6]);
+                starts.push_back(w[8 * i]);
+                if (wave_times_coop_) {  // k_nn_coop's layout
+                    setup.push_back(w[8 * i + 2]); pro.push_back(w[8 * i + 3]); swp.push_back(w[8 * i + 4]);
+                    mwait.push_back(w[8 * i + 5]); epi.push_back(w[8 * i + 6]); stg.push_back(w[8 * i + 7]);
+                } else {
+                    pro.push_back(w[8 * i + 3]); swp.push_back(w[8 * i + 4]); epi.push_back(w[8 * i + 5]); stg.push_back(w[8 * i + 6]);
+                }
             }
         if (!ends.empty()) {
             std::sort(ends.begin(), ends.end());
@@ -814,11 +876,19 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
                          (ends[ends.size() * 9 / 10] - t0) / span, (ends[ends.size() * 99 / 100] - t0) / span,
                          busy / ends.size() / span);
             auto med = [](std::vector<unsigned long long>& v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+            if (wave_times_coop_) {
+                std::sort(starts.begin(), starts.end());
+                std::fprintf(stderr, "[mola_icp debug]   cooperative kernel: last wave starts %.0f ticks after the first; per wave, shader cycles "
+                                     "(median / p90 / max): setup %llu / %llu / %llu, merge wait %llu / %llu / %llu, sweep max %llu, staged max %llu\n",
+                             (double)(starts.back() - t0), med(setup, 0.5), med(setup, 0.9), med(setup, 1.0), med(mwait, 0.5), med(mwait, 0.9),
+                             med(mwait, 1.0), med(swp, 1.0), med(stg, 1.0));
+            }
             std::fprintf(stderr, "[mola_icp debug]   first item of a wave, shader cycles (median / p90): prologue %llu / %llu, sweep %llu / %llu, "
                                  "epilogue %llu / %llu; staged points %llu / %llu\n",
                          med(pro, 0.5), med(pro, 0.9), med(swp, 0.5), med(swp, 0.9), med(epi, 0.5), med(epi, 0.9), med(stg, 0.5), med(stg, 0.9));
         }
         HIPCHK(hipMemset(wave_times_, 0, w.size() * sizeof(unsigned long long)));
+        wave_times_coop_ = false;
     }
     if (dbg_stats_ && !wave_times_) {
         unsigned long long h[16] = {};
@@ -896,7 +966,10 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
     HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     if (kernel == MOLA_ICP_NN_TILED) {
         const bool use_seed = seed_valid_ && pairing_sorted_ && !g_knobs.no_warm_start;
-        const int rc = launch_tiled(P, thr2, use_seed, counter);
+        // fewer 128-query items than persistent wave slots: the launch would be one item long -> one WORKGROUP per item
+        const size_t n128 = (N_ + kQPW - 1) / kQPW;
+        const bool coop = g_knobs.coop >= 0 ? g_knobs.coop != 0 : n128 <= (size_t)num_cus_ * 3 * 4;
+        const int rc = coop ? launch_coop(P, thr2, use_seed) : launch_tiled(P, thr2, use_seed, counter);
         if (rc) return rc;
         last_kernel_ = MOLA_ICP_NN_TILED;
         pairing_sorted_ = true;
@@ -1103,6 +1176,212 @@ int HipWorkspace::copy_pairing(int32_t* idx_out, float* d2_out)
         if (d2_out) HIPCHK(hipMemcpyAsync(d2_out, d2_.p, sizeof(float) * N_, hipMemcpyDeviceToHost, stream_));
     }
     HIPCHK(hipStreamSynchronize(stream_));
+    return MOLA_ICP_OK;
+}
+
+// ------------------------------------------------------------------ HipBatch: K problems per launch
+static TiledMap tiled_map_of(const SortedCloud& sc)
+{
+    const float* sx = sc.sorted.as<float>();
+    return TiledMap{sx, sx + sc.padded, sx + 2 * sc.padded, sc.perm.as<int>(), sc.tbox.as<float>(), sc.n_tiles_p,
+                    sc.sbox.as<float>(), sc.n_super, sc.ubox.as<float>(), sc.n_top};
+}
+
+HipBatch::HipBatch(HipWorkspace& ws, std::vector<BatchProblem> probs) : ws_(ws), probs_(std::move(probs)), buf_(probs_.size()) {}
+
+HipBatch::~HipBatch()
+{
+    if (!inited_) return;
+    (void)hipSetDevice(ws_.device_);
+    (void)hipStreamSynchronize(ws_.stream_);
+    for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+    for (Buffers& b : buf_) { b.pos.release(); b.idx.release(); b.d2.release(); b.outlier.release(); b.redo.release(); b.partials.release(); }
+    acc_dev_.release(); counters_.release(); stats_.release();
+    if (acc_host_) (void)hipHostFree(acc_host_);
+    if (stats_host_) (void)hipHostFree(stats_host_);
+}
+
+int HipBatch::init()
+{
+    if (inited_) return MOLA_ICP_OK;
+    int rc = ws_.init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ws_.device_));
+    const size_t K = probs_.size();
+    for (size_t k = 0; k < K; ++k) {
+        const BatchProblem& pr = probs_[k];
+        if (!pr.map || !pr.loc) return fail(MOLA_ICP_E_BADARG, "batch problem without clouds");
+        if (pr.loc->n == 0 || pr.map->n == 0) continue;  // never matched (the loop ends such a problem at once)
+        if (!pr.map->ready || !pr.loc->ready) return fail(MOLA_ICP_E_INTERNAL, "batch problem with an unprepared cloud");
+        Buffers& b = buf_[k];
+        const size_t np = (pr.loc->n + kQPW - 1) / kQPW * kQPW;
+        if ((rc = b.pos.reserve(sizeof(int) * np))) return rc;
+        if ((rc = b.idx.reserve(sizeof(int) * np))) return rc;
+        if ((rc = b.d2.reserve(sizeof(float) * np))) return rc;
+        if ((rc = b.outlier.reserve(pr.loc->n))) return rc;
+        if ((rc = b.redo.reserve(sizeof(int) * (np / kQPW)))) return rc;
+        if ((rc = b.partials.reserve(sizeof(double) * kNAcc * kAccMaxBlocks))) return rc;
+    }
+    if ((rc = acc_dev_.reserve(sizeof(double) * 32 * (K ? K : 1)))) return rc;
+    if ((rc = counters_.reserve(sizeof(unsigned int) * (K ? K : 1)))) return rc;
+    if ((rc = stats_.reserve(sizeof(unsigned long long) * kStatSlots * kStatStride))) return rc;
+    HIPCHK(hipMemsetAsync(counters_.p, 0, sizeof(unsigned int) * (K ? K : 1), ws_.stream_));
+    HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, ws_.stream_));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * 32 * (K ? K : 1), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(acc_host_, 0, sizeof(double) * 32 * (K ? K : 1));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&stats_host_), sizeof(unsigned long long) * kStatSlots * kStatStride, hipHostMallocDefault));
+    inited_ = true;
+    return MOLA_ICP_OK;
+}
+
+int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, const mola_icp_params& p)
+{
+    (void)p;
+    int rc = init();
+    if (rc) return rc;
+    if (!(threshold > 0)) return fail(MOLA_ICP_E_BADARG, "matcher threshold must be > 0");
+    HIPCHK(hipSetDevice(ws_.device_));
+    const float thr2 = (float)(threshold * threshold);
+    while (ev_.size() < ev_used_ + 2) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ev_.push_back(e);
+    }
+    HIPCHK(hipEventRecord(ev_[ev_used_], ws_.stream_));
+    const int K = (int)probs_.size();
+    for (int k0 = 0; k0 < K;) {  // chunks of up to kCoopMaxBatch active problems per launch
+        NnBatch<kCoopMaxBatch> b;
+        std::memset(&b, 0, sizeof b);
+        int n = 0, max_items = 0;
+        size_t max_box_bytes = 0;
+        for (; k0 < K && n < kCoopMaxBatch; ++k0) {
+            if (!active[k0]) continue;
+            const BatchProblem& pr = probs_[(size_t)k0];
+            Buffers& bf = buf_[(size_t)k0];
+            if (pr.loc->n == 0 || pr.map->n == 0) return fail(MOLA_ICP_E_INTERNAL, "empty problem in a batched match");
+            NnProblem& pb = b.p[n++];
+            const float* sl = pr.loc->sorted.as<float>();
+            pb.slx = sl; pb.sly = sl + pr.loc->padded; pb.slz = sl + 2 * pr.loc->padded;
+            pb.N = (int)pr.loc->n;
+            pb.mp = tiled_map_of(*pr.map);
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) pb.P.R[3 * r + c] = (float)T[k0](r, c);
+                pb.P.t[r] = (float)T[k0](r, 3);
+            }
+            pb.thr2 = thr2;
+            pb.use_seed = (bf.seed_valid && !g_knobs.no_warm_start) ? 1 : 0;
+            pb.pos_s = bf.pos.as<int>(); pb.idx_s = bf.idx.as<int>(); pb.d2_s = bf.d2.as<float>();
+            pb.redo_count = counters_.as<unsigned int>() + k0;
+            pb.redo_list = bf.redo.as<int>();
+            pb.staged = stats_.as<unsigned long long>();
+            bf.seed_valid = true;
+            const int items = (int)((pr.loc->n + kQPW - 1) / kQPW);
+            if (items > max_items) max_items = items;
+            const size_t bb = sizeof(float) * 6u * ((size_t)pb.mp.n_top + (size_t)pb.mp.n_super);
+            if (bb > max_box_bytes) max_box_bytes = bb;
+        }
+        if (n == 0) break;
+        const int lds_boxes = max_box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
+        const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
+        hipLaunchKernelGGL((k_nn_coop<false, kCoopMaxBatch>), dim3(max_items, n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
+                           (unsigned long long*)nullptr);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_nn_coop<true, kCoopMaxBatch>), dim3(max_items < 16 ? max_items : 16, n), dim3(256), dyn_lds,
+                           ws_.stream_, b, lds_boxes, (unsigned long long*)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ev_[ev_used_ + 1], ws_.stream_));
+    ev_used_ += 2;
+    return MOLA_ICP_OK;
+}
+
+int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const Mat4* Tcur, int stage, const double (*cl)[3],
+                         const double (*cg)[3], bool reset_outliers, double (*acc)[kNAcc])
+{
+    int rc = init();
+    if (rc) return rc;
+    if (stage != 0 && stage != 1) return fail(MOLA_ICP_E_BADARG, "stage must be 0 or 1");
+    if (stage == 1 && (!cl || !cg)) return fail(MOLA_ICP_E_BADARG, "stage 1 needs the centroids");
+    HIPCHK(hipSetDevice(ws_.device_));
+    const int K = (int)probs_.size();
+    const unsigned long long seq = ++seq_;
+    int n_active = 0;
+    for (int k0 = 0; k0 < K;) {
+        AccBatch ab;
+        ReduceBatch rb;
+        std::memset(&ab, 0, sizeof ab);
+        std::memset(&rb, 0, sizeof rb);
+        int n = 0, max_blocks = 0;
+        for (; k0 < K && n < kAccMaxBatch; ++k0) {
+            if (!active[k0]) continue;
+            const BatchProblem& pr = probs_[(size_t)k0];
+            Buffers& bf = buf_[(size_t)k0];
+            if (!bf.seed_valid) return fail(MOLA_ICP_E_BADARG, "batched accumulate() before match()");
+            const size_t N = pr.loc->n;
+            if (reset_outliers && (bf.outliers_dirty || bf.outlier_cleared_for != N)) {
+                HIPCHK(hipMemsetAsync(bf.outlier.p, 0, N, ws_.stream_));
+                bf.outliers_dirty = false;
+                bf.outlier_cleared_for = N;
+            }
+            if (stage == 1 && p.use_scale_outlier_detector) bf.outliers_dirty = true;
+            int nblocks = (int)((N + kAccThreads - 1) / kAccThreads);
+            if (nblocks > kAccMaxBlocks) nblocks = kAccMaxBlocks;
+            AccArgs& a = ab.a[n];
+            const float* sl = pr.loc->sorted.as<float>();
+            const float* sm = pr.map->sorted.as<float>();
+            a.lx = sl; a.ly = sl + pr.loc->padded; a.lz = sl + 2 * pr.loc->padded;
+            a.gx = sm; a.gy = sm + pr.map->padded; a.gz = sm + 2 * pr.map->padded;
+            a.idx = bf.pos.as<int>(); a.d2 = bf.d2.as<float>();
+            a.outlier = bf.outlier.as<unsigned char>();
+            a.N = (int)N; a.stage = stage;
+            a.use_scale = p.use_scale_outlier_detector; a.use_robust = p.use_robust_kernel;
+            a.scale_thr = p.scale_outlier_threshold; a.rk_param = p.robust_kernel_param; a.rk_scale = p.robust_kernel_scale;
+            for (int c = 0; c < 3; ++c) { a.cl[c] = cl ? cl[k0][c] : 0.0; a.cg[c] = cg ? cg[k0][c] : 0.0; }
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) a.R[3 * r + c] = Tcur[k0](r, c);
+            ab.nblocks[n] = nblocks;
+            ab.partials[n] = bf.partials.as<double>();
+            rb.partials[n] = bf.partials.as<double>();
+            rb.nblocks[n] = nblocks;
+            rb.slot[n] = k0;
+            if (nblocks > max_blocks) max_blocks = nblocks;
+            ++n;
+        }
+        if (n == 0) break;
+        n_active += n;
+        hipLaunchKernelGGL(k_accumulate_batch, dim3(max_blocks, n), dim3(kAccThreads), 0, ws_.stream_, ab);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_reduce_partials_batch, dim3(n), dim3(kNAcc * kRedSlices), 0, ws_.stream_, rb, acc_dev_.as<double>(),
+                           acc_host_, counters_.as<unsigned int>(), seq);
+        HIPCHK(hipGetLastError());
+    }
+    if (n_active == 0) return MOLA_ICP_OK;
+    for (int k = 0; k < K; ++k) {
+        if (!active[k]) continue;
+        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(acc_host_ + 32 * (size_t)k) + kNAcc + 6;
+        if ((rc = ws_.spin_for(flag, seq))) return rc;
+        for (int c = 0; c < kNAcc; ++c) acc[k][c] = acc_host_[32 * (size_t)k + c];
+    }
+    return MOLA_ICP_OK;
+}
+
+int HipBatch::collect_stats(double* ms_total, uint32_t* launches, uint64_t* pairs)
+{
+    if (!inited_) { if (ms_total) *ms_total = 0; if (launches) *launches = 0; if (pairs) *pairs = 0; return MOLA_ICP_OK; }
+    HIPCHK(hipSetDevice(ws_.device_));
+    HIPCHK(hipMemcpyAsync(stats_host_, stats_.p, sizeof(unsigned long long) * kStatSlots * kStatStride, hipMemcpyDeviceToHost, ws_.stream_));
+    HIPCHK(hipStreamSynchronize(ws_.stream_));
+    unsigned long long staged = 0;
+    for (int k = 0; k < kStatSlots; ++k) staged += stats_host_[(size_t)k * kStatStride];
+    double tot = 0;
+    for (size_t i = 0; i + 1 < ev_used_; i += 2) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev_[i], ev_[i + 1]));
+        tot += ms;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = (uint32_t)(ev_used_ / 2);
+    if (pairs) *pairs = (uint64_t)staged * 64u;
     return MOLA_ICP_OK;
 }
 

@@ -16,6 +16,7 @@ namespace mola_icp_amd {
 
 struct PoseF;
 struct TiledMap;
+struct NnProblem;
 
 // RCCL, loaded at run time (rccl_dl.cpp)
 struct RcclUniqueId { char internal[128]; };
@@ -48,7 +49,10 @@ struct SortedCloud {
     ~SortedCloud() { raw.release(); sorted.release(); perm.release(); tbox.release(); sbox.release(); ubox.release(); }
 };
 
+class HipBatch;
+
 class HipWorkspace final : public Stages {
+    friend class HipBatch;
    public:
     explicit HipWorkspace(int device);
     ~HipWorkspace() override;
@@ -104,6 +108,8 @@ class HipWorkspace final : public Stages {
     int prepare_queries();  // Morton-sorted local cloud
     int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);
     int launch_tiled(const struct PoseF& P, float thr2, bool use_seed, unsigned int* counter);
+    int fill_nn_problem(const struct PoseF& P, float thr2, bool use_seed, NnProblem& pb);
+    int launch_coop(const struct PoseF& P, float thr2, bool use_seed);
     TiledMap tiled_map() const;
     int spin_for(volatile unsigned long long* flag, unsigned long long seq);
     int launch_nn(const Mat4& T, float thr2, int kernel);
@@ -138,6 +144,8 @@ class HipWorkspace final : public Stages {
     double planes_eig_thr_ = -1.0;  // planeEigenThreshold the planes in plane_cache_ were decided with
     double knn_changed_items_ = -1.0;  // items whose neighbour lists changed in the last iteration (-1: unknown)
     bool knn_seed_valid_ = false;  // knn_pos_ holds the last launch's neighbours for the clouds in place
+    DevBuf stats_;                    // the cooperative matcher's slotted statistics counters
+    unsigned long long* stats_host_ = nullptr;  // pinned
     DevBuf redo_list_;                // work items with exact distance ties: redone with the full lexicographic key
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
     bool cost_valid_ = false, order_valid_ = false;
@@ -164,7 +172,47 @@ class HipWorkspace final : public Stages {
     uint32_t last_kernel_ = 0;
     uint64_t dense_pairs_ = 0;
     unsigned long long* wave_times_ = nullptr; // MOLA_ICP_DEBUG_STATS=2 only
+    bool wave_times_coop_ = false;             // ... written by k_nn_coop (its own record layout)
     unsigned long long* dbg_stats_ = nullptr;  // MOLA_ICP_DEBUG_STATS=1 only
+};
+
+// K point-to-point problems on ONE device advanced by batched launches (BatchStages of icp_loop.hpp): k_nn_coop with
+// blockIdx.y = problem, k_accumulate_batch, k_reduce_partials_batch, one pinned read-back per pass.  Problems are
+// pairs of prepared clouds (shared: the K guesses of the loop-closure Monte-Carlo use the same two).  Runs on the
+// stream and scratch of a workspace the caller holds for the batch's lifetime.
+struct BatchProblem {
+    std::shared_ptr<SortedCloud> map, loc;
+};
+class HipBatch final : public BatchStages {
+   public:
+    HipBatch(HipWorkspace& ws, std::vector<BatchProblem> probs);
+    ~HipBatch() override;
+    int init();  // per-problem pairing buffers, pinned read-back block
+    int size() const override { return (int)probs_.size(); }
+    int match(const uint8_t* active, const Mat4* T, double threshold, const mola_icp_params& p) override;
+    int accumulate(const uint8_t* active, const mola_icp_params& p, const Mat4* Tcur, int stage, const double (*cl)[3],
+                   const double (*cg)[3], bool reset_outliers, double (*acc)[kNAcc]) override;
+    uint64_t n_local_total(int k) const override { return probs_[(size_t)k].loc->n; }
+    uint64_t n_map_total(int k) const override { return probs_[(size_t)k].map->n; }
+    // statistics of the matcher launches since init(): total HIP-event time, launches, evaluated pairs (whole batch)
+    int collect_stats(double* ms_total, uint32_t* launches, uint64_t* pairs);
+
+   private:
+    struct Buffers {
+        DevBuf pos, idx, d2, outlier, redo, partials;
+        bool seed_valid = false, outliers_dirty = false;
+        size_t outlier_cleared_for = 0;
+    };
+    HipWorkspace& ws_;
+    std::vector<BatchProblem> probs_;
+    std::vector<Buffers> buf_;
+    DevBuf acc_dev_, counters_, stats_;
+    double* acc_host_ = nullptr;                 // pinned: 32 doubles per problem (24 sums, flag in slot 30)
+    unsigned long long* stats_host_ = nullptr;   // pinned
+    unsigned long long seq_ = 0;
+    std::vector<hipEvent_t> ev_;
+    size_t ev_used_ = 0;
+    bool inited_ = false;
 };
 
 }  // namespace mola_icp_amd

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace mola_icp_amd {
 
@@ -174,6 +175,126 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     }
     out->ms_iterations = t1 - t0;
     out->ms_quality = t2 - t1;
+    return MOLA_ICP_OK;
+}
+
+// ---- K problems in lockstep (see icp_loop.hpp).  Mirrors run_icp_loop + solve_on_pairing step by step; a problem that
+// terminates simply drops out of the active set of the following launches.
+int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params& p, mola_icp_result* out)
+{
+    int rc = validate_params(p);
+    if (rc) return rc;
+    if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD)
+        return fail(MOLA_ICP_E_UNSUPPORTED, "the batched loop runs the point-to-point pipeline only");
+    const int K = st.size();
+    if (K <= 0) return MOLA_ICP_OK;
+    struct State {
+        Mat4 T, Tprev;
+        uint32_t term = MOLA_ICP_TERM_UNDEFINED, its = 0;
+        double last_acc[kNAcc] = {};
+        bool have_solution = false, done = false;
+    };
+    std::vector<State> s((size_t)K);
+    std::vector<Mat4> Tn((size_t)K), Tcur((size_t)K);
+    std::vector<uint8_t> active((size_t)K), sub((size_t)K);
+    std::vector<double> accv((size_t)K * kNAcc), clv((size_t)K * 3), cgv((size_t)K * 3);
+    auto acc = reinterpret_cast<double(*)[kNAcc]>(accv.data());
+    auto cl = reinterpret_cast<double(*)[3]>(clv.data());
+    auto cg = reinterpret_cast<double(*)[3]>(cgv.data());
+    for (int k = 0; k < K; ++k) { s[k].T = init[k]; s[k].Tprev = init[k]; }
+    auto any = [&](const std::vector<uint8_t>& m) { for (uint8_t v : m) if (v) return true; return false; };
+    const bool weighted = p.use_scale_outlier_detector || p.use_robust_kernel;
+    const double t0 = now_ms();
+    for (uint32_t it = 0; it < p.max_iterations; ++it) {
+        const bool run_matcher = it >= p.run_from_iteration && (p.run_up_to_iteration == 0 || it <= p.run_up_to_iteration);
+        for (int k = 0; k < K; ++k) {
+            active[k] = s[k].done ? 0 : 1;
+            if (active[k] && (!run_matcher || st.n_local_total(k) == 0 || st.n_map_total(k) == 0)) {
+                s[k].term = MOLA_ICP_TERM_NO_PAIRINGS; s[k].its = it; s[k].done = true; active[k] = 0;
+            }
+            Tcur[k] = s[k].T;
+            Tn[k] = s[k].T;
+        }
+        if (!any(active)) break;
+        if ((rc = st.match(active.data(), Tcur.data(), p.matcher_threshold, p))) return rc;
+        // solve_on_pairing, batched
+        if ((rc = st.accumulate(active.data(), p, Tcur.data(), 0, nullptr, nullptr, true, acc))) return rc;
+        sub = active;  // problems still inside this iteration's solve
+        std::vector<uint8_t> solver_error((size_t)K, 0);
+        for (int k = 0; k < K; ++k) {
+            if (!sub[k]) continue;
+            if (!(acc[k][16] > 0)) {  // NoPairings
+                s[k].term = MOLA_ICP_TERM_NO_PAIRINGS; s[k].its = it; s[k].done = true; sub[k] = 0; active[k] = 0;
+            } else if (!weighted) {
+                if (!solve_horn(acc[k], nullptr, nullptr, Tn[k])) solver_error[k] = 1;
+                sub[k] = 0;
+            }
+        }
+        if (weighted) {
+            const int passes = p.use_scale_outlier_detector ? 2 : 1;
+            for (int pass = 0; pass < passes && any(sub); ++pass) {
+                if (pass > 0)
+                    if ((rc = st.accumulate(sub.data(), p, Tcur.data(), 0, nullptr, nullptr, false, acc))) return rc;
+                for (int k = 0; k < K; ++k) {
+                    if (!sub[k]) continue;
+                    if (!(acc[k][0] > 0)) { solver_error[k] = 1; sub[k] = 0; continue; }
+                    for (int a = 0; a < 3; ++a) { cl[k][a] = acc[k][1 + a] / acc[k][0]; cg[k][a] = acc[k][4 + a] / acc[k][0]; }
+                }
+                if (!any(sub)) break;
+                if ((rc = st.accumulate(sub.data(), p, Tcur.data(), 1, cl, cg, false, acc))) return rc;
+                for (int k = 0; k < K; ++k) {
+                    if (!sub[k]) continue;
+                    if (!solve_horn(acc[k], cl[k], cg[k], Tn[k])) { solver_error[k] = 1; sub[k] = 0; }
+                }
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            if (!active[k]) continue;
+            if (solver_error[k]) { s[k].term = MOLA_ICP_TERM_SOLVER_ERROR; s[k].its = it; s[k].done = true; continue; }
+            std::memcpy(s[k].last_acc, acc[k], sizeof s[k].last_acc);
+            s[k].have_solution = true;
+            s[k].T = Tn[k];
+            double d_xyz, d_rot;
+            stall_deltas(s[k].T, s[k].Tprev, d_xyz, d_rot);
+            if (!p.fixed_iterations && std::fabs(d_xyz) < p.min_abs_step_trans && std::fabs(d_rot) < p.min_abs_step_rot) {
+                s[k].term = MOLA_ICP_TERM_STALLED; s[k].its = it + 1; s[k].done = true;
+                continue;
+            }
+            s[k].Tprev = s[k].T;
+        }
+    }
+    for (int k = 0; k < K; ++k)
+        if (!s[k].done) { s[k].term = MOLA_ICP_TERM_MAX_ITERATIONS; s[k].its = p.max_iterations; }
+    const double t1 = now_ms();
+    // quality (row a11) of every problem at its final pose
+    std::vector<double> quality((size_t)K, 0.0);
+    if (p.skip_quality) {
+        for (int k = 0; k < K; ++k) quality[k] = -1.0;
+    } else {
+        for (int k = 0; k < K; ++k) { active[k] = (st.n_local_total(k) > 0 && st.n_map_total(k) > 0) ? 1 : 0; Tcur[k] = s[k].T; }
+        if (any(active)) {
+            if ((rc = st.match(active.data(), Tcur.data(), p.quality_threshold, p))) return rc;
+            if ((rc = st.accumulate(active.data(), p, Tcur.data(), 0, nullptr, nullptr, true, acc))) return rc;
+            for (int k = 0; k < K; ++k)
+                if (active[k]) {
+                    const uint64_t nl = st.n_local_total(k), nm = st.n_map_total(k);
+                    quality[k] = acc[k][16] / (double)(nl < nm ? nl : nm);
+                }
+        }
+    }
+    const double t2 = now_ms();
+    for (int k = 0; k < K; ++k) {
+        mola_icp_result& o = out[k];
+        std::memcpy(o.T, s[k].T.m, sizeof o.T);
+        o.quality = quality[k];
+        o.n_iterations = s[k].its;
+        o.termination = s[k].term;
+        o.n_pairs = s[k].have_solution ? (uint64_t)s[k].last_acc[16] : 0;
+        o.rmse = (s[k].have_solution && s[k].last_acc[16] > 0) ? std::sqrt(s[k].last_acc[17] / s[k].last_acc[16]) : 0.0;
+        if (!s[k].have_solution || !pose_covariance(s[k].last_acc, s[k].T, o.cov)) std::memset(o.cov, 0, sizeof o.cov);
+        o.ms_iterations = t1 - t0;   // the whole batch's loop / quality pass (the problems ran together)
+        o.ms_quality = t2 - t1;
+    }
     return MOLA_ICP_OK;
 }
 

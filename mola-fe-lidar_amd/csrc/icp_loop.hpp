@@ -49,6 +49,22 @@ struct Stages {
     virtual uint64_t n_map_total() const = 0;
 };
 
+// K independent point-to-point problems advanced in lockstep, every stage ONE batched launch over the problems still
+// iterating: the loop-closure Monte-Carlo (K initial poses on one cloud pair, src/LidarOdometry.cpp:767-788) and the
+// nearby-keyframe batch (K pairs, cpp:704-741).  `active[k] != 0` selects the problems a call works on.
+struct BatchStages {
+    virtual ~BatchStages() = default;
+    virtual int size() const = 0;
+    virtual int match(const uint8_t* active, const Mat4* T, double threshold, const mola_icp_params& p) = 0;
+    virtual int accumulate(const uint8_t* active, const mola_icp_params& p, const Mat4* Tcur, int stage,
+                           const double (*cl)[3], const double (*cg)[3], bool reset_outliers, double (*acc)[kNAcc]) = 0;
+    virtual uint64_t n_local_total(int k) const = 0;
+    virtual uint64_t n_map_total(int k) const = 0;
+};
+// Per problem the same sequence of operations as run_icp_loop (point-to-point pipeline): results are bit-identical to
+// K separate runs over stages that compute the same sums.  out = K results.
+int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params& p, mola_icp_result* out);
+
 // Runs the loop; fills T, quality, n_iterations, termination, n_pairs, rmse, cov,
 // ms_iterations, ms_quality of *out (other fields untouched).
 int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_icp_result* out);

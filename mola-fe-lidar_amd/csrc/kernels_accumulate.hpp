@@ -24,12 +24,14 @@ struct AccArgs {
 constexpr int kAccThreads = 256;
 constexpr int kAccMaxBlocks = 512;   // rows of partial sums (fixed for a given N: deterministic reduction)
 
-__global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* __restrict__ partials)
+// block `bx` of `nblocks` over one problem's pairing -> one row of partial sums (the summation order depends on
+// (N, nblocks) only: the single-problem and the batched launch produce the same bits)
+__device__ __forceinline__ void accumulate_rows(const AccArgs& a, int bx, int nblocks, double* __restrict__ partials)
 {
     double s[kNAcc];
 #pragma unroll
     for (int k = 0; k < kNAcc; ++k) s[k] = 0.0;
-    const int stride = gridDim.x * kAccThreads;
+    const int stride = nblocks * kAccThreads;
     // one pairing -> the 24 sums; elements are taken in ascending i per thread (fixed summation order)
     auto element = [&](int i, int j, unsigned char out, double l0, double l1, double l2, double g0, double g1, double g2,
                        float d2v) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* _
     };
     // two elements per trip with all their loads issued up front (the gather by neighbour position is a dependent
     // load: this halves the exposed latency); they are summed in the same order as a one-by-one loop
-    for (int i = blockIdx.x * kAccThreads + threadIdx.x; i < a.N; i += 2 * stride) {
+    for (int i = bx * kAccThreads + threadIdx.x; i < a.N; i += 2 * stride) {
         const int i2 = i + stride;
         const bool in2 = i2 < a.N;
         const int ic2 = in2 ? i2 : i;
@@ -92,15 +94,33 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* _
     }
     // fixed-order block sum -> one row per block
     static_assert(kAccThreads == 256, "block_sum_256");
-    block_sum_256<kNAcc>(s, partials + (size_t)blockIdx.x * kNAcc);
+    block_sum_256<kNAcc>(s, partials + (size_t)bx * kNAcc);
+}
+
+__global__ __launch_bounds__(kAccThreads) void k_accumulate(AccArgs a, double* __restrict__ partials)
+{
+    accumulate_rows(a, (int)blockIdx.x, (int)gridDim.x, partials);
+}
+
+// K problems in one launch (grid = (max rows, K)): per problem the SAME partition as its own k_accumulate launch
+constexpr int kAccMaxBatch = 12;   // 12 x sizeof(AccArgs) stays below the 4 KB of kernel arguments
+struct AccBatch {
+    AccArgs a[kAccMaxBatch];
+    int nblocks[kAccMaxBatch];
+    double* partials[kAccMaxBatch];
+};
+__global__ __launch_bounds__(kAccThreads) void k_accumulate_batch(const AccBatch b)
+{
+    const int y = (int)blockIdx.y;
+    const int nb = b.nblocks[y];
+    if ((int)blockIdx.x >= nb) return;
+    accumulate_rows(b.a[y], (int)blockIdx.x, nb, b.partials[y]);
 }
 
 // sums the per-block rows in a fixed order: 32 interleaved slices per accumulator, then the slices in order
 constexpr int kRedSlices = 32;
-__global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const double* __restrict__ partials, int nblocks,
-                                                                        double* __restrict__ acc,
-                                                                        double* __restrict__ host_out /*pinned, may be null*/,
-                                                                        unsigned long long seq)
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int nblocks, double* __restrict__ acc,
+                                            double* __restrict__ host_out, unsigned long long seq)
 {
     __shared__ double sm[kRedSlices][kNAcc];
     const int k = threadIdx.x % kNAcc, sl = threadIdx.x / kNAcc;
@@ -122,10 +142,35 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const do
             __threadfence_system();
         }
     }
+}
+
+__global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const double* __restrict__ partials, int nblocks,
+                                                                        double* __restrict__ acc,
+                                                                        double* __restrict__ host_out /*pinned, may be null*/,
+                                                                        unsigned long long seq)
+{
+    reduce_rows(partials, nblocks, acc, host_out, seq);
     // the matcher's work-queue / kept / redo counters sit right behind the block: leave them zero for its next launch
     if (threadIdx.x == kNAcc) { acc[kNAcc] = 0.0; acc[kNAcc + 1] = 0.0; }
     if (threadIdx.x >= 32 && threadIdx.x < 32 + 2 * kQueues)  // the tiled matcher's work-queue counters
         reinterpret_cast<unsigned int*>(acc + kNAcc + 8)[(threadIdx.x - 32) * kQueueStride] = 0u;
+}
+
+// K problems: block y reduces problem y's rows into acc + 32 y and publishes them at host_out + 32 y (flag in slot 30
+// of that stride); the problems' redo counters (the cooperative matcher's) are left zero for its next launch
+struct ReduceBatch {
+    const double* partials[kAccMaxBatch];
+    int nblocks[kAccMaxBatch];
+    int slot[kAccMaxBatch];              // the problem's index in acc / host_out / counters
+};
+__global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials_batch(const ReduceBatch b, double* __restrict__ acc,
+                                                                              double* __restrict__ host_out,
+                                                                              unsigned int* __restrict__ counters,
+                                                                              unsigned long long seq)
+{
+    const int y = (int)blockIdx.x, s = b.slot[y];
+    reduce_rows(b.partials[y], b.nblocks[y], acc + 32 * (size_t)s, host_out + 32 * (size_t)s, seq);
+    if (threadIdx.x == kNAcc) counters[s] = 0u;
 }
 
 // hands a device block of n doubles to the host through its pinned block: data, then the sequence number the host

@@ -87,8 +87,12 @@ __device__ __forceinline__ void load_boxes_to_lds(const TiledMap& mp, lds_f32* l
 // `visit(nm, jb0, jb1)` is called once per staged pass: sm[0..2][0..nm) hold x,y,z of the staged points
 // (sm[3] their original indices if NEED_PERM); points [0,32) have sorted positions jb0.., [32,64) jb1...
 // Returns the number of staged points.
-template <int QPL, bool NEED_PERM, class Visit>
-__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane,
+// NPARTS > 1 (cooperative items, kernels_coop.hpp): NPARTS waves hold the SAME queries and run the same box scan;
+// wave `part` stages and evaluates only every NPARTS-th candidate tile (round-robin over the candidates in scan
+// order), the per-query results are merged by the caller.  Each wave's live bound then only sees its own tiles:
+// still exact (a bound can only be looser than in the one-wave sweep), slightly more staged points in total.
+template <int QPL, bool NEED_PERM, int NPARTS, class Visit>
+__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane, int part,
                                                           float (*sm)[64], const float (&qx)[QPL], const float (&qy)[QPL],
                                                           const float (&qz)[QPL], const float (&reach)[QPL],
                                                           const float (&bound2)[QPL], Visit&& visit,
@@ -173,6 +177,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
 
     // ---- the listed super-tiles: tile boxes of entry e+1 in flight while entry e's tiles are processed ----
     int n_list = 0;
+    int cand_no = 0;  // running number of the candidate tiles (wave-uniform): the cooperative split deals them round-robin
     auto process_list = [&]() {
         if (n_list == 0) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -201,6 +206,11 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
                 while (cand) {
                     const int t = __builtin_ctzll(cand);
                     cand &= cand - 1;
+                    if constexpr (NPARTS > 1) {
+                        const bool mine = (cand_no & (NPARTS - 1)) == part;
+                        ++cand_no;
+                        if (!mine) continue;
+                    }
                     if (prof) p_tiles += 1;
                     if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
                                   bcast_lane(b4, t), bcast_lane(b5, t)))
@@ -346,6 +356,92 @@ struct WaveQueue {
     }
 };
 
+// The two visitors of the NN kernels (one staged pass: sm[0..2][0..nm) = x, y, z, sm[3] = original indices; points
+// [0,32) have sorted positions jb0.., [32,64) jb1..), shared by k_nn_tiled and the cooperative k_nn_coop.
+// exact: per-pair argmin on the packed key (d2 bits << 32 | original index) -- the full lexicographic rule
+template <int QPL>
+__device__ __forceinline__ void nn_visit_exact(float (*sm)[64], int nm, int jb0, int jb1, const float (&qx)[QPL],
+                                               const float (&qy)[QPL], const float (&qz)[QPL],
+                                               unsigned long long (&key)[QPL], float (&best)[QPL], int (&bpos)[QPL])
+{
+    for (int m = 0; m < nm; m += 4) {
+        const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+        const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+        const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
+        const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+        const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+        const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
+                                    __float_as_uint(O.w)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < QPL; ++k) {
+                const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
+                const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
+                const bool better = ck < key[k];
+                key[k] = better ? ck : key[k];
+                best[k] = better ? d : best[k];  // the sweep's box tests read it
+                bpos[k] = better ? ((m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32) : bpos[k];
+            }
+        }
+    }
+}
+
+// fast: per kGroup-point group only the group minimum meets the running best; (best, group position, tie flag)
+template <int QPL>
+__device__ __forceinline__ void nn_visit_fast(float (*sm)[64], int nm, int jb0, int jb1, const float (&qx)[QPL],
+                                              const float (&qy)[QPL], const float (&qz)[QPL], float (&best)[QPL],
+                                              int (&bpos)[QPL], int (&tie)[QPL])
+{
+    // per kGroup-point group: packed sub/mul/fma (v_pk_*_f32) serve two (query, point) pairs per
+    // instruction -- the lane's two queries (QPL = 2) or two consecutive points (QPL = 1) -- the group
+    // minimum is a chain of v_min3, and the (best, position, tie) bookkeeping runs once per group
+#pragma unroll 2
+    for (int m = 0; m < nm; m += kGroup) {
+        float gm[QPL];
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) gm[k] = INFINITY;
+#pragma unroll
+        for (int h = 0; h < kGroup; h += 8) {
+            const float4 X0 = *reinterpret_cast<const float4*>(&sm[0][m + h]);
+            const float4 X1 = *reinterpret_cast<const float4*>(&sm[0][m + h + 4]);
+            const float4 Y0 = *reinterpret_cast<const float4*>(&sm[1][m + h]);
+            const float4 Y1 = *reinterpret_cast<const float4*>(&sm[1][m + h + 4]);
+            const float4 Z0 = *reinterpret_cast<const float4*>(&sm[2][m + h]);
+            const float4 Z1 = *reinterpret_cast<const float4*>(&sm[2][m + h + 4]);
+            const float xs[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
+            const float ys[8] = {Y0.x, Y0.y, Y0.z, Y0.w, Y1.x, Y1.y, Y1.z, Y1.w};
+            const float zs[8] = {Z0.x, Z0.y, Z0.z, Z0.w, Z1.x, Z1.y, Z1.z, Z1.w};
+            if constexpr (QPL == 2) {
+                const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    const v2f da = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                    const v2f db = dist2_pk(q2x, q2y, q2z, xs[u + 1], ys[u + 1], zs[u + 1]);
+                    gm[0] = fminf(fminf(gm[0], da.x), db.x);
+                    gm[1] = fminf(fminf(gm[1], da.y), db.y);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    const v2f mx = {xs[u], xs[u + 1]}, my = {ys[u], ys[u + 1]}, mz = {zs[u], zs[u + 1]};
+                    const v2f dd = dist2_pk2(qx[0], qy[0], qz[0], mx, my, mz);
+                    gm[0] = fminf(fminf(gm[0], dd.x), dd.y);
+                }
+            }
+        }
+        const int gpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this group
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) {
+            const bool lt = gm[k] < best[k];
+            const int eq = (int)(gm[k] == best[k]) & (int)(gpos != bpos[k]);
+            tie[k] = lt ? 0 : (tie[k] | eq);
+            best[k] = lt ? gm[k] : best[k];
+            bpos[k] = lt ? gpos : bpos[k];
+        }
+    }
+}
+
 // EXACT = false: the fast sweep.  Per (query, 4-point chunk) only the chunk minimum is compared with the
 //   running best (~6 VALU ops per pair); the winning chunk is re-evaluated once at the end to recover the
 //   exact point and the lowest-original-index rule inside it.  If an EQUAL minimum showed up in a different
@@ -443,78 +539,9 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
         unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
         const unsigned long long t_sweep0 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
-        const unsigned long long n_staged = tiled_sweep<QPL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
-            if constexpr (EXACT) {
-                for (int m = 0; m < nm; m += 4) {
-                    const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
-                    const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
-                    const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
-                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
-                    const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
-                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
-                                                __float_as_uint(O.w)};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                        for (int k = 0; k < QPL; ++k) {
-                            const float d = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
-                            const unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | os[u];
-                            const bool better = ck < key[k];
-                            key[k] = better ? ck : key[k];
-                            best[k] = better ? d : best[k];  // the sweep's box tests read it
-                            bpos[k] = better ? ((m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32) : bpos[k];
-                        }
-                    }
-                }
-            } else {
-                // per kGroup-point group: packed sub/mul/fma (v_pk_*_f32) serve two (query, point) pairs per
-                // instruction -- the lane's two queries (QPL = 2) or two consecutive points (QPL = 1) -- the group
-                // minimum is a chain of v_min3, and the (best, position, tie) bookkeeping runs once per group
-#pragma unroll 2
-                for (int m = 0; m < nm; m += kGroup) {
-                    float gm[QPL];
-#pragma unroll
-                    for (int k = 0; k < QPL; ++k) gm[k] = INFINITY;
-#pragma unroll
-                    for (int h = 0; h < kGroup; h += 8) {
-                        const float4 X0 = *reinterpret_cast<const float4*>(&sm[0][m + h]);
-                        const float4 X1 = *reinterpret_cast<const float4*>(&sm[0][m + h + 4]);
-                        const float4 Y0 = *reinterpret_cast<const float4*>(&sm[1][m + h]);
-                        const float4 Y1 = *reinterpret_cast<const float4*>(&sm[1][m + h + 4]);
-                        const float4 Z0 = *reinterpret_cast<const float4*>(&sm[2][m + h]);
-                        const float4 Z1 = *reinterpret_cast<const float4*>(&sm[2][m + h + 4]);
-                        const float xs[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
-                        const float ys[8] = {Y0.x, Y0.y, Y0.z, Y0.w, Y1.x, Y1.y, Y1.z, Y1.w};
-                        const float zs[8] = {Z0.x, Z0.y, Z0.z, Z0.w, Z1.x, Z1.y, Z1.z, Z1.w};
-                        if constexpr (QPL == 2) {
-                            const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
-#pragma unroll
-                            for (int u = 0; u < 8; u += 2) {
-                                const v2f da = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
-                                const v2f db = dist2_pk(q2x, q2y, q2z, xs[u + 1], ys[u + 1], zs[u + 1]);
-                                gm[0] = fminf(fminf(gm[0], da.x), db.x);
-                                gm[1] = fminf(fminf(gm[1], da.y), db.y);
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < 8; u += 2) {
-                                const v2f mx = {xs[u], xs[u + 1]}, my = {ys[u], ys[u + 1]}, mz = {zs[u], zs[u + 1]};
-                                const v2f dd = dist2_pk2(qx[0], qy[0], qz[0], mx, my, mz);
-                                gm[0] = fminf(fminf(gm[0], dd.x), dd.y);
-                            }
-                        }
-                    }
-                    const int gpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this group
-#pragma unroll
-                    for (int k = 0; k < QPL; ++k) {
-                        const bool lt = gm[k] < best[k];
-                        const int eq = (int)(gm[k] == best[k]) & (int)(gpos != bpos[k]);
-                        tie[k] = lt ? 0 : (tie[k] | eq);
-                        best[k] = lt ? gm[k] : best[k];
-                        bpos[k] = lt ? gpos : bpos[k];
-                    }
-                }
-            }
+        const unsigned long long n_staged = tiled_sweep<QPL, EXACT, 1>(mp, lbox, lds_boxes != 0, slist, lane, 0, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+            if constexpr (EXACT) nn_visit_exact<QPL>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
+            else nn_visit_fast<QPL>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
         }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
         const unsigned long long t_sweep1 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
         // the popped entry has long arrived: its lookup (and a steal, if the segment is dry) overlaps the epilogue's loads

@@ -180,6 +180,64 @@ class Results:
         return IterTermReason.get(self.terminationReason, "?")
 
 
+def _align_batch(fn, handle, pairs, init_guesses, params: "Parameters") -> list["Results"]:
+    n = len(pairs)
+    keep = []
+    FPP = C.POINTER(C.c_float) * n
+    arrs = [FPP() for _ in range(6)]
+    Ms, Ns = (C.c_size_t * n)(), (C.c_size_t * n)()
+    for i, (f, t) in enumerate(pairs):
+        fx, fy, fz, M = _soa(f)
+        tx, ty, tz, N = _soa(t)
+        keep += [fx, fy, fz, tx, ty, tz]
+        for a, v in zip(arrs, (fx, fy, fz, tx, ty, tz)):
+            a[i] = _fp(v)
+        Ms[i], Ns[i] = M, N
+    Ts = np.ascontiguousarray(np.stack([_pose16(g) for g in init_guesses]) if n else np.zeros((0, 16)))
+    res = (L.CResult * max(1, n))()
+    L.check(fn(handle, n, arrs[0], arrs[1], arrs[2], Ms, arrs[3], arrs[4], arrs[5], Ns, _dp(Ts), C.byref(params.c), res))
+    return [Results.from_c(res[k]) for k in range(n)]
+
+
+def pool_assignment(n_pairs: int, n_devices: int) -> list[int]:
+    """the device pool's dealing rule (mola_icp_pool_assignment): pair i -> device slot i mod n"""
+    out = (C.c_int * max(1, n_pairs))()
+    L.check(L.lib().mola_icp_pool_assignment(n_pairs, n_devices, out))
+    return list(out[:n_pairs])
+
+
+class DevicePool:
+    """One ICP handle per GPU of the node; independent pairs are dealt round-robin (BASELINE config[3]: the
+    nearby-KF / loop-closure batch of src/LidarOdometry.cpp:704-741 over 8 x MI355X, no collective)."""
+
+    def __init__(self, devices=None):
+        self._h = L._H()
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            L.check(L.lib().mola_icp_pool_create(arr, len(devices), C.byref(self._h)))
+        else:
+            L.check(L.lib().mola_icp_pool_create(None, 0, C.byref(self._h)))
+
+    def __len__(self):
+        n = C.c_int()
+        L.check(L.lib().mola_icp_pool_size(self._h, C.byref(n)))
+        return n.value
+
+    def align_batch(self, pairs, init_guesses, params: "Parameters") -> list["Results"]:
+        return _align_batch(L.lib().mola_icp_pool_align_batch, self._h, pairs, init_guesses, params)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            L.lib().mola_icp_pool_destroy(self._h)
+            self._h = L._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ the ICP object
 
 
@@ -223,23 +281,7 @@ class ICP:
     def align_batch(self, pairs, init_guesses, params: Parameters) -> list[Results]:
         """pairs = [(pcs_from, pcs_to), ...]: the nearby-KF / loop-closure batch
         (src/LidarOdometry.cpp:704-741)."""
-        n = len(pairs)
-        keep = []
-        FPP = C.POINTER(C.c_float) * n
-        arrs = [FPP() for _ in range(6)]
-        Ms, Ns = (C.c_size_t * n)(), (C.c_size_t * n)()
-        for i, (f, t) in enumerate(pairs):
-            fx, fy, fz, M = _soa(f)
-            tx, ty, tz, N = _soa(t)
-            keep += [fx, fy, fz, tx, ty, tz]
-            for a, v in zip(arrs, (fx, fy, fz, tx, ty, tz)):
-                a[i] = _fp(v)
-            Ms[i], Ns[i] = M, N
-        Ts = np.ascontiguousarray(np.stack([_pose16(g) for g in init_guesses]) if n else np.zeros((0, 16)))
-        res = (L.CResult * n)()
-        L.check(L.lib().mola_icp_align_batch(self._h, n, arrs[0], arrs[1], arrs[2], Ms, arrs[3], arrs[4], arrs[5], Ns,
-                                             _dp(Ts), C.byref(params.c), res))
-        return [Results.from_c(r) for r in res]
+        return _align_batch(L.lib().mola_icp_align_batch, self._h, pairs, init_guesses, params)
 
     def align_multi_init(self, pcs_from, pcs_to, init_guesses, params: Parameters):
         """Loop-closure Monte-Carlo (src/LidarOdometry.cpp:767-788): one pair, several initial poses, the
@@ -412,11 +454,8 @@ class ICP:
         return acc
 
 
-def run_loop(match_fn, accumulate_fn, init_guess, params: Parameters, n_local_total: int, n_map_total: int,
-             allreduce_fn=None) -> Results:
-    """The library's own iteration-control loop over caller-supplied stages
-    (mola_icp_run_loop): `match_fn(T4x4, threshold) -> n_pairs`,
-    `accumulate_fn(params, T4x4, stage, cl, cg, reset) -> acc[24]`, `allreduce_fn(acc) -> None`."""
+def _stage_callbacks(match_fn, accumulate_fn, n_local_total, n_map_total, allreduce_fn=None):
+    """ctypes stage callbacks around python functions; returns (CStageCallbacks, objects to keep alive)"""
 
     def _m(user, Tp, thr, n_out):
         try:
@@ -459,6 +498,31 @@ def run_loop(match_fn, accumulate_fn, init_guess, params: Parameters, n_local_to
     cb.user = None
     cb.n_local_total = n_local_total
     cb.n_map_total = n_map_total
+    return cb, (cb.match, cb.accumulate, cb.allreduce)
+
+
+def run_loop_batch(stages, init_guesses, params: Parameters) -> list[Results]:
+    """The lockstep loop of the batched aligners (mola_icp_run_loop_batch) over caller-supplied stages:
+    `stages` = [(match_fn, accumulate_fn, n_local_total, n_map_total), ...], one entry per problem."""
+    n = len(stages)
+    cbs = (L.CStageCallbacks * max(1, n))()
+    keep = []
+    for k, (m, a, nl, nm) in enumerate(stages):
+        cb, ka = _stage_callbacks(m, a, nl, nm)
+        cbs[k] = cb
+        keep.append(ka)
+    Ts = np.ascontiguousarray(np.stack([_pose16(g) for g in init_guesses]) if n else np.zeros((0, 16)))
+    res = (L.CResult * max(1, n))()
+    L.check(L.lib().mola_icp_run_loop_batch(cbs, n, _dp(Ts), C.byref(params.c), res))
+    return [Results.from_c(res[k]) for k in range(n)]
+
+
+def run_loop(match_fn, accumulate_fn, init_guess, params: Parameters, n_local_total: int, n_map_total: int,
+             allreduce_fn=None) -> Results:
+    """The library's own iteration-control loop over caller-supplied stages
+    (mola_icp_run_loop): `match_fn(T4x4, threshold) -> n_pairs`,
+    `accumulate_fn(params, T4x4, stage, cl, cg, reset) -> acc[24]`, `allreduce_fn(acc) -> None`."""
+    cb, _keep = _stage_callbacks(match_fn, accumulate_fn, n_local_total, n_map_total, allreduce_fn)
     T = _pose16(init_guess)
     r = L.CResult()
     L.check(L.lib().mola_icp_run_loop(C.byref(cb), _dp(T), C.byref(params.c), C.byref(r)))

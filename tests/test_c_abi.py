@@ -77,3 +77,27 @@ def test_comm_api_without_gpu(pkg):
     assert lib.mola_icp_comm_init(None, None, 1, 0) == pkg._lib.E_BADARG
     assert lib.mola_icp_comm_destroy(None) == pkg._lib.E_BADARG
     assert lib.mola_icp_comm_set_library(None) == 0
+
+
+def test_device_pool_assignment_is_round_robin(pkg):
+    """config[3]: 64 independent pairs over the 8 GPUs of a node -- pair i goes to device slot i mod 8 (SURVEY section 8e);
+    the dealing rule is a pure function of the C-ABI and needs no GPU."""
+    a = pkg.pool_assignment(64, 8)
+    assert a == [i % 8 for i in range(64)]
+    assert all(a.count(d) == 8 for d in range(8))                     # 8 pairs per GPU
+    assert pkg.pool_assignment(10, 4) == [0, 1, 2, 3, 0, 1, 2, 3, 0, 1]
+    assert pkg.pool_assignment(0, 3) == []
+    assert pkg.pool_assignment(3, 1) == [0, 0, 0]
+    with pytest.raises(pkg.IcpError):
+        pkg.pool_assignment(4, 0)
+
+
+def test_device_pool_needs_a_gpu_or_fails_loudly(pkg):
+    import ctypes
+    n = ctypes.c_int(0)
+    pkg._lib.lib().mola_icp_device_count(ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.IcpError) as e:
+        pkg.DevicePool()
+    assert e.value.status == pkg._lib.E_NODEVICE

@@ -191,3 +191,86 @@ def test_config5_10m_map_sequential_shards(pkg, O, synth):
         tot += icp.accumulate(p, np.eye(4))
     np.testing.assert_allclose(tot, full, rtol=1e-12, atol=1e-6)
     icp.close()
+
+
+def test_config4_64_pairs_of_100k_batch_and_device_pool(pkg, O, synth):
+    """BASELINE configs[3] at its workload: 64 independent 100k x 100k scan pairs (seeds 100..163), <= 100 iterations with
+    the stall test.  mola_icp_align_batch advances them a dozen at a time (one launch per stage over the pairs still
+    iterating); the device pool deals them round-robin to one handle per device (two handles on this one GPU here,
+    eight GPUs on a node).  Every result is bit-equal to the pair's stand-alone align; four sampled pairs also equal
+    the CPU oracle."""
+    import time
+    pairs = [synth.make_pair(100_000, 100_000, seed=100 + s)[:2] for s in range(64)]
+    p = p2p_params(pkg, max_iterations=100)
+    icp = pkg.ICP(device=0)
+    icp.align(pairs[0][0], pairs[0][1], np.eye(4), p)           # warm-up (first launches, pools)
+    t0 = time.perf_counter()
+    res = icp.align_batch(pairs, [np.eye(4)] * 64, p)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    singles = [icp.align(g, l, np.eye(4), p) for g, l in pairs]
+    dt1 = time.perf_counter() - t0
+    print(f"\n[config 4] align_batch: 64 pairs in {dt*1e3:.1f} ms = {64/dt:.0f} pairs/s "
+          f"({sum(r.nIterations for r in res)/dt:.0f} iterations/s); one after another: {64/dt1:.0f} pairs/s")
+    for r, s in zip(res, singles):
+        assert r.nIterations == s.nIterations and r.terminationReason == s.terminationReason
+        assert np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality
+        assert r.n_pairs == s.n_pairs and r.rmse == s.rmse and np.array_equal(r.optimal_tf_cov, s.optimal_tf_cov)
+        assert r.nn_kernel_used == pkg.NN_TILED
+    assert len({r.nIterations for r in res}) > 1                # the pairs stop at different iterations
+    for k in (0, 21, 42, 63):
+        ref = O.align(pairs[k][0], pairs[k][1], np.eye(4), O.params_from_product(p))
+        assert res[k].nIterations == ref["n_iterations"] and res[k].terminationReason == ref["termination"]
+        rot, trans = O.pose_error(res[k].optimal_tf, ref["T"])
+        assert rot <= 1e-4 and trans <= 1e-3 and rot < 1e-7 and trans < 1e-8, (k, rot, trans)
+        assert res[k].quality == pytest.approx(ref["quality"], abs=1e-12)
+    # the device pool: one handle per visible device ...
+    pool = pkg.DevicePool()
+    assert len(pool) >= 1
+    rp = pool.align_batch(pairs[:16], [np.eye(4)] * 16, p)
+    for r, s in zip(rp, singles[:16]):
+        assert r.nIterations == s.nIterations and np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality
+    pool.close()
+    # ... and the multi-handle dispatch exercised on this one GPU: two device slots, pairs 0,2,4,.. / 1,3,5,..
+    pool2 = pkg.DevicePool([0, 0])
+    assert len(pool2) == 2
+    rp = pool2.align_batch(pairs[:25], [np.eye(4)] * 25, p)
+    for r, s in zip(rp, singles[:25]):
+        assert r.nIterations == s.nIterations and np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality
+    assert pool2.align_batch([], [], p) == []
+    pool2.close()
+    icp.close()
+
+
+def test_loop_closure_montecarlo_10_guesses_at_100k(pkg, O, synth):
+    """row f2 (src/LidarOdometry.cpp:767-788): 10 perturbed guesses on ONE 100k x 100k pair as a batch dimension on the
+    device -- each attempt bit-equal to a stand-alone align from that guess, first-best selection, and the wall time
+    of the batch against the stand-alone aligns one after another."""
+    import time
+    g, l, Tgt = synth.make_pair(100_000, 100_000, seed=42)
+    p = p2p_params(pkg, max_iterations=100)
+    rng = np.random.default_rng(7)
+    guesses = []
+    for _ in range(10):
+        d = rng.normal(0, 1, 4) * np.array([0.3, 0.3, 0.3, np.deg2rad(2.0)])
+        guesses.append(synth.pose_from_xyzypr(d[0], d[1], d[2], d[3], 0, 0))
+    icp = pkg.ICP(device=0)
+    icp.align_multi_init(g, l, guesses[:2], p)                   # warm-up
+    t0 = time.perf_counter()
+    res, best = icp.align_multi_init(g, l, guesses, p)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    singles = [icp.align(g, l, T0, p) for T0 in guesses]
+    dt1 = time.perf_counter() - t0
+    print(f"\n[f2] 10 guesses on 100k x 100k: batched {dt*1e3:.1f} ms, stand-alone aligns one after another {dt1*1e3:.1f} ms "
+          f"(x{dt1/dt:.1f}); iterations {[r.nIterations for r in res]}")
+    for r, s in zip(res, singles):
+        assert r.nIterations == s.nIterations and r.terminationReason == s.terminationReason
+        assert np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality and r.n_pairs == s.n_pairs
+    q = [r.quality for r in res]
+    assert best == int(np.argmax(q))                              # first best (strictly greater wins, cpp:785)
+    assert dt < dt1                                               # (the measured ratio is printed above and in DESIGN.md)
+    ref = O.align(g, l, guesses[best], O.params_from_product(p))
+    rot, trans = O.pose_error(res[best].optimal_tf, ref["T"])
+    assert res[best].nIterations == ref["n_iterations"] and rot < 1e-7 and trans < 1e-8
+    icp.close()

@@ -86,6 +86,7 @@ def test_tiled_both_item_sizes(pkg, O, synth, small_scene, qpl, monkeypatch):
     """The tiled matcher picks 64- or 128-query items from the cloud size (64 only for ~0.4-0.8M queries); both
     flavours forced here on ragged sizes, exact ties, a warm-started second launch and a full align."""
     monkeypatch.setenv("MOLA_ICP_QPL", qpl)
+    monkeypatch.setenv("MOLA_ICP_COOP", "0")     # the persistent-wave kernel also at sizes where the cooperative one is the default
     pkg._lib.lib().mola_icp_debug_reload_env()
     icp = pkg.ICP(device=0)
     T = synth.pose_from_xyzypr(0.1, -0.05, 0.02, 0.01, 0.002, -0.003)
@@ -111,7 +112,51 @@ def test_tiled_both_item_sizes(pkg, O, synth, small_scene, qpl, monkeypatch):
     assert rot < 1e-7 and trans < 1e-9
     icp.close()
     monkeypatch.delenv("MOLA_ICP_QPL")
+    monkeypatch.delenv("MOLA_ICP_COOP")
     pkg._lib.lib().mola_icp_debug_reload_env()
+
+
+@pytest.mark.parametrize("coop", ["0", "1"])
+def test_tiled_cooperative_equals_persistent(pkg, O, synth, small_scene, coop, monkeypatch):
+    """k_nn_coop (one workgroup per 128-query item, the default below ~0.4M queries) and k_nn_tiled (persistent waves)
+    are the same matcher: both forced here on ragged sizes, exact ties (the exact flavour over the queued items), a
+    warm-started second launch at another pose, and a 300k-query cloud (more workgroups than resident slots)."""
+    monkeypatch.setenv("MOLA_ICP_COOP", coop)
+    pkg._lib.lib().mola_icp_debug_reload_env()
+    try:
+        icp = pkg.ICP(device=0)
+        T = synth.pose_from_xyzypr(0.1, -0.05, 0.02, 0.01, 0.002, -0.003)
+        for N, M in ((1, 1), (63, 5), (129, 4000), (9000, 9000), (30011, 20011), (300_007, 150_001)):
+            g, l, _ = synth.make_pair(N, M, seed=7 + N, scene=small_scene if N < 100_000 else None)
+            tree = O.KdTree(g)
+            icp.set_map(g)
+            icp.set_local(l)
+            for Tq in (T, np.eye(4), T):                   # launches 2 and 3 are seeded by the one before
+                idx, d2, n = icp.match(Tq, 0.7, N, pkg.NN_TILED)
+                oidx, od2, on = O.match(g, l, Tq, 0.7, tree)
+                assert n == on and np.array_equal(idx, oidx), (N, M, int((idx != oidx).sum()))
+                assert np.array_equal(d2[oidx >= 0], od2[oidx >= 0])
+        ax = np.arange(8, dtype=np.float32)
+        g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij")).reshape(3, -1)
+        g = np.ascontiguousarray(np.concatenate([g, g], axis=1))        # every map point twice: 16-way exact ties
+        l = np.ascontiguousarray((g[:, :512] + np.float32(0.5)).astype(np.float32))
+        idx, _ = _check_match(pkg, O, icp, g, l, np.eye(4), 2.0, pkg.NN_TILED)
+        assert (idx < 512).all() and (idx >= 0).all()
+        idx2, _, _ = icp.match(np.eye(4), 2.0, l.shape[1], pkg.NN_TILED)   # seeded, still the lowest index
+        assert np.array_equal(idx, idx2)
+        g, l, _ = synth.make_pair(20000, 20000, seed=5, scene=small_scene)
+        p = p2p_params(pkg, max_iterations=30)
+        p.nn_kernel = pkg.NN_TILED
+        r = icp.align(g, l, np.eye(4), p)
+        ref = O.align(g, l, np.eye(4), O.params_from_product(p))
+        assert r.nIterations == ref["n_iterations"] and r.n_pairs == ref["n_pairs"]
+        rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+        assert rot < 1e-7 and trans < 1e-9
+        assert r.nn_pairs_evaluated > 0
+        icp.close()
+    finally:
+        monkeypatch.delenv("MOLA_ICP_COOP")
+        pkg._lib.lib().mola_icp_debug_reload_env()
 
 
 @pytest.mark.parametrize("kern", [1, 2, 3])

@@ -111,3 +111,51 @@ def test_stage_failure_propagates(pkg):
     with pytest.raises(pkg.IcpError) as e:
         pkg.run_loop(lambda T, thr: 1, lambda *a: np.ones(24), np.eye(4), p2p_params(pkg), 10, 10, bad_reduce)
     assert e.value.status == pkg._lib.E_COMM
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(use_scale_outlier_detector=1, scale_outlier_threshold=1.1),
+    dict(use_scale_outlier_detector=1, scale_outlier_threshold=1.05, use_robust_kernel=1,
+         robust_kernel_param=np.deg2rad(0.05), robust_kernel_scale=100.0),
+    dict(fixed_iterations=1, max_iterations=9),
+    dict(skip_quality=1, max_iterations=25),
+])
+def test_lockstep_batch_loop_equals_single_loops(pkg, O, golden, synth, small_scene, kw):
+    """mola_icp_run_loop_batch (the loop behind align_multi_init / align_batch: every stage issued for all problems
+    still iterating) == one mola_icp_run_loop per problem, bit for bit -- different clouds, different initial poses,
+    problems that stop at different iterations, an empty one and one with nothing inside the gate."""
+    gA, lA = golden["A_map"], golden["A_local"]
+    g2, l2, _ = synth.make_pair(3000, 2500, seed=23, scene=small_scene)
+    far = np.ascontiguousarray(l2 + np.float32(400))
+    empty = np.zeros((3, 0), np.float32)
+    problems = [(gA, lA, np.eye(4)),
+                (gA, lA, synth.pose_from_xyzypr(0.2, -0.1, 0.02, 0.01, 0, 0)),
+                (g2, l2, np.eye(4)),
+                (g2, far, np.eye(4)),          # NoPairings at iteration 0
+                (g2, empty, np.eye(4)),        # empty local cloud
+                (g2, l2, synth.pose_from_xyzypr(-0.1, 0.15, 0.0, -0.02, 0.003, 0.0))]
+    p = p2p_params(pkg, **kw)
+    singles = []
+    for g, l, T0 in problems:
+        r, _ = _run(pkg, O, g, l, p, T0)
+        singles.append(r)
+    stages = [OracleStages(O, g, l) for g, l, _ in problems]
+    res = pkg.run_loop_batch([(st.match, st.accumulate, l.shape[1], g.shape[1]) for st, (g, l, _) in zip(stages, problems)],
+                             [T0 for _, _, T0 in problems], p)
+    if not kw.get("fixed_iterations"):
+        assert len({r.nIterations for r in singles}) >= 3      # they really stop at different iterations
+    for r, s, st in zip(res, singles, stages):
+        assert r.nIterations == s.nIterations and r.terminationReason == s.terminationReason
+        assert np.array_equal(r.optimal_tf, s.optimal_tf) and np.array_equal(r.optimal_tf_cov, s.optimal_tf_cov)
+        assert r.quality == s.quality and r.n_pairs == s.n_pairs and r.rmse == s.rmse
+    # a finished problem is not matched again: one matcher pass per iteration it ran (+ the quality pass)
+    for r, st, (g, l, _) in zip(res, stages, problems):
+        if l.shape[1] and r.terminationReason != pkg.TERM_NO_PAIRINGS:
+            assert st.n_match == r.nIterations + (0 if kw.get("skip_quality") else 1)
+    assert pkg.run_loop_batch([], [], p) == []
+    pp = pkg.Parameters.load_from(open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(
+        __import__("os").path.abspath(__file__))), "params", "icp-settings-regular.yaml")).read())
+    with pytest.raises(pkg.IcpError) as e:                     # the lockstep loop is point-to-point only
+        pkg.run_loop_batch([(stages[0].match, stages[0].accumulate, 1, 1)], [np.eye(4)], pp)
+    assert e.value.status == pkg._lib.E_UNSUPPORTED
