@@ -87,10 +87,13 @@ __device__ __forceinline__ void load_boxes_to_lds(const TiledMap& mp, lds_f32* l
 // `visit(nm, jb0, jb1)` is called once per staged pass: sm[0..2][0..nm) hold x,y,z of the staged points
 // (sm[3] their original indices if NEED_PERM); points [0,32) have sorted positions jb0.., [32,64) jb1...
 // Returns the number of staged points.
-// NPARTS > 1 (cooperative items, kernels_coop.hpp): NPARTS waves hold the SAME queries and run the same box scan;
-// wave `part` stages and evaluates only every NPARTS-th candidate tile (round-robin over the candidates in scan
-// order), the per-query results are merged by the caller.  Each wave's live bound then only sees its own tiles:
-// still exact (a bound can only be looser than in the one-wave sweep), slightly more staged points in total.
+// NPARTS > 1 (cooperative items, kernels_coop.hpp): NPARTS waves hold the SAME queries; wave `part` stages and
+// evaluates only every NPARTS-th candidate tile of a super-tile, the per-query results are merged by the caller.
+// The deal must not depend on anything a wave learns during its own sweep (each wave's live bound only sees its own
+// tiles, so the waves list different super-tiles and drop different tiles): a tile's owner is a function of the
+// super-tile id and the tile's rank among the super-tile's WAVE-BOX candidates -- the wave box comes from the initial
+// reaches, which are the same in all NPARTS waves.  A tile no wave's bound reaches is exactly cullable, every other
+// tile is evaluated by its owner: still exact, slightly more staged points in total (looser bounds).
 template <int QPL, bool NEED_PERM, int NPARTS, class Visit>
 __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane, int part,
                                                           float (*sm)[64], const float (&qx)[QPL], const float (&qy)[QPL],
@@ -177,7 +180,6 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
 
     // ---- the listed super-tiles: tile boxes of entry e+1 in flight while entry e's tiles are processed ----
     int n_list = 0;
-    int cand_no = 0;  // running number of the candidate tiles (wave-uniform): the cooperative split deals them round-robin
     auto process_list = [&]() {
         if (n_list == 0) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -202,6 +204,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
             // tile tested after its neighbours were swept meets the tighter best (a first launch, or one after a
             // large pose step, culls many of a super-tile's later tiles this way).
             const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+            int cand_no = Sc;  // cooperative deal: rank among this super-tile's wave-box candidates, rotated by its id
             auto next_tile = [&]() -> int {  // next candidate some query still reaches, or -1
                 while (cand) {
                     const int t = __builtin_ctzll(cand);
