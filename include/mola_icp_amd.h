@@ -392,6 +392,48 @@ typedef int (*mola_lo_align_fn)(void* user, const float* from_x, const float* fr
                                 const float* to_x, const float* to_y, const float* to_z, size_t N,
                                 const double init_T[16], const mola_icp_params* p, mola_icp_result* out);
 
+/* ---- nearby-keyframe / loop-closure policy around the ICP -------------------------
+ * Host logic on plain arrays; the pose graph itself (MRPT CNetworkOfPoses, Dijkstra) stays with the caller, who
+ * hands in, per keyframe of the local graph, its Euclidean and topological distance to the current keyframe. */
+typedef struct mola_lo_kf_candidate {
+    uint64_t kf_id;
+    double   eucl_dist;        /* |pose of the KF w.r.t. the current KF|, cpp:551 */
+    uint32_t topo_dist;        /* Dijkstra hop count, cpp:542-550 */
+    int32_t  already_checked;  /* pair in checked_KF_pairs, cpp:600-604 */
+} mola_lo_kf_candidate;
+/* LidarOdometry::checkForNearbyKFs, the selection half (src/LidarOdometry.cpp:572-599, 679-697, 700-729): keyframes in
+ * the band [min_dist_to_matching, max(max_dist_to_loop_closure, max_dist_to_matching)] in order of distance; one whose
+ * topological distance reaches min_topo_dist_to_consider_loopclosure is a loop-closure candidate, the others are
+ * nearby checks only up to max_dist_to_matching.  Nearby checks are thinned with the stride
+ * max(1, n / max_nearby_align_checks); of the loop-closure candidates only the closest is sent.
+ * *n_nearby = number selected (MOLA_ICP_E_BADARG if it exceeds nearby_capacity; the count is still set). */
+int mola_lo_select_checks(const mola_lo_params* p, const mola_lo_kf_candidate* kfs, size_t n_kfs,
+                          uint64_t* nearby_ids, size_t nearby_capacity, size_t* n_nearby,
+                          uint64_t* loop_closure_id, int* has_loop_closure);
+/* The Monte-Carlo guesses of a loop-closure check (cpp:767-783): sample i = init + N(0, 0.1*max_dist_to_loop_closure)
+ * on x, y, z and N(0, 2 deg) on yaw, drawn in that order from a seeded in-repo generator (the reference's is
+ * time-seeded).  guesses_xyzypr (n x 6) and guesses_T (n x 16, row-major) may each be NULL. */
+int mola_lo_montecarlo_guesses(const double init_xyzypr[6], double max_dist_to_loop_closure, uint32_t n_samples,
+                               uint64_t seed, double* guesses_xyzypr, double* guesses_T);
+typedef struct mola_lo_check_result {
+    mola_icp_result icp;          /* the kept attempt (goodness = icp.quality); quality 0 if none was better than 0 */
+    int32_t  best_guess;          /* index of the kept Monte-Carlo sample, 0 for a nearby check, -1: none */
+    uint32_t n_attempts;
+    double   init_guess_used[6];  /* d->init_guess_to_wrt_from as the accept test sees it: for a loop closure the LAST
+                                     sample's guess (the reference overwrites it in the loop, cpp:776-780) */
+    double   correction_percent;  /* cpp:795-798 */
+    int32_t  edge_accepted;       /* a FactorRelativePose3(from, to, rel_pose) would be added, cpp:815-817 */
+} mola_lo_check_result;
+/* LidarOdometry::doCheckForNonAdjacentKFs (cpp:743-848) without the back-end calls: a nearby check is one ICP with the
+ * NearbyAlign case; a loop closure runs loop_closure_montecarlo_samples perturbed guesses with the LoopClosure case
+ * as ONE batched device problem (mola_icp_align_multi_init) and keeps the first best goodness.  `icp` may be NULL if
+ * align_cb is given (then the attempts run one after another through it). */
+int mola_lo_check_nonadjacent(mola_icp_handle* icp, mola_lo_align_fn align_cb, void* user, const mola_lo_params* lp,
+                              int is_loop_closure,
+                              const float* from_x, const float* from_y, const float* from_z, size_t M,
+                              const float* to_x, const float* to_y, const float* to_z, size_t N,
+                              const double init_xyzypr[6], uint64_t seed, mola_lo_check_result* out);
+
 int mola_lo_params_default(mola_lo_params* p);
 /* reads the keys LidarOdometry::initialize() reads (cpp:105-128) from a kitti-default.yaml-style file */
 int mola_lo_params_from_yaml_file(const char* path, const char* mola_dir, mola_lo_params* p);

@@ -107,6 +107,15 @@ class CLoStep(C.Structure):
     ]
 
 
+class CLoKfCandidate(C.Structure):
+    _fields_ = [("kf_id", C.c_uint64), ("eucl_dist", C.c_double), ("topo_dist", C.c_uint32), ("already_checked", C.c_int32)]
+
+
+class CLoCheckResult(C.Structure):
+    _fields_ = [("icp", CResult), ("best_guess", C.c_int32), ("n_attempts", C.c_uint32), ("init_guess_used", C.c_double * 6),
+                ("correction_percent", C.c_double), ("edge_accepted", C.c_int32)]
+
+
 LO_ALIGN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
                           C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
                           C.POINTER(C.c_double), C.POINTER(CParams), C.POINTER(CResult))
@@ -198,6 +207,11 @@ SIGNATURES = {
     "mola_lo_destroy": (C.c_int, [_H]),
     "mola_lo_reset": (C.c_int, [_H]),
     "mola_lo_process_scan": (C.c_int, [_H, C.c_double, _FP, _FP, _FP, C.c_size_t, C.POINTER(CLoStep)]),
+    "mola_lo_select_checks": (C.c_int, [C.POINTER(CLoParams), C.POINTER(CLoKfCandidate), C.c_size_t, C.POINTER(C.c_uint64),
+                                        C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "mola_lo_montecarlo_guesses": (C.c_int, [_DP, C.c_double, C.c_uint32, C.c_uint64, _DP, _DP]),
+    "mola_lo_check_nonadjacent": (C.c_int, [_H, LO_ALIGN_FN, C.c_void_p, C.POINTER(CLoParams), C.c_int, _FP, _FP, _FP, C.c_size_t,
+                                            _FP, _FP, _FP, C.c_size_t, _DP, C.c_uint64, C.POINTER(CLoCheckResult)]),
 }
 
 _lib = None

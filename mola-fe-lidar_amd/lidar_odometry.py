@@ -75,6 +75,75 @@ class LidarOdometryParams:
             object.__setattr__(self, name, value)
 
 
+def _align_callback(align_fn):
+    """wraps `align_fn(from(3,M), to(3,N), T0 4x4, Parameters) -> (T, quality, nIterations, terminationReason)` as a
+    mola_lo_align_fn"""
+    def _cb(user, fx, fy, fz, M, tx, ty, tz, N, T0, pp, out):
+        try:
+            f = np.stack([np.ctypeslib.as_array(a, shape=(M,)) for a in (fx, fy, fz)]) if M else np.zeros((3, 0), np.float32)
+            t = np.stack([np.ctypeslib.as_array(a, shape=(N,)) for a in (tx, ty, tz)]) if N else np.zeros((3, 0), np.float32)
+            p = Parameters()
+            C.memmove(C.byref(p.c), pp, C.sizeof(L.CParams))
+            T, q, nit, term = align_fn(f, t, np.ctypeslib.as_array(T0, shape=(16,)).reshape(4, 4).copy(), p)
+            out[0].T[:] = list(np.asarray(T, dtype=np.float64).reshape(16))
+            out[0].quality, out[0].n_iterations, out[0].termination = float(q), int(nit), int(term)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return L.E_INTERNAL
+    return L.LO_ALIGN_FN(_cb)
+
+
+def select_checks(params: LidarOdometryParams, kfs):
+    """`checkForNearbyKFs`' selection (src/LidarOdometry.cpp:572-599, 700-729).  kfs: iterable of
+    (kf_id, eucl_dist, topo_dist, already_checked).  Returns (nearby ids in sending order, loop-closure id or None)."""
+    kfs = list(kfs)
+    arr = (L.CLoKfCandidate * max(1, len(kfs)))()
+    for i, (kid, d, topo, chk) in enumerate(kfs):
+        arr[i].kf_id, arr[i].eucl_dist, arr[i].topo_dist, arr[i].already_checked = int(kid), float(d), int(topo), int(bool(chk))
+    ids = (C.c_uint64 * max(1, len(kfs)))()
+    n, lc, has = C.c_size_t(0), C.c_uint64(0), C.c_int(0)
+    L.check(L.lib().mola_lo_select_checks(C.byref(params.c), arr, len(kfs), ids, len(kfs), C.byref(n), C.byref(lc), C.byref(has)))
+    return [int(ids[i]) for i in range(n.value)], (int(lc.value) if has.value else None)
+
+
+def montecarlo_guesses(init_xyzypr, max_dist_to_loop_closure: float, n_samples: int, seed: int):
+    """the loop-closure Monte-Carlo's perturbed guesses (cpp:767-783): (n,6) xyzypr and (n,4,4) poses"""
+    g0 = np.ascontiguousarray(init_xyzypr, dtype=np.float64).reshape(6)
+    g6 = np.zeros((max(1, n_samples), 6))
+    gT = np.zeros((max(1, n_samples), 16))
+    L.check(L.lib().mola_lo_montecarlo_guesses(g0.ctypes.data_as(L._DP), float(max_dist_to_loop_closure), int(n_samples),
+                                               int(seed), g6.ctypes.data_as(L._DP), gT.ctypes.data_as(L._DP)))
+    return g6[:n_samples], gT[:n_samples].reshape(-1, 4, 4)
+
+
+@dataclass
+class CheckResult:
+    icp: Results
+    best_guess: int
+    n_attempts: int
+    init_guess_used: np.ndarray
+    correction_percent: float
+    edge_accepted: bool
+
+
+def check_nonadjacent(params: LidarOdometryParams, from_pc, to_pc, init_xyzypr, is_loop_closure: bool, seed: int = 0,
+                      icp: ICP | None = None, align_fn=None) -> CheckResult:
+    """`doCheckForNonAdjacentKFs` (cpp:743-848) without the back-end calls"""
+    assert (icp is None) != (align_fn is None)
+    cb = _align_callback(align_fn) if align_fn is not None else L.LO_ALIGN_FN()
+    fx, fy, fz, M = _soa(from_pc)
+    tx, ty, tz, N = _soa(to_pc)
+    g0 = np.ascontiguousarray(init_xyzypr, dtype=np.float64).reshape(6)
+    out = L.CLoCheckResult()
+    L.check(L.lib().mola_lo_check_nonadjacent(icp._h if icp is not None else None, cb, None, C.byref(params.c),
+                                              1 if is_loop_closure else 0, _fp(fx), _fp(fy), _fp(fz), M, _fp(tx), _fp(ty),
+                                              _fp(tz), N, g0.ctypes.data_as(L._DP), int(seed), C.byref(out)))
+    return CheckResult(Results.from_c(out.icp), out.best_guess, out.n_attempts, np.array(out.init_guess_used),
+                       out.correction_percent, bool(out.edge_accepted))
+
+
 class LidarOdometry:
     """`icp`: an `ICP` (GPU) -- or `align_fn(from(3,M), to(3,N), T0 4x4, Parameters) -> (T 4x4, quality, nIterations,
     terminationReason)` to drive the same host logic with another registration (CPU tests)."""
@@ -84,21 +153,7 @@ class LidarOdometry:
         self._icp = icp
         self._cb = None
         if align_fn is not None:
-            def _cb(user, fx, fy, fz, M, tx, ty, tz, N, T0, pp, out):
-                try:
-                    f = np.stack([np.ctypeslib.as_array(a, shape=(M,)) for a in (fx, fy, fz)]) if M else np.zeros((3, 0), np.float32)
-                    t = np.stack([np.ctypeslib.as_array(a, shape=(N,)) for a in (tx, ty, tz)]) if N else np.zeros((3, 0), np.float32)
-                    p = Parameters()
-                    C.memmove(C.byref(p.c), pp, C.sizeof(L.CParams))
-                    T, q, nit, term = align_fn(f, t, np.ctypeslib.as_array(T0, shape=(16,)).reshape(4, 4).copy(), p)
-                    out[0].T[:] = list(np.asarray(T, dtype=np.float64).reshape(16))
-                    out[0].quality, out[0].n_iterations, out[0].termination = float(q), int(nit), int(term)
-                    return 0
-                except Exception:
-                    import traceback
-                    traceback.print_exc()
-                    return L.E_INTERNAL
-            self._cb = L.LO_ALIGN_FN(_cb)
+            self._cb = _align_callback(align_fn)
         self._h = L._H()
         L.check(L.lib().mola_lo_create(icp._h if icp is not None else None, self._cb or L.LO_ALIGN_FN(), None,
                                        C.byref(params.c), C.byref(self._h)))
