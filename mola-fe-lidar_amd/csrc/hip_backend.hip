@@ -106,7 +106,7 @@ HipWorkspace::~HipWorkspace()
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
     map_sc_.reset();
     loc_sc_.reset();
-    ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
+    ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); ts_gs_.release(); rows_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
     planes_.release(); knn_pos_.release(); plane_acc_.release(); plane_cache_.release();
     if (plane_acc_host_) (void)hipHostFree(plane_acc_host_);
     sort_scratch_.release();
@@ -554,6 +554,9 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     if ((rc = ts_pos_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_idx_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_d2_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
+    if ((rc = ts_gs_.reserve(sizeof(float) * 3 * loc_sc_->padded))) return rc;
+    float* gs = ts_gs_.as<float>();
+    const size_t gs_n = loc_sc_->padded;
     const float* sl = loc_sc_->sorted.as<float>();
     if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
@@ -566,19 +569,20 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     do {                                                                                                              \
         hipLaunchKernelGGL((k_nn_tiled<false, QPL>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,  \
                            sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),        \
-                           ts_idx_.as<int>(), ts_d2_.as<float>(), order, item_cost_.as<unsigned int>(), tq, counter + 2, \
+                           ts_idx_.as<int>(), ts_d2_.as<float>(), gs, gs + gs_n, gs + 2 * gs_n, order, item_cost_.as<unsigned int>(), tq, counter + 2, \
                            redo_list_.as<int>(), staged, dbg, lds_boxes, wave_times_);                                \
         HIPCHK(hipGetLastError());                                                                                    \
         hipLaunchKernelGGL((k_nn_tiled<true, QPL>), dim3(grid < 64 ? grid : 64), dim3(256), dyn_lds, stream_, sl,     \
                            sl + loc_sc_->padded, sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2,                       \
                            /*seed = fast pass's result*/ 1, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(), \
-                           (const int*)nullptr, (unsigned int*)nullptr, tq + kQueues * kQueueStride, counter + 2,     \
+                           gs, gs + gs_n, gs + 2 * gs_n, (const int*)nullptr, (unsigned int*)nullptr, tq + kQueues * kQueueStride, counter + 2,     \
                            redo_list_.as<int>(), staged, dbg, lds_boxes, (unsigned long long*)nullptr);               \
     } while (0)
     if (qpl == 2) MOLA_LAUNCH_TILED(2);
     else MOLA_LAUNCH_TILED(1);
 #undef MOLA_LAUNCH_TILED
     cost_valid_ = true;
+    rows_valid_ = false;
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
 }
@@ -590,10 +594,10 @@ int HipWorkspace::fill_nn_problem(const PoseF& P, float thr2, bool use_seed, NnP
     if ((rc = ts_pos_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_idx_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_d2_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
+    if ((rc = ts_gs_.reserve(sizeof(float) * 3 * loc_sc_->padded))) return rc;
     const size_t n_items = (N_ + kQPW - 1) / kQPW;
-    if ((rc = redo_list_.reserve(sizeof(int) * n_items))) return rc;
+    if ((rc = rows_.reserve(sizeof(double) * kNAcc * n_items))) return rc;
     const float* sl = loc_sc_->sorted.as<float>();
-    unsigned int* counter = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc);
     pb.slx = sl; pb.sly = sl + loc_sc_->padded; pb.slz = sl + 2 * loc_sc_->padded;
     pb.N = (int)N_;
     pb.mp = tiled_map();
@@ -601,13 +605,13 @@ int HipWorkspace::fill_nn_problem(const PoseF& P, float thr2, bool use_seed, NnP
     pb.thr2 = thr2;
     pb.use_seed = use_seed ? 1 : 0;
     pb.pos_s = ts_pos_.as<int>(); pb.idx_s = ts_idx_.as<int>(); pb.d2_s = ts_d2_.as<float>();
-    pb.redo_count = counter + 2;
-    pb.redo_list = redo_list_.as<int>();
+    pb.gsx = ts_gs_.as<float>(); pb.gsy = pb.gsx + loc_sc_->padded; pb.gsz = pb.gsx + 2 * loc_sc_->padded;
+    pb.rows = rows_.as<double>();
     pb.staged = stats_.as<unsigned long long>();
     return MOLA_ICP_OK;
 }
 
-// Small clouds: one workgroup per 128-query item (k_nn_coop), fast flavour then the exact flavour over the items it queued.
+// Small clouds: one workgroup per 128-query item (k_nn_coop): pairing + the item's row of unit-weight sums, one launch.
 int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
 {
     NnBatch<1> b;
@@ -618,12 +622,10 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
-    hipLaunchKernelGGL((k_nn_coop<false, 1>), dim3(n_items), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
+    hipLaunchKernelGGL((k_nn_coop<1>), dim3(n_items), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
     HIPCHK(hipGetLastError());
     wave_times_coop_ = true;
-    hipLaunchKernelGGL((k_nn_coop<true, 1>), dim3(n_items < 16 ? n_items : 16), dim3(256), dyn_lds, stream_, b, lds_boxes,
-                       (unsigned long long*)nullptr);
-    HIPCHK(hipGetLastError());
+    rows_valid_ = true;
     return MOLA_ICP_OK;
 }
 
@@ -852,14 +854,19 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipMemcpy(w.data(), wave_times_, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t1 = 0ull;
-        std::vector<unsigned long long> ends, pro, swp, epi, stg, setup, mwait, starts;
+        std::vector<unsigned long long> ends, pro, swp, epi, stg, setup, mwait, starts, entered, tiles, supers, boxwait, tiletest, stagec, visitc;
         for (size_t i = 0; i < 8192; ++i)
             if (w[8 * i + 1]) {
                 t0 = std::min(t0, w[8 * i]); t1 = std::max(t1, w[8 * i + 1]); ends.push_back(w[8 * i + 1]);
                 starts.push_back(w[8 * i]);
-                if (wave_times_coop_) {  // k_nn_coop's layout
-                    setup.push_back(w[8 * i + 2]); pro.push_back(w[8 * i + 3]); swp.push_back(w[8 * i + 4]);
-                    mwait.push_back(w[8 * i + 5]); epi.push_back(w[8 * i + 6]); stg.push_back(w[8 * i + 7]);
+                if (wave_times_coop_) {  // k_nn_coop's layout: two 32-bit cycle counts per slot
+                    auto lo = [&](int k) { return w[8 * i + k] & 0xffffffffull; };
+                    auto hi = [&](int k) { return w[8 * i + k] >> 32; };
+                    setup.push_back(lo(2)); pro.push_back(hi(2)); swp.push_back(lo(3)); mwait.push_back(hi(3)); epi.push_back(lo(4));
+                    boxwait.push_back(hi(4)); tiletest.push_back(lo(5)); stagec.push_back(hi(5)); visitc.push_back(lo(6));
+                    stg.push_back(w[8 * i + 7] & 0xffffull);
+                    entered.push_back((w[8 * i + 7] >> 16) & 0xffffull); tiles.push_back((w[8 * i + 7] >> 32) & 0xffffull);
+                    supers.push_back(w[8 * i + 7] >> 48);
                 } else {
                     pro.push_back(w[8 * i + 3]); swp.push_back(w[8 * i + 4]); epi.push_back(w[8 * i + 5]); stg.push_back(w[8 * i + 6]);
                 }
@@ -882,6 +889,14 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
                                      "(median / p90 / max): setup %llu / %llu / %llu, merge wait %llu / %llu / %llu, sweep max %llu, staged max %llu\n",
                              (double)(starts.back() - t0), med(setup, 0.5), med(setup, 0.9), med(setup, 1.0), med(mwait, 0.5), med(mwait, 0.9),
                              med(mwait, 1.0), med(swp, 1.0), med(stg, 1.0));
+                std::fprintf(stderr, "[mola_icp debug]   per wave (median / p90 / max): super tests %llu / %llu / %llu, supers entered %llu / %llu / %llu, "
+                                     "own tile tests %llu / %llu / %llu\n",
+                             med(supers, 0.5), med(supers, 0.9), med(supers, 1.0), med(entered, 0.5), med(entered, 0.9), med(entered, 1.0),
+                             med(tiles, 0.5), med(tiles, 0.9), med(tiles, 1.0));
+                std::fprintf(stderr, "[mola_icp debug]   inside the sweep (median / p90 / max cycles): tile-box wait %llu / %llu / %llu, tile tests + passes %llu / %llu / %llu, "
+                                     "of which staging (wait for points) %llu / %llu / %llu, distance passes %llu / %llu / %llu\n",
+                             med(boxwait, 0.5), med(boxwait, 0.9), med(boxwait, 1.0), med(tiletest, 0.5), med(tiletest, 0.9), med(tiletest, 1.0),
+                             med(stagec, 0.5), med(stagec, 0.9), med(stagec, 1.0), med(visitc, 0.5), med(visitc, 0.9), med(visitc, 1.0));
             }
             std::fprintf(stderr, "[mola_icp debug]   first item of a wave, shader cycles (median / p90): prologue %llu / %llu, sweep %llu / %llu, "
                                  "epilogue %llu / %llu; staged points %llu / %llu\n",
@@ -1011,6 +1026,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
     HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
     ev_used_ += 2;
     pairing_sorted_ = false;
+    rows_valid_ = false;
     counters_clean_ = false;
     dense_pairs_ += (uint64_t)N_ * (uint64_t)M_;
     return MOLA_ICP_OK;
@@ -1109,6 +1125,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         a.lx = sl; a.ly = sl + loc_sc_->padded; a.lz = sl + 2 * loc_sc_->padded;
         a.gx = sm; a.gy = sm + map_sc_->padded; a.gz = sm + 2 * map_sc_->padded;
         a.idx = ts_pos_.as<int>(); a.d2 = ts_d2_.as<float>();
+        a.nx = ts_gs_.as<float>(); a.ny = a.nx + loc_sc_->padded; a.nz = a.nx + 2 * loc_sc_->padded;
     } else {
         a.lx = lx_; a.ly = ly_; a.lz = lz_; a.gx = gx_; a.gy = gy_; a.gz = gz_;
         a.idx = idx_.as<int>(); a.d2 = d2_.as<float>();
@@ -1120,15 +1137,23 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     for (int k = 0; k < 3; ++k) { a.cl[k] = cl ? cl[k] : 0.0; a.cg[k] = cg ? cg[k] : 0.0; }
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) a.R[3 * r + c] = Tcur(r, c);
-    hipLaunchKernelGGL(k_accumulate, dim3(nblocks), dim3(kAccThreads), 0, stream_, a, partials_.as<double>());
-    HIPCHK(hipGetLastError());
+    // the first pass of an iteration after a cooperative match: the matcher already summed the unit-weight terms per item
+    const bool fused = pairing_sorted_ && rows_valid_ && stage == 0 && reset_outliers;
+    const double* rows = partials_.as<double>();
+    if (fused) {
+        rows = rows_.as<double>();
+        nblocks = (int)((N_ + kQPW - 1) / kQPW);
+    } else {
+        hipLaunchKernelGGL(k_accumulate, dim3(nblocks), dim3(kAccThreads), 0, stream_, a, partials_.as<double>());
+        HIPCHK(hipGetLastError());
+    }
     // Single GPU: the reduction writes the 24 sums straight into the pinned host block and then a sequence number;
     // the host spins on that number instead of a copy + stream synchronisation (both cost a launch gap and the
     // driver's wake-up latency on a ~0.2 ms iteration).  Sharded over RCCL: the collective runs in between on the
     // device block, then the block is copied.
     const bool direct = !comm_ && !g_knobs.no_direct_readback;
     const unsigned long long seq = ++readback_seq_;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kNAcc * kRedSlices), 0, stream_, partials_.as<double>(), nblocks,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kNAcc * kRedSlices), 0, stream_, rows, nblocks,
                        acc_dev_.as<double>(), direct ? acc_host_ : (double*)nullptr, seq);
     HIPCHK(hipGetLastError());
     counters_clean_ = true;
@@ -1195,8 +1220,8 @@ HipBatch::~HipBatch()
     (void)hipSetDevice(ws_.device_);
     (void)hipStreamSynchronize(ws_.stream_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
-    for (Buffers& b : buf_) { b.pos.release(); b.idx.release(); b.d2.release(); b.outlier.release(); b.redo.release(); b.partials.release(); }
-    acc_dev_.release(); counters_.release(); stats_.release();
+    for (Buffers& b : buf_) { b.pos.release(); b.idx.release(); b.d2.release(); b.gs.release(); b.rows.release(); b.outlier.release(); b.partials.release(); }
+    acc_dev_.release(); stats_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
     if (stats_host_) (void)hipHostFree(stats_host_);
 }
@@ -1218,14 +1243,13 @@ int HipBatch::init()
         if ((rc = b.pos.reserve(sizeof(int) * np))) return rc;
         if ((rc = b.idx.reserve(sizeof(int) * np))) return rc;
         if ((rc = b.d2.reserve(sizeof(float) * np))) return rc;
+        if ((rc = b.gs.reserve(sizeof(float) * 3 * np))) return rc;
+        if ((rc = b.rows.reserve(sizeof(double) * kNAcc * (np / kQPW)))) return rc;
         if ((rc = b.outlier.reserve(pr.loc->n))) return rc;
-        if ((rc = b.redo.reserve(sizeof(int) * (np / kQPW)))) return rc;
         if ((rc = b.partials.reserve(sizeof(double) * kNAcc * kAccMaxBlocks))) return rc;
     }
     if ((rc = acc_dev_.reserve(sizeof(double) * 32 * (K ? K : 1)))) return rc;
-    if ((rc = counters_.reserve(sizeof(unsigned int) * (K ? K : 1)))) return rc;
     if ((rc = stats_.reserve(sizeof(unsigned long long) * kStatSlots * kStatStride))) return rc;
-    HIPCHK(hipMemsetAsync(counters_.p, 0, sizeof(unsigned int) * (K ? K : 1), ws_.stream_));
     HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, ws_.stream_));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * 32 * (K ? K : 1), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(acc_host_, 0, sizeof(double) * 32 * (K ? K : 1));
@@ -1271,8 +1295,11 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
             pb.thr2 = thr2;
             pb.use_seed = (bf.seed_valid && !g_knobs.no_warm_start) ? 1 : 0;
             pb.pos_s = bf.pos.as<int>(); pb.idx_s = bf.idx.as<int>(); pb.d2_s = bf.d2.as<float>();
-            pb.redo_count = counters_.as<unsigned int>() + k0;
-            pb.redo_list = bf.redo.as<int>();
+            {
+                const size_t np = (pr.loc->n + kQPW - 1) / kQPW * kQPW;
+                pb.gsx = bf.gs.as<float>(); pb.gsy = pb.gsx + np; pb.gsz = pb.gsx + 2 * np;
+            }
+            pb.rows = bf.rows.as<double>();
             pb.staged = stats_.as<unsigned long long>();
             bf.seed_valid = true;
             const int items = (int)((pr.loc->n + kQPW - 1) / kQPW);
@@ -1283,11 +1310,8 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         if (n == 0) break;
         const int lds_boxes = max_box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
         const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
-        hipLaunchKernelGGL((k_nn_coop<false, kCoopMaxBatch>), dim3(max_items, n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
+        hipLaunchKernelGGL((k_nn_coop<kCoopMaxBatch>), dim3(max_items, n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
                            (unsigned long long*)nullptr);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_nn_coop<true, kCoopMaxBatch>), dim3(max_items < 16 ? max_items : 16, n), dim3(256), dyn_lds,
-                           ws_.stream_, b, lds_boxes, (unsigned long long*)nullptr);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ev_[ev_used_ + 1], ws_.stream_));
@@ -1305,6 +1329,7 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
     HIPCHK(hipSetDevice(ws_.device_));
     const int K = (int)probs_.size();
     const unsigned long long seq = ++seq_;
+    const bool fused = stage == 0 && reset_outliers;  // (every batched match is a cooperative one: its rows are in place)
     int n_active = 0;
     for (int k0 = 0; k0 < K;) {
         AccBatch ab;
@@ -1332,6 +1357,10 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
             a.lx = sl; a.ly = sl + pr.loc->padded; a.lz = sl + 2 * pr.loc->padded;
             a.gx = sm; a.gy = sm + pr.map->padded; a.gz = sm + 2 * pr.map->padded;
             a.idx = bf.pos.as<int>(); a.d2 = bf.d2.as<float>();
+            {
+                const size_t np = (N + kQPW - 1) / kQPW * kQPW;
+                a.nx = bf.gs.as<float>(); a.ny = a.nx + np; a.nz = a.nx + 2 * np;
+            }
             a.outlier = bf.outlier.as<unsigned char>();
             a.N = (int)N; a.stage = stage;
             a.use_scale = p.use_scale_outlier_detector; a.use_robust = p.use_robust_kernel;
@@ -1341,18 +1370,21 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
                 for (int c = 0; c < 3; ++c) a.R[3 * r + c] = Tcur[k0](r, c);
             ab.nblocks[n] = nblocks;
             ab.partials[n] = bf.partials.as<double>();
-            rb.partials[n] = bf.partials.as<double>();
-            rb.nblocks[n] = nblocks;
+            // the first pass of an iteration: k_nn_coop already summed the unit-weight terms per item (rows)
+            rb.partials[n] = fused ? bf.rows.as<double>() : bf.partials.as<double>();
+            rb.nblocks[n] = fused ? (int)((N + kQPW - 1) / kQPW) : nblocks;
             rb.slot[n] = k0;
             if (nblocks > max_blocks) max_blocks = nblocks;
             ++n;
         }
         if (n == 0) break;
         n_active += n;
-        hipLaunchKernelGGL(k_accumulate_batch, dim3(max_blocks, n), dim3(kAccThreads), 0, ws_.stream_, ab);
-        HIPCHK(hipGetLastError());
+        if (!fused) {
+            hipLaunchKernelGGL(k_accumulate_batch, dim3(max_blocks, n), dim3(kAccThreads), 0, ws_.stream_, ab);
+            HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_reduce_partials_batch, dim3(n), dim3(kNAcc * kRedSlices), 0, ws_.stream_, rb, acc_dev_.as<double>(),
-                           acc_host_, counters_.as<unsigned int>(), seq);
+                           acc_host_, seq);
         HIPCHK(hipGetLastError());
     }
     if (n_active == 0) return MOLA_ICP_OK;

@@ -136,6 +136,9 @@ class HipWorkspace final : public Stages {
     std::shared_ptr<SortedCloud> map_sc_, loc_sc_;
     DevBuf sort_scratch_;
     DevBuf ts_pos_, ts_idx_, ts_d2_;  // the tiled matcher's pairing, in SORTED query order
+    DevBuf ts_gs_;                    // ... and each neighbour's coordinates (3 x padded floats): next launch's seeds, accumulate's g
+    DevBuf rows_;                     // k_nn_coop's fused stage-0 sums, one row of kNAcc doubles per 128-query item
+    bool rows_valid_ = false;         // rows_ belongs to the pairing in place
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
     DevBuf planes_, knn_pos_, plane_acc_, plane_cache_;  // point-to-plane pairing (sorted query order) + its accumulators
     double* plane_acc_host_ = nullptr;
@@ -199,14 +202,14 @@ class HipBatch final : public BatchStages {
 
    private:
     struct Buffers {
-        DevBuf pos, idx, d2, outlier, redo, partials;
+        DevBuf pos, idx, d2, gs, rows, outlier, partials;
         bool seed_valid = false, outliers_dirty = false;
         size_t outlier_cleared_for = 0;
     };
     HipWorkspace& ws_;
     std::vector<BatchProblem> probs_;
     std::vector<Buffers> buf_;
-    DevBuf acc_dev_, counters_, stats_;
+    DevBuf acc_dev_, stats_;
     double* acc_host_ = nullptr;                 // pinned: 32 doubles per problem (24 sums, flag in slot 30)
     unsigned long long* stats_host_ = nullptr;   // pinned
     unsigned long long seq_ = 0;

@@ -9,6 +9,7 @@ namespace mola_icp_amd {
 // ---- accumulation (row a8) ---------------------------------------------------------
 struct AccArgs {
     const float *lx, *ly, *lz, *gx, *gy, *gz;
+    const float *nx, *ny, *nz;  // non-null: the neighbour's coordinates per query (tiled matchers store them) -- no gather
     const int* idx;
     const float* d2;
     unsigned char* outlier;
@@ -86,9 +87,15 @@ __device__ __forceinline__ void accumulate_rows(const AccArgs& a, int bx, int nb
         const unsigned char oA = a.outlier[i], oB = a.outlier[ic2];
         const float lA0 = a.lx[i], lA1 = a.ly[i], lA2 = a.lz[i], dA = a.d2[i];
         const float lB0 = a.lx[ic2], lB1 = a.ly[ic2], lB2 = a.lz[ic2], dB = a.d2[ic2];
-        const int jcA = jA >= 0 ? jA : 0, jcB = jB >= 0 ? jB : 0;
-        const float gA0 = a.gx[jcA], gA1 = a.gy[jcA], gA2 = a.gz[jcA];
-        const float gB0 = a.gx[jcB], gB1 = a.gy[jcB], gB2 = a.gz[jcB];
+        float gA0, gA1, gA2, gB0, gB1, gB2;
+        if (a.nx) {  // (uniform) same values as the gather: the matcher copied them from the map
+            gA0 = a.nx[i]; gA1 = a.ny[i]; gA2 = a.nz[i];
+            gB0 = a.nx[ic2]; gB1 = a.ny[ic2]; gB2 = a.nz[ic2];
+        } else {
+            const int jcA = jA >= 0 ? jA : 0, jcB = jB >= 0 ? jB : 0;
+            gA0 = a.gx[jcA]; gA1 = a.gy[jcA]; gA2 = a.gz[jcA];
+            gB0 = a.gx[jcB]; gB1 = a.gy[jcB]; gB2 = a.gz[jcB];
+        }
         element(i, jA, oA, lA0, lA1, lA2, gA0, gA1, gA2, dA);
         element(i2, jB, oB, lB0, lB1, lB2, gB0, gB1, gB2, dB);
     }
@@ -124,8 +131,18 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
 {
     __shared__ double sm[kRedSlices][kNAcc];
     const int k = threadIdx.x % kNAcc, sl = threadIdx.x / kNAcc;
+    // rows sl, sl + 32, sl + 64, ... in order; eight loads are issued before the first add (one block, latency-bound:
+    // a load-add-load chain over 25 rows of a 100k-point cloud took 11 us)
     double v = 0.0;
-    for (int b = sl; b < nblocks; b += kRedSlices) v += partials[(size_t)b * kNAcc + k];
+    int b = sl;
+    for (; b + 7 * kRedSlices < nblocks; b += 8 * kRedSlices) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = partials[(size_t)(b + u * kRedSlices) * kNAcc + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; b < nblocks; b += kRedSlices) v += partials[(size_t)b * kNAcc + k];
     sm[sl][k] = v;
     __syncthreads();
     if (threadIdx.x < kNAcc) {
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const do
 }
 
 // K problems: block y reduces problem y's rows into acc + 32 y and publishes them at host_out + 32 y (flag in slot 30
-// of that stride); the problems' redo counters (the cooperative matcher's) are left zero for its next launch
+// of that stride)
 struct ReduceBatch {
     const double* partials[kAccMaxBatch];
     int nblocks[kAccMaxBatch];
@@ -165,12 +182,10 @@ struct ReduceBatch {
 };
 __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials_batch(const ReduceBatch b, double* __restrict__ acc,
                                                                               double* __restrict__ host_out,
-                                                                              unsigned int* __restrict__ counters,
                                                                               unsigned long long seq)
 {
     const int y = (int)blockIdx.x, s = b.slot[y];
     reduce_rows(b.partials[y], b.nblocks[y], acc + 32 * (size_t)s, host_out + 32 * (size_t)s, seq);
-    if (threadIdx.x == kNAcc) counters[s] = 0u;
 }
 
 // hands a device block of n doubles to the host through its pinned block: data, then the sequence number the host

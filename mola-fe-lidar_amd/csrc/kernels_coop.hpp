@@ -1,15 +1,27 @@
 // kernels_coop.hpp -- k_nn_coop: the tiled matcher for SMALL and BATCHED problems (odometry-size clouds, the
-// loop-closure Monte-Carlo, the nearby-keyframe batch).
+// loop-closure Monte-Carlo, the nearby-keyframe batch), with the unit-weight accumulation fused in.
 // Device code of the ICP core for gfx950; included by hip_backend.hip only.  Numeric contract: hip_backend.hip / DESIGN.md.
 //
 // k_nn_tiled gives every persistent wave whole 128-query items; with <= ~0.4M queries there are fewer items than
-// wave slots, a launch is ONE item long and that item is a chain of dependent round trips on a lone wave (measured at
-// 100k x 100k: 24 us for the median item, 49 us for the launch).  Here ONE WORKGROUP owns one item: its four waves
-// hold the same 128 queries, run the same (cheap) box scan and deal the candidate tiles round-robin among themselves
-// (tiled_sweep<.., NPARTS = 4>); the four partial results are merged per query through LDS and waves 0/1 finish 64
-// queries each.  No work queue, no atomics on the launch path, no persistent loop: grid = (items, problems), a block
-// that has no item leaves at once.  blockIdx.y selects the problem, so K independent problems -- K initial poses on
-// one cloud pair (src/LidarOdometry.cpp:767-788) or K different pairs (cpp:704-741) -- share one launch.
+// wave slots, a launch is ONE item long and that item is a chain of dependent memory round trips on a lone wave.
+// Here ONE WORKGROUP owns one item: its four waves hold the same 128 queries, run the same (cheap) box scan and
+// deal the candidate tiles among themselves (coop_sweep); the four partial results are merged per
+// query through LDS and waves 0/1 finish 64 queries each.  No work queue, no atomics, no persistent loop: grid =
+// (items, problems), a block that has no item leaves at once.  blockIdx.y selects the problem, so K independent
+// problems -- K initial poses on one cloud pair (src/LidarOdometry.cpp:767-788) or K different pairs (cpp:704-741)
+// -- share one launch.
+//
+// The item is a chain of dependent round trips (each ~1 us when the whole grid issues it at once), so the chain is
+// kept short:
+//   A  queries + last launch's neighbour (position, original index, COORDINATES -- the epilogue stores them, so the
+//      seed distance needs no second trip) + the upper box levels into LDS, all issued together;
+//   B  tile boxes of the listed super-tiles (the next entry's boxes in flight);  C  the candidate tiles' points;
+//   D  the winning 8-point group, re-read once to resolve the exact point.
+// Exact distance ties (duplicate points, lattices) are rare: the workgroup that meets one redoes ITS item with the
+// exact-key visitor in the same launch (no second kernel, no redo queue).
+// Fused accumulation (row a8, stage 0): the finishing lanes hold (l, g, d2) of their pairing; the workgroup sums the
+// 24 unit-weight terms in a fixed order and writes ONE row per item -- the first accumulation pass of an iteration is
+// then only the fixed-order row reduction (k_reduce_partials), no second pass over the pairing.
 // Results are bit-identical to k_nn_tiled / the dense kernels / the CPU checker (same contract, same tie rule).
 #pragma once
 #include "kernels_tiled.hpp"
@@ -22,12 +34,12 @@ struct NnProblem {
     TiledMap mp;                   // Hilbert-sorted map + box levels
     PoseF P;
     float thr2;
-    int use_seed;                  // pos_s holds the previous launch's neighbours (sorted-map positions)
-    int* pos_s;                    // in: seeds, out: neighbour position   } the pairing, in SORTED query order
-    int* idx_s;                    // out: neighbour's original map index   }
-    float* d2_s;                   // out: squared distance                 }
-    unsigned int* redo_count;      // items with exact distance ties: queued by the fast flavour, consumed by the exact one
-    int* redo_list;
+    int use_seed;                  // pos_s / idx_s / g_s hold the previous launch's neighbours
+    int* pos_s;                    // in: seeds, out: neighbour's sorted-map position   } the pairing, in SORTED query order
+    int* idx_s;                    // in/out: neighbour's original map index             }
+    float* d2_s;                   // out: squared distance                              }
+    float *gsx, *gsy, *gsz;        // in/out: the neighbour's coordinates (as stored in the map)
+    double* rows;                  // out: kNAcc unit-weight sums per item (fused stage-0 accumulation)
     unsigned long long* staged;    // statistics: kStatSlots counters on separate lines (units of 64 evaluated pairs)
 };
 constexpr int kStatSlots = 64, kStatStride = 16;  // (u64 units: one 128-byte line per slot)
@@ -36,206 +48,502 @@ template <int KMAX> struct NnBatch { NnProblem p[KMAX]; };
 
 constexpr int kCoopParts = 4;  // waves of a workgroup = parts of an item
 
-template <bool EXACT, int KMAX>
+// what the two finishing waves hold for their 64 queries after the merge
+struct CoopResult {
+    int rpos, roi;      // sorted-map position / original index of the neighbour, -1: none inside the gate
+    float rd;           // its squared distance (gate^2 if none)
+    float gx, gy, gz;   // its coordinates
+};
+
+// The cooperative sweep.  Same tests and staging as tiled_sweep (kernels_tiled.hpp), split differently:
+//   * wave 0 alone derives the wave box and walks the two upper box levels (LDS copy), listing the super-tiles some
+//     query reaches in the workgroup's shared list -- the other waves wait at the barrier instead of repeating it (the
+//     SIMDs' issue slots are what this kernel is short of: 57 % of all cycles issuing at 100k x 100k);
+//   * all four waves stream the list; wave `part` owns the tiles t of super-tile S with (t + S) % 4 == part -- a fixed
+//     function of the ids, so a wave visits only its own candidate bits (no walk over the others') and the waves,
+//     whose live bounds differ, can never disagree on who evaluates a tile.  A tile its owner's bound cannot reach is
+//     exactly cullable for every query, so the merged result is exact.
+template <bool NEED_PERM, class Visit>
+__device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* s_list,
+                                                         float* s_wbox, int* s_ctl, int lane, int part, float (*sm)[64],
+                                                         const float (&qx)[2], const float (&qy)[2], const float (&qz)[2],
+                                                         const float (&reach)[2], const float (&bound2)[2], Visit&& visit,
+                                                         bool prof, unsigned long long (&pc)[4], unsigned int (&pn)[3])
+{
+    unsigned long long n_staged = 0;
+    // squared distance from each query to the box vs its live bound (see tiled_sweep::any_reach: exact, no margins)
+    auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
+        const v2f s_qx = {qx[0], qx[1]}, s_qy = {qy[0], qy[1]}, s_qz = {qz[0], qz[1]};
+        const v2f zero = {0.f, 0.f};
+        const v2f ax = __builtin_elementwise_max(__builtin_elementwise_max(m0 - s_qx, s_qx - m3), zero);
+        const v2f ay = __builtin_elementwise_max(__builtin_elementwise_max(m1 - s_qy, s_qy - m4), zero);
+        const v2f az = __builtin_elementwise_max(__builtin_elementwise_max(m2 - s_qz, s_qz - m5), zero);
+        const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+        return __any(D.x <= bound2[0] || D.y <= bound2[1]);
+    };
+
+    // ---- wave 0: the wave box (union of the query boxes [q - r, q + r]) and the scan state of the upper levels ----
+    const lds_f32* l_ubox = lbox;
+    const lds_f32* l_sbox = lbox + 6 * mp.n_top;
+    int ub = 0, sb = 0;
+    unsigned long long ucand = 0, scand = 0;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
+    bool c_valid = false;  // c0..c5 hold the super-tile boxes [sb, sb+64)
+    Box w;
+    if (part == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { w.lo[a] = INFINITY; w.hi[a] = -INFINITY; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (reach[k] >= 0.f) {
+                w.lo[0] = fminf(w.lo[0], qx[k] - reach[k]); w.hi[0] = fmaxf(w.hi[0], qx[k] + reach[k]);
+                w.lo[1] = fminf(w.lo[1], qy[k] - reach[k]); w.hi[1] = fmaxf(w.hi[1], qy[k] + reach[k]);
+                w.lo[2] = fminf(w.lo[2], qz[k] - reach[k]); w.hi[2] = fmaxf(w.hi[2], qz[k] + reach[k]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
+                w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
+            }
+        }
+        if (lane == 0) {
+            s_wbox[0] = w.lo[0]; s_wbox[1] = w.lo[1]; s_wbox[2] = w.lo[2];
+            s_wbox[3] = w.hi[0]; s_wbox[4] = w.hi[1]; s_wbox[5] = w.hi[2];
+        }
+    }
+    auto load_super_boxes = [&]() {
+        const int si = sb + lane;
+        if (use_lbox) {
+            c0 = l_sbox[si]; c1 = l_sbox[mp.n_super + si]; c2 = l_sbox[2 * mp.n_super + si];
+            c3 = l_sbox[3 * mp.n_super + si]; c4 = l_sbox[4 * mp.n_super + si]; c5 = l_sbox[5 * mp.n_super + si];
+        } else {
+            c0 = mp.sbox[si]; c1 = mp.sbox[mp.n_super + si]; c2 = mp.sbox[2 * mp.n_super + si];
+            c3 = mp.sbox[3 * mp.n_super + si]; c4 = mp.sbox[4 * mp.n_super + si]; c5 = mp.sbox[5 * mp.n_super + si];
+        }
+        c_valid = true;
+    };
+    auto fill_list = [&]() -> int {  // wave 0: resume the scan, collect up to kMaxList super-tiles
+        int n_list = 0;
+        while (n_list < kMaxList) {
+            if (scand) {
+                if (!c_valid) load_super_boxes();  // resumed after a full list
+                const int sl = __builtin_ctzll(scand);
+                scand &= scand - 1;
+                if (prof) pn[0] += 1;
+                if (any_reach(bcast_lane(c0, sl), bcast_lane(c1, sl), bcast_lane(c2, sl), bcast_lane(c3, sl),
+                              bcast_lane(c4, sl), bcast_lane(c5, sl))) {
+                    if (lane == 0) s_list[n_list] = sb + sl;
+                    ++n_list;
+                }
+            } else if (ucand) {
+                sb = (ub - 64 + __builtin_ctzll(ucand)) * 64;  // first super-tile of this top box (ub already advanced)
+                ucand &= ucand - 1;
+                load_super_boxes();
+                scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] && c4 >= w.lo[1] &&
+                                 c5 >= w.lo[2]);
+            } else if (ub < mp.n_top) {
+                const int ui = ub + lane;
+                float u0 = INFINITY, u1 = INFINITY, u2 = INFINITY, u3 = -INFINITY, u4 = -INFINITY, u5 = -INFINITY;
+                if (ui < mp.n_top) {
+                    if (use_lbox) {
+                        u0 = l_ubox[ui]; u1 = l_ubox[mp.n_top + ui]; u2 = l_ubox[2 * mp.n_top + ui];
+                        u3 = l_ubox[3 * mp.n_top + ui]; u4 = l_ubox[4 * mp.n_top + ui]; u5 = l_ubox[5 * mp.n_top + ui];
+                    } else {
+                        u0 = mp.ubox[ui]; u1 = mp.ubox[mp.n_top + ui]; u2 = mp.ubox[2 * mp.n_top + ui];
+                        u3 = mp.ubox[3 * mp.n_top + ui]; u4 = mp.ubox[4 * mp.n_top + ui]; u5 = mp.ubox[5 * mp.n_top + ui];
+                    }
+                }
+                ucand = __ballot(u0 <= w.hi[0] && u1 <= w.hi[1] && u2 <= w.hi[2] && u3 >= w.lo[0] && u4 >= w.lo[1] &&
+                                 u5 >= w.lo[2]);
+                ub += 64;
+            } else {
+                break;
+            }
+        }
+        return n_list;
+    };
+
+    // ---- all waves: staging pipeline (two tiles = 64 points per pass, the next pair's loads in flight) ----
+    int pend_a = -1, pend_b = -1;  // tile ids whose points sit in the registers below
+    float px = 0.f, py = 0.f, pz = 0.f;
+    int po = 0;
+    auto load_pair = [&](int ta, int tb) {
+        const int tt = lane < 32 ? ta : tb;
+        px = py = pz = 1.0e18f;  // padding points: d2 ~ 3e36, never a neighbour
+        po = 0x7fffffff;
+        if (tt >= 0) {
+            const int j = tt * kTileG + (lane & 31);
+            px = mp.sx[j]; py = mp.sy[j]; pz = mp.sz[j];
+            if (NEED_PERM) po = mp.perm[j];
+        }
+    };
+    auto compute_pending = [&](int next_a, int next_b) {
+        const int ca = pend_a, cb = pend_b;
+        const unsigned long long tp0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        sm[0][lane] = px; sm[1][lane] = py; sm[2][lane] = pz;
+        if (NEED_PERM) sm[3][lane] = __int_as_float(po);
+        pend_a = next_a; pend_b = next_b;
+        if (pend_a >= 0) load_pair(pend_a, pend_b);  // next pass's loads fly while this pass computes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nm = cb >= 0 ? 64 : 32;
+        n_staged += nm;
+        const unsigned long long tp1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        visit(nm, ca * kTileG, (cb >= 0 ? cb : ca) * kTileG);
+        __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next pass
+        if (prof) { const unsigned long long tp2 = __builtin_amdgcn_s_memtime(); pc[0] += tp1 - tp0; pc[1] += tp2 - tp1; }
+    };
+
+    bool have_w = part == 0;
+    for (;;) {
+        if (part == 0) {
+            const int n = fill_list();
+            if (lane == 0) s_ctl[0] = n;
+        }
+        __syncthreads();
+        const int n_list = s_ctl[0];  // (workgroup-uniform)
+        if (n_list == 0) break;
+        if (!have_w) {
+            w.lo[0] = s_wbox[0]; w.lo[1] = s_wbox[1]; w.lo[2] = s_wbox[2];
+            w.hi[0] = s_wbox[3]; w.hi[1] = s_wbox[4]; w.hi[2] = s_wbox[5];
+            have_w = true;
+        }
+        // the listed super-tiles: tile boxes of entry e+1 in flight while entry e's tiles are processed
+        int S = __builtin_amdgcn_readfirstlane(s_list[0]);
+        int ti = S * kSuper + lane;
+        float n0 = mp.tbox[ti], n1 = mp.tbox[mp.n_tiles_p + ti], n2 = mp.tbox[2 * mp.n_tiles_p + ti],
+              n3 = mp.tbox[3 * mp.n_tiles_p + ti], n4 = mp.tbox[4 * mp.n_tiles_p + ti], n5 = mp.tbox[5 * mp.n_tiles_p + ti];
+        for (int e = 0; e < n_list; ++e) {
+            const unsigned long long tb0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+            const float b0 = n0, b1 = n1, b2 = n2, b3 = n3, b4 = n4, b5 = n5;
+            const int Sc = S;
+            if (e + 1 < n_list) {
+                S = __builtin_amdgcn_readfirstlane(s_list[e + 1]);
+                ti = S * kSuper + lane;
+                n0 = mp.tbox[ti]; n1 = mp.tbox[mp.n_tiles_p + ti]; n2 = mp.tbox[2 * mp.n_tiles_p + ti];
+                n3 = mp.tbox[3 * mp.n_tiles_p + ti]; n4 = mp.tbox[4 * mp.n_tiles_p + ti]; n5 = mp.tbox[5 * mp.n_tiles_p + ti];
+            }
+            unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
+                                               b4 >= w.lo[1] && b5 >= w.lo[2]);
+            cand &= 0x1111111111111111ull << ((part - Sc) & 3);  // this wave's tiles of the super-tile
+            const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+            auto next_tile = [&]() -> int {  // next own candidate some query still reaches (live bound), or -1
+                while (cand) {
+                    const int t = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    if (prof) pn[2] += 1;
+                    if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
+                                  bcast_lane(b4, t), bcast_lane(b5, t)))
+                        return Sc * kSuper + t;
+                }
+                return -1;
+            };
+            for (;;) {
+                const int t0 = next_tile();
+                if (t0 < 0) break;
+                const int t1 = next_tile();
+                if (pend_a < 0) {  // nothing in flight yet: just issue this pair's loads
+                    pend_a = t0; pend_b = t1;
+                    load_pair(t0, t1);
+                } else {
+                    compute_pending(t0, t1);
+                }
+            }
+            if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); pc[2] += tb1 - tb0; pc[3] += tb2 - tb1; pn[1] += 1; }
+        }
+        __syncthreads();  // the shared list is rewritten from here on
+        if (n_list < kMaxList) break;  // the scan of the upper levels has ended
+    }
+    if (pend_a >= 0) compute_pending(-1, -1);
+    return n_staged;
+}
+
+// One pass over the workgroup's item with the fast (EXACT = false) or the exact-key visitor.  All four waves call it
+// with the same queries; on return waves 0/1 hold the merged result for the queries k = wave of every lane.
+// Returns (workgroup-uniform) whether some query met an exact distance tie the fast visitor cannot resolve.
+template <bool EXACT>
+__device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledMap& mp, const lds_f32* lbox, bool lds_boxes, int* s_list,
+                                               float* s_wbox, int* s_ctl,
+                                               float (*sm)[64], unsigned int (*s_mg)[6][64], unsigned int* s_flag, int lane,
+                                               int wave, const float (&qx)[2], const float (&qy)[2], const float (&qz)[2],
+                                               const int (&qi)[2], const int (&js)[2],
+                                               const float (&sd)[2], float thr2, CoopResult& res, bool prof,
+                                               unsigned long long (&dbg)[8])
+{
+    const int N = pb.N;
+    float reach[2], best[2];
+    unsigned long long key[2];  // EXACT: packed (d2, original index)
+    int bpos[2];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
+    int tie[2] = {0, 0};
+    int jo[2] = {0, 0};  // EXACT: the seeds' original indices (one more trip on this rare path)
+    if constexpr (EXACT) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (js[k] >= 0) jo[k] = pb.idx_s[qi[k] < N ? qi[k] : N - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
+        best[k] = thr2;
+        bpos[k] = -1;
+        if (js[k] >= 0 && sd[k] < thr2) {  // warm start: last launch's neighbour is an exact candidate
+            best[k] = sd[k];
+            bpos[k] = EXACT ? js[k] : (js[k] & ~(kGroup - 1));
+            if (EXACT) key[k] = ((unsigned long long)__float_as_uint(sd[k]) << 32) | (unsigned int)jo[k];
+        }
+        reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
+        if (qi[k] >= N) {  // padding lane: reaches nothing, is never written
+            reach[k] = -1.0f;
+            best[k] = -1.0f;
+            bpos[k] = -1;
+        }
+    }
+    unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned int pn[3] = {0u, 0u, 0u};
+    const unsigned long long n_staged = coop_sweep<EXACT>(
+        mp, lbox, lds_boxes, s_list, s_wbox, s_ctl, lane, wave, sm, qx, qy, qz, reach, best,
+        [&](int nm, int jb0, int jb1) {
+            if constexpr (EXACT) nn_visit_exact<2>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
+            else nn_visit_fast<2>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
+        },
+        prof, pc, pn);
+    if (prof) {
+        dbg[0] = __builtin_amdgcn_s_memtime();
+        dbg[1] = n_staged | ((unsigned long long)pn[1] << 16) | ((unsigned long long)pn[2] << 32) | ((unsigned long long)pn[0] << 48);
+        dbg[4] = pc[0]; dbg[5] = pc[1]; dbg[6] = pc[2]; dbg[7] = pc[3];  // staging, distance passes, tile-box wait, tile tests (+ the passes inside)
+    }
+
+    // ---- merge the four partial results per query through LDS ----
+    unsigned int(*mg)[64] = s_mg[wave];
+    if constexpr (EXACT) {
+        mg[0][lane] = (unsigned int)(key[0] & 0xffffffffu); mg[1][lane] = (unsigned int)(key[0] >> 32);
+        mg[2][lane] = (unsigned int)(key[1] & 0xffffffffu); mg[3][lane] = (unsigned int)(key[1] >> 32);
+        mg[4][lane] = (unsigned int)bpos[0]; mg[5][lane] = (unsigned int)bpos[1];
+    } else {
+        mg[0][lane] = __float_as_uint(best[0]); mg[1][lane] = __float_as_uint(best[1]);
+        mg[2][lane] = (unsigned int)bpos[0]; mg[3][lane] = (unsigned int)bpos[1];
+        mg[4][lane] = (unsigned int)tie[0]; mg[5][lane] = (unsigned int)tie[1];
+    }
+    if (lane == 0) atomicAdd(&s_flag[2], (unsigned int)n_staged);  // LDS atomic: the workgroup's staged points
+    __syncthreads();
+    if (prof) dbg[2] = __builtin_amdgcn_s_memtime();
+
+    bool any_tie = false;
+    res.rpos = -1; res.roi = -1; res.rd = thr2; res.gx = res.gy = res.gz = 0.f;
+    if (wave < 2) {  // wave w finishes the queries k = w of every lane (64 consecutive queries, coalesced stores)
+        const int k = wave;
+        const float fqx = k ? qx[1] : qx[0], fqy = k ? qy[1] : qy[0], fqz = k ? qz[1] : qz[0];
+        const int fqi = k ? qi[1] : qi[0];
+        if constexpr (EXACT) {
+            unsigned long long mk = ((unsigned long long)s_mg[0][2 * k + 1][lane] << 32) | s_mg[0][2 * k][lane];
+            int mp_ = (int)s_mg[0][4 + k][lane];
+#pragma unroll
+            for (int w = 1; w < kCoopParts; ++w) {
+                const unsigned long long k2 = ((unsigned long long)s_mg[w][2 * k + 1][lane] << 32) | s_mg[w][2 * k][lane];
+                const int p2 = (int)s_mg[w][4 + k][lane];
+                const bool better = k2 < mk;  // equal keys = the same point (same d2, same original index)
+                mk = better ? k2 : mk;
+                mp_ = better ? p2 : mp_;
+            }
+            const float d = __uint_as_float((unsigned int)(mk >> 32));
+            if (d < thr2 && fqi < N) {
+                res.rd = d; res.rpos = mp_; res.roi = (int)(unsigned int)(mk & 0xffffffffu);
+                res.gx = mp.sx[mp_]; res.gy = mp.sy[mp_]; res.gz = mp.sz[mp_];  // (rare path: one more trip)
+            }
+        } else {
+            float b = __uint_as_float(s_mg[0][k][lane]);
+            int p = (int)s_mg[0][2 + k][lane];
+            int t = (int)s_mg[0][4 + k][lane];
+#pragma unroll
+            for (int w = 1; w < kCoopParts; ++w) {
+                const float b2 = __uint_as_float(s_mg[w][k][lane]);
+                const int p2 = (int)s_mg[w][2 + k][lane], t2 = (int)s_mg[w][4 + k][lane];
+                const bool lt = b2 < b, eq = b2 == b;
+                // an EQUAL minimum in a different group is a tie the exact visitor must resolve; the same group on
+                // both sides (the common seed group, or a group two waves met) is the same candidate
+                t = lt ? t2 : (eq ? (t | t2 | (int)(p2 != p)) : t);
+                p = lt ? p2 : p;
+                b = lt ? b2 : b;
+            }
+            // resolve inside the winning group: the point(s) with d2 == best, lowest original index first
+            const int bp = p >= 0 ? p : 0;
+            float4 RX[kGroup / 4], RY[kGroup / 4], RZ[kGroup / 4];
+            int4 RP[kGroup / 4];
+#pragma unroll
+            for (int c = 0; c < kGroup / 4; ++c) {
+                RX[c] = *reinterpret_cast<const float4*>(mp.sx + bp + 4 * c);
+                RY[c] = *reinterpret_cast<const float4*>(mp.sy + bp + 4 * c);
+                RZ[c] = *reinterpret_cast<const float4*>(mp.sz + bp + 4 * c);
+                RP[c] = *reinterpret_cast<const int4*>(mp.perm + bp + 4 * c);
+            }
+            unsigned int bo = 0xffffffffu;
+            int pos = -1;
+            float wx = 0.f, wy = 0.f, wz = 0.f;
+#pragma unroll
+            for (int c = 0; c < kGroup / 4; ++c) {
+                const float xs[4] = {RX[c].x, RX[c].y, RX[c].z, RX[c].w};
+                const float ys[4] = {RY[c].x, RY[c].y, RY[c].z, RY[c].w};
+                const float zs[4] = {RZ[c].x, RZ[c].y, RZ[c].z, RZ[c].w};
+                const int ps[4] = {RP[c].x, RP[c].y, RP[c].z, RP[c].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float du = dist2(fqx, fqy, fqz, xs[u], ys[u], zs[u]);
+                    const bool take = du == b && (unsigned int)ps[u] < bo;
+                    bo = take ? (unsigned int)ps[u] : bo;
+                    pos = take ? p + 4 * c + u : pos;
+                    wx = take ? xs[u] : wx; wy = take ? ys[u] : wy; wz = take ? zs[u] : wz;
+                }
+            }
+            if (p >= 0 && fqi < N) {
+                res.rd = b; res.rpos = pos; res.roi = (int)bo;
+                res.gx = wx; res.gy = wy; res.gz = wz;
+                if (pos < 0) { t = 1; res.roi = -1; }  // cannot happen (same arithmetic); be safe: exact pass
+            }
+            any_tie = fqi < N && t != 0;
+        }
+        if (!EXACT) {
+            const bool wt = __any(any_tie);
+            if (lane == 0) s_flag[k] = wt ? 1u : 0u;
+        }
+    }
+    __syncthreads();  // the tie flags of both finishing waves are in; s_mg may be rewritten
+    const bool redo = !EXACT && (s_flag[0] | s_flag[1]) != 0u;
+    if (prof) dbg[3] = __builtin_amdgcn_s_memtime();
+    return redo;
+}
+
+template <int KMAX>
 __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, int lds_boxes,
                                                     unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
-    __shared__ int s_list[4][kMaxList];
+    __shared__ int s_list[kMaxList];                  // super-tiles some query reaches (written by wave 0, streamed by all)
+    __shared__ float s_wbox[6];                       // the wave box (wave 0's reduction)
+    __shared__ int s_ctl[2];                          // [0] entries in s_list
     __shared__ unsigned int s_mg[kCoopParts][6][64];  // per wave: its partial result for the 128 queries
-    __shared__ unsigned int s_flag[4];                // [0..1] tie seen by finishing wave 0/1, [2..3] staged points (lo/hi not needed: < 2^32)
+    __shared__ unsigned int s_flag[4];                // [0..1] tie seen by finishing wave 0/1, [2] staged points
+    __shared__ double s_acc[12][128];                 // fused accumulation: 12 terms x 128 pairings per round
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float(*sm)[64] = s_m[wave];
-    int* slist = s_list[wave];
     const NnProblem& pb = batch.p[KMAX == 1 ? 0 : blockIdx.y];
     const int N = pb.N;
+    const int item = (int)blockIdx.x;
+    if (item * kQPW >= N) return;  // nothing for this workgroup (uniform: before any barrier)
     const float thr2 = pb.thr2;
     const int use_seed = pb.use_seed;
-    const unsigned int n_work = EXACT ? *pb.redo_count : (unsigned int)((N + kQPW - 1) / kQPW);
-    if (blockIdx.x >= n_work) return;  // nothing for this workgroup (uniform: before any barrier)
     const TiledMap mp = pb.mp;
     const PoseF P = pb.P;
     const lds_f32* lbox = (const lds_f32*)s_dyn;
-    const unsigned long long t_wave0 = wave_times ? wall_clock64() : 0ull;  // 100 MHz, the same on every XCD
-    const unsigned long long c0 = wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
+    const bool prof = wave_times != nullptr;
+    const unsigned long long t_wave0 = prof ? wall_clock64() : 0ull;  // 100 MHz, the same on every XCD
+    const unsigned long long c0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    // round trip A: the lane's two queries, their seeds with coordinates -- and the box levels, issued behind them
+    int qi[2], js[2];
+    float lx[2], ly[2], lz[2], gsx[2], gsy[2], gsz[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        qi[k] = item * kQPW + k * 64 + lane;
+        if (qi[k] >= N) qi[k] = N;  // padding lane
+        const int ic = qi[k] < N ? qi[k] : N - 1;
+        lx[k] = pb.slx[ic]; ly[k] = pb.sly[ic]; lz[k] = pb.slz[ic];
+        js[k] = -1; gsx[k] = gsy[k] = gsz[k] = 0.f;
+        if (use_seed) {
+            js[k] = pb.pos_s[ic];
+            gsx[k] = pb.gsx[ic]; gsy[k] = pb.gsy[ic]; gsz[k] = pb.gsz[ic];
+        }
+    }
     if (threadIdx.x < 4) s_flag[threadIdx.x] = 0u;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);  // (ends with a barrier)
     else __syncthreads();
-    unsigned int block_staged = 0u;
-    const unsigned long long c1 = wave_times ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned long long c2 = 0ull, c3 = 0ull, c4 = 0ull, st_dbg = 0ull;
-
-    for (unsigned int e = blockIdx.x; e < n_work; e += gridDim.x) {  // (fast flavour: grid.x >= items, one trip)
-        const int item = EXACT ? pb.redo_list[e] : (int)e;
-        float qx[2], qy[2], qz[2], reach[2];
-        unsigned long long key[2];  // EXACT: packed (d2, original index)
-        float best[2];              // running minimum (the sweep's box tests read it)
-        int bpos[2];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
-        int tie[2] = {0, 0};
-        int qi[2], js[2];
-        float lx[2], ly[2], lz[2];
-        // round trip 1: the lane's two queries and their seeds (every wave of the workgroup loads the same 128)
+    const unsigned long long c1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    float qx[2], qy[2], qz[2], sd[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            qi[k] = item * kQPW + k * 64 + lane;
-            if (qi[k] >= N) qi[k] = N;  // padding lane
-            const int ic = qi[k] < N ? qi[k] : N - 1;
-            lx[k] = pb.slx[ic]; ly[k] = pb.sly[ic]; lz[k] = pb.slz[ic];
-            js[k] = use_seed ? pb.pos_s[ic] : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
-        // round trip 2: the seeds' coordinates
-        float gsx[2], gsy[2], gsz[2];
-        unsigned int gso[2] = {0u, 0u};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int jc = js[k] >= 0 ? js[k] : 0;
-            gsx[k] = mp.sx[jc]; gsy[k] = mp.sy[jc]; gsz[k] = mp.sz[jc];
-            if (EXACT) gso[k] = (unsigned int)mp.perm[jc];
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
-            best[k] = thr2;
-            bpos[k] = -1;
-            const float d = dist2(qx[k], qy[k], qz[k], gsx[k], gsy[k], gsz[k]);
-            if (js[k] >= 0 && d < thr2) {  // warm start: last launch's neighbour is an exact candidate
-                best[k] = d;
-                bpos[k] = EXACT ? js[k] : (js[k] & ~(kGroup - 1));
-                if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | gso[k];
-            }
-            reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
-            if (qi[k] >= N) {  // padding lane: reaches nothing, is never written
-                qx[k] = qy[k] = qz[k] = 1.0e18f;
-                reach[k] = -1.0f;
-                best[k] = -1.0f;
-                bpos[k] = -1;
-            }
-        }
-
-        if (wave_times) c2 = __builtin_amdgcn_s_memtime();
-        unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
-        unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
-        const unsigned long long n_staged = tiled_sweep<2, EXACT, kCoopParts>(
-            mp, lbox, lds_boxes != 0, slist, lane, wave, sm, qx, qy, qz, reach, best,
-            [&](int nm, int jb0, int jb1) {
-                if constexpr (EXACT) nn_visit_exact<2>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
-                else nn_visit_fast<2>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
-            },
-            false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
-
-        if (wave_times) { c3 = __builtin_amdgcn_s_memtime(); st_dbg = n_staged; }
-        // ---- merge the four partial results per query through LDS ----
-        unsigned int(*mg)[64] = s_mg[wave];
-        if constexpr (EXACT) {
-            mg[0][lane] = (unsigned int)(key[0] & 0xffffffffu); mg[1][lane] = (unsigned int)(key[0] >> 32);
-            mg[2][lane] = (unsigned int)(key[1] & 0xffffffffu); mg[3][lane] = (unsigned int)(key[1] >> 32);
-            mg[4][lane] = (unsigned int)bpos[0]; mg[5][lane] = (unsigned int)bpos[1];
-        } else {
-            mg[0][lane] = __float_as_uint(best[0]); mg[1][lane] = __float_as_uint(best[1]);
-            mg[2][lane] = (unsigned int)bpos[0]; mg[3][lane] = (unsigned int)bpos[1];
-            mg[4][lane] = (unsigned int)tie[0]; mg[5][lane] = (unsigned int)tie[1];
-        }
-        if (lane == 0) atomicAdd(&s_flag[2], (unsigned int)n_staged);  // LDS atomic: the workgroup's staged points
-        __syncthreads();
-        if (wave_times) c4 = __builtin_amdgcn_s_memtime();
-
-        if (wave < 2) {  // wave w finishes the queries k = w of every lane (64 consecutive queries, coalesced stores)
-            const int k = wave;
-            const float fqx = k ? qx[1] : qx[0], fqy = k ? qy[1] : qy[0], fqz = k ? qz[1] : qz[0];
-            const int fqi = k ? qi[1] : qi[0];
-            int rpos = -1, roi = -1;
-            float rd = thr2;
-            bool any_tie = false;
-            if constexpr (EXACT) {
-                unsigned long long mk = ((unsigned long long)s_mg[0][2 * k + 1][lane] << 32) | s_mg[0][2 * k][lane];
-                int mp_ = (int)s_mg[0][4 + k][lane];
-#pragma unroll
-                for (int w = 1; w < kCoopParts; ++w) {
-                    const unsigned long long k2 = ((unsigned long long)s_mg[w][2 * k + 1][lane] << 32) | s_mg[w][2 * k][lane];
-                    const int p2 = (int)s_mg[w][4 + k][lane];
-                    const bool better = k2 < mk;  // equal keys = the same point (same d2, same original index)
-                    mk = better ? k2 : mk;
-                    mp_ = better ? p2 : mp_;
-                }
-                const float d = __uint_as_float((unsigned int)(mk >> 32));
-                if (d < thr2) { rd = d; rpos = mp_; roi = (int)(unsigned int)(mk & 0xffffffffu); }
-            } else {
-                float b = __uint_as_float(s_mg[0][k][lane]);
-                int p = (int)s_mg[0][2 + k][lane];
-                int t = (int)s_mg[0][4 + k][lane];
-#pragma unroll
-                for (int w = 1; w < kCoopParts; ++w) {
-                    const float b2 = __uint_as_float(s_mg[w][k][lane]);
-                    const int p2 = (int)s_mg[w][2 + k][lane], t2 = (int)s_mg[w][4 + k][lane];
-                    const bool lt = b2 < b, eq = b2 == b;
-                    // an EQUAL minimum in a different group is a tie the exact flavour must resolve; the same group on
-                    // both sides (the common seed group, or a group two waves met) is the same candidate
-                    t = lt ? t2 : (eq ? (t | t2 | (int)(p2 != p)) : t);
-                    p = lt ? p2 : p;
-                    b = lt ? b2 : b;
-                }
-                // resolve inside the winning group: the point(s) with d2 == best, lowest original index first
-                const int bp = p >= 0 ? p : 0;
-                float4 RX[kGroup / 4], RY[kGroup / 4], RZ[kGroup / 4];
-                int4 RP[kGroup / 4];
-#pragma unroll
-                for (int c = 0; c < kGroup / 4; ++c) {
-                    RX[c] = *reinterpret_cast<const float4*>(mp.sx + bp + 4 * c);
-                    RY[c] = *reinterpret_cast<const float4*>(mp.sy + bp + 4 * c);
-                    RZ[c] = *reinterpret_cast<const float4*>(mp.sz + bp + 4 * c);
-                    RP[c] = *reinterpret_cast<const int4*>(mp.perm + bp + 4 * c);
-                }
-                unsigned int bo = 0xffffffffu;
-                int pos = -1;
-#pragma unroll
-                for (int c = 0; c < kGroup / 4; ++c) {
-                    const float xs[4] = {RX[c].x, RX[c].y, RX[c].z, RX[c].w};
-                    const float ys[4] = {RY[c].x, RY[c].y, RY[c].z, RY[c].w};
-                    const float zs[4] = {RZ[c].x, RZ[c].y, RZ[c].z, RZ[c].w};
-                    const int ps[4] = {RP[c].x, RP[c].y, RP[c].z, RP[c].w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float du = dist2(fqx, fqy, fqz, xs[u], ys[u], zs[u]);
-                        const bool take = du == b && (unsigned int)ps[u] < bo;
-                        bo = take ? (unsigned int)ps[u] : bo;
-                        pos = take ? p + 4 * c + u : pos;
-                    }
-                }
-                if (p >= 0) {
-                    rd = b; rpos = pos; roi = (int)bo;
-                    if (pos < 0) t = 1;  // cannot happen (same arithmetic); be safe: exact pass
-                }
-                any_tie = fqi < N && t != 0;
-            }
-            if (fqi < N) {  // coalesced: the pairing stays in sorted query order
-                pb.pos_s[fqi] = rpos;
-                pb.idx_s[fqi] = rpos >= 0 ? roi : -1;
-                pb.d2_s[fqi] = rd;
-            }
-            if (!EXACT) {
-                const bool wt = __any(any_tie);
-                if (lane == 0) s_flag[k] = wt ? 1u : 0u;
-            }
-        }
-        __syncthreads();  // s_mg / s_flag are rewritten by the next trip; the tie flags of both finishing waves are in
-        if (threadIdx.x == 0) {
-            if (!EXACT && (s_flag[0] | s_flag[1])) pb.redo_list[atomicAdd(pb.redo_count, 1u)] = item;
-            block_staged += s_flag[2];
-            s_flag[2] = 0u;
-        }
-        if (e + gridDim.x < n_work) __syncthreads();  // (exact flavour only: thread 0's reset before the next trip's adds)
+    for (int k = 0; k < 2; ++k) {
+        xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
+        sd[k] = dist2(qx[k], qy[k], qz[k], gsx[k], gsy[k], gsz[k]);
+        if (qi[k] >= N) qx[k] = qy[k] = qz[k] = 1.0e18f;  // padding lane
     }
-    if (wave_times && lane == 0 && blockIdx.y == 0 && blockIdx.x * 4 + wave < 8192) {
-        // [start, end (wall clock)], then shader cycles: setup (boxes -> LDS), prologue, sweep, wait for the other waves, epilogue; staged points
+    const unsigned long long c2 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    CoopResult res;
+    unsigned long long dbg[8] = {};
+    if (coop_item_pass<false>(pb, mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, sm, s_mg, s_flag, lane, wave, qx, qy, qz, qi, js, sd, thr2,
+                              res, prof, dbg)) {
+        // exact distance ties in this item: once more with the per-pair (d2, original index) key
+        unsigned long long dbg2[8];
+        (void)coop_item_pass<true>(pb, mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, sm, s_mg, s_flag, lane, wave, qx, qy, qz, qi, js, sd,
+                                   thr2, res, false, dbg2);
+    }
+
+    // ---- the pairing (sorted query order, coalesced) and the item's row of unit-weight sums ----
+    float al0 = 0.f, al1 = 0.f, al2 = 0.f, ag0 = 0.f, ag1 = 0.f, ag2 = 0.f, ad = 0.f;
+    bool paired = false;
+    if (wave < 2) {
+        const int k = wave;
+        const int fqi = k ? qi[1] : qi[0];
+        if (fqi < N) {
+            pb.pos_s[fqi] = res.rpos;
+            pb.idx_s[fqi] = res.rpos >= 0 ? res.roi : -1;
+            pb.d2_s[fqi] = res.rd;
+            pb.gsx[fqi] = res.gx; pb.gsy[fqi] = res.gy; pb.gsz[fqi] = res.gz;
+            paired = res.rpos >= 0;
+            al0 = pb.slx[fqi]; al1 = pb.sly[fqi]; al2 = pb.slz[fqi];  // (re-read: cheaper than six registers held through the sweep)
+            ag0 = res.gx; ag1 = res.gy; ag2 = res.gz; ad = res.rd;
+        }
+    }
+    // The terms of k_accumulate's stage 0 for one pairing (w = 1), summed over the item's 128 pairings in a fixed order:
+    // twelve terms per round go through LDS ([term][pairing]), 16 threads per term add 8 entries each in index order,
+    // then a 16-wide shuffle tree.  Unpaired lanes contribute zeros.
+    {
+        const double m = paired ? 1.0 : 0.0;
+        const double l0 = m * al0, l1 = m * al1, l2 = m * al2, g0 = ag0, g1 = ag1, g2 = ag2;
+        double* row = pb.rows + (size_t)item * kNAcc;
+        const int term = threadIdx.x >> 4, sub = threadIdx.x & 15;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (wave < 2) {
+                const int q = wave * 64 + lane;
+                if (r == 0) {
+                    s_acc[0][q] = m; s_acc[1][q] = l0; s_acc[2][q] = l1; s_acc[3][q] = l2;
+                    s_acc[4][q] = m * g0; s_acc[5][q] = m * g1; s_acc[6][q] = m * g2;
+                    s_acc[7][q] = l0 * g0; s_acc[8][q] = l0 * g1; s_acc[9][q] = l0 * g2;
+                    s_acc[10][q] = l1 * g0; s_acc[11][q] = l1 * g1;
+                } else {
+                    s_acc[0][q] = l1 * g2; s_acc[1][q] = l2 * g0; s_acc[2][q] = l2 * g1; s_acc[3][q] = l2 * g2;
+                    s_acc[4][q] = m; s_acc[5][q] = m * (double)ad;
+                    s_acc[6][q] = l0 * al0; s_acc[7][q] = l0 * al1; s_acc[8][q] = l0 * al2;
+                    s_acc[9][q] = l1 * al1; s_acc[10][q] = l1 * al2; s_acc[11][q] = l2 * al2;
+                }
+            }
+            __syncthreads();
+            double t = 0.0;
+            if (term < 12) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += s_acc[term][sub + 16 * j];
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) t += __shfl_down(t, off, 16);
+            if (term < 12 && sub == 0) row[12 * r + term] = t;
+            __syncthreads();
+        }
+    }
+
+    if (prof && lane == 0 && blockIdx.y == 0 && blockIdx.x * 4 + wave < 8192) {
+        // [start, end (wall clock)], then shader cycles: setup (round trip A + boxes -> LDS), sweep, wait for the other
+        // waves, finish (group re-read, row sum); packed: staged points | supers entered << 16 | tile tests << 32 | super tests << 48
         unsigned long long* w = wave_times + 8 * (size_t)(blockIdx.x * 4 + wave);
-        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = c1 - c0; w[3] = c2 - c1; w[4] = c3 - c2; w[5] = c4 - c3;
-        w[6] = __builtin_amdgcn_s_memtime() - c4; w[7] = st_dbg;
+        // (two 32-bit cycle counts per slot from [2] on)
+        auto pk = [](unsigned long long lo, unsigned long long hi) { return (lo & 0xffffffffull) | (hi << 32); };
+        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = pk(c1 - c0, c2 - c1); w[3] = pk(dbg[0] - c2, dbg[2] - dbg[0]);
+        w[4] = pk(__builtin_amdgcn_s_memtime() - dbg[2], dbg[6]); w[5] = pk(dbg[7], dbg[4]); w[6] = pk(dbg[5], 0ull); w[7] = dbg[1];
     }
-    if (threadIdx.x == 0 && block_staged)  // executed work in units of 64 (query, point) pairs; slotted: no same-address burst
-        atomicAdd(pb.staged + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, (unsigned long long)block_staged * 2ull);
+    if (threadIdx.x == 0 && s_flag[2])  // executed work in units of 64 (query, point) pairs; slotted: no same-address burst
+        atomicAdd(pb.staged + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, (unsigned long long)s_flag[2] * 2ull);
 }
 
 }  // namespace mola_icp_amd

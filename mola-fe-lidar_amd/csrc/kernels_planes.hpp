@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
         unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
         unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
-        const unsigned long long n_staged = tiled_sweep<2, !VERIFY, 1>(mp, lbox, lds_boxes != 0, slist, lane, 0, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
+        const unsigned long long n_staged = tiled_sweep<2, !VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
             for (int m = 0; m < nm; m += 4) {
                 const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
                 const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);

@@ -87,15 +87,8 @@ __device__ __forceinline__ void load_boxes_to_lds(const TiledMap& mp, lds_f32* l
 // `visit(nm, jb0, jb1)` is called once per staged pass: sm[0..2][0..nm) hold x,y,z of the staged points
 // (sm[3] their original indices if NEED_PERM); points [0,32) have sorted positions jb0.., [32,64) jb1...
 // Returns the number of staged points.
-// NPARTS > 1 (cooperative items, kernels_coop.hpp): NPARTS waves hold the SAME queries; wave `part` stages and
-// evaluates only every NPARTS-th candidate tile of a super-tile, the per-query results are merged by the caller.
-// The deal must not depend on anything a wave learns during its own sweep (each wave's live bound only sees its own
-// tiles, so the waves list different super-tiles and drop different tiles): a tile's owner is a function of the
-// super-tile id and the tile's rank among the super-tile's WAVE-BOX candidates -- the wave box comes from the initial
-// reaches, which are the same in all NPARTS waves.  A tile no wave's bound reaches is exactly cullable, every other
-// tile is evaluated by its owner: still exact, slightly more staged points in total (looser bounds).
-template <int QPL, bool NEED_PERM, int NPARTS, class Visit>
-__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane, int part,
+template <int QPL, bool NEED_PERM, class Visit>
+__device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane,
                                                           float (*sm)[64], const float (&qx)[QPL], const float (&qy)[QPL],
                                                           const float (&qz)[QPL], const float (&reach)[QPL],
                                                           const float (&bound2)[QPL], Visit&& visit,
@@ -204,16 +197,10 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
             // tile tested after its neighbours were swept meets the tighter best (a first launch, or one after a
             // large pose step, culls many of a super-tile's later tiles this way).
             const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-            int cand_no = Sc;  // cooperative deal: rank among this super-tile's wave-box candidates, rotated by its id
             auto next_tile = [&]() -> int {  // next candidate some query still reaches, or -1
                 while (cand) {
                     const int t = __builtin_ctzll(cand);
                     cand &= cand - 1;
-                    if constexpr (NPARTS > 1) {
-                        const bool mine = (cand_no & (NPARTS - 1)) == part;
-                        ++cand_no;
-                        if (!mine) continue;
-                    }
                     if (prof) p_tiles += 1;
                     if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
                                   bcast_lane(b4, t), bcast_lane(b5, t)))
@@ -455,7 +442,8 @@ template <bool EXACT, int QPL>
 __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
-                                                  float* __restrict__ d2_s, const int* __restrict__ item_order,
+                                                  float* __restrict__ d2_s, float* __restrict__ gs_x, float* __restrict__ gs_y,
+                                                  float* __restrict__ gs_z, const int* __restrict__ item_order,
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
                                                   unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
                                                   unsigned long long* __restrict__ staged_total,
@@ -494,31 +482,30 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         float best[QPL];              // fast: running minimum
         int bpos[QPL];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
         int tie[QPL] = {};
-        // round trip 1: the two queries of the lane and their seeds (clamped indices: every load is unconditional)
+        // ONE round trip: the two queries of the lane and their seeds -- position, original index and COORDINATES as the
+        // last launch's epilogue stored them (gs_*), so the seed distance needs no dependent second trip
         int qi[QPL], js[QPL];
         float lx[QPL], ly[QPL], lz[QPL];
+        float gsx[QPL], gsy[QPL], gsz[QPL];
+        unsigned int gso[QPL] = {};
 #pragma unroll
         for (int k = 0; k < QPL; ++k) {
             qi[k] = item * kQ + k * 64 + lane;
             if (qi[k] >= N) qi[k] = N;  // padding lane
             const int ic = qi[k] < N ? qi[k] : N - 1;
             lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
-            js[k] = use_seed ? pos_s[ic] : -1;
+            js[k] = -1; gsx[k] = gsy[k] = gsz[k] = 0.f;
+            if (use_seed) {
+                js[k] = pos_s[ic];
+                gsx[k] = gs_x[ic]; gsy[k] = gs_y[ic]; gsz[k] = gs_z[ic];
+                if (EXACT) gso[k] = (unsigned int)idx_s[ic];
+            }
         }
         // the next entry's pop goes out BEHIND these loads: memory results return in order, and a device-scope atomic
         // (slow, slower still in the burst at kernel start) ahead of them would sit on the prologue's critical path
         const int next_raw_v = wq.pop();
 #pragma unroll
         for (int k = 0; k < QPL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
-        // round trip 2: the seeds' coordinates
-        float gsx[QPL], gsy[QPL], gsz[QPL];
-        unsigned int gso[QPL] = {};
-#pragma unroll
-        for (int k = 0; k < QPL; ++k) {
-            const int jc = js[k] >= 0 ? js[k] : 0;
-            gsx[k] = mp.sx[jc]; gsy[k] = mp.sy[jc]; gsz[k] = mp.sz[jc];
-            if (EXACT) gso[k] = (unsigned int)mp.perm[jc];
-        }
 #pragma unroll
         for (int k = 0; k < QPL; ++k) {
             key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
@@ -542,7 +529,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
         unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
         const unsigned long long t_sweep0 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
-        const unsigned long long n_staged = tiled_sweep<QPL, EXACT, 1>(mp, lbox, lds_boxes != 0, slist, lane, 0, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+        const unsigned long long n_staged = tiled_sweep<QPL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
             if constexpr (EXACT) nn_visit_exact<QPL>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
             else nn_visit_fast<QPL>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
         }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
@@ -552,14 +539,17 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
 
         bool any_tie = false;
         int rpos[QPL], roi[QPL];
-        float rd[QPL];
+        float rd[QPL], wx[QPL], wy[QPL], wz[QPL];  // (w*: the neighbour's coordinates, next launch's seed)
 #pragma unroll
-        for (int k = 0; k < QPL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; }
+        for (int k = 0; k < QPL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; wx[k] = wy[k] = wz[k] = 0.f; }
         if constexpr (EXACT) {
 #pragma unroll
             for (int k = 0; k < QPL; ++k) {
                 const float d = __uint_as_float((unsigned int)(key[k] >> 32));
-                if (d < thr2) { rd[k] = d; rpos[k] = bpos[k]; roi[k] = (int)(unsigned int)(key[k] & 0xffffffffu); }
+                if (d < thr2) {
+                    rd[k] = d; rpos[k] = bpos[k]; roi[k] = (int)(unsigned int)(key[k] & 0xffffffffu);
+                    wx[k] = mp.sx[bpos[k]]; wy[k] = mp.sy[bpos[k]]; wz[k] = mp.sz[bpos[k]];
+                }
             }
         } else {
             // resolve inside the winning group: the point(s) with d2 == best, lowest original index first.
@@ -593,6 +583,11 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                         const bool take = du == best[k] && (unsigned int)ps[u] < bo;
                         bo = take ? (unsigned int)ps[u] : bo;
                         pos = take ? bpos[k] + 4 * c + u : pos;
+                        // (bit-select: three plain selects on one condition were turned into a scratch-array lookup)
+                        const unsigned int tm = take ? 0xffffffffu : 0u;
+                        wx[k] = __uint_as_float((__float_as_uint(xs[u]) & tm) | (__float_as_uint(wx[k]) & ~tm));
+                        wy[k] = __uint_as_float((__float_as_uint(ys[u]) & tm) | (__float_as_uint(wy[k]) & ~tm));
+                        wz[k] = __uint_as_float((__float_as_uint(zs[u]) & tm) | (__float_as_uint(wz[k]) & ~tm));
                     }
                 }
                 if (bpos[k] >= 0) {
@@ -607,6 +602,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 pos_s[qi[k]] = rpos[k];
                 idx_s[qi[k]] = rpos[k] >= 0 ? roi[k] : -1;
                 d2_s[qi[k]] = rd[k];
+                gs_x[qi[k]] = wx[k]; gs_y[qi[k]] = wy[k]; gs_z[qi[k]] = wz[k];
                 any_tie |= tie[k] != 0;
             }
         }

@@ -57,8 +57,9 @@ int main(void)
         printf("     (%s)\n", mola_icp_last_error());
     } else {
         const float x[4] = {0.f, 1.f, 0.f, 1.f}, y[4] = {0.f, 0.f, 1.f, 1.f}, z[4] = {0.f, 0.f, 0.f, 0.f};
-        q.max_iterations = 0;
-        expect(mola_icp_align(h, x, y, z, 4, x, y, z, 4, T, &q, &res) == MOLA_ICP_E_BADARG, "GPU: maxIterations = 0 -> BADARG");
+        q.matcher_threshold = -1.0;
+        expect(mola_icp_align(h, x, y, z, 4, x, y, z, 4, T, &q, &res) == MOLA_ICP_E_BADARG, "GPU: negative matcher threshold -> BADARG");
+        q.matcher_threshold = 0.75;
         q.max_iterations = 5;
         T[0] = NAN;
         expect(mola_icp_align(h, x, y, z, 4, x, y, z, 4, T, &q, &res) == MOLA_ICP_E_BADARG, "GPU: NaN pose -> BADARG");
