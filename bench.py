@@ -10,15 +10,30 @@ skipped) between two barrier+synchronize brackets; `value` = K / max-over-ranks 
 N GPUs: strong scaling of the SAME 1M x 1M job -- the queries are sharded contiguously over the
 ranks (map replicated), one RCCL all-reduce of the accumulator block per iteration.
 
+Beside the headline the single-GPU run reports (all outside the timed region, all in the ONE JSON line):
+  roofline      the dominant kernel against the HBM roofline: HIP-event duration of the matcher launches of an identical
+                profiled repetition; `traffic` / `pmc` from the committed rocprofv3 passes, stamped with the commit and
+                date they were recorded at and withheld when the kernel sources have changed since;
+  align_e2e     `mola_icp_align` from HOST buffers (upload + Hilbert sort + iterations with the stall test + quality) for
+                configs[0], [1], [2], `prepare_ms` broken out, with the CPU checker's end-to-end time INCLUDING its kd-tree
+                build beside it;
+  config3_batch configs[3]'s shape on this one GPU (64 independent 100k x 100k pairs through `align_batch`) and the
+                all-core CPU leg SURVEY.md section 8(d)(ii) asks for: max(2, nproc/2) threads, one pair each
+                (src/LidarOdometry.cpp:94-96);
+  cpu_baseline  the single-thread CPU leg on a bounded sample of the headline workload, built -O3 -march=native on the
+                machine that runs it.
+
     python bench.py                      # 1 GPU, 40 steps, 3 warmup
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 40 --warmup 3
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -41,7 +56,7 @@ def main():
     ap.add_argument("--n-map", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--nn-kernel", choices=["auto", "valu", "mfma", "tiled"], default="auto")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=5, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=5, help="0 disables every CPU leg")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed code path (process group + RCCL communicator) even with one rank")
     ap.add_argument("--allreduce", choices=["rccl", "hook"], default="rccl",
@@ -53,6 +68,8 @@ def main():
     ap.add_argument("--shipped-iters", type=int, default=20,
                     help="iterations of the shipped Point2Plane+GaussNewton pipeline measured beside the default path")
     ap.add_argument("--dense-iters", type=int, default=3, help="iterations of the dense MFMA kernel measured beside the default path (0 = skip)")
+    ap.add_argument("--e2e", type=int, default=1, help="0 skips the align_e2e legs (configs[0], [1], [2] from host buffers)")
+    ap.add_argument("--batch-pairs", type=int, default=64, help="pairs of the configs[3] leg (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -145,6 +162,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert res.nIterations == args.steps, (res.nIterations, args.steps)
+    # Kernel statistics -- HIP events around every matcher launch, recorded on the library's own stream, and the
+    # executed-pair counters -- come from an IDENTICAL repetition right after the timed region: the two event packets per
+    # launch cost ~8 us per iteration, which the timed region does not pay (mola_icp_set_profiling, off by default).
+    icp.set_profiling(True)
+    res_prof = icp.align_resident(T0, p)
+    barrier()
+    icp.set_profiling(False)
+    assert np.array_equal(res_prof.optimal_tf, res.optimal_tf)
 
     # dominant kernel: the NN matcher; duration from HIP events on the kernel's own stream
     def roofline_of(r, n_local):
@@ -156,11 +181,13 @@ def main():
         tf_exe = 8.0 * pairs_exec / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
         flop_view = {"algorithmic_tflops": tf_alg, "algorithmic_frac_of_fp32_peak": tf_alg / PEAK_FP32_TFLOPS,
                      "flops_per_launch": flops_alg, "pairs_evaluated_per_launch": pairs_exec,
+                     "pairs_evaluated_per_query": pairs_exec / max(1, n_local),
                      "executed_tflops": tf_exe, "executed_frac_of_fp32_peak": tf_exe / PEAK_FP32_TFLOPS}
         if kern == "tiled":
             # exact tile culling evaluates ~5e8 of the 1e12 pairs, so the flop view says little about the kernel;
-            # its compulsory traffic does: both sorted clouds once + the sorted pairing (pos, idx, d2) written
-            bytes_alg = 12.0 * n_local + 12.0 * M + 12.0 * n_local
+            # its compulsory traffic does: both sorted clouds once + the sorted pairing (position, index, d2 and the
+            # neighbour's coordinates -- next launch's seed and the accumulation's g) written
+            bytes_alg = 12.0 * n_local + 12.0 * M + 24.0 * n_local
             gbs = bytes_alg / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
             return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                     "traffic": None, "kernel": "k_nn_tiled", "kernel_ms": nn_ms, "bytes_per_launch": bytes_alg,
@@ -171,10 +198,9 @@ def main():
                 "pipe": "fp32 MFMA" if kern == "mfma" else "fp32 VALU (same 157.3 TFLOP/s peak as the fp32 MFMA)",
                 "flop_view": flop_view}
 
-    roof = roofline_of(res, hi - lo)
-    roof["traffic"] = _recorded_traffic(roof["kernel"], N, M) if world == 1 else None
-    if world == 1 and roof["kernel"] == "k_nn_tiled" and (N, M) == (1_000_000, 1_000_000):
-        roof["pmc"] = _recorded_pmc()   # committed counters of this kernel on this workload (VALU busy, waits, L2 latency)
+    roof = roofline_of(res_prof, hi - lo)
+    if world == 1:
+        roof.update(_recorded_counters(roof["kernel"], N, M))
     if world > 1:
         t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)     # the slowest rank's kernel
@@ -202,22 +228,25 @@ def main():
         "roofline": roof,
         "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(res.optimal_tf, T_gt))),
     }
+    extras = rank == 0 and world == 1
 
-    if rank == 0 and world == 1 and args.nn_kernel in ("auto", "tiled") and args.dense_iters > 0:
+    if extras and args.nn_kernel in ("auto", "tiled") and args.dense_iters > 0:
         # the dense N x M kernel (no culling) on the same clouds, outside the timed region: its roofline
         pd = p.copy()
         pd.nn_kernel = pkg.NN_MFMA
         pd.max_iterations = args.dense_iters
+        icp.set_profiling(True)
         t0 = time.perf_counter()
         rd = icp.align_resident(T0, pd)
         torch.cuda.synchronize()
         td = time.perf_counter() - t0
+        icp.set_profiling(False)
         out["dense_mfma"] = {"value": args.dense_iters / td, "unit": "iterations/s", "iterations": args.dense_iters,
                              "roofline": roofline_of(rd, hi - lo),
                              "pose_err_vs_default_path": dict(zip(("rot_rad", "trans_m"), _pose_err(
                                  rd.optimal_tf, _first_iters_pose(icp, T0, p, args.dense_iters))))}
 
-    if rank == 0 and world == 1 and args.shipped_iters > 0:
+    if extras and args.shipped_iters > 0:
         # the reference's shipped pipeline (Point2Plane knn 6 + Gauss-Newton, icp-settings-regular.yaml) on the same clouds
         ps = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-regular.yaml"))
         ps.fixed_iterations, ps.skip_quality, ps.max_iterations = 1, 1, args.shipped_iters
@@ -226,20 +255,33 @@ def main():
         rs = icp.align_resident(T0, ps)
         torch.cuda.synchronize()
         ts = time.perf_counter() - t0
+        icp.set_profiling(True)
+        rs = icp.align_resident(T0, ps)
+        icp.set_profiling(False)
         out["shipped_point2plane_gn"] = {"value": args.shipped_iters / ts, "unit": "iterations/s",
                                          "iterations": args.shipped_iters, "knn": int(ps.knn),
                                          "gate_m": float(ps.matcher_threshold),
                                          "kernel_ms": rs.ms_nn_kernel / max(1, rs.n_nn_launches), "pairs": int(rs.n_pairs),
                                          "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(rs.optimal_tf, T_gt)))}
 
-    if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
-        out["cpu_baseline"], ref_T = cpu_baseline(g, l, args.cpu_baseline_iters)
-        # pose parity on the same pair: GPU vs the CPU oracle after the same number of iterations
+    cpu_flags = None
+    if extras and args.cpu_baseline_iters > 0:
+        from oracle import oracle as O
+        cpu_flags = O.use_native()   # -O3 -march=native, built on this machine
+        out["cpu_baseline"], ref_T = cpu_baseline(g, l, args.cpu_baseline_iters, cpu_flags)
+        # pose parity on the same pair: GPU vs the CPU oracle after the same number of iterations (the timed run did
+        # args.steps iterations; the pairings are bit-identical per iteration, so the first iterations are the same ones)
         p.max_iterations = args.cpu_baseline_iters
         r5 = icp.align_resident(T0, p)
         rot, trans = _pose_err(r5.optimal_tf, ref_T)
         out["pose_err_vs_cpu"] = {"rot_rad": rot, "trans_m": trans, "iterations": args.cpu_baseline_iters,
+                                  "note": f"compared after {args.cpu_baseline_iters} iterations (the timed region runs {args.steps})",
                                   "tolerance": "1e-4 rad / 1e-3 m"}
+
+    if extras and args.e2e:
+        out["align_e2e"] = align_e2e(pkg, synth, icp, g, l, args.seed, args.cpu_baseline_iters > 0, cpu_flags)
+    if extras and args.batch_pairs > 0:
+        out["config3_batch"] = config3_batch(pkg, synth, icp, args.batch_pairs, args.cpu_baseline_iters > 0, cpu_flags)
 
     if use_dist:
         if allreduce_used == "rccl":
@@ -252,33 +294,38 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def _recorded_traffic(kernel, N, M):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*/traffic.json, written by tools/rocprof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate
-    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if not recorded."""
+def kernel_sources_sha1():
+    """identifies the device code the committed counter files were recorded with"""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mola-fe-lidar_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith("kernels_") or f in ("hip_backend.hip", "map_sort.hip"):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def _recorded_counters(kernel, N, M):
+    """`traffic` (HBM bytes per launch) and `pmc` of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/*/counters.json, written by tools/rocprof_headline.sh + tools/pmc_record.py: FETCH_SIZE and WRITE_SIZE in
+    separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Every record carries the commit,
+    the date and the SHA-1 of the kernel sources it was measured with: a record of OTHER sources is withheld."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+    sha = kernel_sources_sha1()
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "counters.json")), reverse=True):
         try:
             for e in json.load(open(f)):
                 if e.get("kernel") == kernel and e.get("n_local") == N and e.get("n_map") == M:
-                    best = e.get("hbm_bytes_per_launch")
+                    stamp = {"commit": e.get("commit"), "date": e.get("date"), "file": os.path.relpath(f, ROOT)}
+                    if e.get("kernel_sources_sha1") == sha:
+                        return {"traffic": e.get("hbm_bytes_per_launch"), "pmc": e.get("derived"), "counters_recorded_at": stamp}
+                    stale = stale or stamp
         except Exception:
             pass
-    return best
-
-
-def _recorded_pmc():
-    """Derived counters of the tiled matcher from the committed rocprofv3 --pmc passes (profiles/*/tiled_pmc_summary.json,
-    written from tools/rocprof_lat.sh runs).  None if not recorded."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "tiled_pmc_summary.json"))):
-        try:
-            best = json.load(open(f)).get("derived")
-        except Exception:
-            pass
-    return best
+    return {"traffic": None, "counters_recorded_at": None,
+            "counters_note": ("withheld: the committed counters were recorded with other kernel sources "
+                              f"({stale})" if stale else "no committed counters for this kernel and workload")}
 
 
 def _first_iters_pose(icp, T0, p, iters):
@@ -293,7 +340,7 @@ def _pose_err(T, Tref):
     return float(np.arccos(c)), float(np.linalg.norm(T[:3, 3] - Tref[:3, 3]))
 
 
-def cpu_baseline(g, l, iters):
+def cpu_baseline(g, l, iters, flags):
     """The CPU oracle (single-thread exact kd-tree ICP, a port of the reference's mp2p_icp CPU path,
     which cannot be built here) on a bounded sample of the same workload: `iters` fixed iterations of
     the same pair.  A reported baseline, not the optimisation target."""
@@ -302,8 +349,112 @@ def cpu_baseline(g, l, iters):
     r = O.align(g, l, np.eye(4), op)
     return ({"value": iters / r["iter_s"], "unit": "iterations/s", "cores": 1, "kind": "port",
              "sample": f"{iters} fixed iterations of the same {l.shape[1]}x{g.shape[1]} pair, single thread, "
-                       f"kd-tree build ({r['kdtree_build_s']:.2f} s) excluded",
-             "kdtree_build_s": r["kdtree_build_s"], "host_cores_available": os.cpu_count()}, r["T"])
+                       f"kd-tree build ({r['kdtree_build_s']:.2f} s) excluded here and included in align_e2e",
+             "kdtree_build_s": r["kdtree_build_s"], "host_cores_available": os.cpu_count(), "compiler_flags": flags}, r["T"])
+
+
+def _median_align(icp, g, l, T0, p, reps=3):
+    """wall time of `mola_icp_align` from host buffers (upload + sort + iterations + quality), median of `reps`"""
+    icp.align(g, l, T0, p)   # first call: allocations
+    ts, r = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = icp.align(g, l, T0, p)
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3, r
+
+
+def align_e2e(pkg, synth, icp, g1m, l1m, seed, with_cpu, cpu_flags):
+    """End-to-end `mola_icp_align` from HOST buffers per config, the CPU checker's end-to-end (kd-tree build included) beside."""
+    from oracle import oracle as O
+    out = {}
+    # configs[0]: one KITTI-like scan pair (64-ring model of the scene, ~115k points, 1 m apart) through the odometry
+    # case of params/kitti-default.yaml = the reference's shipped Point2Plane + Gauss-Newton pipeline
+    lp = pkg.LidarOdometryParams.load_from_file(os.path.join(ROOT, "params", "kitti-default.yaml"), ROOT)
+    p0 = lp.icp_case("with_vel")
+    a = synth.lidar_scan(synth.pose_from_xyzypr(-10.0, 0.2, 0, 0.01, 0, 0), seed=11)
+    b = synth.lidar_scan(synth.pose_from_xyzypr(-9.0, 0.25, 0, 0.02, 0, 0), seed=12)
+    cases = [("config0", "KITTI-like pair through kitti-default.yaml (Point2Plane knn 6 + Gauss-Newton, <= 100 its, stall test)", a, b, p0, "p2pl"),
+             ("config1", "100k x 100k, point-to-point (gate 1.0 m) + Horn, <= 100 its, stall test", None, None, None, "p2p"),
+             ("config2", "1M x 1M, point-to-point (gate 1.0 m) + Horn, 40 fixed iterations + quality", g1m, l1m, None, "p2p")]
+    for name, what, gg, ll, pp, kind in cases:
+        if gg is None:
+            gg, ll, _ = synth.make_pair(100_000, 100_000, seed=seed)
+        if pp is None:
+            pp = pkg.Parameters()
+            pp.matcher_threshold = GATE_M
+            if name == "config2":
+                pp.max_iterations, pp.fixed_iterations = 40, 1
+            else:
+                pp.max_iterations, pp.min_abs_step_trans, pp.min_abs_step_rot = 100, 5e-5, 1e-5
+        ms, r = _median_align(icp, gg, ll, np.eye(4), pp)
+        e = {"workload": what, "n_from": int(gg.shape[1]), "n_to": int(ll.shape[1]),
+             "gpu": {"ms": ms, "prepare_ms": r.ms_upload, "iterations_ms": r.ms_iterations, "quality_ms": r.ms_quality,
+                     "iterations": int(r.nIterations), "termination": r.termination_name, "quality": r.quality,
+                     "note": "host buffers in, pose out: H2D + Hilbert sort + tile boxes (prepare_ms), the loop, the PairedRatio pass"}}
+        if with_cpu:
+            op = O.params_from_product(pp)
+            if name == "config2":    # bounded: 5 of the 40 iterations, the kd-tree build in full
+                op.max_iterations = 5
+            t0 = time.perf_counter()
+            rc = (O.align_p2pl(gg, ll, np.eye(4), op, pp.plane_eigen_threshold, int(pp.knn), int(pp.solver_max_iterations))
+                  if kind == "p2pl" else O.align(gg, ll, np.eye(4), op))
+            wall = (time.perf_counter() - t0) * 1e3
+            c = {"ms": wall, "iterations": int(rc["n_iterations"]), "cores": 1, "kind": "port", "compiler_flags": cpu_flags,
+                 "note": "kd-tree build + iterations + quality pass, single thread"}
+            if "kdtree_build_s" in rc:
+                c["kdtree_build_ms"] = rc["kdtree_build_s"] * 1e3
+            if name == "config2":
+                per_it = rc["iter_s"] / max(1, rc["n_iterations"]) * 1e3
+                c["note"] += "; bounded sample: 5 of the 40 iterations timed"
+                c["ms_extrapolated_40_iterations"] = wall + 35 * per_it
+            else:
+                rot, trans = _pose_err(r.optimal_tf, rc["T"])
+                e["pose_err_vs_cpu"] = {"rot_rad": rot, "trans_m": trans, "same_iterations": int(r.nIterations) == int(rc["n_iterations"])}
+            e["cpu"] = c
+        out[name] = e
+    return out
+
+
+def config3_batch(pkg, synth, icp, n_pairs, with_cpu, cpu_flags):
+    """configs[3] on ONE GPU: independent 100k x 100k pairs (seeds 100...), <= 100 iterations with the stall test, through
+    `align_batch`; and SURVEY §8(d)(ii)'s all-core CPU leg: max(2, nproc/2) threads, one pair each (cpp:94-96)."""
+    pairs = [synth.make_pair(100_000, 100_000, seed=100 + s)[:2] for s in range(n_pairs)]
+    p = pkg.Parameters()
+    p.matcher_threshold, p.max_iterations, p.min_abs_step_trans, p.min_abs_step_rot = GATE_M, 100, 5e-5, 1e-5
+    icp.align_batch(pairs[:2], [np.eye(4)] * 2, p)   # warm-up
+    t0 = time.perf_counter()
+    res = icp.align_batch(pairs, [np.eye(4)] * n_pairs, p)
+    dt = time.perf_counter() - t0
+    its = int(sum(r.nIterations for r in res))
+    out = {"workload": f"{n_pairs} independent 100k x 100k pairs (seeds 100..{99 + n_pairs}), point-to-point + Horn, <= 100 its, "
+                       "host buffers in (uploads and sorts inside the time)",
+           "gpu": {"pairs_per_s": n_pairs / dt, "iterations_per_s": its / dt, "ms": dt * 1e3, "iterations_total": its,
+                   "n_gpus": 1, "note": "one MI355X; the 8-GPU form deals the pairs round-robin (mola_icp_pool_*), no collective"}}
+    if with_cpu:
+        from oracle import oracle as O
+        n_thr = max(2, (os.cpu_count() or 2) // 2)          # worker_pool_past_KFs_ size, src/LidarOdometry.cpp:94-96
+        n_thr = min(n_thr, n_pairs)
+        op = O.params_from_product(p)
+        O.lib()
+        done = [None] * n_thr
+
+        def work(k):
+            done[k] = O.align(pairs[k][0], pairs[k][1], np.eye(4), op)   # (ctypes releases the GIL inside the call)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(n_thr)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dtc = time.perf_counter() - t0
+        itc = int(sum(d["n_iterations"] for d in done))
+        out["cpu"] = {"pairs_per_s": n_thr / dtc, "iterations_per_s": itc / dtc, "threads": n_thr, "cores": n_thr, "kind": "port",
+                      "host_cores_available": os.cpu_count(), "compiler_flags": cpu_flags,
+                      "sample": f"{n_thr} of the pairs, one per thread (kd-tree build included), {dtc:.1f} s wall"}
+        rot, trans = _pose_err(res[0].optimal_tf, done[0]["T"])
+        out["pose_err_vs_cpu_pair0"] = {"rot_rad": rot, "trans_m": trans}
+    return out
 
 
 if __name__ == "__main__":

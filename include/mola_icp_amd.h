@@ -266,6 +266,11 @@ int mola_icp_voxel_downsample(mola_icp_handle* h, const float* x, const float* y
  * buffers must be completely written -- the producing stream synchronised, or the producer run on the stream handed
  * to mola_icp_set_stream() -- BEFORE the call that first uses them (the next match / align), and must not be
  * rewritten while an align runs.  (The Python binding synchronises torch's current stream in set_map / set_local.) */
+/* Kernel statistics of the following aligns on this handle: HIP events around every matcher launch (ms_nn_kernel) and
+ * the executed-pair counters (nn_pairs_evaluated).  OFF by default -- the event packets cost ~8 us per ICP iteration at
+ * odometry sizes and the counter read-back a stream synchronisation per align; n_nn_launches is always filled.
+ * (The reference's counterpart is its mrpt::system::CTimeLogger profiler, src/LidarOdometry.cpp:296-297, 858.) */
+int mola_icp_set_profiling(mola_icp_handle* h, int on);
 int mola_icp_set_map_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M);
 int mola_icp_set_map_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t M);
 int mola_icp_set_local_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t N);

@@ -145,6 +145,7 @@ _H = C.c_void_p
 #: every symbol include/mola_icp_amd.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "mola_icp_abi_version": (C.c_int, []),
+    "mola_icp_set_profiling": (C.c_int, [_H, C.c_int]),
     "mola_icp_last_error": (C.c_char_p, []),
     "mola_icp_status_string": (C.c_char_p, [C.c_int]),
     "mola_icp_device_count": (C.c_int, [C.POINTER(C.c_int)]),

@@ -32,6 +32,7 @@ struct mola_icp_handle {
     std::mutex mtx;                                   // guards pool + resident
     std::vector<std::unique_ptr<HipWorkspace>> pool;  // idle workspaces for mola_icp_align()
     std::unique_ptr<HipWorkspace> resident;           // the resident-cloud API's workspace
+    std::atomic<int> profiling{0};                    // mola_icp_set_profiling
     mola_icp_allreduce_fn ar_fn = nullptr;
     void* ar_user = nullptr;
     void* comm = nullptr;  // RCCL communicator of the query-sharded path
@@ -147,6 +148,7 @@ struct Lease {
             ws.reset(new HipWorkspace(h->device));
             rc = ws->init();
         }
+        ws->set_profiling(h->profiling.load() != 0);
     }
     ~Lease()
     {
@@ -405,6 +407,15 @@ int mola_icp_set_stream(mola_icp_handle* h, void* hip_stream)
         std::lock_guard<std::mutex> lk(h->mtx);
         return h->resident->set_external_stream(hip_stream);
     });
+}
+
+int mola_icp_set_profiling(mola_icp_handle* h, int on)
+{
+    if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+    std::lock_guard<std::mutex> lk(h->mtx);
+    h->profiling = on ? 1 : 0;
+    if (h->resident) h->resident->set_profiling(on != 0);
+    return MOLA_ICP_OK;
 }
 
 int mola_icp_set_allreduce(mola_icp_handle* h, mola_icp_allreduce_fn fn, void* user)

@@ -660,7 +660,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         HIPCHK(hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 8, 0, sizeof(unsigned int) * 2 * kQueues * kQueueStride, stream_));
     }
     counters_clean_ = false;
-    HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
+    ++nn_launches_;
+    if (profiling_) HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
     const float* sl = loc_sc_->sorted.as<float>();
     const TiledMap mp = tiled_map();
@@ -721,8 +722,10 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 #undef MOLA_LAUNCH_KNN_ALL
 #undef MOLA_LAUNCH_KNN
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
-    ev_used_ += 2;
+    if (profiling_) {
+        HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
+        ev_used_ += 2;
+    }
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;
     planes_eig_thr_ = p.plane_eigen_threshold;
@@ -815,9 +818,10 @@ int HipWorkspace::copy_planes(uint8_t* valid, double* centroid, double* normal, 
 void HipWorkspace::reset_stats()
 {
     ev_used_ = 0;
+    nn_launches_ = 0;
     last_kernel_ = 0;
     dense_pairs_ = 0;
-    if (inited_) {
+    if (inited_ && profiling_) {
         (void)hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 4, 0, sizeof(unsigned long long), stream_);
         (void)hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, stream_);
     }
@@ -827,7 +831,7 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
 {
     if (pairs) {
         unsigned long long staged = 0;
-        if (inited_) {
+        if (inited_ && profiling_) {  // (a copy + stream synchronisation: only when the caller asked for statistics)
             HIPCHK(hipSetDevice(device_));
             HIPCHK(hipMemcpyAsync(acc_host_ + kNAcc + 4, acc_dev_.as<double>() + kNAcc + 4, sizeof staged,
                                   hipMemcpyDeviceToHost, stream_));
@@ -942,7 +946,7 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
         }
     }
     if (ms_total) *ms_total = tot;
-    if (launches) *launches = (uint32_t)(ev_used_ / 2);
+    if (launches) *launches = nn_launches_;
     if (kernel_used) *kernel_used = last_kernel_;
     return MOLA_ICP_OK;
 }
@@ -978,7 +982,8 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         HIPCHK(hipMemsetAsync(counter, 0, 4 * sizeof(unsigned int), stream_));
         HIPCHK(hipMemsetAsync(acc_dev_.as<double>() + kNAcc + 8, 0, sizeof(unsigned int) * 2 * kQueues * kQueueStride, stream_));
     }
-    HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
+    ++nn_launches_;
+    if (profiling_) HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     if (kernel == MOLA_ICP_NN_TILED) {
         const bool use_seed = seed_valid_ && pairing_sorted_ && !g_knobs.no_warm_start;
         // fewer 128-query items than persistent wave slots: the launch would be one item long -> one WORKGROUP per item
@@ -989,8 +994,10 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         last_kernel_ = MOLA_ICP_NN_TILED;
         pairing_sorted_ = true;
         counters_clean_ = false;
-        HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
-        ev_used_ += 2;
+        if (profiling_) {
+            HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
+            ev_used_ += 2;
+        }
         return MOLA_ICP_OK;
     }
     const bool use_mfma = kernel == MOLA_ICP_NN_MFMA;
@@ -1023,8 +1030,10 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         last_kernel_ = MOLA_ICP_NN_VALU;
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
-    ev_used_ += 2;
+    if (profiling_) {
+        HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
+        ev_used_ += 2;
+    }
     pairing_sorted_ = false;
     rows_valid_ = false;
     counters_clean_ = false;
@@ -1271,7 +1280,8 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         HIPCHK(hipEventCreate(&e));
         ev_.push_back(e);
     }
-    HIPCHK(hipEventRecord(ev_[ev_used_], ws_.stream_));
+    ++nn_launches_;
+    if (ws_.profiling_) HIPCHK(hipEventRecord(ev_[ev_used_], ws_.stream_));
     const int K = (int)probs_.size();
     for (int k0 = 0; k0 < K;) {  // chunks of up to kCoopMaxBatch active problems per launch
         NnBatch<kCoopMaxBatch> b;
@@ -1314,8 +1324,10 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
                            (unsigned long long*)nullptr);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(ev_[ev_used_ + 1], ws_.stream_));
-    ev_used_ += 2;
+    if (ws_.profiling_) {
+        HIPCHK(hipEventRecord(ev_[ev_used_ + 1], ws_.stream_));
+        ev_used_ += 2;
+    }
     return MOLA_ICP_OK;
 }
 
@@ -1401,10 +1413,12 @@ int HipBatch::collect_stats(double* ms_total, uint32_t* launches, uint64_t* pair
 {
     if (!inited_) { if (ms_total) *ms_total = 0; if (launches) *launches = 0; if (pairs) *pairs = 0; return MOLA_ICP_OK; }
     HIPCHK(hipSetDevice(ws_.device_));
-    HIPCHK(hipMemcpyAsync(stats_host_, stats_.p, sizeof(unsigned long long) * kStatSlots * kStatStride, hipMemcpyDeviceToHost, ws_.stream_));
-    HIPCHK(hipStreamSynchronize(ws_.stream_));
     unsigned long long staged = 0;
-    for (int k = 0; k < kStatSlots; ++k) staged += stats_host_[(size_t)k * kStatStride];
+    if (ws_.profiling_) {
+        HIPCHK(hipMemcpyAsync(stats_host_, stats_.p, sizeof(unsigned long long) * kStatSlots * kStatStride, hipMemcpyDeviceToHost, ws_.stream_));
+        HIPCHK(hipStreamSynchronize(ws_.stream_));
+        for (int k = 0; k < kStatSlots; ++k) staged += stats_host_[(size_t)k * kStatStride];
+    }
     double tot = 0;
     for (size_t i = 0; i + 1 < ev_used_; i += 2) {
         float ms = 0;
@@ -1412,7 +1426,7 @@ int HipBatch::collect_stats(double* ms_total, uint32_t* launches, uint64_t* pair
         tot += ms;
     }
     if (ms_total) *ms_total = tot;
-    if (launches) *launches = (uint32_t)(ev_used_ / 2);
+    if (launches) *launches = nn_launches_;
     if (pairs) *pairs = (uint64_t)staged * 64u;
     return MOLA_ICP_OK;
 }

@@ -95,6 +95,9 @@ class HipWorkspace final : public Stages {
     int sync();
 
     // NN-kernel timing (HIP events on this workspace's stream)
+    // per-launch HIP events + executed-pair counters (ms_nn_kernel, nn_pairs_evaluated of the results).  Off by default:
+    // the two event packets cost ~8 us per iteration at odometry sizes, the counter read-back a stream synchronisation.
+    void set_profiling(bool on) { profiling_ = on; }
     void reset_stats();
     int collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used, uint64_t* pairs = nullptr);
 
@@ -173,6 +176,8 @@ class HipWorkspace final : public Stages {
     std::vector<hipEvent_t> ev_;  // pairs: start, stop
     size_t ev_used_ = 0;
     uint32_t last_kernel_ = 0;
+    uint32_t nn_launches_ = 0;
+    bool profiling_ = false;
     uint64_t dense_pairs_ = 0;
     unsigned long long* wave_times_ = nullptr; // MOLA_ICP_DEBUG_STATS=2 only
     bool wave_times_coop_ = false;             // ... written by k_nn_coop (its own record layout)
@@ -215,6 +220,7 @@ class HipBatch final : public BatchStages {
     unsigned long long seq_ = 0;
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;
+    uint32_t nn_launches_ = 0;
     bool inited_ = false;
 };
 

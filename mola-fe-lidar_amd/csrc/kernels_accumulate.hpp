@@ -131,18 +131,21 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
 {
     __shared__ double sm[kRedSlices][kNAcc];
     const int k = threadIdx.x % kNAcc, sl = threadIdx.x / kNAcc;
-    // rows sl, sl + 32, sl + 64, ... in order; eight loads are issued before the first add (one block, latency-bound:
-    // a load-add-load chain over 25 rows of a 100k-point cloud took 11 us)
+    // rows sl, sl + 32, sl + 64, ... added in order.  One block, latency-bound: all loads of up to 16 rows per thread are
+    // issued before the first add (a load-add-load chain over the 25 rows of a 100k-point cloud took 11 us)
     double v = 0.0;
     int b = sl;
-    for (; b + 7 * kRedSlices < nblocks; b += 8 * kRedSlices) {
-        double t[8];
+    for (; b < nblocks; b += 16 * kRedSlices) {
+        double t[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = partials[(size_t)(b + u * kRedSlices) * kNAcc + k];
+        for (int u = 0; u < 16; ++u) {
+            const int r = b + u * kRedSlices;
+            t[u] = r < nblocks ? partials[(size_t)r * kNAcc + k] : 0.0;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v += t[u];
+        for (int u = 0; u < 16; ++u)
+            if (b + u * kRedSlices < nblocks) v += t[u];
     }
-    for (; b < nblocks; b += kRedSlices) v += partials[(size_t)b * kNAcc + k];
     sm[sl][k] = v;
     __syncthreads();
     if (threadIdx.x < kNAcc) {

@@ -362,6 +362,11 @@ class ICP:
     def set_stream(self, hip_stream_ptr: int | None):
         L.check(L.lib().mola_icp_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
 
+    def set_profiling(self, on: bool = True):
+        """kernel statistics (`ms_nn_kernel`, `nn_pairs_evaluated`) of the following aligns; off by default (the HIP events
+        around every matcher launch cost ~8 us per iteration at odometry sizes)"""
+        L.check(L.lib().mola_icp_set_profiling(self._h, 1 if on else 0))
+
     def set_allreduce(self, fn):
         """fn(np.ndarray[float64] of 24) -> None, summing in place across ranks (None = single GPU)."""
         if fn is None:

@@ -55,6 +55,21 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def use_native() -> str:
+    """bench.py's cpu_baseline legs: build the checker with -march=native on THIS machine (oracle/Makefile `native`) and
+    switch to it; the portable x86-64-v3 build stays in use if that fails.  Returns the flags in effect."""
+    global _lib, LIB_PATH
+    native = os.path.join(_HERE, "_build", "libicp_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        C.CDLL(native)          # loads on this CPU?
+    except Exception:
+        return "-O3 -march=x86-64-v3 (portable build; the -march=native build failed here)"
+    LIB_PATH = native
+    _lib = None
+    return "-O3 -march=native"
+
+
 _lib = None
 _FP = C.POINTER(C.c_float)
 _DP = C.POINTER(C.c_double)

@@ -147,6 +147,7 @@ def test_tiled_cooperative_equals_persistent(pkg, O, synth, small_scene, coop, m
         g, l, _ = synth.make_pair(20000, 20000, seed=5, scene=small_scene)
         p = p2p_params(pkg, max_iterations=30)
         p.nn_kernel = pkg.NN_TILED
+        icp.set_profiling(True)
         r = icp.align(g, l, np.eye(4), p)
         ref = O.align(g, l, np.eye(4), O.params_from_product(p))
         assert r.nIterations == ref["n_iterations"] and r.n_pairs == ref["n_pairs"]
@@ -219,6 +220,7 @@ def test_accumulate_deterministic(pkg, icp, golden):
 def test_align_equals_oracle(pkg, O, icp, golden, kw):
     g, l = golden["A_map"], golden["A_local"]
     p = p2p_params(pkg, **kw)
+    icp.set_profiling(True)          # per-launch HIP events + executed-pair counters (off by default)
     r = icp.align(g, l, np.eye(4), p)
     ref = O.align(g, l, np.eye(4), O.params_from_product(p))
     assert r.nIterations == ref["n_iterations"] and r.terminationReason == ref["termination"]
@@ -228,6 +230,9 @@ def test_align_equals_oracle(pkg, O, icp, golden, kw):
     assert r.quality == pytest.approx(ref["quality"], abs=1e-12)
     assert r.n_pairs == ref["n_pairs"] and r.rmse == pytest.approx(ref["rmse"], rel=1e-9)
     assert r.n_nn_launches == r.nIterations + 1 and r.ms_nn_kernel > 0
+    icp.set_profiling(False)
+    r0 = icp.align(g, l, np.eye(4), p)
+    assert r0.n_nn_launches == r.n_nn_launches and r0.ms_nn_kernel == 0 and np.array_equal(r0.optimal_tf, r.optimal_tf)
 
 
 def test_align_golden_result(pkg, icp, golden):

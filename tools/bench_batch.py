@@ -20,6 +20,7 @@ pairs = [synth.make_pair(a.n, a.n, seed=100 + s)[:2] for s in range(a.pairs)]
 p = pkg.Parameters()
 p.max_iterations, p.matcher_threshold, p.min_abs_step_trans, p.min_abs_step_rot = 100, 1.0, 5e-5, 1e-5
 icp = pkg.ICP(device=0)
+icp.set_profiling(True)  # kernel times / executed pairs are printed below
 icp.align(pairs[0][0], pairs[0][1], np.eye(4), p)  # warm-up
 t0 = time.perf_counter()
 res = icp.align_batch(pairs, [np.eye(4)] * len(pairs), p)

@@ -31,6 +31,8 @@ def emit(**kw):
 
 
 icp = pkg.ICP(device=0)
+
+
 p2p = pkg.Parameters()
 p2p.matcher_threshold = 1.0
 p2pl = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-regular.yaml"))
@@ -47,6 +49,9 @@ for n, m in sizes:
         t0 = time.perf_counter()
         r = icp.align_resident(np.eye(4), p)
         dt = time.perf_counter() - t0
+        icp.set_profiling(True)   # the matcher's own duration: HIP events around every launch (a separate, slower run)
+        r = icp.align_resident(np.eye(4), p)
+        icp.set_profiling(False)
         emit(what="resident_iteration", pipeline=name, n=n, m=m, us_per_iteration=dt / 40 * 1e6,
              kernel_us=r.ms_nn_kernel / max(1, r.n_nn_launches) * 1e3)
         q = base.copy()

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turns the merged output of tools/rocprof_headline.sh / rocprof_small.sh into the committed counter record bench.py
+reads: profiles/<round>/counters.json (appended / replaced per kernel+workload), plus copies of the kernel-stats CSV and
+the raw summary.  Every record is stamped with the commit, the date and the SHA-1 of the kernel sources, so that bench.py
+can withhold it once the sources change.   Usage: pmc_record.py <gpurun_out/prof_tag> <profiles/rNN> [--kernel k_nn_tiled]"""
+import datetime
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha1  # noqa: E402
+
+src, dst = sys.argv[1], sys.argv[2]
+kernel = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "k_nn_tiled"
+summ = json.load(open(os.path.join(src, "pmc_summary.json")))
+n, m = (int(x) for x in open(os.path.join(src, "workload.txt")).read().split()) if os.path.exists(os.path.join(src, "workload.txt")) else (1_000_000, 1_000_000)
+pick = [k for k in summ if kernel in k]
+# the fast flavour (<false, ...>) is the dominant one; take the entry with the most VALU instructions
+pick.sort(key=lambda k: -summ[k].get("SQ_INSTS_VALU", {}).get("mean", 0))
+c = {name: v["last"] for name, v in summ[pick[0]].items()}     # warm-started launch: the last of each pass
+items = (n + 127) // 128
+d = {}
+if "GRBM_GUI_ACTIVE" in c:
+    d["kernel_cycles_per_xcd"] = c["GRBM_GUI_ACTIVE"] / 8
+    if "SQ_ACTIVE_INST_VALU" in c:
+        d["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * d["kernel_cycles_per_xcd"])
+if "SQ_WAVE_CYCLES" in c:
+    d["wave_cycles_waiting_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]
+    d["wave_cycles_issuing_frac"] = c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
+if c.get("TCP_TCC_READ_REQ_sum"):
+    d["l2_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
+if "SQ_INSTS_VALU" in c:
+    d["valu_insts_per_item"] = c["SQ_INSTS_VALU"] / items
+    d["salu_insts_per_item"] = c.get("SQ_INSTS_SALU", 0) / items
+rec = {"kernel": kernel, "kernel_symbol": pick[0], "n_local": n, "n_map": m, "counters": c, "derived": d,
+       "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+       "date": datetime.date.today().isoformat(), "kernel_sources_sha1": kernel_sources_sha1(),
+       "note": "warm-started launches, last launch of each --pmc pass; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
+               "tallies 128-B requests at 64 B), WRITE_SIZE as read; FETCH_SIZE / WRITE_SIZE are in KiB"}
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    rec["FETCH_SIZE_KiB_per_launch"] = c["FETCH_SIZE"]
+    rec["WRITE_SIZE_KiB_per_launch"] = c["WRITE_SIZE"]
+    rec["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+os.makedirs(dst, exist_ok=True)
+path = os.path.join(dst, "counters.json")
+recs = json.load(open(path)) if os.path.exists(path) else []
+recs = [r for r in recs if not (r["kernel"] == kernel and r["n_local"] == n and r["n_map"] == m)] + [rec]
+json.dump(recs, open(path, "w"), indent=1)
+tag = f"{kernel}_{n}x{m}"
+for f, name in (("kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("pmc_summary.txt", f"{tag}_pmc_summary.txt")):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, name))
+print(json.dumps({k: rec[k] for k in ("kernel", "n_local", "n_map", "derived", "commit", "kernel_sources_sha1") if k in rec}, indent=1))
+if "hbm_bytes_per_launch" in rec:
+    print("hbm_bytes_per_launch", rec["hbm_bytes_per_launch"])

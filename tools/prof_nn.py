@@ -21,6 +21,7 @@ pkg = importlib.import_module("mola-fe-lidar_amd")
 synth = importlib.import_module("mola-fe-lidar_amd.synth")
 g, l, _ = synth.make_pair(a.n, a.m, seed=42)
 icp = pkg.ICP(device=0)
+icp.set_profiling(True)  # kernel times / executed pairs are printed below
 icp.set_map(g)
 icp.set_local(l)
 k = {"mfma": pkg.NN_MFMA, "valu": pkg.NN_VALU, "tiled": pkg.NN_TILED}[a.kernel]

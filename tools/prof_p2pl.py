@@ -19,6 +19,7 @@ g, l, _ = synth.make_pair(a.n, a.n, seed=42)
 p = pkg.Parameters.load_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "params",
                                                "icp-settings-regular.yaml"))
 icp = pkg.ICP(device=0)
+icp.set_profiling(True)  # kernel times / executed pairs are printed below
 icp.set_map(g)
 icp.set_local(l)
 for its in (1, a.iters):

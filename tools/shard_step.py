@@ -17,6 +17,7 @@ order = sharded.spatial_order(l)
 p = pkg.Parameters()
 p.matcher_threshold, p.fixed_iterations, p.skip_quality, p.max_iterations = 1.0, 1, 1, 20
 icp = pkg.ICP(device=0)
+icp.set_profiling(True)  # kernel times / executed pairs are printed below
 icp.set_map(g)
 for world in (1, 2, 4, 8):
     lo, hi = sharded.shard_bounds(l.shape[1], 0, world)

@@ -18,6 +18,7 @@ pp.matcher_threshold = 1.0
 for p in (pl, pp):
     p.fixed_iterations, p.skip_quality, p.max_iterations = 1, 1, 6
 icp = pkg.ICP(device=0)
+icp.set_profiling(True)  # kernel times / executed pairs are printed below
 for n, m in ((9000, 9000), (50_000, 200_000), (393_216, 393_216), (500_000, 500_000), (777_777, 1_234_567),
              (2_000_000, 1_000_000), (1_000_000, 4_000_000), (3_000_000, 3_000_000)):
     g, l, _ = synth.make_pair(n, m, seed=n % 97)
