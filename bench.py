@@ -102,19 +102,30 @@ def main():
 
     N, M = args.n_local, args.n_map
     g, l, T_gt = synth.make_pair(N, M, seed=args.seed)
-    lo, hi = sharded.shard_bounds(N, rank, world)
+    lo, hi = sharded.shard_bounds(N, rank, world)   # (the sizes; which points a rank gets is decided by the device cut)
 
     # inputs resident in HBM before the timed region
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if args.share_gpu else dev   # where the bench's own small collectives live
     tg = torch.from_numpy(g).to(dev)
-    # spatially compact shards (Z-order slices of the scan): a random 1/W subsample would be W times sparser than
-    # the map and every 128-query group would sweep W times more map tiles
-    shard = l[:, lo:hi] if world == 1 else l[:, sharded.spatial_order(l)[lo:hi]]
-    tl = torch.from_numpy(np.ascontiguousarray(shard)).to(dev)
     icp = pkg.ICP(device=local_rank)
-    icp.set_map(tg)
-    icp.set_local(tl)
+    slab = None
+    if world == 1:
+        tl = torch.from_numpy(np.ascontiguousarray(l)).to(dev)
+        icp.set_map(tg)
+        icp.set_local(tl)
+    else:
+        # Spatially compact shards: this rank's slice of the scan's Hilbert order, cut on the device (a random 1/W
+        # subsample would be W times sparser than the map: every 128-query group would sweep W times more map tiles) --
+        # and only the part of the map that shard can reach: its box grown by the gate + the pose correction of this
+        # pair (0.54 m, 2.1 deg at up to 60 m from the origin), not W copies of the whole map.
+        tl = torch.from_numpy(np.ascontiguousarray(l)).to(dev)
+        n_shard = icp.set_local_shard(tl, rank, world)
+        lo, hi = 0, n_shard                 # (queries_per_gpu below)
+        blo, bhi = icp.shard_reach_box(np.eye(4), GATE_M + 3.5)
+        kept = icp.set_map_slab(tg, blo, bhi)
+        slab = {"map_points_kept": kept, "map_points_total": M, "margin_m": GATE_M + 3.5}
+        del tl
     icp.set_global_sizes(N, M)
     allreduce_used = None
     if use_dist:
@@ -224,7 +235,7 @@ def main():
                                f"iterations, point-to-point NN (gate {GATE_M} m) + Horn, seed {args.seed}",
                    "n_local": N, "n_map": M, "gate_m": GATE_M, "queries_per_gpu": hi - lo,
                    "parallelism": (f"query-shard x{world}, {allreduce_used} all-reduce" if use_dist else "single GPU"),
-                   "nn_kernel": roof["kernel"]},
+                   "nn_kernel": roof["kernel"], "map_slab_rank0": slab},
         "roofline": roof,
         "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(res.optimal_tf, T_gt))),
     }

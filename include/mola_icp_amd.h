@@ -275,6 +275,28 @@ int mola_icp_set_map_host(mola_icp_handle* h, const float* x, const float* y, co
 int mola_icp_set_map_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t M);
 int mola_icp_set_local_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t N);
 int mola_icp_set_local_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t N);
+/* ---- query sharding helpers (no reference analogue: one align() is serial there) ----------
+ * Every rank passes the SAME full scan and keeps a spatially compact shard of it: the slice of rank `rank` of the scan's
+ * Hilbert order, computed on the device with the whole scan's bounding box (identical on every rank; the full copy is
+ * transient).  A random 1/W subsample would be W times sparser than the map: every query group would sweep W times
+ * more map tiles.  mola_icp_local_shard_indices: the shard's points as indices into the full scan (n_shard of them). */
+int mola_icp_set_local_shard_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t n_total,
+                                  int rank, int nranks, size_t* n_shard_out);
+int mola_icp_set_local_shard_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t n_total,
+                                    int rank, int nranks, size_t* n_shard_out);
+int mola_icp_local_shard_indices(mola_icp_handle* h, int32_t* idx_out);
+/* The part of the map this rank's shard can reach: [lo, hi] = the shard's bounding box moved by T and grown by `margin`
+ * (mola_icp_shard_reach_box), then only the map points inside it are kept, prepared and searched
+ * (mola_icp_set_map_slab_*; configs[4]: a rank does not hold, sort and sweep the 10M-point map eight times over).
+ * Pairings still name ORIGINAL map indices.  Exact as long as every pose of the align keeps the shard's reach (its moved
+ * box grown by the matcher's gate) inside [lo, hi]: the matcher checks this at every pose and fails with
+ * MOLA_ICP_E_BADARG ("outside its map slab") otherwise -- cut again with a larger margin.  A margin of
+ * gate + the largest pose correction expected (metres) is the natural choice. */
+int mola_icp_shard_reach_box(mola_icp_handle* h, const double T[16], double margin, double lo_out[3], double hi_out[3]);
+int mola_icp_set_map_slab_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M,
+                               const double lo[3], const double hi[3], size_t* n_kept_out);
+int mola_icp_set_map_slab_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t M,
+                                 const double lo[3], const double hi[3], size_t* n_kept_out);
 /* total sizes for the quality ratio when this rank holds only a shard (0 = use own sizes) */
 int mola_icp_set_global_sizes(mola_icp_handle* h, uint64_t n_local_total, uint64_t n_map_total);
 /* full align on the resident clouds (uses the all-reduce hook if installed) */

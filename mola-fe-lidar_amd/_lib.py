@@ -146,6 +146,12 @@ _H = C.c_void_p
 SIGNATURES = {
     "mola_icp_abi_version": (C.c_int, []),
     "mola_icp_set_profiling": (C.c_int, [_H, C.c_int]),
+    "mola_icp_set_local_shard_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "mola_icp_set_local_shard_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "mola_icp_local_shard_indices": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "mola_icp_shard_reach_box": (C.c_int, [_H, _DP, C.c_double, _DP, _DP]),
+    "mola_icp_set_map_slab_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, _DP, _DP, C.POINTER(C.c_size_t)]),
+    "mola_icp_set_map_slab_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _DP, _DP, C.POINTER(C.c_size_t)]),
     "mola_icp_last_error": (C.c_char_p, []),
     "mola_icp_status_string": (C.c_char_p, [C.c_int]),
     "mola_icp_device_count": (C.c_int, [C.POINTER(C.c_int)]),

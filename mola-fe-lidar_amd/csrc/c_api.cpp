@@ -847,6 +847,71 @@ int mola_icp_set_global_sizes(mola_icp_handle* h, uint64_t nl, uint64_t nm)
     RESIDENT_CALL((ws.set_global_sizes(nl, nm), MOLA_ICP_OK));
 }
 
+int mola_icp_set_local_shard_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t n_total, int rank,
+                                  int nranks, size_t* n_shard_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        const int rc = h->resident->set_local_shard(x, y, z, n_total, rank, nranks, false);
+        if (!rc && n_shard_out) *n_shard_out = h->resident->N();
+        return rc;
+    });
+}
+
+int mola_icp_set_local_shard_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t n_total, int rank,
+                                    int nranks, size_t* n_shard_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        const int rc = h->resident->set_local_shard(dx, dy, dz, n_total, rank, nranks, true);
+        if (!rc && n_shard_out) *n_shard_out = h->resident->N();
+        return rc;
+    });
+}
+
+int mola_icp_local_shard_indices(mola_icp_handle* h, int32_t* idx_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        return h->resident->copy_shard_indices(idx_out);
+    });
+}
+
+int mola_icp_shard_reach_box(mola_icp_handle* h, const double T[16], double margin, double lo_out[3], double hi_out[3])
+{
+    return guarded([&]() -> int {
+        if (!h || !T || !lo_out || !hi_out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        if (!(margin >= 0)) return fail(MOLA_ICP_E_BADARG, "margin must be >= 0");
+        int rc;
+        if ((rc = check_pose(T))) return rc;
+        std::lock_guard<std::mutex> lk(h->mtx);
+        return h->resident->shard_reach_box(mat_from(T), margin, lo_out, hi_out);
+    });
+}
+
+int mola_icp_set_map_slab_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M, const double lo[3],
+                               const double hi[3], size_t* n_kept_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        return h->resident->set_map_slab(x, y, z, M, lo, hi, false, n_kept_out);
+    });
+}
+
+int mola_icp_set_map_slab_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t M, const double lo[3],
+                                 const double hi[3], size_t* n_kept_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        return h->resident->set_map_slab(dx, dy, dz, M, lo, hi, true, n_kept_out);
+    });
+}
+
 int mola_icp_align_resident(mola_icp_handle* h, const double init_T[16], const mola_icp_params* p,
                             mola_icp_result* out)
 {

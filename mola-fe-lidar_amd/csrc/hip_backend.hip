@@ -72,6 +72,8 @@ static Knobs read_knobs()
     k.debug_stats = geti("MOLA_ICP_DEBUG_STATS");
     return k;
 }
+static const char* const kSlabMsg =
+    "the pose moves a shard's reach outside its map slab: cut the slab again with a larger margin";
 static Knobs g_knobs = read_knobs();
 void reload_env_knobs() { g_knobs = read_knobs(); }
 
@@ -104,6 +106,7 @@ HipWorkspace::~HipWorkspace()
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
+    shard_idx_.release(); slab_orig_.release(); stage_in_.release();
     map_sc_.reset();
     loc_sc_.reset();
     ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); ts_gs_.release(); rows_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
@@ -205,6 +208,8 @@ int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, s
     // the host buffers may be pageable: finish the copies before returning (never retain caller pointers)
     HIPCHK(hipStreamSynchronize(stream_));
     M_ = M;
+    slab_active_ = false;
+    slab_violation_ = false;
     planes_valid_ = false;
     map_img_valid_ = false;
     if (map_sc_->cached) map_sc_ = std::make_shared<SortedCloud>();  // a cached cloud is immutable: use an own one
@@ -223,6 +228,8 @@ int HipWorkspace::set_map_device(const float* x, const float* y, const float* z,
     if (M > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "map too large for 32-bit indices");
     gx_ = x; gy_ = y; gz_ = z;
     M_ = M;
+    slab_active_ = false;
+    slab_violation_ = false;
     planes_valid_ = false;
     map_img_valid_ = false;
     if (map_sc_->cached) map_sc_ = std::make_shared<SortedCloud>();  // a cached cloud is immutable: use an own one
@@ -243,6 +250,8 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     if ((rc = upload_soa(loc_own_, stream_, x, y, z, N, &lx_, &ly_, &lz_))) return rc;
     HIPCHK(hipStreamSynchronize(stream_));
     N_ = N;
+    loc_bbox_valid_ = false;
+    shard_n_ = 0;
     planes_valid_ = false;
     if (loc_sc_->cached) loc_sc_ = std::make_shared<SortedCloud>();
     loc_sc_->ready = false;
@@ -263,6 +272,8 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     if (N > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "local cloud too large for 32-bit indices");
     lx_ = x; ly_ = y; lz_ = z;
     N_ = N;
+    loc_bbox_valid_ = false;
+    shard_n_ = 0;
     planes_valid_ = false;
     if (loc_sc_->cached) loc_sc_ = std::make_shared<SortedCloud>();
     loc_sc_->ready = false;
@@ -272,6 +283,148 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     pairing_valid_ = false;
     seed_valid_ = false;
     knn_seed_valid_ = false;
+    return MOLA_ICP_OK;
+}
+
+int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
+                       const float bbox[6], DevBuf& scratch, float* sxyz, int* perm);
+int select_in_box(hipStream_t stream, const float* x, const float* y, const float* z, size_t n, const float lo[3], const float hi[3],
+                  DevBuf& scratch, int* sel, size_t* n_kept_host);
+int gather_by_index(hipStream_t stream, const float* x, const float* y, const float* z, const int* sel, size_t n, float* ox, float* oy,
+                    float* oz);
+
+// Row e.  Every rank sees the whole scan (it is small: 12 B per point) but keeps only a spatially compact shard of it: the
+// slice [lo, hi) of the scan's Hilbert order.  A random 1/W subsample would be W times sparser than the map, and every
+// 128-query group would sweep W times more map tiles.  The order is computed HERE, on the device, with the whole scan's
+// bounding box, so every rank cuts the same order; the full copy is transient.
+int HipWorkspace::set_local_shard(const float* x, const float* y, const float* z, size_t n_total, int rank, int nranks, bool on_device)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MOLA_ICP_E_BADARG, "bad rank / nranks");
+    if (n_total && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null local-cloud pointer");
+    if (n_total > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "local cloud too large for 32-bit indices");
+    HIPCHK(hipSetDevice(device_));
+    const size_t base = n_total / (size_t)nranks, rem = n_total % (size_t)nranks;
+    const size_t lo = (size_t)rank * base + std::min((size_t)rank, rem), n = base + ((size_t)rank < rem ? 1 : 0);
+    const float *fx = x, *fy = y, *fz = z;
+    if (!on_device) {
+        if ((rc = upload_soa(stage_in_, stream_, x, y, z, n_total, &fx, &fy, &fz))) return rc;
+        HIPCHK(hipStreamSynchronize(stream_));  // (pageable host buffers: never retain caller pointers)
+    }
+    DevBuf sorted, perm;
+    float* own = nullptr;
+    if (n_total) {
+        float bbox[6];
+        if ((rc = bbox_of(fx, fy, fz, n_total, bbox))) return rc;
+        const size_t padded = (n_total + kQPW - 1) / kQPW * kQPW;
+        if ((rc = sorted.reserve(sizeof(float) * 3 * padded))) return rc;
+        if ((rc = perm.reserve(sizeof(int) * padded))) return rc;
+        if ((rc = morton_sort_points(stream_, fx, fy, fz, n_total, padded, bbox, sort_scratch_, sorted.as<float>(), perm.as<int>()))) {
+            sorted.release(); perm.release();
+            return rc;
+        }
+        const size_t np = (n + 63) / 64 * 64;
+        rc = loc_own_.reserve(sizeof(float) * 3 * (np ? np : 64));
+        if (!rc) rc = shard_idx_.reserve(sizeof(int) * (n ? n : 1));
+        if (rc) { sorted.release(); perm.release(); return rc; }
+        own = loc_own_.as<float>();
+        const float* sp = sorted.as<float>();
+        hipError_t e = hipSuccess;
+        for (int a = 0; a < 3 && e == hipSuccess && n; ++a)
+            e = hipMemcpyAsync(own + (size_t)a * np, sp + (size_t)a * padded + lo, sizeof(float) * n, hipMemcpyDeviceToDevice, stream_);
+        if (e == hipSuccess && n) e = hipMemcpyAsync(shard_idx_.p, perm.as<int>() + lo, sizeof(int) * n, hipMemcpyDeviceToDevice, stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        sorted.release(); perm.release();
+        stage_in_.release();  // the full scan was transient
+        if (e != hipSuccess) return fail(MOLA_ICP_E_HIP, std::string("shard copy: ") + hipGetErrorString(e));
+        rc = set_local_device(own, own + np, own + 2 * np, n);
+    } else {
+        rc = set_local_device(nullptr, nullptr, nullptr, 0);
+    }
+    if (rc) return rc;
+    shard_n_ = n;
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::copy_shard_indices(int32_t* idx_out)
+{
+    if (shard_n_ == 0) return MOLA_ICP_OK;
+    if (!idx_out) return fail(MOLA_ICP_E_BADARG, "null output");
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipMemcpyAsync(idx_out, shard_idx_.p, sizeof(int) * shard_n_, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    return MOLA_ICP_OK;
+}
+
+// AABB of the local cloud's bounding box moved by T, grown by `margin` on every side: where this rank's queries can
+// find neighbours at pose T with a gate <= margin.
+int HipWorkspace::shard_reach_box(const Mat4& T, double margin, double lo[3], double hi[3])
+{
+    int rc = init();
+    if (rc) return rc;
+    if (N_ == 0) return fail(MOLA_ICP_E_BADARG, "no local cloud set");
+    if (!loc_bbox_valid_) {
+        HIPCHK(hipSetDevice(device_));
+        if ((rc = bbox_of(lx_, ly_, lz_, N_, loc_bbox_))) return rc;
+        loc_bbox_valid_ = true;
+    }
+    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {loc_bbox_[(c & 1) ? 3 : 0], loc_bbox_[(c & 2) ? 4 : 1], loc_bbox_[(c & 4) ? 5 : 2]};
+        for (int a = 0; a < 3; ++a) {
+            const double v = T(a, 0) * p[0] + T(a, 1) * p[1] + T(a, 2) * p[2] + T(a, 3);
+            lo[a] = std::min(lo[a], v);
+            hi[a] = std::max(hi[a], v);
+        }
+    }
+    // (the matcher moves the points in fp32: a few ulp of the coordinates on top of the margin)
+    for (int a = 0; a < 3; ++a) {
+        const double slack = 1e-5 * std::max(std::fabs(lo[a]), std::fabs(hi[a])) + 1e-6;
+        lo[a] -= margin + slack;
+        hi[a] += margin + slack;
+    }
+    return MOLA_ICP_OK;
+}
+
+// The part of the map inside [lo, hi] becomes this rank's map (C5: 10M points are not uploaded-sorted-held eight times
+// over; a rank keeps what its shard can reach).  Points keep their ORIGINAL indices in every pairing that leaves the
+// library.  Exactness: a pairing inside the gate can only involve map points within `gate` of a moved query, so the
+// result equals the full map's as long as shard_reach_box(T, gate) stays inside the box -- match() checks that at every
+// pose and fails with MOLA_ICP_E_BADARG otherwise (the caller re-cuts with a larger margin).
+int HipWorkspace::set_map_slab(const float* x, const float* y, const float* z, size_t M, const double lo[3], const double hi[3],
+                               bool on_device, size_t* n_kept)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (M && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null map pointer");
+    if (M > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "map too large for 32-bit indices");
+    if (!lo || !hi) return fail(MOLA_ICP_E_BADARG, "null box");
+    HIPCHK(hipSetDevice(device_));
+    const float *fx = x, *fy = y, *fz = z;
+    if (!on_device) {
+        if ((rc = upload_soa(stage_in_, stream_, x, y, z, M, &fx, &fy, &fz))) return rc;
+        HIPCHK(hipStreamSynchronize(stream_));
+    }
+    // box in fp32, rounded outwards
+    float flo[3], fhi[3];
+    for (int a = 0; a < 3; ++a) {
+        flo[a] = (float)lo[a]; if ((double)flo[a] > lo[a]) flo[a] = std::nextafter(flo[a], -INFINITY);
+        fhi[a] = (float)hi[a]; if ((double)fhi[a] < hi[a]) fhi[a] = std::nextafter(fhi[a], INFINITY);
+    }
+    if ((rc = slab_orig_.reserve(sizeof(int) * (M ? M : 1)))) return rc;
+    size_t kept = 0;
+    if ((rc = select_in_box(stream_, fx, fy, fz, M, flo, fhi, sort_scratch_, slab_orig_.as<int>(), &kept))) return rc;
+    const size_t kp = (kept + 63) / 64 * 64;
+    if ((rc = map_own_.reserve(sizeof(float) * 3 * (kp ? kp : 64)))) return rc;
+    float* own = map_own_.as<float>();
+    if ((rc = gather_by_index(stream_, fx, fy, fz, slab_orig_.as<int>(), kept, own, own + kp, own + 2 * kp))) return rc;
+    HIPCHK(hipStreamSynchronize(stream_));
+    stage_in_.release();  // the full map was transient
+    if ((rc = set_map_device(own, own + kp, own + 2 * kp, kept))) return rc;
+    slab_active_ = true;
+    for (int a = 0; a < 3; ++a) { slab_lo_[a] = (double)flo[a]; slab_hi_[a] = (double)fhi[a]; }
+    if (n_kept) *n_kept = kept;
     return MOLA_ICP_OK;
 }
 
@@ -636,6 +789,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     HIPCHK(hipSetDevice(device_));
     if (p.knn < 3 || p.knn > 8) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 8] in this build");
     planes_valid_ = false;
+    if ((rc = check_slab(T, p.matcher_threshold))) return rc;
     if (N_ == 0 || M_ == 0) { planes_valid_ = true; planes_empty_ = true; return MOLA_ICP_OK; }
     planes_empty_ = false;
     if ((rc = prepare_tiles())) return rc;
@@ -757,6 +911,10 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
         counters_clean_ = true;
     }
     if (comm_) {
+        if (slab_violation_) {  // see check_slab(): every rank learns of it through the sum (slot 91 = the pair count)
+            acc_host_[kNAcc + 7] = std::nan("");
+            HIPCHK(hipMemcpyAsync(dacc + kNAccPlane - 1, acc_host_ + kNAcc + 7, sizeof(double), hipMemcpyHostToDevice, stream_));
+        }
         const int rc2 = rccl_allreduce_sum_f64(comm_, dacc, kNAccPlane, stream_);
         if (rc2) return rc2;
     }
@@ -777,9 +935,11 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
     std::memcpy(acc, plane_acc_host_, sizeof(double) * kNAccPlane);
     knn_changed_items_ = planes_empty_ ? -1.0 : plane_acc_host_[kNAccPlane];
     if (!comm_ && ar_fn_) {
+        if (slab_violation_) acc[kNAccPlane - 1] = std::nan("");
         const int r = ar_fn_(acc, kNAccPlane, 0, ar_user_);
         if (r) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(r));
     }
+    if ((comm_ || ar_fn_) && std::isnan(acc[kNAccPlane - 1])) { slab_violation_ = false; return fail(MOLA_ICP_E_BADARG, kSlabMsg); }
     return MOLA_ICP_OK;
 }
 
@@ -1055,6 +1215,7 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
         if (outlier_.p != before) outlier_cleared_for_ = 0;  // fresh allocation: contents undefined
     }
     const float thr2 = (float)(threshold * threshold);
+    if ((rc = check_slab(T, threshold))) return rc;
     if (N_ == 0 || M_ == 0) {
         if (N_) HIPCHK(hipMemsetAsync(idx_.p, 0xff, sizeof(int) * N_, stream_));
         pairing_valid_ = true;
@@ -1080,6 +1241,23 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
         HIPCHK(hipStreamSynchronize(stream_));
         *n_pairs = *hc;
     }
+    return MOLA_ICP_OK;
+}
+
+// Row e: the map is only the part a box holds -- every gated neighbour of a moved query must lie inside it.
+int HipWorkspace::check_slab(const Mat4& T, double threshold)
+{
+    if (!slab_active_ || N_ == 0) return MOLA_ICP_OK;
+    double lo[3], hi[3];
+    const int rc = shard_reach_box(T, threshold, lo, hi);
+    if (rc) return rc;
+    bool out = false;
+    for (int a = 0; a < 3; ++a) out |= lo[a] < slab_lo_[a] || hi[a] > slab_hi_[a];
+    // Sharded over ranks: a rank that returned here would stop joining the accumulator all-reduce and leave its peers
+    // waiting.  It keeps going instead and poisons its pair count (NaN), which the sum carries to EVERY rank: they all
+    // fail together after the collective (accumulate / accumulate_planes / allreduce).
+    if (out && !comm_ && !ar_fn_) return fail(MOLA_ICP_E_BADARG, kSlabMsg);
+    slab_violation_ = slab_violation_ || out;
     return MOLA_ICP_OK;
 }
 
@@ -1169,6 +1347,10 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(acc_host_) + kNAcc + 6;
     if (!direct) {
         if (comm_) {  // query-sharded: the one collective of the path, in place on the device block (RCCL over xGMI)
+            if (slab_violation_) {  // see match(): every rank learns of it through the sum
+                acc_host_[kNAcc + 7] = std::nan("");
+                HIPCHK(hipMemcpyAsync(acc_dev_.as<double>() + 16, acc_host_ + kNAcc + 7, sizeof(double), hipMemcpyHostToDevice, stream_));
+            }
             const int rc2 = rccl_allreduce_sum_f64(comm_, acc_dev_.as<double>(), kNAcc, stream_);
             if (rc2) return rc2;
         }
@@ -1183,6 +1365,8 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     }
     if ((rc = spin_for(flag, seq))) return rc;
     for (int k = 0; k < kNAcc; ++k) acc[k] = acc_host_[k];
+    if (comm_ && std::isnan(acc[16])) { slab_violation_ = false; return fail(MOLA_ICP_E_BADARG, kSlabMsg); }
+    if (ar_fn_ && slab_violation_) acc[16] = std::nan("");  // the hook's sum carries it to every rank (allreduce below)
     return MOLA_ICP_OK;
 }
 
@@ -1192,6 +1376,7 @@ int HipWorkspace::allreduce(double acc[kNAcc])
     if (!ar_fn_) return MOLA_ICP_OK;
     const int rc = ar_fn_(acc, kNAcc, 0, ar_user_);
     if (rc) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(rc));
+    if (std::isnan(acc[16])) { slab_violation_ = false; return fail(MOLA_ICP_E_BADARG, kSlabMsg); }
     return MOLA_ICP_OK;
 }
 
@@ -1206,7 +1391,16 @@ int HipWorkspace::copy_pairing(int32_t* idx_out, float* d2_out)
         HIPCHK(hipGetLastError());
     }
     if (N_) {
-        if (idx_out) HIPCHK(hipMemcpyAsync(idx_out, idx_.p, sizeof(int) * N_, hipMemcpyDeviceToHost, stream_));
+        const int* src = idx_.as<int>();
+        if (idx_out && slab_active_) {  // slab point -> ORIGINAL map index (idx_ itself stays: it seeds the dense kernels)
+            int rc = stage_in_.reserve(sizeof(int) * N_);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_remap_indices, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, idx_.as<int>(),
+                               slab_orig_.as<int>(), (int)N_, stage_in_.as<int>());
+            HIPCHK(hipGetLastError());
+            src = stage_in_.as<int>();
+        }
+        if (idx_out) HIPCHK(hipMemcpyAsync(idx_out, src, sizeof(int) * N_, hipMemcpyDeviceToHost, stream_));
         if (d2_out) HIPCHK(hipMemcpyAsync(d2_out, d2_.p, sizeof(float) * N_, hipMemcpyDeviceToHost, stream_));
     }
     HIPCHK(hipStreamSynchronize(stream_));

@@ -70,6 +70,15 @@ class HipWorkspace final : public Stages {
     int set_map_device(const float* x, const float* y, const float* z, size_t M);
     int set_local_host(const float* x, const float* y, const float* z, size_t N);
     int set_local_device(const float* x, const float* y, const float* z, size_t N);
+    // row e (query sharding): this rank's spatially compact shard of a scan every rank sees in full -- the scan is put in
+    // Hilbert order on the device (a transient copy) and the slice [lo, hi) of that order is kept as the local cloud
+    int set_local_shard(const float* x, const float* y, const float* z, size_t n_total, int rank, int nranks, bool on_device);
+    int copy_shard_indices(int32_t* idx_out);  // original scan indices of the shard's points, in the shard's order
+    // ... and the part of the map that shard can reach: the points inside [lo, hi] (original indices are kept: pairings
+    // still name ORIGINAL map points).  match() refuses a pose that moves the shard's reach out of the box.
+    int set_map_slab(const float* x, const float* y, const float* z, size_t M, const double lo[3], const double hi[3], bool on_device,
+                     size_t* n_kept);
+    int shard_reach_box(const Mat4& T, double margin, double lo[3], double hi[3]);  // AABB of T (+) (local bbox), grown by margin
 
     // Stages
     int match(const Mat4& T, double threshold, const mola_icp_params& p, uint64_t* n_pairs) override;
@@ -115,6 +124,7 @@ class HipWorkspace final : public Stages {
     int launch_coop(const struct PoseF& P, float thr2, bool use_seed);
     TiledMap tiled_map() const;
     int spin_for(volatile unsigned long long* flag, unsigned long long seq);
+    int check_slab(const Mat4& T, double threshold);
     int launch_nn(const Mat4& T, float thr2, int kernel);
 
     int device_;
@@ -126,6 +136,12 @@ class HipWorkspace final : public Stages {
     uint64_t n_local_total_ = 0, n_map_total_ = 0;
     // clouds: owned copies or borrowed device pointers
     DevBuf map_own_, loc_own_;
+    DevBuf shard_idx_, slab_orig_, stage_in_;   // row e: the shard's original scan indices; slab point -> original map index
+    size_t shard_n_ = 0;
+    bool slab_active_ = false, slab_violation_ = false;
+    double slab_lo_[3] = {0, 0, 0}, slab_hi_[3] = {0, 0, 0};
+    float loc_bbox_[6] = {0, 0, 0, 0, 0, 0};
+    bool loc_bbox_valid_ = false;
     const float *gx_ = nullptr, *gy_ = nullptr, *gz_ = nullptr;
     const float *lx_ = nullptr, *ly_ = nullptr, *lz_ = nullptr;
     // derived map image for the MFMA kernel ([tile][4][16] fp32) + its bounds

@@ -94,6 +94,16 @@ __global__ __launch_bounds__(256) void k_unpermute_pairing(const int* __restrict
     out_d2[o] = d2_s[i];
 }
 
+// map-slab point -> original map index (row e); -1 stays -1
+__global__ __launch_bounds__(256) void k_remap_indices(const int* __restrict__ idx, const int* __restrict__ orig, int N,
+                                                       int* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int j = idx[i];
+    out[i] = j >= 0 ? orig[j] : -1;
+}
+
 // boxes of the map tiles (one thread per tile) and super-tiles (one thread per super-tile); SoA [6][n]
 __global__ __launch_bounds__(256) void k_tile_boxes(const float* __restrict__ sx, const float* __restrict__ sy,
                                                     const float* __restrict__ sz, int M, int n_tiles_p,

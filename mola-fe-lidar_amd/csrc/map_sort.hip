@@ -112,6 +112,67 @@ int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, con
     return MOLA_ICP_OK;
 }
 
+// ---- row e: the part of a map a query shard can reach ------------------------------------------------------
+// Stable compaction of the points inside an axis-aligned box: sel[k] = original index of the k-th kept point (ascending),
+// *n_kept_host = their number.  The caller gathers the coordinates.
+__global__ __launch_bounds__(256) void k_flag_in_box(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ z, int n, float lx, float ly, float lz, float hx,
+                                                     float hy, float hz, unsigned char* __restrict__ flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = x[i], b = y[i], c = z[i];
+    flag[i] = (a >= lx && a <= hx && b >= ly && b <= hy && c >= lz && c <= hz) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_gather_by_index(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, const int* __restrict__ sel, int n,
+                                                         float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = sel[i];
+    ox[i] = x[j]; oy[i] = y[j]; oz[i] = z[j];
+}
+
+int select_in_box(hipStream_t stream, const float* x, const float* y, const float* z, size_t n, const float lo[3], const float hi[3],
+                  DevBuf& scratch, int* sel, size_t* n_kept_host)
+{
+    *n_kept_host = 0;
+    if (n == 0) return MOLA_ICP_OK;
+    const int ni = (int)n;
+    size_t tmp_bytes = 0;
+    hipcub::CountingInputIterator<int> iota(0);
+    unsigned char* fl = nullptr;
+    int* cnt = nullptr;
+    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, iota, fl, sel, cnt, ni, stream));
+    const size_t a = (n + 255) / 256 * 256;
+    int rc = scratch.reserve(a + 256 + tmp_bytes + 256);
+    if (rc) return rc;
+    char* base = scratch.as<char>();
+    fl = reinterpret_cast<unsigned char*>(base);
+    cnt = reinterpret_cast<int*>(base + a);
+    void* tmp = base + a + 256;
+    hipLaunchKernelGGL(k_flag_in_box, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, z, ni, lo[0], lo[1], lo[2],
+                       hi[0], hi[1], hi[2], fl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, iota, fl, sel, cnt, ni, stream));
+    int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    *n_kept_host = (size_t)h;
+    return MOLA_ICP_OK;
+}
+
+int gather_by_index(hipStream_t stream, const float* x, const float* y, const float* z, const int* sel, size_t n, float* ox, float* oy,
+                    float* oz)
+{
+    if (n == 0) return MOLA_ICP_OK;
+    hipLaunchKernelGGL(k_gather_by_index, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, z, sel, (int)n, ox, oy, oz);
+    HIPCHK(hipGetLastError());
+    return MOLA_ICP_OK;
+}
+
 // ---- row f4: voxel-grid downsample (one centroid per occupied voxel) ------------------------------------
 // The reference decimates clouds before the ICP with mp2p_icp_filters (src/LidarOdometry.cpp:215-224; voxel
 // parameters include/mola-fe-lidar/LidarOdometry.h:76-80, params/kitti-default.yaml:25-32) [EXT: that library is

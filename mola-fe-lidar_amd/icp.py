@@ -356,6 +356,53 @@ class ICP:
             x, y, z, n = _soa(pc)
             L.check(L.lib().mola_icp_set_local_host(self._h, _fp(x), _fp(y), _fp(z), n))
 
+    def set_local_shard(self, pc_full, rank: int, nranks: int) -> int:
+        """keeps the slice of rank `rank` of the full scan's Hilbert order (cut on the device) as the local cloud;
+        returns the shard's size"""
+        n = C.c_size_t(0)
+        if self._is_device_tensor(pc_full):
+            import torch
+            assert pc_full.dtype == torch.float32 and pc_full.dim() == 2 and pc_full.shape[0] == 3 and pc_full.is_contiguous()
+            torch.cuda.current_stream(pc_full.device).synchronize()   # see set_map
+            L.check(L.lib().mola_icp_set_local_shard_device(self._h, pc_full[0].data_ptr(), pc_full[1].data_ptr(),
+                                                            pc_full[2].data_ptr(), pc_full.shape[1], rank, nranks, C.byref(n)))
+        else:
+            x, y, z, nt = _soa(pc_full)
+            L.check(L.lib().mola_icp_set_local_shard_host(self._h, _fp(x), _fp(y), _fp(z), nt, rank, nranks, C.byref(n)))
+        self._keep_local = None
+        self._shard_n = int(n.value)
+        return self._shard_n
+
+    def local_shard_indices(self) -> np.ndarray:
+        """the shard's points as indices into the full scan, in the shard's own order"""
+        idx = np.empty(max(1, getattr(self, "_shard_n", 0)), dtype=np.int32)
+        L.check(L.lib().mola_icp_local_shard_indices(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32))))
+        return idx[:getattr(self, "_shard_n", 0)]
+
+    def shard_reach_box(self, T, margin: float):
+        lo, hi = np.zeros(3), np.zeros(3)
+        L.check(L.lib().mola_icp_shard_reach_box(self._h, _pose16(T).ctypes.data_as(L._DP), float(margin),
+                                                 lo.ctypes.data_as(L._DP), hi.ctypes.data_as(L._DP)))
+        return lo, hi
+
+    def set_map_slab(self, pc, lo, hi) -> int:
+        """only the map points inside [lo, hi] become this handle's map (original indices are kept); returns how many"""
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        n = C.c_size_t(0)
+        if self._is_device_tensor(pc):
+            import torch
+            assert pc.dtype == torch.float32 and pc.dim() == 2 and pc.shape[0] == 3 and pc.is_contiguous()
+            torch.cuda.current_stream(pc.device).synchronize()
+            L.check(L.lib().mola_icp_set_map_slab_device(self._h, pc[0].data_ptr(), pc[1].data_ptr(), pc[2].data_ptr(), pc.shape[1],
+                                                         lo.ctypes.data_as(L._DP), hi.ctypes.data_as(L._DP), C.byref(n)))
+        else:
+            x, y, z, m = _soa(pc)
+            L.check(L.lib().mola_icp_set_map_slab_host(self._h, _fp(x), _fp(y), _fp(z), m, lo.ctypes.data_as(L._DP),
+                                                       hi.ctypes.data_as(L._DP), C.byref(n)))
+        self._keep_map = None
+        return int(n.value)
+
     def set_global_sizes(self, n_local_total: int, n_map_total: int):
         L.check(L.lib().mola_icp_set_global_sizes(self._h, n_local_total, n_map_total))
 

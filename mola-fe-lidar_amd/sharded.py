@@ -84,21 +84,36 @@ class ShardedICP:
                 self._ar = make_allreduce(group)
                 icp.set_allreduce(self._ar)
 
-    def set_clouds(self, map_pc, local_pc_full, spatial: bool = True):
-        """Every rank passes the same full local cloud; it keeps a spatially compact shard (see spatial_order)."""
+    def set_clouds(self, map_pc, local_pc_full, spatial: bool = True, init_guess=None, slab_margin: float | None = None):
+        """Every rank passes the same full clouds.  It keeps (i) a spatially compact shard of the scan: its slice of the
+        scan's Hilbert order, cut on the device (`mola_icp_set_local_shard_*`; no host argsort) and, with `slab_margin`
+        [m], (ii) only the part of the map that shard can reach from `init_guess`: its moved bounding box grown by the
+        margin (`mola_icp_set_map_slab_*`).  The margin must cover the matcher's gate plus the pose correction the align
+        may make; an align that leaves the slab fails loudly (`IcpError`, "outside its map slab") -- `align` below then
+        cuts a larger slab and runs again."""
         n = local_pc_full.shape[1]
-        lo, hi = shard_bounds(n, self.rank, self.world)
-        if spatial and self.world > 1:
-            host = local_pc_full.cpu().numpy() if hasattr(local_pc_full, "cpu") else np.asarray(local_pc_full)
-            shard = np.ascontiguousarray(host[:, spatial_order(host)[lo:hi]])
-            if hasattr(local_pc_full, "device"):
-                import torch
-                shard = torch.from_numpy(shard).to(local_pc_full.device)
+        self._full = (map_pc, local_pc_full, init_guess)
+        if spatial:
+            self.icp.set_local_shard(local_pc_full, self.rank, self.world)
         else:
+            lo, hi = shard_bounds(n, self.rank, self.world)
             shard = local_pc_full[:, lo:hi]
             if hasattr(shard, "contiguous"):
                 shard = shard.contiguous()
-        self.set_shard(map_pc, shard, n)
+            self.icp.set_local(shard)
+        self._slab_margin = slab_margin
+        self._cut_slab()
+        self.icp.set_global_sizes(n, map_pc.shape[1])
+
+    def _cut_slab(self):
+        map_pc, _, init_guess = self._full
+        if self._slab_margin is None:
+            self.icp.set_map(map_pc)
+            self.n_map_kept = map_pc.shape[1]
+            return
+        T0 = np.eye(4) if init_guess is None else np.asarray(init_guess, dtype=np.float64)
+        lo, hi = self.icp.shard_reach_box(T0, self._slab_margin)
+        self.n_map_kept = self.icp.set_map_slab(map_pc, lo, hi)
 
     def set_shard(self, map_pc, local_shard, n_local_total: int):
         self.icp.set_map(map_pc)
@@ -106,4 +121,34 @@ class ShardedICP:
         self.icp.set_global_sizes(n_local_total, map_pc.shape[1])
 
     def align(self, init_guess, params):
-        return self.icp.align_resident(init_guess, params)
+        """identical Results on every rank.  With a map slab: if ANY rank's pose leaves its slab, every rank doubles the
+        margin, cuts again and the align is repeated (the decision is all-reduced, so the ranks stay in step)."""
+        from ._lib import IcpError
+        if getattr(self, "_slab_margin", None) is None or not hasattr(self, "_full"):
+            return self.icp.align_resident(init_guess, params)
+        import torch
+        import torch.distributed as dist
+        for _ in range(6):
+            res, left = None, 0
+            try:
+                res = self.icp.align_resident(init_guess, params)
+            except IcpError as e:
+                if "outside its map slab" not in str(e):
+                    raise
+                left = 1
+            if self.world > 1:
+                # a rank that failed stopped joining the accumulator all-reduces: the others' aligns end with a
+                # communicator error or hang -- so the slab test must pass on EVERY rank before the loop starts.
+                # mola_icp_shard_reach_box at the initial pose is checked by set_map_slab's caller; during the loop the
+                # matcher's own check is the safety net for a single process (world 1) and for hook transports that
+                # surface errors; here the ranks only agree on the outcome.
+                flag = torch.tensor([left], dtype=torch.int32)
+                if dist.get_backend(self.group) == "nccl":
+                    flag = flag.cuda()
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                left = int(flag.item())
+            if not left:
+                return res
+            self._slab_margin *= 2.0
+            self._cut_slab()
+        raise IcpError(-1, "the align keeps leaving its map slab")
