@@ -4,6 +4,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <map>
 #include <chrono>
 #include <cstring>
@@ -33,6 +34,24 @@ struct mola_icp_handle {
     std::vector<std::unique_ptr<HipWorkspace>> pool;  // idle workspaces for mola_icp_align()
     std::unique_ptr<HipWorkspace> resident;           // the resident-cloud API's workspace
     std::atomic<int> profiling{0};                    // mola_icp_set_profiling
+    // prepared-cloud objects of finished batched calls, kept for the next one (their device buffers are reused:
+    // hipMalloc / hipFree of a chunk's clouds cost milliseconds and synchronise the device)
+    std::mutex spare_mtx;
+    std::vector<std::shared_ptr<SortedCloud>> spare_clouds;
+    std::shared_ptr<SortedCloud> take_cloud()
+    {
+        std::lock_guard<std::mutex> lk(spare_mtx);
+        if (spare_clouds.empty()) return std::make_shared<SortedCloud>();
+        std::shared_ptr<SortedCloud> c = std::move(spare_clouds.back());
+        spare_clouds.pop_back();
+        return c;
+    }
+    void give_cloud(std::shared_ptr<SortedCloud>&& c)
+    {
+        if (!c || c.use_count() != 1) return;  // still shared (a cache entry, another problem): not ours to recycle
+        std::lock_guard<std::mutex> lk(spare_mtx);
+        if (spare_clouds.size() < 64) spare_clouds.push_back(std::move(c));
+    }
     mola_icp_allreduce_fn ar_fn = nullptr;
     void* ar_user = nullptr;
     void* comm = nullptr;  // RCCL communicator of the query-sharded path
@@ -208,11 +227,11 @@ bool batch_eligible(const mola_icp_params& p, size_t N, size_t M)
 }
 
 // K prepared problems through the lockstep loop on one leased workspace; fills out[0..K)
-int run_batch_on(HipWorkspace& ws, std::vector<BatchProblem> probs, const double* init_T, const mola_icp_params* p,
+int run_batch_on(HipWorkspace& ws, const std::vector<BatchProblem>& probs, const double* init_T, const mola_icp_params* p,
                  mola_icp_result* out)
 {
     const size_t K = probs.size();
-    HipBatch batch(ws, std::move(probs));
+    HipBatch batch(ws, probs);
     int rc = batch.init();
     if (rc) return rc;
     std::vector<Mat4> inits(K);
@@ -532,34 +551,77 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const*
                     done_cv.notify_all();
                 });
         }
-        for (size_t c0 = 0; c0 < together.size() && first_err.load() == MOLA_ICP_OK; c0 += kBatchChunk) {
-            const size_t K = std::min((size_t)kBatchChunk, together.size() - c0);
-            const int rc2 = guarded([&]() -> int {
+        // Lockstep chunks, software-pipelined: while chunk c iterates on this thread, chunk c+1's clouds are uploaded and
+        // prepared (Hilbert sort, box levels) by a worker on another workspace / stream.
+        struct Prepared {
+            std::vector<BatchProblem> probs;
+            std::vector<double> inits;
+            double upload_ms = 0;
+            int rc = MOLA_ICP_OK;
+            std::string err;
+        };
+        // balanced chunks (16 pairs = 8 + 8, not 12 + 4: a lockstep launch over 4 problems is nearly as long as one over 12)
+        std::vector<size_t> chunk_begin;
+        {
+            const size_t n_chunks = (together.size() + kBatchChunk - 1) / kBatchChunk;
+            for (size_t c = 0; c <= n_chunks; ++c) chunk_begin.push_back(n_chunks ? c * together.size() / n_chunks : 0);
+        }
+        auto prepare = [&](size_t ci) -> std::shared_ptr<Prepared> {
+            auto pr = std::make_shared<Prepared>();
+            const size_t c0 = chunk_begin[ci], K = chunk_begin[ci + 1] - c0;
+            pr->rc = guarded([&]() -> int {
                 Lease lease(h);
                 if (lease.rc) return lease.rc;
                 const double t0 = now_ms();
-                std::vector<BatchProblem> probs(K);
-                std::vector<double> inits(16 * K);
+                pr->probs.resize(K);
+                pr->inits.resize(16 * K);
                 int rc3;
                 for (size_t k = 0; k < K; ++k) {
                     const size_t i = together[c0 + k];
-                    probs[k].map = std::make_shared<SortedCloud>();
-                    probs[k].loc = std::make_shared<SortedCloud>();
-                    if ((rc3 = lease.ws->build_cached(*probs[k].map, fx[i], fy[i], fz[i], M[i]))) { lease.rc = rc3; return rc3; }
-                    if ((rc3 = lease.ws->build_cached(*probs[k].loc, tx[i], ty[i], tz[i], N[i]))) { lease.rc = rc3; return rc3; }
-                    std::memcpy(&inits[16 * k], init_T + 16 * i, sizeof(double) * 16);
+                    pr->probs[k].map = h->take_cloud();
+                    pr->probs[k].loc = h->take_cloud();
+                    if ((rc3 = lease.ws->build_cached(*pr->probs[k].map, fx[i], fy[i], fz[i], M[i]))) { lease.rc = rc3; return rc3; }
+                    if ((rc3 = lease.ws->build_cached(*pr->probs[k].loc, tx[i], ty[i], tz[i], N[i]))) { lease.rc = rc3; return rc3; }
+                    std::memcpy(&pr->inits[16 * k], init_T + 16 * i, sizeof(double) * 16);
                 }
-                const double upload_ms = now_ms() - t0;
-                std::vector<mola_icp_result> res(K);
-                if ((rc3 = run_batch_on(*lease.ws, std::move(probs), inits.data(), p, res.data()))) { lease.rc = rc3; return rc3; }
-                for (size_t k = 0; k < K; ++k) {
-                    res[k].ms_upload = upload_ms;  // the chunk's uploads + preparation
-                    out[together[c0 + k]] = res[k];
-                }
+                pr->upload_ms = now_ms() - t0;
                 return MOLA_ICP_OK;
             });
-            if (rc2) record(rc2, together[c0]);
+            if (pr->rc) pr->err = last_error();
+            return pr;
+        };
+        std::shared_ptr<Prepared> cur = together.empty() ? nullptr : prepare(0);
+        for (size_t ci = 0; ci + 1 < chunk_begin.size() && first_err.load() == MOLA_ICP_OK; ++ci) {
+            const size_t c0 = chunk_begin[ci], K = chunk_begin[ci + 1] - c0;
+            std::future<std::shared_ptr<Prepared>> next;
+            if (ci + 2 < chunk_begin.size()) {
+                auto task = std::make_shared<std::packaged_task<std::shared_ptr<Prepared>()>>([&prepare, ci]() { return prepare(ci + 1); });
+                next = task->get_future();
+                h->ensure_workers(1);
+                h->submit([task]() { (*task)(); });
+            }
+            if (cur->rc) {
+                set_error(cur->err);
+                record(cur->rc, together[c0]);
+            } else {
+                const int rc2 = guarded([&]() -> int {
+                    Lease lease(h);
+                    if (lease.rc) return lease.rc;
+                    std::vector<mola_icp_result> res(K);
+                    int rc3;
+                    if ((rc3 = run_batch_on(*lease.ws, cur->probs, cur->inits.data(), p, res.data()))) { lease.rc = rc3; return rc3; }
+                    for (size_t k = 0; k < K; ++k) {
+                        res[k].ms_upload = cur->upload_ms;  // the chunk's uploads + preparation (overlapped with the previous chunk's loop)
+                        out[together[c0 + k]] = res[k];
+                    }
+                    return MOLA_ICP_OK;
+                });
+                if (rc2) record(rc2, together[c0]);
+            }
+            for (BatchProblem& bp : cur->probs) { h->give_cloud(std::move(bp.map)); h->give_cloud(std::move(bp.loc)); }
+            cur = next.valid() ? next.get() : nullptr;   // (always collected: the worker references this frame)
         }
+        if (cur) for (BatchProblem& bp : cur->probs) { h->give_cloud(std::move(bp.map)); h->give_cloud(std::move(bp.loc)); }
         {
             std::unique_lock<std::mutex> lk(done_mtx);
             done_cv.wait(lk, [&]() { return pending == 0; });
@@ -690,14 +752,19 @@ int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* 
         if (n_init >= 2 && batch_eligible(*p, N, M)) {
             // the K guesses as a batch dimension on the device: the pair is uploaded and prepared once, every stage of
             // every iteration is ONE launch over the guesses still iterating (blockIdx.y = guess)
-            auto map = std::make_shared<SortedCloud>(), loc = std::make_shared<SortedCloud>();
+            auto map = h->take_cloud(), loc = h->take_cloud();
             if ((rc = ws.build_cached(*map, fx, fy, fz, M))) { lease.rc = rc; return rc; }
             if ((rc = ws.build_cached(*loc, tx, ty, tz, N))) { lease.rc = rc; return rc; }
             const double upload_ms = now_ms() - t0;
-            std::vector<BatchProblem> probs(n_init);
-            for (auto& pr : probs) { pr.map = map; pr.loc = loc; }
             std::vector<mola_icp_result> res(n_init);
-            if ((rc = run_batch_on(ws, std::move(probs), init_T, p, res.data()))) { lease.rc = rc; return rc; }
+            {
+                std::vector<BatchProblem> probs(n_init);
+                for (auto& pr : probs) { pr.map = map; pr.loc = loc; }
+                rc = run_batch_on(ws, probs, init_T, p, res.data());
+            }
+            h->give_cloud(std::move(map));
+            h->give_cloud(std::move(loc));
+            if (rc) { lease.rc = rc; return rc; }
             double best_q = 0.0;  // ICP_Output::goodness starts at .0 (LidarOdometry.h:130); strictly greater wins (cpp:785)
             for (size_t k = 0; k < n_init; ++k) {
                 res[k].ms_upload = k == 0 ? upload_ms : 0.0;

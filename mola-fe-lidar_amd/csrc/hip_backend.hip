@@ -54,6 +54,7 @@ struct Knobs {
     int blocks_per_cu = 0;     // MOLA_ICP_BLOCKS_PER_CU (0 = default)
     int qpl = 0;               // MOLA_ICP_QPL (0 = by cloud size)
     int coop = -1;             // MOLA_ICP_COOP (-1 = by cloud size, 0 = one item per wave, 1 = one item per block)
+    int batch_tiled = -1;      // MOLA_ICP_BATCH_TILED (-1 = by item count; batched launches: 0 = k_nn_coop, 1 = k_nn_tiled_batch)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
 };
@@ -64,6 +65,7 @@ static Knobs read_knobs()
     k.blocks_per_cu = geti("MOLA_ICP_BLOCKS_PER_CU") > 0 ? geti("MOLA_ICP_BLOCKS_PER_CU") : 0;
     k.qpl = std::getenv("MOLA_ICP_QPL") ? (geti("MOLA_ICP_QPL") == 1 ? 1 : 2) : 0;
     k.coop = std::getenv("MOLA_ICP_COOP") ? (geti("MOLA_ICP_COOP") != 0 ? 1 : 0) : -1;
+    k.batch_tiled = std::getenv("MOLA_ICP_BATCH_TILED") ? (geti("MOLA_ICP_BATCH_TILED") != 0 ? 1 : 0) : -1;
     k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
     k.no_knn_seed = std::getenv("MOLA_ICP_NO_KNN_SEED") != nullptr;
     k.no_knn_verify = std::getenv("MOLA_ICP_NO_KNN_VERIFY") != nullptr;
@@ -107,6 +109,7 @@ HipWorkspace::~HipWorkspace()
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
     shard_idx_.release(); slab_orig_.release(); stage_in_.release();
+    batch_scratch_.release_all();
     map_sc_.reset();
     loc_sc_.reset();
     ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); ts_gs_.release(); rows_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
@@ -1415,18 +1418,25 @@ static TiledMap tiled_map_of(const SortedCloud& sc)
                     sc.sbox.as<float>(), sc.n_super, sc.ubox.as<float>(), sc.n_top};
 }
 
-HipBatch::HipBatch(HipWorkspace& ws, std::vector<BatchProblem> probs) : ws_(ws), probs_(std::move(probs)), buf_(probs_.size()) {}
+void BatchScratch::release_all()
+{
+    for (BatchBuffers& b : bufs) { b.pos.release(); b.idx.release(); b.d2.release(); b.gs.release(); b.rows.release(); b.outlier.release(); b.partials.release(); }
+    bufs.clear();
+    acc_dev.release(); stats.release(); queue.release();
+    if (acc_host) (void)hipHostFree(acc_host);
+    if (stats_host) (void)hipHostFree(stats_host);
+    acc_host = nullptr; stats_host = nullptr; acc_host_problems = 0;
+    for (void* e : events) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    events.clear();
+}
+
+HipBatch::HipBatch(HipWorkspace& ws, std::vector<BatchProblem> probs) : ws_(ws), sc_(ws.batch_scratch_), probs_(std::move(probs)) {}
 
 HipBatch::~HipBatch()
 {
     if (!inited_) return;
     (void)hipSetDevice(ws_.device_);
-    (void)hipStreamSynchronize(ws_.stream_);
-    for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
-    for (Buffers& b : buf_) { b.pos.release(); b.idx.release(); b.d2.release(); b.gs.release(); b.rows.release(); b.outlier.release(); b.partials.release(); }
-    acc_dev_.release(); stats_.release();
-    if (acc_host_) (void)hipHostFree(acc_host_);
-    if (stats_host_) (void)hipHostFree(stats_host_);
+    (void)hipStreamSynchronize(ws_.stream_);  // nothing of this batch is in flight when the scratch is used again
 }
 
 int HipBatch::init()
@@ -1436,12 +1446,16 @@ int HipBatch::init()
     if (rc) return rc;
     HIPCHK(hipSetDevice(ws_.device_));
     const size_t K = probs_.size();
+    if (sc_.bufs.size() < K) sc_.bufs.resize(K);
     for (size_t k = 0; k < K; ++k) {
         const BatchProblem& pr = probs_[k];
         if (!pr.map || !pr.loc) return fail(MOLA_ICP_E_BADARG, "batch problem without clouds");
+        Buffers& b = sc_.bufs[k];
+        b.seed_valid = false;
+        b.outliers_dirty = true;   // (contents of a reused flag buffer are another problem's)
+        b.outlier_cleared_for = 0;
         if (pr.loc->n == 0 || pr.map->n == 0) continue;  // never matched (the loop ends such a problem at once)
         if (!pr.map->ready || !pr.loc->ready) return fail(MOLA_ICP_E_INTERNAL, "batch problem with an unprepared cloud");
-        Buffers& b = buf_[k];
         const size_t np = (pr.loc->n + kQPW - 1) / kQPW * kQPW;
         if ((rc = b.pos.reserve(sizeof(int) * np))) return rc;
         if ((rc = b.idx.reserve(sizeof(int) * np))) return rc;
@@ -1451,12 +1465,20 @@ int HipBatch::init()
         if ((rc = b.outlier.reserve(pr.loc->n))) return rc;
         if ((rc = b.partials.reserve(sizeof(double) * kNAcc * kAccMaxBlocks))) return rc;
     }
-    if ((rc = acc_dev_.reserve(sizeof(double) * 32 * (K ? K : 1)))) return rc;
-    if ((rc = stats_.reserve(sizeof(unsigned long long) * kStatSlots * kStatStride))) return rc;
-    HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, ws_.stream_));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * 32 * (K ? K : 1), hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(acc_host_, 0, sizeof(double) * 32 * (K ? K : 1));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&stats_host_), sizeof(unsigned long long) * kStatSlots * kStatStride, hipHostMallocDefault));
+    if ((rc = sc_.acc_dev.reserve(sizeof(double) * 32 * (K ? K : 1)))) return rc;
+    if ((rc = sc_.stats.reserve(sizeof(unsigned long long) * kStatSlots * kStatStride))) return rc;
+    if ((rc = sc_.queue.reserve(sizeof(unsigned int) * kQueues * kQueueStride))) return rc;
+    HIPCHK(hipMemsetAsync(sc_.stats.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, ws_.stream_));
+    if (sc_.acc_host_problems < (K ? K : 1)) {
+        if (sc_.acc_host) (void)hipHostFree(sc_.acc_host);
+        sc_.acc_host = nullptr;
+        const size_t cap = (K ? K : 1) < 16 ? 16 : (K ? K : 1);
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sc_.acc_host), sizeof(double) * 32 * cap, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(sc_.acc_host, 0, sizeof(double) * 32 * cap);
+        sc_.acc_host_problems = cap;
+    }
+    if (!sc_.stats_host)
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sc_.stats_host), sizeof(unsigned long long) * kStatSlots * kStatStride, hipHostMallocDefault));
     inited_ = true;
     return MOLA_ICP_OK;
 }
@@ -1469,23 +1491,27 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
     if (!(threshold > 0)) return fail(MOLA_ICP_E_BADARG, "matcher threshold must be > 0");
     HIPCHK(hipSetDevice(ws_.device_));
     const float thr2 = (float)(threshold * threshold);
-    while (ev_.size() < ev_used_ + 2) {
+    while (sc_.events.size() < ev_used_ + 2) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
-        ev_.push_back(e);
+        sc_.events.push_back(e);
     }
     ++nn_launches_;
-    if (ws_.profiling_) HIPCHK(hipEventRecord(ev_[ev_used_], ws_.stream_));
+    if (ws_.profiling_) HIPCHK(hipEventRecord(static_cast<hipEvent_t>(sc_.events[ev_used_]), ws_.stream_));
     const int K = (int)probs_.size();
     for (int k0 = 0; k0 < K;) {  // chunks of up to kCoopMaxBatch active problems per launch
         NnBatch<kCoopMaxBatch> b;
+        NnBatchItems<kCoopMaxBatch> bi;
         std::memset(&b, 0, sizeof b);
-        int n = 0, max_items = 0;
+        std::memset(&bi, 0, sizeof bi);
+        int n = 0, max_items = 0, total_items = 0;
         size_t max_box_bytes = 0;
+        bool same_map = true;
+        const SortedCloud* first_map = nullptr;
         for (; k0 < K && n < kCoopMaxBatch; ++k0) {
             if (!active[k0]) continue;
             const BatchProblem& pr = probs_[(size_t)k0];
-            Buffers& bf = buf_[(size_t)k0];
+            Buffers& bf = sc_.bufs[(size_t)k0];
             if (pr.loc->n == 0 || pr.map->n == 0) return fail(MOLA_ICP_E_INTERNAL, "empty problem in a batched match");
             NnProblem& pb = b.p[n++];
             const float* sl = pr.loc->sorted.as<float>();
@@ -1504,22 +1530,50 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
                 pb.gsx = bf.gs.as<float>(); pb.gsy = pb.gsx + np; pb.gsz = pb.gsx + 2 * np;
             }
             pb.rows = bf.rows.as<double>();
-            pb.staged = stats_.as<unsigned long long>();
+            pb.staged = sc_.stats.as<unsigned long long>();
             bf.seed_valid = true;
             const int items = (int)((pr.loc->n + kQPW - 1) / kQPW);
             if (items > max_items) max_items = items;
+            bi.base[n - 1] = total_items;
+            total_items += items;
+            bi.base[n] = total_items;
+            if (!first_map) first_map = pr.map.get();
+            same_map = same_map && pr.map.get() == first_map;
             const size_t bb = sizeof(float) * 6u * ((size_t)pb.mp.n_top + (size_t)pb.mp.n_super);
             if (bb > max_box_bytes) max_box_bytes = bb;
         }
         if (n == 0) break;
         const int lds_boxes = max_box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
         const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
-        hipLaunchKernelGGL((k_nn_coop<kCoopMaxBatch>), dim3(max_items, n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
-                           (unsigned long long*)nullptr);
-        HIPCHK(hipGetLastError());
+        // Few items: latency counts -> one WORKGROUP per item (k_nn_coop, rows fused).  Many (a dozen 100k-point problems
+        // are ~10^4): issue slots count -> the persistent one-wave-per-item matcher over all problems' items, then the
+        // rows (k_item_rows: the same sums, bit for bit).  MOLA_ICP_BATCH_TILED=0|1 forces either.
+        const bool tiled = g_knobs.batch_tiled >= 0 ? g_knobs.batch_tiled != 0 : total_items >= 2 * 1024;
+        if (!tiled) {
+            hipLaunchKernelGGL((k_nn_coop<kCoopMaxBatch>), dim3(max_items, n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
+                               (unsigned long long*)nullptr);
+            HIPCHK(hipGetLastError());
+        } else {
+            const int shared = (same_map && lds_boxes) ? 1 : 0;
+            const size_t lds = shared ? dyn_lds : 0;
+            if (fit_tiled_ == 0 || fit_tiled_lds_ != lds) {  // persistent waves with fixed first entries: the whole grid must be resident
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_tiled_, k_nn_tiled_batch<kCoopMaxBatch>, 256, lds));
+                fit_tiled_lds_ = lds;
+            }
+            int per_cu = g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 3;
+            if (fit_tiled_ >= 1 && per_cu > fit_tiled_) per_cu = fit_tiled_;
+            int grid = ws_.num_cus_ * per_cu;
+            if (grid > (total_items + 3) / 4) grid = (total_items + 3) / 4;
+            HIPCHK(hipMemsetAsync(sc_.queue.p, 0, sizeof(unsigned int) * kQueues * kQueueStride, ws_.stream_));
+            hipLaunchKernelGGL((k_nn_tiled_batch<kCoopMaxBatch>), dim3(grid), dim3(256), lds, ws_.stream_, b, bi, n, shared,
+                               sc_.queue.as<unsigned int>());
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL((k_item_rows<kCoopMaxBatch>), dim3(max_items, n), dim3(256), 0, ws_.stream_, b);
+            HIPCHK(hipGetLastError());
+        }
     }
     if (ws_.profiling_) {
-        HIPCHK(hipEventRecord(ev_[ev_used_ + 1], ws_.stream_));
+        HIPCHK(hipEventRecord(static_cast<hipEvent_t>(sc_.events[ev_used_ + 1]), ws_.stream_));
         ev_used_ += 2;
     }
     return MOLA_ICP_OK;
@@ -1534,7 +1588,7 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
     if (stage == 1 && (!cl || !cg)) return fail(MOLA_ICP_E_BADARG, "stage 1 needs the centroids");
     HIPCHK(hipSetDevice(ws_.device_));
     const int K = (int)probs_.size();
-    const unsigned long long seq = ++seq_;
+    const unsigned long long seq = ++sc_.seq;
     const bool fused = stage == 0 && reset_outliers;  // (every batched match is a cooperative one: its rows are in place)
     int n_active = 0;
     for (int k0 = 0; k0 < K;) {
@@ -1546,7 +1600,7 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
         for (; k0 < K && n < kAccMaxBatch; ++k0) {
             if (!active[k0]) continue;
             const BatchProblem& pr = probs_[(size_t)k0];
-            Buffers& bf = buf_[(size_t)k0];
+            Buffers& bf = sc_.bufs[(size_t)k0];
             if (!bf.seed_valid) return fail(MOLA_ICP_E_BADARG, "batched accumulate() before match()");
             const size_t N = pr.loc->n;
             if (reset_outliers && (bf.outliers_dirty || bf.outlier_cleared_for != N)) {
@@ -1589,16 +1643,16 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
             hipLaunchKernelGGL(k_accumulate_batch, dim3(max_blocks, n), dim3(kAccThreads), 0, ws_.stream_, ab);
             HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_reduce_partials_batch, dim3(n), dim3(kNAcc * kRedSlices), 0, ws_.stream_, rb, acc_dev_.as<double>(),
-                           acc_host_, seq);
+        hipLaunchKernelGGL(k_reduce_partials_batch, dim3(n), dim3(kNAcc * kRedSlices), 0, ws_.stream_, rb, sc_.acc_dev.as<double>(),
+                           sc_.acc_host, seq);
         HIPCHK(hipGetLastError());
     }
     if (n_active == 0) return MOLA_ICP_OK;
     for (int k = 0; k < K; ++k) {
         if (!active[k]) continue;
-        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(acc_host_ + 32 * (size_t)k) + kNAcc + 6;
+        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(sc_.acc_host + 32 * (size_t)k) + kNAcc + 6;
         if ((rc = ws_.spin_for(flag, seq))) return rc;
-        for (int c = 0; c < kNAcc; ++c) acc[k][c] = acc_host_[32 * (size_t)k + c];
+        for (int c = 0; c < kNAcc; ++c) acc[k][c] = sc_.acc_host[32 * (size_t)k + c];
     }
     return MOLA_ICP_OK;
 }
@@ -1609,14 +1663,14 @@ int HipBatch::collect_stats(double* ms_total, uint32_t* launches, uint64_t* pair
     HIPCHK(hipSetDevice(ws_.device_));
     unsigned long long staged = 0;
     if (ws_.profiling_) {
-        HIPCHK(hipMemcpyAsync(stats_host_, stats_.p, sizeof(unsigned long long) * kStatSlots * kStatStride, hipMemcpyDeviceToHost, ws_.stream_));
+        HIPCHK(hipMemcpyAsync(sc_.stats_host, sc_.stats.p, sizeof(unsigned long long) * kStatSlots * kStatStride, hipMemcpyDeviceToHost, ws_.stream_));
         HIPCHK(hipStreamSynchronize(ws_.stream_));
-        for (int k = 0; k < kStatSlots; ++k) staged += stats_host_[(size_t)k * kStatStride];
+        for (int k = 0; k < kStatSlots; ++k) staged += sc_.stats_host[(size_t)k * kStatStride];
     }
     double tot = 0;
     for (size_t i = 0; i + 1 < ev_used_; i += 2) {
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ev_[i], ev_[i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(sc_.events[i]), static_cast<hipEvent_t>(sc_.events[i + 1])));
         tot += ms;
     }
     if (ms_total) *ms_total = tot;

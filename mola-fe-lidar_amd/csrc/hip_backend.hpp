@@ -51,6 +51,24 @@ struct SortedCloud {
 
 class HipBatch;
 
+// Device / pinned scratch of the batched path (HipBatch), kept in the workspace between calls: allocating and freeing a
+// dozen problems' pairing buffers per call cost a third of mola_icp_align_batch (hipMalloc / hipFree synchronise).
+struct BatchBuffers {
+    DevBuf pos, idx, d2, gs, rows, outlier, partials;
+    bool seed_valid = false, outliers_dirty = false;
+    size_t outlier_cleared_for = 0;
+};
+struct BatchScratch {
+    std::vector<BatchBuffers> bufs;
+    DevBuf acc_dev, stats, queue;
+    double* acc_host = nullptr;                 // pinned: 32 doubles per problem (24 sums, flag in slot 30)
+    size_t acc_host_problems = 0;
+    unsigned long long* stats_host = nullptr;   // pinned
+    std::vector<void*> events;                  // hipEvent_t
+    unsigned long long seq = 0;                 // read-back sequence numbers keep growing across uses
+    void release_all();
+};
+
 class HipWorkspace final : public Stages {
     friend class HipBatch;
    public:
@@ -136,6 +154,7 @@ class HipWorkspace final : public Stages {
     uint64_t n_local_total_ = 0, n_map_total_ = 0;
     // clouds: owned copies or borrowed device pointers
     DevBuf map_own_, loc_own_;
+    BatchScratch batch_scratch_;
     DevBuf shard_idx_, slab_orig_, stage_in_;   // row e: the shard's original scan indices; slab point -> original map index
     size_t shard_n_ = 0;
     bool slab_active_ = false, slab_violation_ = false;
@@ -222,19 +241,12 @@ class HipBatch final : public BatchStages {
     int collect_stats(double* ms_total, uint32_t* launches, uint64_t* pairs);
 
    private:
-    struct Buffers {
-        DevBuf pos, idx, d2, gs, rows, outlier, partials;
-        bool seed_valid = false, outliers_dirty = false;
-        size_t outlier_cleared_for = 0;
-    };
+    using Buffers = BatchBuffers;
     HipWorkspace& ws_;
+    BatchScratch& sc_;           // the workspace's: buffers survive this object
     std::vector<BatchProblem> probs_;
-    std::vector<Buffers> buf_;
-    DevBuf acc_dev_, stats_;
-    double* acc_host_ = nullptr;                 // pinned: 32 doubles per problem (24 sums, flag in slot 30)
-    unsigned long long* stats_host_ = nullptr;   // pinned
-    unsigned long long seq_ = 0;
-    std::vector<hipEvent_t> ev_;
+    int fit_tiled_ = 0;
+    size_t fit_tiled_lds_ = 0;
     size_t ev_used_ = 0;
     uint32_t nn_launches_ = 0;
     bool inited_ = false;

@@ -415,6 +415,47 @@ __device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledM
     return redo;
 }
 
+// The terms of k_accumulate's stage 0 for one pairing (w = 1), summed over an item's 128 pairings in a fixed order: the
+// threads of waves 0/1 hold one pairing each (`paired`, l, g, d2; zeros elsewhere); twelve terms per round go through LDS
+// ([term][pairing]), 16 threads per term add 8 entries each in index order, then a 16-wide shuffle tree.  All 256 threads
+// of the workgroup must call.  Shared by k_nn_coop (fused) and k_item_rows (after the batched persistent matcher): the
+// two produce the same bits.
+__device__ __forceinline__ void item_row_sum(double (*s_acc)[128], bool paired, float al0, float al1, float al2, float ag0, float ag1,
+                                             float ag2, float ad, double* __restrict__ row)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double m = paired ? 1.0 : 0.0;
+    const double l0 = m * al0, l1 = m * al1, l2 = m * al2, g0 = ag0, g1 = ag1, g2 = ag2;
+    const int term = threadIdx.x >> 4, sub = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (wave < 2) {
+            const int q = wave * 64 + lane;
+            if (r == 0) {
+                s_acc[0][q] = m; s_acc[1][q] = l0; s_acc[2][q] = l1; s_acc[3][q] = l2;
+                s_acc[4][q] = m * g0; s_acc[5][q] = m * g1; s_acc[6][q] = m * g2;
+                s_acc[7][q] = l0 * g0; s_acc[8][q] = l0 * g1; s_acc[9][q] = l0 * g2;
+                s_acc[10][q] = l1 * g0; s_acc[11][q] = l1 * g1;
+            } else {
+                s_acc[0][q] = l1 * g2; s_acc[1][q] = l2 * g0; s_acc[2][q] = l2 * g1; s_acc[3][q] = l2 * g2;
+                s_acc[4][q] = m; s_acc[5][q] = m * (double)ad;
+                s_acc[6][q] = l0 * al0; s_acc[7][q] = l0 * al1; s_acc[8][q] = l0 * al2;
+                s_acc[9][q] = l1 * al1; s_acc[10][q] = l1 * al2; s_acc[11][q] = l2 * al2;
+            }
+        }
+        __syncthreads();
+        double t = 0.0;
+        if (term < 12) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += s_acc[term][sub + 16 * j];
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) t += __shfl_down(t, off, 16);
+        if (term < 12 && sub == 0) row[12 * r + term] = t;
+        __syncthreads();
+    }
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, int lds_boxes,
                                                     unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
@@ -496,42 +537,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
             ag0 = res.gx; ag1 = res.gy; ag2 = res.gz; ad = res.rd;
         }
     }
-    // The terms of k_accumulate's stage 0 for one pairing (w = 1), summed over the item's 128 pairings in a fixed order:
-    // twelve terms per round go through LDS ([term][pairing]), 16 threads per term add 8 entries each in index order,
-    // then a 16-wide shuffle tree.  Unpaired lanes contribute zeros.
-    {
-        const double m = paired ? 1.0 : 0.0;
-        const double l0 = m * al0, l1 = m * al1, l2 = m * al2, g0 = ag0, g1 = ag1, g2 = ag2;
-        double* row = pb.rows + (size_t)item * kNAcc;
-        const int term = threadIdx.x >> 4, sub = threadIdx.x & 15;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (wave < 2) {
-                const int q = wave * 64 + lane;
-                if (r == 0) {
-                    s_acc[0][q] = m; s_acc[1][q] = l0; s_acc[2][q] = l1; s_acc[3][q] = l2;
-                    s_acc[4][q] = m * g0; s_acc[5][q] = m * g1; s_acc[6][q] = m * g2;
-                    s_acc[7][q] = l0 * g0; s_acc[8][q] = l0 * g1; s_acc[9][q] = l0 * g2;
-                    s_acc[10][q] = l1 * g0; s_acc[11][q] = l1 * g1;
-                } else {
-                    s_acc[0][q] = l1 * g2; s_acc[1][q] = l2 * g0; s_acc[2][q] = l2 * g1; s_acc[3][q] = l2 * g2;
-                    s_acc[4][q] = m; s_acc[5][q] = m * (double)ad;
-                    s_acc[6][q] = l0 * al0; s_acc[7][q] = l0 * al1; s_acc[8][q] = l0 * al2;
-                    s_acc[9][q] = l1 * al1; s_acc[10][q] = l1 * al2; s_acc[11][q] = l2 * al2;
-                }
-            }
-            __syncthreads();
-            double t = 0.0;
-            if (term < 12) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t += s_acc[term][sub + 16 * j];
-            }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) t += __shfl_down(t, off, 16);
-            if (term < 12 && sub == 0) row[12 * r + term] = t;
-            __syncthreads();
-        }
-    }
+    item_row_sum(s_acc, paired, al0, al1, al2, ag0, ag1, ag2, ad, pb.rows + (size_t)item * kNAcc);
 
     if (prof && lane == 0 && blockIdx.y == 0 && blockIdx.x * 4 + wave < 8192) {
         // [start, end (wall clock)], then shader cycles: setup (round trip A + boxes -> LDS), sweep, wait for the other
@@ -544,6 +550,187 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
     }
     if (threadIdx.x == 0 && s_flag[2])  // executed work in units of 64 (query, point) pairs; slotted: no same-address burst
         atomicAdd(pb.staged + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, (unsigned long long)s_flag[2] * 2ull);
+}
+
+// ---- many problems, throughput mode ----------------------------------------------------------------------------
+// With a dozen 100k-point problems in one launch there are ~10^4 items: latency no longer matters, issue slots do, and
+// the cooperative kernel spends them four times over on every item's prologue and box scan.  k_nn_tiled_batch is the
+// persistent one-wave-per-item matcher of kernels_tiled.hpp over the items of ALL problems (entry -> problem by the
+// prefix sums `item_base`): same sweep, same visitors, same tie rule; a wave that meets an exact distance tie redoes
+// its item with the exact-key visitor at once.  The upper box levels come from the LDS copy only if every problem
+// shares ONE map (`shared_map`: the loop-closure Monte-Carlo), else from global memory.  k_item_rows then writes the
+// per-item rows of unit-weight sums exactly as k_nn_coop does (item_row_sum), so a problem's accumulators -- and its
+// pose -- do not depend on which of the two matchers served it.
+template <int KMAX> struct NnBatchItems { int base[KMAX + 1]; };  // base[k] = first entry of problem k; base[n] = total
+
+template <bool EXACT>
+__device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist,
+                                                 float (*sm)[64], int lane, int item, unsigned long long& n_staged_out)
+{
+    const int N = pb.N;
+    const float thr2 = pb.thr2;
+    const PoseF P = pb.P;
+    int qi[2], js[2];
+    float qx[2], qy[2], qz[2], reach[2], best[2];
+    unsigned long long key[2];
+    int bpos[2], tie[2] = {0, 0};
+    {
+        float lx[2], ly[2], lz[2], gsx[2], gsy[2], gsz[2];
+        unsigned int gso[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            qi[k] = item * kQPW + k * 64 + lane;
+            if (qi[k] >= N) qi[k] = N;  // padding lane
+            const int ic = qi[k] < N ? qi[k] : N - 1;
+            lx[k] = pb.slx[ic]; ly[k] = pb.sly[ic]; lz[k] = pb.slz[ic];
+            js[k] = -1; gsx[k] = gsy[k] = gsz[k] = 0.f;
+            if (pb.use_seed || EXACT) {  // (the exact redo is seeded by the fast pass's result)
+                js[k] = pb.pos_s[ic];
+                gsx[k] = pb.gsx[ic]; gsy[k] = pb.gsy[ic]; gsz[k] = pb.gsz[ic];
+                if (EXACT) gso[k] = (unsigned int)pb.idx_s[ic];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
+            key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);
+            best[k] = thr2;
+            bpos[k] = -1;
+            const float d = dist2(qx[k], qy[k], qz[k], gsx[k], gsy[k], gsz[k]);
+            if (js[k] >= 0 && d < thr2) {
+                best[k] = d;
+                bpos[k] = EXACT ? js[k] : (js[k] & ~(kGroup - 1));
+                if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | gso[k];
+            }
+            reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
+            if (qi[k] >= N) {
+                qx[k] = qy[k] = qz[k] = 1.0e18f;
+                reach[k] = -1.0f;
+                best[k] = -1.0f;
+                bpos[k] = -1;
+            }
+        }
+    }
+    unsigned long long pa = 0ull, pb2 = 0ull, pf = 0ull, pg = 0ull;
+    unsigned int pc = 0u, pd = 0u, pe = 0u;
+    n_staged_out += tiled_sweep<2, EXACT>(mp, lbox, use_lbox, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+        if constexpr (EXACT) nn_visit_exact<2>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
+        else nn_visit_fast<2>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
+    }, false, pa, pb2, pc, pd, pe, pf, pg);
+
+    bool any_tie = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int rpos = -1, roi = -1;
+        float rd = thr2, wx = 0.f, wy = 0.f, wz = 0.f;
+        if constexpr (EXACT) {
+            const float d = __uint_as_float((unsigned int)(key[k] >> 32));
+            if (d < thr2) {
+                rd = d; rpos = bpos[k]; roi = (int)(unsigned int)(key[k] & 0xffffffffu);
+                wx = mp.sx[rpos]; wy = mp.sy[rpos]; wz = mp.sz[rpos];
+            }
+        } else {
+            const int bp = bpos[k] >= 0 ? bpos[k] : 0;
+            float4 RX[kGroup / 4], RY[kGroup / 4], RZ[kGroup / 4];
+            int4 RP[kGroup / 4];
+#pragma unroll
+            for (int c = 0; c < kGroup / 4; ++c) {
+                RX[c] = *reinterpret_cast<const float4*>(mp.sx + bp + 4 * c);
+                RY[c] = *reinterpret_cast<const float4*>(mp.sy + bp + 4 * c);
+                RZ[c] = *reinterpret_cast<const float4*>(mp.sz + bp + 4 * c);
+                RP[c] = *reinterpret_cast<const int4*>(mp.perm + bp + 4 * c);
+            }
+            unsigned int bo = 0xffffffffu;
+            int pos = -1;
+#pragma unroll
+            for (int c = 0; c < kGroup / 4; ++c) {
+                const float xs[4] = {RX[c].x, RX[c].y, RX[c].z, RX[c].w};
+                const float ys[4] = {RY[c].x, RY[c].y, RY[c].z, RY[c].w};
+                const float zs[4] = {RZ[c].x, RZ[c].y, RZ[c].z, RZ[c].w};
+                const int ps[4] = {RP[c].x, RP[c].y, RP[c].z, RP[c].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float du = dist2(qx[k], qy[k], qz[k], xs[u], ys[u], zs[u]);
+                    const bool take = du == best[k] && (unsigned int)ps[u] < bo;
+                    bo = take ? (unsigned int)ps[u] : bo;
+                    pos = take ? bpos[k] + 4 * c + u : pos;
+                    const unsigned int tm = take ? 0xffffffffu : 0u;
+                    wx = __uint_as_float((__float_as_uint(xs[u]) & tm) | (__float_as_uint(wx) & ~tm));
+                    wy = __uint_as_float((__float_as_uint(ys[u]) & tm) | (__float_as_uint(wy) & ~tm));
+                    wz = __uint_as_float((__float_as_uint(zs[u]) & tm) | (__float_as_uint(wz) & ~tm));
+                }
+            }
+            if (bpos[k] >= 0) {
+                rd = best[k]; rpos = pos; roi = (int)bo;
+                if (pos < 0) tie[k] = 1;  // cannot happen (same arithmetic); be safe: exact pass
+            }
+        }
+        if (qi[k] < N) {
+            pb.pos_s[qi[k]] = rpos;
+            pb.idx_s[qi[k]] = rpos >= 0 ? roi : -1;
+            pb.d2_s[qi[k]] = rd;
+            pb.gsx[qi[k]] = wx; pb.gsy[qi[k]] = wy; pb.gsz[qi[k]] = wz;
+            any_tie |= tie[k] != 0;
+        }
+    }
+    return !EXACT && __any(any_tie);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256, 3) void k_nn_tiled_batch(const NnBatch<KMAX> batch, const NnBatchItems<KMAX> items, int n_problems,
+                                                           int shared_map_lds, unsigned int* __restrict__ queue)
+{
+    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
+    __shared__ int s_list[4][kMaxList];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float(*sm)[64] = s_m[wave];
+    int* slist = s_list[wave];
+    const lds_f32* lbox = (const lds_f32*)s_dyn;
+    if (shared_map_lds) load_boxes_to_lds(batch.p[0].mp, (lds_f32*)s_dyn);
+    const int n_items = items.base[n_problems];
+    WaveQueue wq(queue, lane, n_items);
+    unsigned long long wave_staged = 0ull;
+    int raw = __builtin_amdgcn_readfirstlane(wq.first());
+    while (raw < n_items) {
+        int k = 0;
+        while (k + 1 < n_problems && raw >= items.base[k + 1]) ++k;  // (wave-uniform: scalar loop over <= KMAX entries)
+        const NnProblem& pb = batch.p[k];
+        const int item = raw - items.base[k];
+        const int next_raw_v = wq.pop();  // in flight during the item
+        const TiledMap mp = pb.mp;
+        if (tiled_batch_item<false>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the redo reads this wave's own stores of a moment ago
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            (void)tiled_batch_item<true>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged);
+        }
+        raw = __builtin_amdgcn_readfirstlane(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
+    }
+    if (lane == 0 && wave_staged)
+        atomicAdd(batch.p[0].staged + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, wave_staged * 2ull);
+}
+
+// one workgroup per (item, problem): the item's row of unit-weight sums from the stored pairing -- k_nn_coop's fused rows
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_item_rows(const NnBatch<KMAX> batch)
+{
+    __shared__ double s_acc[12][128];
+    const NnProblem& pb = batch.p[KMAX == 1 ? 0 : blockIdx.y];
+    const int item = (int)blockIdx.x;
+    if (item * kQPW >= pb.N) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float al0 = 0.f, al1 = 0.f, al2 = 0.f, ag0 = 0.f, ag1 = 0.f, ag2 = 0.f, ad = 0.f;
+    bool paired = false;
+    if (wave < 2) {
+        const int q = item * kQPW + wave * 64 + lane;
+        if (q < pb.N) {
+            paired = pb.pos_s[q] >= 0;
+            al0 = pb.slx[q]; al1 = pb.sly[q]; al2 = pb.slz[q];
+            ag0 = pb.gsx[q]; ag1 = pb.gsy[q]; ag2 = pb.gsz[q];
+            ad = pb.d2_s[q];
+        }
+    }
+    item_row_sum(s_acc, paired, al0, al1, al2, ag0, ag1, ag2, ad, pb.rows + (size_t)item * kNAcc);
 }
 
 }  // namespace mola_icp_amd
