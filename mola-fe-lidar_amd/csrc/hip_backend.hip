@@ -55,6 +55,7 @@ struct Knobs {
     int qpl = 0;               // MOLA_ICP_QPL (0 = by cloud size)
     int coop = -1;             // MOLA_ICP_COOP (-1 = by cloud size, 0 = one item per wave, 1 = one item per block)
     int batch_tiled = -1;      // MOLA_ICP_BATCH_TILED (-1 = by item count; batched launches: 0 = k_nn_coop, 1 = k_nn_tiled_batch)
+    bool no_split = false;     // MOLA_ICP_NO_SPLIT: never list a heavy 128-query item as its two halves
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
 };
@@ -67,6 +68,7 @@ static Knobs read_knobs()
     k.coop = std::getenv("MOLA_ICP_COOP") ? (geti("MOLA_ICP_COOP") != 0 ? 1 : 0) : -1;
     k.batch_tiled = std::getenv("MOLA_ICP_BATCH_TILED") ? (geti("MOLA_ICP_BATCH_TILED") != 0 ? 1 : 0) : -1;
     k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
+    k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
     k.no_knn_seed = std::getenv("MOLA_ICP_NO_KNN_SEED") != nullptr;
     k.no_knn_verify = std::getenv("MOLA_ICP_NO_KNN_VERIFY") != nullptr;
     k.no_direct_readback = std::getenv("MOLA_ICP_NO_DIRECT_READBACK") != nullptr;
@@ -690,15 +692,25 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     int grid = num_cus_ * per_cu;
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     int rc;
-    if ((rc = item_cost_.reserve(sizeof(unsigned int) * (size_t)n_items))) return rc;
-    if ((rc = item_order_.reserve(sizeof(int) * ((size_t)n_items + kQueues + 1)))) return rc;  // + the segment boundaries
+    // 128-query items keep two cost slots each (the item, or its two halves) and up to two list entries
+    const size_t cost_slots = qpl == 2 ? 2 * (size_t)n_items : (size_t)n_items;
+    {
+        const void* before = item_cost_.p;
+        if ((rc = item_cost_.reserve(sizeof(unsigned int) * cost_slots))) return rc;
+        if (item_cost_.p != before) cost_valid_ = false;
+    }
+    if ((rc = item_order_.reserve(sizeof(int) * (cost_slots + kQueues + 2)))) return rc;  // + the range boundaries + the entry count
     const int* order = nullptr;
     if (cost_valid_ && !g_knobs.no_lpt) {
         // the cost profile drifts slowly with the pose: re-sort at launch 1, 2, 4, 8 after the clouds were set,
         // then every 16th; the order is reused in between
         if (!order_valid_ || launches_since_order_ >= plan_interval_) {
-            hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
-                               item_order_.as<int>());
+            if (qpl == 2)
+                hipLaunchKernelGGL(k_order_entries, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
+                                   g_knobs.no_split ? 1 : grid * 4, item_order_.as<int>());
+            else
+                hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
+                                   item_order_.as<int>());
             HIPCHK(hipGetLastError());
             plan_interval_ = order_valid_ ? (plan_interval_ < 16 ? plan_interval_ * 2 : 16) : 1;
             order_valid_ = true;
@@ -714,7 +726,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     float* gs = ts_gs_.as<float>();
     const size_t gs_n = loc_sc_->padded;
     const float* sl = loc_sc_->sorted.as<float>();
-    if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
+    if ((rc = redo_list_.reserve(sizeof(int) * cost_slots))) return rc;
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
     // counter[2] = redo count; tq = the fast pass's queue counters, tq + kQueues * kQueueStride the exact pass's
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
@@ -1050,6 +1062,38 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
                          (ends[ends.size() * 9 / 10] - t0) / span, (ends[ends.size() * 99 / 100] - t0) / span,
                          busy / ends.size() / span);
             auto med = [](std::vector<unsigned long long>& v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+            if (!wave_times_coop_) {  // the persistent kernel: per XCD (block & 7) when its waves end and how many items they took
+                double last[8] = {}, sum[8] = {}, items[8] = {};
+                int cnt[8] = {};
+                unsigned long long imin = ~0ull, imax = 0;
+                for (size_t i = 0; i < 8192; ++i)
+                    if (w[8 * i + 1]) {
+                        const int x = (int)((i / 4) & 7);
+                        const double e = (double)(w[8 * i + 1] - t0) / span;
+                        const unsigned long long ni = w[8 * i + 2] & 0xffffffffull;
+                        last[x] = std::max(last[x], e); sum[x] += e; items[x] += (double)ni; ++cnt[x];
+                        imin = std::min(imin, ni); imax = std::max(imax, ni);
+                    }
+                std::fprintf(stderr, "[mola_icp debug]   per XCD: last wave ends at / mean end / items per wave:");
+                for (int x = 0; x < 8; ++x) std::fprintf(stderr, " %.2f/%.2f/%.1f", last[x], cnt[x] ? sum[x] / cnt[x] : 0.0, cnt[x] ? items[x] / cnt[x] : 0.0);
+                std::fprintf(stderr, "; items per wave min %llu max %llu\n", imin, imax);
+                // the waves that end last: how long their LAST entry ran, when it began, which entry it was
+                std::vector<size_t> late;
+                for (size_t i = 0; i < 8192; ++i) if (w[8 * i + 1]) late.push_back(i);
+                std::sort(late.begin(), late.end(), [&](size_t a, size_t b) { return w[8 * a + 1] > w[8 * b + 1]; });
+                for (size_t r = 0; r < late.size() && r < 400; r = (r < 4 ? r + 1 : r * 3)) {
+                    const size_t i = late[r];
+                    const unsigned int code = (unsigned int)(w[8 * i + 2] >> 32);
+                    std::fprintf(stderr, "[mola_icp debug]   end rank %zu: wave ends %.2f, %llu entries, last entry %s%u began %.2f ran %.2f of the span\n", r,
+                                 (double)(w[8 * i + 1] - t0) / span, w[8 * i + 2] & 0xffffffffull, (code & 0x40000000u) ? "half " : "", code & 0x3fffffffu,
+                                 (double)(w[8 * i + 7] - t0) / span, (double)(w[8 * i + 1] - w[8 * i + 7]) / span);
+                }
+                std::vector<double> lastdur;
+                for (size_t i : late) lastdur.push_back((double)(w[8 * i + 1] - w[8 * i + 7]) / span);
+                std::sort(lastdur.begin(), lastdur.end());
+                std::fprintf(stderr, "[mola_icp debug]   duration of a wave's last entry (of the span): p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+                             lastdur[lastdur.size() / 10], lastdur[lastdur.size() / 2], lastdur[lastdur.size() * 9 / 10], lastdur.back());
+            }
             if (wave_times_coop_) {
                 std::sort(starts.begin(), starts.end());
                 std::fprintf(stderr, "[mola_icp debug]   cooperative kernel: last wave starts %.0f ticks after the first; per wave, shader cycles "

@@ -74,10 +74,10 @@ __device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, con
     // squared distance from each query to the box vs its live bound (see tiled_sweep::any_reach: exact, no margins)
     auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
         const v2f s_qx = {qx[0], qx[1]}, s_qy = {qy[0], qy[1]}, s_qz = {qz[0], qz[1]};
-        const v2f zero = {0.f, 0.f};
-        const v2f ax = __builtin_elementwise_max(__builtin_elementwise_max(m0 - s_qx, s_qx - m3), zero);
-        const v2f ay = __builtin_elementwise_max(__builtin_elementwise_max(m1 - s_qy, s_qy - m4), zero);
-        const v2f az = __builtin_elementwise_max(__builtin_elementwise_max(m2 - s_qz, s_qz - m5), zero);
+        const v2f cx = {__builtin_amdgcn_fmed3f(qx[0], m0, m3), __builtin_amdgcn_fmed3f(qx[1], m0, m3)};
+        const v2f cy = {__builtin_amdgcn_fmed3f(qy[0], m1, m4), __builtin_amdgcn_fmed3f(qy[1], m1, m4)};
+        const v2f cz = {__builtin_amdgcn_fmed3f(qz[0], m2, m5), __builtin_amdgcn_fmed3f(qz[1], m2, m5)};
+        const v2f ax = s_qx - cx, ay = s_qy - cy, az = s_qz - cz;   // (q - clamp(q, lo, hi): see tiled_sweep::any_reach)
         const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
         return __any(D.x <= bound2[0] || D.y <= bound2[1]);
     };
@@ -362,9 +362,9 @@ __device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledM
                 const float b2 = __uint_as_float(s_mg[w][k][lane]);
                 const int p2 = (int)s_mg[w][2 + k][lane], t2 = (int)s_mg[w][4 + k][lane];
                 const bool lt = b2 < b, eq = b2 == b;
-                // an EQUAL minimum in a different group is a tie the exact visitor must resolve; the same group on
-                // both sides (the common seed group, or a group two waves met) is the same candidate
-                t = lt ? t2 : (eq ? (t | t2 | (int)(p2 != p)) : t);
+                // t = number of groups at the best (nn_visit_fast): every tile has ONE owner, so the waves' counts add
+                // up; two groups at an equal minimum are a tie the exact visitor must resolve
+                t = lt ? t2 : (eq ? t + t2 : t);
                 p = lt ? p2 : p;
                 b = lt ? b2 : b;
             }
@@ -400,9 +400,9 @@ __device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledM
             if (p >= 0 && fqi < N) {
                 res.rd = b; res.rpos = pos; res.roi = (int)bo;
                 res.gx = wx; res.gy = wy; res.gz = wz;
-                if (pos < 0) { t = 1; res.roi = -1; }  // cannot happen (same arithmetic); be safe: exact pass
+                if (pos < 0) { t = 2; res.roi = -1; }  // cannot happen (same arithmetic); be safe: exact pass
             }
-            any_tie = fqi < N && t != 0;
+            any_tie = fqi < N && t >= 2;
         }
         if (!EXACT) {
             const bool wt = __any(any_tie);
@@ -662,7 +662,7 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
             }
             if (bpos[k] >= 0) {
                 rd = best[k]; rpos = pos; roi = (int)bo;
-                if (pos < 0) tie[k] = 1;  // cannot happen (same arithmetic); be safe: exact pass
+                if (pos < 0) tie[k] = 2;  // cannot happen (same arithmetic); be safe: exact pass
             }
         }
         if (qi[k] < N) {
@@ -670,7 +670,7 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
             pb.idx_s[qi[k]] = rpos >= 0 ? roi : -1;
             pb.d2_s[qi[k]] = rd;
             pb.gsx[qi[k]] = wx; pb.gsy[qi[k]] = wy; pb.gsz[qi[k]] = wz;
-            any_tie |= tie[k] != 0;
+            any_tie |= tie[k] >= 2;
         }
     }
     return !EXACT && __any(any_tie);

@@ -94,6 +94,93 @@ __global__ __launch_bounds__(256) void k_unpermute_pairing(const int* __restrict
     out_d2[o] = d2_s[i];
 }
 
+// The work list of k_nn_tiled<., 2> (128-query items): as k_order_items -- kQueues contiguous ranges of equal cost, one
+// per XCD, heaviest first inside a range -- but an item whose cost exceeds kSplitShare of a wave's fair share of the
+// launch (total cost / resident waves) is listed as its two 64-query HALVES (kHalfFlag | 2 * item + half).  A launch is
+// as long as its longest wave: at 1M x 1M the heaviest 1 % of the items alone took 1.2-1.3 x the fair share, and the
+// waves sat idle 30 % of the launch.  cost2[2 i], cost2[2 i + 1]: last launch's cycles of item i (whole: second slot 0)
+// or of its halves.  Layout of `order`: 2 n_items entry slots, kQueues + 1 boundaries (in entries), the entry count.
+constexpr float kSplitShare = 0.55f;
+__global__ __launch_bounds__(1024) void k_order_entries(const unsigned int* __restrict__ cost2, int n_items, int n_slots,
+                                                        int* __restrict__ order)
+{
+    __shared__ unsigned int s_max, s_cnt[kQueues][32], s_off[kQueues][32];
+    __shared__ unsigned long long s_pre[1024];
+    __shared__ int s_seg[kQueues + 1], s_ebase[kQueues + 1];
+    const int cap = 2 * n_items;
+    if (threadIdx.x == 0) s_max = 1u;
+    if (threadIdx.x < kQueues * 32) (&s_cnt[0][0])[threadIdx.x] = 0u;
+    if (threadIdx.x <= kQueues) s_seg[threadIdx.x] = threadIdx.x == kQueues ? n_items : 0;
+    auto cost = [&](int i) -> unsigned long long { return (unsigned long long)cost2[2 * i] + cost2[2 * i + 1]; };
+    const int chunk = (n_items + 1023) / 1024, i0 = min(n_items, (int)threadIdx.x * chunk), i1 = min(n_items, i0 + chunk);
+    unsigned long long mine = 0;
+    unsigned int mx = 1u;
+    for (int i = i0; i < i1; ++i) { const unsigned long long c = cost(i); mine += c; mx = max(mx, (unsigned int)min(c, 0xffffffffull)); }
+    s_pre[threadIdx.x] = mine;
+    __syncthreads();
+    atomicMax(&s_max, mx);
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned long long add = threadIdx.x >= (unsigned)off ? s_pre[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        s_pre[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const unsigned long long total = s_pre[1023];
+    unsigned long long run = s_pre[threadIdx.x] - mine;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned long long c = cost(i);
+        for (int q = 1; q < kQueues; ++q) {
+            const unsigned long long want = total / kQueues * (unsigned long long)q;
+            if (run < want && run + c >= want) s_seg[q] = i + 1;
+        }
+        run += c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int q = 1; q <= kQueues; ++q) if (s_seg[q] < s_seg[q - 1]) s_seg[q] = s_seg[q - 1];
+    __syncthreads();
+    auto seg_of = [&](int i) -> int {
+        int q = 0;
+        while (q + 1 < kQueues && s_seg[q + 1] <= i) ++q;
+        return q;
+    };
+    const unsigned long long thr = (unsigned long long)((double)total / (double)(n_slots > 0 ? n_slots : 1) * (double)kSplitShare);
+    const float scale = 32.0f / (float)s_max;
+    // an item -> one entry, or two: (cost, code) of entry e in {0, 1}; returns the number of entries
+    auto entries_of = [&](int i, unsigned int (&ec)[2], int (&code)[2]) -> int {
+        const unsigned long long c = cost(i);
+        if (total == 0 || c <= thr) { ec[0] = (unsigned int)min(c, 0xffffffffull); code[0] = i; return 1; }
+        const unsigned int h1 = cost2[2 * i + 1];
+        // halves measured last time, or 0.58 of the whole each (a half costs more than half: the per-item work is shared)
+        ec[0] = h1 ? cost2[2 * i] : (unsigned int)min(c * 58ull / 100ull, 0xffffffffull);
+        ec[1] = h1 ? h1 : ec[0];
+        code[0] = kHalfFlag | (2 * i); code[1] = kHalfFlag | (2 * i + 1);
+        return 2;
+    };
+    for (int i = threadIdx.x; i < n_items; i += 1024) {
+        unsigned int ec[2]; int code[2];
+        const int ne = entries_of(i, ec, code), q = seg_of(i);
+        for (int e = 0; e < ne; ++e) atomicAdd(&s_cnt[q][31 - min(31, (int)((float)ec[e] * scale))], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int o = 0;
+        for (int q = 0; q < kQueues; ++q) {
+            s_ebase[q] = (int)o;
+            for (int b = 0; b < 32; ++b) { s_off[q][b] = o; o += s_cnt[q][b]; }
+        }
+        s_ebase[kQueues] = (int)o;
+    }
+    __syncthreads();
+    if (threadIdx.x <= kQueues) order[cap + threadIdx.x] = s_ebase[threadIdx.x];
+    if (threadIdx.x == 0) order[cap + kQueues + 1] = s_ebase[kQueues];
+    for (int i = threadIdx.x; i < n_items; i += 1024) {
+        unsigned int ec[2]; int code[2];
+        const int ne = entries_of(i, ec, code), q = seg_of(i);
+        for (int e = 0; e < ne; ++e) order[atomicAdd(&s_off[q][31 - min(31, (int)((float)ec[e] * scale))], 1u)] = code[e];
+    }
+}
+
 // map-slab point -> original map index (row e); -1 stays -1
 __global__ __launch_bounds__(256) void k_remap_indices(const int* __restrict__ idx, const int* __restrict__ orig, int N,
                                                        int* __restrict__ out)

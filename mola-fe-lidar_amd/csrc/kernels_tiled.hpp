@@ -2,6 +2,8 @@
 // Device code of the ICP core for gfx950; included by hip_backend.hip only (one translation unit: the kernels are
 // launched from there).  Numeric contract and data layout: hip_backend.hip / DESIGN.md.
 #pragma once
+#include <type_traits>
+
 #include "kernels_common.hpp"
 
 namespace mola_icp_amd {
@@ -68,6 +70,7 @@ constexpr size_t kMaxLdsBoxBytes = 40 * 1024;  // upper box levels kept in LDS u
 constexpr size_t kDbgItems = 1u << 17;  // MOLA_ICP_DEBUG_STATS: per-item records for clouds up to 16M points
 constexpr int kQueues = 8, kQueueStride = 32;  // work-queue counters, one 128-byte line each
 constexpr int kMaxList = 64;   // super-tiles collected before their tiles are streamed
+constexpr int kHalfFlag = 0x40000000;  // work-list entry = one 64-query half of a 128-query item (id = 2 * item + half)
 
 // LDS copy of the two upper box levels (one per workgroup): [6][n_top] then [6][n_super] floats.  The upper
 // levels of the scan then cost LDS reads instead of dependent global round trips.
@@ -126,11 +129,13 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
     // Padding lanes carry bound2 < 0 and reach nothing; empty boxes (+inf, -inf) give inf.
     auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool {
         if constexpr (QPL == 2) {  // both queries of the lane per packed instruction
+            // gap to the box per axis = q - clamp(q, lo, hi) (v_med3_f32): the same magnitude as max(lo - q, q - hi, 0),
+            // one instruction less per axis; only boxes that passed the wave-box test come here (never an empty one)
             const v2f s_qx = {qx[0], qx[1]}, s_qy = {qy[0], qy[1]}, s_qz = {qz[0], qz[1]};
-            const v2f zero = {0.f, 0.f};
-            const v2f ax = __builtin_elementwise_max(__builtin_elementwise_max(m0 - s_qx, s_qx - m3), zero);
-            const v2f ay = __builtin_elementwise_max(__builtin_elementwise_max(m1 - s_qy, s_qy - m4), zero);
-            const v2f az = __builtin_elementwise_max(__builtin_elementwise_max(m2 - s_qz, s_qz - m5), zero);
+            const v2f cx = {__builtin_amdgcn_fmed3f(qx[0], m0, m3), __builtin_amdgcn_fmed3f(qx[1], m0, m3)};
+            const v2f cy = {__builtin_amdgcn_fmed3f(qy[0], m1, m4), __builtin_amdgcn_fmed3f(qy[1], m1, m4)};
+            const v2f cz = {__builtin_amdgcn_fmed3f(qz[0], m2, m5), __builtin_amdgcn_fmed3f(qz[1], m2, m5)};
+            const v2f ax = s_qx - cx, ay = s_qy - cy, az = s_qz - cz;
             const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
             return __any(D.x <= bound2[0] || D.y <= bound2[1]);
         } else {
@@ -377,11 +382,11 @@ __device__ __forceinline__ void nn_visit_exact(float (*sm)[64], int nm, int jb0,
     }
 }
 
-// fast: per kGroup-point group only the group minimum meets the running best; (best, group position, tie flag)
+// fast: per kGroup-point group only the group minimum meets the running best; (best, group position, groups at the best)
 template <int QPL>
 __device__ __forceinline__ void nn_visit_fast(float (*sm)[64], int nm, int jb0, int jb1, const float (&qx)[QPL],
                                               const float (&qy)[QPL], const float (&qz)[QPL], float (&best)[QPL],
-                                              int (&bpos)[QPL], int (&tie)[QPL])
+                                              int (&bpos)[QPL], int (&cnt)[QPL])
 {
     // per kGroup-point group: packed sub/mul/fma (v_pk_*_f32) serve two (query, point) pairs per
     // instruction -- the lane's two queries (QPL = 2) or two consecutive points (QPL = 1) -- the group
@@ -421,13 +426,17 @@ __device__ __forceinline__ void nn_visit_fast(float (*sm)[64], int nm, int jb0, 
             }
         }
         const int gpos = m < 32 ? jb0 + m : jb1 + m - 32;  // sorted position of this group
+        // (best, its group, HOW MANY groups reached that best): a group that beats the best restarts the count, one that
+        // equals it adds to it.  The seed starts with a count of 0 -- its own group is always swept (its tile holds a
+        // point at exactly the bound) and counts itself -- so "count >= 2 at the end" is an exact distance tie between
+        // two groups, which the exact-key pass resolves.  Six instructions per query and group.
 #pragma unroll
         for (int k = 0; k < QPL; ++k) {
             const bool lt = gm[k] < best[k];
-            const int eq = (int)(gm[k] == best[k]) & (int)(gpos != bpos[k]);
-            tie[k] = lt ? 0 : (tie[k] | eq);
-            best[k] = lt ? gm[k] : best[k];
+            const int eq = (int)(gm[k] == best[k]);
+            cnt[k] = lt ? 1 : cnt[k] + eq;
             bpos[k] = lt ? gpos : bpos[k];
+            best[k] = fminf(best[k], gm[k]);
         }
     }
 }
@@ -459,37 +468,47 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     if (EXACT && *redo_count == 0u) return;  // the usual case: no exact ties in this launch (uniform: before any barrier)
     const lds_f32* lbox = (const lds_f32*)s_dyn;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
-    constexpr int kQ = 64 * QPL;  // queries per item: QPL per lane (2 for large clouds, 1 when there are few items per wave)
-    const int n_items = EXACT ? (int)*redo_count : (N + kQ - 1) / kQ;
+    // Entries of the work list.  QPL = 1: every entry is a 64-query item.  QPL = 2: an entry is a 128-query item (two
+    // queries per lane) or, with kHalfFlag, ONE HALF of one (64 queries, one per lane): k_order_entries cuts the items
+    // whose cost exceeds what a wave's fair share of the launch allows -- a single 128-query item of a dense region
+    // took 1.3x that share, and the launch is as long as its longest wave.
+    const int n_items = (N + 64 * QPL - 1) / (64 * QPL);
+    const int order_cap = QPL == 2 ? 2 * n_items : n_items;  // layout of item_order: entries, then kQueues + 1 boundaries, then the count
+    const int n_entries = EXACT ? (int)*redo_count : ((QPL == 2 && item_order) ? item_order[order_cap + kQueues + 1] : n_items);
 
-    WaveQueue wq(queue, lane, n_items, (!EXACT && item_order) ? item_order + n_items : nullptr);  // boundaries follow the order
+    WaveQueue wq(queue, lane, n_entries, (!EXACT && item_order) ? item_order + order_cap : nullptr);  // boundaries follow the order
     auto lookup = [&](int raw) -> int {  // raw is wave-uniform; -1 = past the end
-        if (raw >= n_items) return -1;
+        if (raw >= n_entries) return -1;
         if (EXACT) return redo_list[raw];
-        return item_order ? item_order[raw] : raw;  // heaviest items of the last launch first
+        return item_order ? item_order[raw] : raw;  // heaviest entries of the last launch first
     };
     unsigned long long wave_staged = 0ull;
     const unsigned long long t_wave0 = wave_times ? wall_clock64() : 0ull;  // 100 MHz, the same on every XCD
     unsigned int wave_items = 0u;
-    unsigned long long ph0 = 0ull, ph1 = 0ull, ph2 = 0ull, ph3 = 0ull;
-    int item = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
-    while (item >= 0) {
+    unsigned long long ph0 = 0ull, ph1 = 0ull, ph2 = 0ull, ph3 = 0ull, last_start = 0ull;
+    unsigned int last_code = 0u;
+    // one entry at the granularity QL (queries per lane); `item` counts in units of 64 * QL queries, `code` is the entry
+    // as listed (what the redo list and the cost record carry).  Returns the next entry's code.
+    auto run_item = [&](auto ql_tag, int item, int code) -> int {
+        constexpr int QL = decltype(ql_tag)::value;
+        constexpr int kQ = 64 * QL;
         ++wave_items;
         const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
+        if (wave_times) { last_start = wall_clock64(); last_code = (unsigned int)code; }
 
-        float qx[QPL], qy[QPL], qz[QPL], reach[QPL];
-        unsigned long long key[QPL];  // EXACT: packed (d2, original index)
-        float best[QPL];              // fast: running minimum
-        int bpos[QPL];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
-        int tie[QPL] = {};
+        float qx[QL], qy[QL], qz[QL], reach[QL];
+        unsigned long long key[QL];  // EXACT: packed (d2, original index)
+        float best[QL];              // fast: running minimum
+        int bpos[QL];                // EXACT: sorted position of the best point; fast: of its kGroup-point group
+        int tie[QL] = {};  // fast: number of groups whose minimum equals the best (>= 2: an exact tie)
         // ONE round trip: the two queries of the lane and their seeds -- position, original index and COORDINATES as the
         // last launch's epilogue stored them (gs_*), so the seed distance needs no dependent second trip
-        int qi[QPL], js[QPL];
-        float lx[QPL], ly[QPL], lz[QPL];
-        float gsx[QPL], gsy[QPL], gsz[QPL];
-        unsigned int gso[QPL] = {};
+        int qi[QL], js[QL];
+        float lx[QL], ly[QL], lz[QL];
+        float gsx[QL], gsy[QL], gsz[QL];
+        unsigned int gso[QL] = {};
 #pragma unroll
-        for (int k = 0; k < QPL; ++k) {
+        for (int k = 0; k < QL; ++k) {
             qi[k] = item * kQ + k * 64 + lane;
             if (qi[k] >= N) qi[k] = N;  // padding lane
             const int ic = qi[k] < N ? qi[k] : N - 1;
@@ -505,9 +524,9 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         // (slow, slower still in the burst at kernel start) ahead of them would sit on the prologue's critical path
         const int next_raw_v = wq.pop();
 #pragma unroll
-        for (int k = 0; k < QPL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
+        for (int k = 0; k < QL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
 #pragma unroll
-        for (int k = 0; k < QPL; ++k) {
+        for (int k = 0; k < QL; ++k) {
             key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (gate^2, index 0): "no neighbour" sentinel
             best[k] = thr2;
             bpos[k] = -1;
@@ -529,22 +548,22 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
         unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
         const unsigned long long t_sweep0 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
-        const unsigned long long n_staged = tiled_sweep<QPL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
-            if constexpr (EXACT) nn_visit_exact<QPL>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
-            else nn_visit_fast<QPL>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
+        const unsigned long long n_staged = tiled_sweep<QL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+            if constexpr (EXACT) nn_visit_exact<QL>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
+            else nn_visit_fast<QL>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
         }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
         const unsigned long long t_sweep1 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
         // the popped entry has long arrived: its lookup (and a steal, if the segment is dry) overlaps the epilogue's loads
         const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
 
         bool any_tie = false;
-        int rpos[QPL], roi[QPL];
-        float rd[QPL], wx[QPL], wy[QPL], wz[QPL];  // (w*: the neighbour's coordinates, next launch's seed)
+        int rpos[QL], roi[QL];
+        float rd[QL], wx[QL], wy[QL], wz[QL];  // (w*: the neighbour's coordinates, next launch's seed)
 #pragma unroll
-        for (int k = 0; k < QPL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; wx[k] = wy[k] = wz[k] = 0.f; }
+        for (int k = 0; k < QL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; wx[k] = wy[k] = wz[k] = 0.f; }
         if constexpr (EXACT) {
 #pragma unroll
-            for (int k = 0; k < QPL; ++k) {
+            for (int k = 0; k < QL; ++k) {
                 const float d = __uint_as_float((unsigned int)(key[k] >> 32));
                 if (d < thr2) {
                     rd[k] = d; rpos[k] = bpos[k]; roi[k] = (int)(unsigned int)(key[k] & 0xffffffffu);
@@ -554,10 +573,10 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         } else {
             // resolve inside the winning group: the point(s) with d2 == best, lowest original index first.
             // One round trip: all loads of both queries are issued before the first use.
-            float4 RX[QPL][kGroup / 4], RY[QPL][kGroup / 4], RZ[QPL][kGroup / 4];
-            int4 RP[QPL][kGroup / 4];
+            float4 RX[QL][kGroup / 4], RY[QL][kGroup / 4], RZ[QL][kGroup / 4];
+            int4 RP[QL][kGroup / 4];
 #pragma unroll
-            for (int k = 0; k < QPL; ++k) {
+            for (int k = 0; k < QL; ++k) {
                 const int bp = bpos[k] >= 0 ? bpos[k] : 0;
 #pragma unroll
                 for (int c = 0; c < kGroup / 4; ++c) {
@@ -568,7 +587,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 }
             }
 #pragma unroll
-            for (int k = 0; k < QPL; ++k) {
+            for (int k = 0; k < QL; ++k) {
                 unsigned int bo = 0xffffffffu;
                 int pos = -1;
 #pragma unroll
@@ -592,31 +611,35 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 }
                 if (bpos[k] >= 0) {
                     rd[k] = best[k]; rpos[k] = pos; roi[k] = (int)bo;
-                    if (pos < 0) tie[k] = 1;  // cannot happen (same arithmetic); be safe: exact pass
+                    if (pos < 0) tie[k] = 2;  // cannot happen (same arithmetic); be safe: exact pass
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < QPL; ++k) {
+        for (int k = 0; k < QL; ++k) {
             if (qi[k] < N) {  // coalesced: the pairing stays in sorted query order
                 pos_s[qi[k]] = rpos[k];
                 idx_s[qi[k]] = rpos[k] >= 0 ? roi[k] : -1;
                 d2_s[qi[k]] = rd[k];
                 gs_x[qi[k]] = wx[k]; gs_y[qi[k]] = wy[k]; gs_z[qi[k]] = wz[k];
-                any_tie |= tie[k] != 0;
+                any_tie |= tie[k] >= 2;
             }
         }
         if (!EXACT && __any(any_tie)) {
-            if (lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
+            if (lane == 0) redo_list[atomicAdd(redo_count, 1u)] = code;
         }
         if (lane == 0) {
             if (!EXACT) {
                 // (a deterministic proxy -- staged points -- orders no better than the measured cycles; without any
                 // order the kernel is 6 % slower)
                 const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
-                if (item_cost) item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+                if (item_cost) {
+                    const unsigned int cc = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+                    if (QPL == 2 && QL == 2) { item_cost[2 * item] = cc; item_cost[2 * item + 1] = 0u; }  // a whole 128-query item
+                    else item_cost[item] = cc;   // a 64-query item / half: slot 2 * (its 128-query item) + half
+                }
             }
-            wave_staged += n_staged * QPL;  // executed work in units of 64 (query, point) pairs (one atomic per wave, at exit)
+            wave_staged += n_staged * QL;  // executed work in units of 64 (query, point) pairs (one atomic per wave, at exit)
             if (dbg_stats) {
                 const unsigned long long t_end = __builtin_amdgcn_s_memtime();
                 atomicAdd(&dbg_stats[2], n_staged); atomicAdd(&dbg_stats[3], 1ull); atomicMax(&dbg_stats[4], n_staged);
@@ -639,12 +662,23 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             const unsigned long long t_end1 = __builtin_amdgcn_s_memtime();
             ph0 = t_sweep0 - t_item0; ph1 = t_sweep1 - t_sweep0; ph2 = t_end1 - t_sweep1; ph3 = n_staged;
         }
-        item = __builtin_amdgcn_readfirstlane(next_item_v);
+        return __builtin_amdgcn_readfirstlane(next_item_v);
+    };
+    int code = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
+    while (code >= 0) {
+        if constexpr (QPL == 2) {
+            if (!(code & kHalfFlag)) {
+                code = run_item(std::integral_constant<int, 2>{}, code, code);
+                continue;
+            }
+        }
+        code = run_item(std::integral_constant<int, 1>{}, code & ~kHalfFlag, code);
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
     if (wave_times && lane == 0) {  // [start, end, items, first item: prologue, sweep, epilogue cycles, staged points] per wave
         unsigned long long* w = wave_times + 8 * (size_t)wq.global_wave();
-        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items; w[3] = ph0; w[4] = ph1; w[5] = ph2; w[6] = ph3;
+        w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items | ((unsigned long long)last_code << 32); w[3] = ph0; w[4] = ph1; w[5] = ph2; w[6] = ph3;
+        w[7] = last_start;  // (the wave's last entry: its code above, when it began here)
     }
 }
 
