@@ -110,8 +110,8 @@ typedef struct mola_icp_result {
     double   ms_upload;      /* host->HBM copies + map preparation                         */
     double   ms_iterations;  /* the iteration loop                                         */
     double   ms_quality;     /* the quality pass                                           */
-    double   ms_nn_kernel;   /* sum of HIP-event durations of the NN kernel launches       */
-    uint32_t n_nn_launches;  /* number of NN kernel launches timed in ms_nn_kernel         */
+    double   ms_nn_kernel;   /* sum of HIP-event durations of the NN kernel launches (0 unless mola_icp_set_profiling) */
+    uint32_t n_nn_launches;  /* number of NN kernel launches (matcher + quality passes)     */
     uint32_t nn_kernel_used; /* MOLA_ICP_NN_VALU / _MFMA / _TILED                              */
     uint64_t nn_pairs_evaluated; /* exact (query, map point) distance evaluations over all launches;
                                     N*M per launch for the dense kernels, fewer under exact tile culling */

@@ -114,7 +114,7 @@ HipWorkspace::~HipWorkspace()
     batch_scratch_.release_all();
     map_sc_.reset();
     loc_sc_.reset();
-    ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); ts_gs_.release(); rows_.release(); item_cost_.release(); item_order_.release(); redo_list_.release();
+    ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); ts_gs_.release(); rows_.release(); item_cost_.release(); item_order_.release(); redo_list_.release(); knn_cost_.release(); knn_order_.release();
     planes_.release(); knn_pos_.release(); plane_acc_.release(); plane_cache_.release();
     if (plane_acc_host_) (void)hipHostFree(plane_acc_host_);
     sort_scratch_.release();
@@ -262,6 +262,8 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     loc_sc_->ready = false;
     cost_valid_ = false;
     order_valid_ = false;
+    knn_cost_valid_ = false;
+    knn_order_valid_ = false;
     knn_seed_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
@@ -284,6 +286,8 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     loc_sc_->ready = false;
     cost_valid_ = false;
     order_valid_ = false;
+    knn_cost_valid_ = false;
+    knn_order_valid_ = false;
     knn_seed_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
@@ -648,6 +652,8 @@ void HipWorkspace::use_cached_local(const std::shared_ptr<SortedCloud>& sc)
     planes_valid_ = false;
     cost_valid_ = false;
     order_valid_ = false;
+    knn_cost_valid_ = false;
+    knn_order_valid_ = false;
     knn_seed_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
@@ -863,6 +869,26 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
                         !g_knobs.no_knn_verify;
     knn_changed_items_ = -1.0;  // consumed: only an accumulate_planes() after this launch renews it
     if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
+    // heavy-first order of the full sweeps (cycles per item of the last full sweep; re-sorted at launch 1, 2, 4, 8, then every 16th)
+    {
+        const void* before = knn_cost_.p;
+        if ((rc = knn_cost_.reserve(sizeof(unsigned int) * (size_t)n_items))) return rc;
+        if (knn_cost_.p != before) knn_cost_valid_ = false;
+    }
+    if ((rc = knn_order_.reserve(sizeof(int) * ((size_t)n_items + kQueues + 1)))) return rc;
+    const int* knn_order = nullptr;
+    if (knn_cost_valid_ && !g_knobs.no_lpt) {
+        if (!knn_order_valid_ || knn_launches_since_order_ >= knn_plan_interval_) {
+            hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, knn_cost_.as<unsigned int>(), n_items, knn_order_.as<int>());
+            HIPCHK(hipGetLastError());
+            knn_plan_interval_ = knn_order_valid_ ? (knn_plan_interval_ < 16 ? knn_plan_interval_ * 2 : 16) : 1;
+            knn_order_valid_ = true;
+            knn_launches_since_order_ = 0;
+        }
+        ++knn_launches_since_order_;
+        knn_order = knn_order_.as<int>();
+    }
+    knn_cost_valid_ = true;
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
     // warm-started launches: the counting flavour over all items, then the insertion flavour over the items it
     // queued (counter[2] = their number); first launch on a cloud pair: the insertion flavour over all items
@@ -870,7 +896,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     hipLaunchKernelGGL((k_knn_planes<KK, VER>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold,   \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
-                       counter + 2, LIST, counter, staged, lds_boxes)
+                       counter + 2, LIST, counter, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>())
 #define MOLA_LAUNCH_KNN_ALL(KK)                                                                                      \
     do {                                                                                                             \
         if (verify) {                                                                                                \

@@ -189,6 +189,9 @@ class HipWorkspace final : public Stages {
     unsigned long long* stats_host_ = nullptr;  // pinned
     DevBuf redo_list_;                // work items with exact distance ties: redone with the full lexicographic key
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
+    DevBuf knn_cost_, knn_order_;     // ... of the kNN (point-to-plane) kernels' full sweeps
+    bool knn_cost_valid_ = false, knn_order_valid_ = false;
+    int knn_plan_interval_ = 1, knn_launches_since_order_ = 0;
     bool cost_valid_ = false, order_valid_ = false;
     unsigned int launches_since_order_ = 0, plan_interval_ = 1;
     int fit_cache_[8] = {};            // resident blocks per CU of the tiled kernels (0 = not queried yet)

@@ -103,6 +103,7 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     double last_acc[kNAcc] = {};
     bool have_solution = false;
     double plane_pairs = 0, plane_rmse = 0;
+    double last_pacc[kNAccPlaneHost] = {};
     const double t0 = now_ms();
     for (; it < p.max_iterations; ++it) {
         const bool run_matcher =
@@ -126,6 +127,7 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
             if (solver_error) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }
             plane_pairs = pairs_global;
             plane_rmse = std::sqrt((cost > 0 ? cost : 0.0) / pairs_global);
+            std::memcpy(last_pacc, pacc, sizeof last_pacc);
         } else {
             if ((rc = st.match(T, p.matcher_threshold, p, nullptr))) return rc;  // count comes from acc[16]
             if ((rc = solve_on_pairing(st, p, T, Tn, acc, &pairs_global, &solver_error))) return rc;
@@ -167,7 +169,7 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) {
         out->n_pairs = have_solution ? (uint64_t)plane_pairs : 0;
         out->rmse = have_solution ? plane_rmse : 0.0;   // rms point-to-plane distance at the last linearisation
-        std::memset(out->cov, 0, sizeof out->cov);
+        if (!have_solution || !pose_covariance_planes(last_pacc, T, out->cov)) std::memset(out->cov, 0, sizeof out->cov);
     } else {
         out->n_pairs = have_solution ? (uint64_t)last_acc[16] : 0;
         out->rmse = (have_solution && last_acc[16] > 0) ? std::sqrt(last_acc[17] / last_acc[16]) : 0.0;

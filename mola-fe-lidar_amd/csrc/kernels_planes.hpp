@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                                                     unsigned int* __restrict__ queue,
                                                     unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
                                                     unsigned int* __restrict__ changed_items,
-                                                    unsigned long long* __restrict__ staged_total, int lds_boxes)
+                                                    unsigned long long* __restrict__ staged_total, int lds_boxes,
+                                                    const int* __restrict__ item_order /*heaviest first, range boundaries behind it (k_order_items); may be null*/,
+                                                    unsigned int* __restrict__ item_cost /*cycles per item of this launch (full sweeps only)*/)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
     __shared__ int s_list[4][kMaxList];
@@ -97,10 +99,14 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
     const int n_items = from_list ? (int)*redo_count : (N + kQPW - 1) / kQPW;
     unsigned long long wave_staged = 0ull;
     unsigned int wave_changed = 0u;  // items of this wave with a lane whose neighbour list differs from its seeds
-    WaveQueue wq(queue, lane, n_items);
+    // full sweeps are served heaviest item first inside each XCD's range (as k_nn_tiled: a launch is as long as its
+    // longest wave, and the dense regions' items take several times the median)
+    const int* order = from_list ? nullptr : item_order;
+    WaveQueue wq(queue, lane, n_items, order ? order + n_items : nullptr);
     for (int raw = wq.first(); raw < n_items;) {
         const int next_raw_v = wq.pop();
-        const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : raw;
+        const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : (order ? __builtin_amdgcn_readfirstlane(order[raw]) : raw);
+        const unsigned long long t_item0 = (item_cost && !from_list) ? __builtin_amdgcn_s_memtime() : 0ull;
 
         float qx[2], qy[2], qz[2], reach[2], kbound[2];
         // the K best of each query, sorted ascending by the packed key (d2 bits << 32 | original index): d2 >= 0, so the
@@ -317,6 +323,10 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         }  // (epilogue)
         wave_changed += item_changed ? 1u : 0u;
         wave_staged += n_staged * 2;  // units of 64 (query, point) pairs
+        if (item_cost && !from_list && lane == 0) {
+            const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
+            item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
+        }
         raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v));
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);

@@ -146,6 +146,8 @@ __global__ __launch_bounds__(1024) void k_order_entries(const unsigned int* __re
     };
     const unsigned long long thr = (unsigned long long)((double)total / (double)(n_slots > 0 ? n_slots : 1) * (double)kSplitShare);
     const float scale = 32.0f / (float)s_max;
+    // (Listing the LIGHTEST items -- the ones served last, whose latency is the launch's tail -- as halves too was measured:
+    //  no gain; a half is still a chain of the same dependent round trips.)
     // an item -> one entry, or two: (cost, code) of entry e in {0, 1}; returns the number of entries
     auto entries_of = [&](int i, unsigned int (&ec)[2], int (&code)[2]) -> int {
         const unsigned long long c = cost(i);

@@ -441,12 +441,12 @@ __device__ __forceinline__ void nn_visit_fast(float (*sm)[64], int nm, int jb0, 
     }
 }
 
-// EXACT = false: the fast sweep.  Per (query, 4-point chunk) only the chunk minimum is compared with the
-//   running best (~6 VALU ops per pair); the winning chunk is re-evaluated once at the end to recover the
-//   exact point and the lowest-original-index rule inside it.  If an EQUAL minimum showed up in a different
-//   chunk (exact ties: duplicate points, lattices) the item is queued for the exact pass.
-// EXACT = true : the exact-key sweep over the queued items: per-pair argmin on the packed key
-//   (d2 bits << 32 | original index), i.e. the full lexicographic rule (~10 ops per pair).
+// EXACT = false: the fast sweep.  Per (query, kGroup = 8 points) only the group minimum meets the running best
+//   (nn_visit_fast); the winning group is re-evaluated once at the end to recover the exact point and the
+//   lowest-original-index rule inside it.  If a second group reached the SAME minimum (exact ties: duplicate
+//   points, lattices) the entry is queued for the exact pass.
+// EXACT = true : the exact-key sweep over the queued entries: per-pair argmin on the packed key
+//   (d2 bits << 32 | original index), i.e. the full lexicographic rule.
 template <bool EXACT, int QPL>
 __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,

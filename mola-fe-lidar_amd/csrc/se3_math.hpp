@@ -396,4 +396,81 @@ inline bool solve_gauss_newton_planes(const double acc[kNAccPlaneForm], const Ma
     return true;
 }
 
+// 6x6 covariance of the pose for the point-to-plane cost (left perturbation, order x,y,z,wx,wy,wz -- as
+// pose_covariance): cov = sigma^2 (J^T A J)^-1 with the quadratic form's A (the Gauss-Newton normal matrix of the
+// last linearisation) at the pose T, sigma^2 = cost(T) / (n - 6).  Own definition: the reference only consumes the
+// mean (src/LidarOdometry.cpp:302, 791).
+inline bool pose_covariance_planes(const double acc[kNAccPlaneForm], const Mat4& T, double cov[36])
+{
+    std::memset(cov, 0, sizeof(double) * 36);
+    const double n = acc[91];
+    if (!(n > 6.0)) return false;
+    double A[12][12], b[12], x[12];
+    int q = 0;
+    for (int i = 0; i < 12; ++i)
+        for (int j = i; j < 12; ++j) { A[i][j] = acc[q]; A[j][i] = acc[q]; ++q; }
+    for (int i = 0; i < 12; ++i) b[i] = acc[78 + i];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) x[3 * r + c] = T(r, c);
+        x[9 + r] = T(r, 3);
+    }
+    double J[12][6] = {};
+    for (int k = 0; k < 3; ++k) J[9 + k][k] = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        double E[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // [e_k]x
+        E[(k + 2) % 3][(k + 1) % 3] = 1.0;
+        E[(k + 1) % 3][(k + 2) % 3] = -1.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                double v = 0;
+                for (int m = 0; m < 3; ++m) v += E[r][m] * T(m, c);
+                J[3 * r + c][3 + k] = v;
+            }
+            double tv = 0;
+            for (int m = 0; m < 3; ++m) tv += E[r][m] * T(m, 3);
+            J[9 + r][3 + k] = tv;
+        }
+    }
+    double cost = acc[90];
+    for (int i = 0; i < 12; ++i) {
+        double v = 0;
+        for (int j = 0; j < 12; ++j) v += A[i][j] * x[j];
+        cost += x[i] * (v - 2 * b[i]);
+    }
+    double H[6][12] = {};
+    for (int a = 0; a < 6; ++a) {
+        for (int k = 0; k < 6; ++k) {
+            double v = 0;
+            for (int i = 0; i < 12; ++i)
+                for (int j = 0; j < 12; ++j) v += J[i][a] * A[i][j] * J[j][k];
+            H[a][k] = v;
+        }
+        H[a][6 + a] = 1.0;
+    }
+    for (int c = 0; c < 6; ++c) {  // Gauss-Jordan with partial pivoting
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r)
+            if (std::fabs(H[r][c]) > std::fabs(H[piv][c])) piv = r;
+        if (std::fabs(H[piv][c]) < 1e-300) return false;
+        if (piv != c)
+            for (int k = 0; k < 12; ++k) { const double t = H[c][k]; H[c][k] = H[piv][k]; H[piv][k] = t; }
+        const double inv = 1.0 / H[c][c];
+        for (int k = 0; k < 12; ++k) H[c][k] *= inv;
+        for (int r = 0; r < 6; ++r) {
+            if (r == c) continue;
+            const double f = H[r][c];
+            if (f == 0) continue;
+            for (int k = 0; k < 12; ++k) H[r][k] -= f * H[c][k];
+        }
+    }
+    const double sigma2 = (cost > 0 ? cost : 0.0) / (n - 6.0);
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const double v = sigma2 * H[i][6 + j];
+            if (!std::isfinite(v)) { std::memset(cov, 0, sizeof(double) * 36); return false; }
+            cov[6 * i + j] = v;
+        }
+    return true;
+}
+
 }  // namespace mola_icp_amd

@@ -211,3 +211,32 @@ def test_product_gn_matches_independent_golden(pkg, golden):
     T, _, _ = pkg.solve_gauss_newton_planes(acc, np.eye(4), 50)
     np.testing.assert_allclose(T, golden["D_T_gn"], atol=1e-9)
     assert k.sum() > 1000
+
+
+@pytest.mark.gpu
+def test_point2plane_pose_covariance(pkg, pair):
+    """ICP_Output::found_pose_to_wrt_from is a CPose3DPDFGaussian (LidarOdometry.h:131): the shipped pipeline fills its
+    covariance too -- sigma^2 (J^T J)^-1 of the plane residuals of the LAST linearisation, evaluated at the final pose
+    (left perturbation, order x y z wx wy wz).  Restated here from the pairing the matcher reports."""
+    g, l, _ = pair
+    p = pkg.Parameters.load_from_file(REGULAR)
+    p.fixed_iterations, p.skip_quality = 1, 1
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    p.max_iterations = 3
+    prev = icp.align_resident(np.eye(4), p)          # pose of the 4th iteration's linearisation
+    p.max_iterations = 4
+    r = icp.align_resident(np.eye(4), p)
+    valid, cen, nor, _, n = icp.match_planes(prev.optimal_tf, p, l.shape[1])
+    k = valid.astype(bool)
+    T = r.optimal_tf
+    pts = (T[:3, :3] @ l[:, k].astype(np.float64)).T + T[:3, 3]
+    res = np.einsum("ij,ij->i", nor[k], pts - cen[k])
+    J = np.hstack([nor[k], np.cross(pts, nor[k])])   # d r / d (v, w): r(delta) = n . ((I + [w]x) p + v - c)
+    H = J.T @ J
+    cov = (res @ res) / (n - 6) * np.linalg.inv(H)
+    got = r.optimal_tf_cov
+    assert np.allclose(got, got.T, rtol=1e-9, atol=0) and np.all(np.linalg.eigvalsh(got) > 0)
+    np.testing.assert_allclose(got, cov, rtol=1e-6, atol=1e-18)
+    icp.close()
