@@ -837,7 +837,6 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     counters_clean_ = false;
     ++nn_launches_;
     if (profiling_) HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
-    const int n_items = (int)((N_ + kQPW - 1) / kQPW);
     const float* sl = loc_sc_->sorted.as<float>();
     const TiledMap mp = tiled_map();
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
@@ -849,15 +848,21 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     size_t& fit_lds = fit_cache_lds_[p.knn < 3 ? 2 : (p.knn > 8 ? 7 : (int)p.knn - 1)];
     if (fit == 0 || fit_lds != dyn_lds)
     switch (p.knn) {  // (the verify flavour needs fewer registers than the insertion flavour)
-        case 3: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<3, false>, 256, dyn_lds)); break;
-        case 4: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<4, false>, 256, dyn_lds)); break;
-        case 5: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<5, false>, 256, dyn_lds)); break;
-        case 6: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<6, false>, 256, dyn_lds)); break;
-        case 7: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<7, false>, 256, dyn_lds)); break;
-        default: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<8, false>, 256, dyn_lds)); break;
+        case 3: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<3, false, 2>, 256, dyn_lds)); break;
+        case 4: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<4, false, 2>, 256, dyn_lds)); break;
+        case 5: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<5, false, 2>, 256, dyn_lds)); break;
+        case 6: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<6, false, 2>, 256, dyn_lds)); break;
+        case 7: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<7, false, 2>, 256, dyn_lds)); break;
+        default: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<8, false, 2>, 256, dyn_lds)); break;
     }
     fit_lds = dyn_lds;
     int grid = num_cus_ * (fit < 1 ? 1 : (fit > 3 ? 3 : fit));
+    // queries per lane: with no more 128-query items than waves every wave runs ONE item and the launch is as long as the
+    // heaviest: 64-query items (one query per lane) nearly halve it (MOLA_ICP_QPL forces either)
+    const size_t n128 = (N_ + kQPW - 1) / kQPW;
+    int ql = n128 <= (size_t)grid * 4 ? 1 : 2;
+    if (g_knobs.qpl) ql = g_knobs.qpl;
+    const int n_items = (int)((N_ + (size_t)(64 * ql) - 1) / (size_t)(64 * ql));
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed) ? 1 : 0;
     // the cached plane of an unchanged neighbour list carries the planar / non-planar decision of the launch that
@@ -877,7 +882,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     }
     if ((rc = knn_order_.reserve(sizeof(int) * ((size_t)n_items + kQueues + 1)))) return rc;
     const int* knn_order = nullptr;
-    if (knn_cost_valid_ && !g_knobs.no_lpt) {
+    // (with at most one item per wave there is nothing to balance, and heavy-first would put the heaviest four on ONE CU)
+    if (knn_cost_valid_ && !g_knobs.no_lpt && n_items > grid * 4) {
         if (!knn_order_valid_ || knn_launches_since_order_ >= knn_plan_interval_) {
             hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, knn_cost_.as<unsigned int>(), n_items, knn_order_.as<int>());
             HIPCHK(hipGetLastError());
@@ -892,19 +898,24 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
     // warm-started launches: the counting flavour over all items, then the insertion flavour over the items it
     // queued (counter[2] = their number); first launch on a cloud pair: the insertion flavour over all items
-#define MOLA_LAUNCH_KNN(KK, VER, QUEUE, LIST)                                                                        \
-    hipLaunchKernelGGL((k_knn_planes<KK, VER>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
+#define MOLA_LAUNCH_KNN(KK, VER, QLL, QUEUE, LIST)                                                                        \
+    hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold,   \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
                        counter + 2, LIST, counter, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>())
-#define MOLA_LAUNCH_KNN_ALL(KK)                                                                                      \
+#define MOLA_LAUNCH_KNN_QL(KK, QLL)                                                                                  \
     do {                                                                                                             \
         if (verify) {                                                                                                \
-            MOLA_LAUNCH_KNN(KK, true, tq, redo_list_.as<int>());                                                     \
-            MOLA_LAUNCH_KNN(KK, false, tq + kQueues * kQueueStride, redo_list_.as<int>());                           \
+            MOLA_LAUNCH_KNN(KK, true, QLL, tq, redo_list_.as<int>());                                                \
+            MOLA_LAUNCH_KNN(KK, false, QLL, tq + kQueues * kQueueStride, redo_list_.as<int>());                      \
         } else {                                                                                                     \
-            MOLA_LAUNCH_KNN(KK, false, tq, (int*)nullptr);                                                           \
+            MOLA_LAUNCH_KNN(KK, false, QLL, tq, (int*)nullptr);                                                      \
         }                                                                                                            \
+    } while (0)
+#define MOLA_LAUNCH_KNN_ALL(KK)                                                                                      \
+    do {                                                                                                             \
+        if (ql == 1) MOLA_LAUNCH_KNN_QL(KK, 1);                                                                      \
+        else MOLA_LAUNCH_KNN_QL(KK, 2);                                                                              \
     } while (0)
     switch (p.knn) {
         case 3: MOLA_LAUNCH_KNN_ALL(3); break;
@@ -915,6 +926,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         default: MOLA_LAUNCH_KNN_ALL(8); break;
     }
 #undef MOLA_LAUNCH_KNN_ALL
+#undef MOLA_LAUNCH_KNN_QL
 #undef MOLA_LAUNCH_KNN
     HIPCHK(hipGetLastError());
     if (profiling_) {

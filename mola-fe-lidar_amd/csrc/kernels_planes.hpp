@@ -66,197 +66,28 @@ __device__ __forceinline__ void eig_sym3_dev(const double Cin[3][3], double ev[3
         for (int k = 0; k < 3; k++) V[r][k] = Vs[r][k];
 }
 
-template <int K, bool VERIFY>
-__global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
-                                                    const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
-                                                    float thr2, double threshold, double plane_eig_thr,
-                                                    PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
-                                                    int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
-                                                    int use_seed, int use_cache /*cached planes were decided with this launch's planeEigenThreshold*/,
-                                                    unsigned int* __restrict__ queue,
-                                                    unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
-                                                    unsigned int* __restrict__ changed_items,
-                                                    unsigned long long* __restrict__ staged_total, int lds_boxes,
-                                                    const int* __restrict__ item_order /*heaviest first, range boundaries behind it (k_order_items); may be null*/,
-                                                    unsigned int* __restrict__ item_cost /*cycles per item of this launch (full sweeps only)*/)
+// Epilogue of one query of the point-to-plane matcher (shared by k_knn_planes and k_knn_coop): kp / kd = its sorted
+// neighbour list (sorted-map positions, squared distances; -1 / gate^2 in the unused tail), (qx, qy, qz) the moved query.
+// Writes knn_pos (next launch's seeds), the plane of the list into `cache` when it had to be solved, the pairing into
+// `out`.  Returns whether SOME lane of the wave had to solve a plane (= the item's lists changed).
+template <int K>
+__device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&kp)[K], const float (&kd)[K], float qx, float qy, float qz,
+                                               int i, int N, float thr2, double threshold, double plane_eig_thr,
+                                               PlanePair* __restrict__ out, PlanePair* __restrict__ cache, int* __restrict__ knn_pos,
+                                               int use_seed, int use_cache)
 {
-    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
-    __shared__ int s_list[4][kMaxList];
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float(*sm)[64] = s_m[wave];
-    int* slist = s_list[wave];
-    // VERIFY = true (warm-started launches): all items; the sweep only COUNTS the points within each query's
-    //   K-th seed distance.  Count == number of seeds <=> the neighbour set is exactly the seeds (every seed lies
-    //   within that distance and is met once), so the sorted seed list IS the answer and no list is maintained
-    //   in the sweep.  Items with a lane whose count differs are queued in redo_list, untouched.
-    // VERIFY = false: the full sweep with sorted-list insertion -- over all items (first launch on a cloud pair:
-    //   redo_list == nullptr) or over the queued items only.
-    const bool from_list = !VERIFY && redo_list != nullptr;
-    if (from_list && *redo_count == 0u) return;  // nothing queued (uniform: before any barrier)
-    const lds_f32* lbox = (const lds_f32*)s_dyn;
-    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
-    const int n_items = from_list ? (int)*redo_count : (N + kQPW - 1) / kQPW;
-    unsigned long long wave_staged = 0ull;
-    unsigned int wave_changed = 0u;  // items of this wave with a lane whose neighbour list differs from its seeds
-    // full sweeps are served heaviest item first inside each XCD's range (as k_nn_tiled: a launch is as long as its
-    // longest wave, and the dense regions' items take several times the median)
-    const int* order = from_list ? nullptr : item_order;
-    WaveQueue wq(queue, lane, n_items, order ? order + n_items : nullptr);
-    for (int raw = wq.first(); raw < n_items;) {
-        const int next_raw_v = wq.pop();
-        const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : (order ? __builtin_amdgcn_readfirstlane(order[raw]) : raw);
-        const unsigned long long t_item0 = (item_cost && !from_list) ? __builtin_amdgcn_s_memtime() : 0ull;
-
-        float qx[2], qy[2], qz[2], reach[2], kbound[2];
-        // the K best of each query, sorted ascending by the packed key (d2 bits << 32 | original index): d2 >= 0, so the
-        // unsigned order of the key IS the lexicographic (d2, index) order -- one 64-bit compare per list step
-        unsigned long long kk[2][K];
-        auto kd_of = [&](int k, int j) -> float { return __uint_as_float((unsigned int)(kk[k][j] >> 32)); };
-        int kp[2][K];            // sorted-map positions
-        // insert (du, o, pos) into the sorted list of query k (caller has checked that it belongs there)
-        auto insert = [&](int k, float du, unsigned int o, int pos) {
-            kk[k][K - 1] = ((unsigned long long)__float_as_uint(du) << 32) | o; kp[k][K - 1] = pos;
-#pragma unroll
-            for (int j = K - 1; j > 0; --j) {
-                const bool sw = kk[k][j] < kk[k][j - 1];
-                if (!__any(sw)) break;  // every inserting lane has found its place (a new entry usually lands near the end)
-                const unsigned long long tk = kk[k][j]; const int tp = kp[k][j];
-                kk[k][j] = sw ? kk[k][j - 1] : tk; kp[k][j] = sw ? kp[k][j - 1] : tp;
-                kk[k][j - 1] = sw ? tk : kk[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
-            }
-        };
-        int qi[2];
-        float lx[2], ly[2], lz[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            qi[k] = item * kQPW + k * 64 + lane;
-            const int ic = qi[k] < N ? qi[k] : N - 1;
-            lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
-#pragma unroll
-            for (int j = 0; j < K; ++j) { kk[k][j] = (unsigned long long)__float_as_uint(thr2) << 32; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
-        }
-        if (use_seed) {
-            // warm start: the K neighbours of the last launch are exact candidates; with them in the list the
-            // reach is the K-th seed distance instead of the gate, and most tiles are never staged
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int ic = qi[k] < N ? qi[k] : N - 1;
-                int js[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) js[j] = knn_pos[(size_t)ic * K + j];
-                float gx[K], gy[K], gz[K];
-                unsigned int go[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int jc = js[j] >= 0 ? js[j] : 0;
-                    gx[j] = mp.sx[jc]; gy[j] = mp.sy[jc]; gz[j] = mp.sz[jc]; go[j] = (unsigned int)mp.perm[jc];
-                }
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float du = dist2(qx[k], qy[k], qz[k], gx[j], gy[j], gz[j]);
-                    if (js[j] >= 0 && du < thr2) insert(k, du, go[j], js[j]);  // distinct positions: no duplicates among the seeds
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            reach[k] = reach_of(kd_of(k, K - 1), qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
-            kbound[k] = kd_of(k, K - 1);  // (fixed during the sweep)
-            if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; kbound[k] = -1.0f; }  // padding lane
-        }
-        // VERIFY: tau = K-th seed distance (list full), else the largest float below gate^2 ("d2 < gate^2" as "<=")
-        float tau[2];
-        int expect[2], cnt[2] = {0, 0};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            int sds = 0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) sds += kp[k][j] >= 0 ? 1 : 0;
-            expect[k] = sds;
-            tau[k] = sds == K ? kd_of(k, K - 1) : __uint_as_float(__float_as_uint(thr2) - 1u);
-            if (VERIFY && qi[k] < N) kbound[k] = tau[k];
-        }
-
-        const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
-        unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
-        unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
-        const unsigned long long n_staged = tiled_sweep<2, !VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
-            for (int m = 0; m < nm; m += 4) {
-                const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
-                const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
-                const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
-                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
-                if constexpr (VERIFY) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
-                        cnt[0] += dv.x <= tau[0] ? 1 : 0;
-                        cnt[1] += dv.y <= tau[1] ? 1 : 0;
-                    }
-                    continue;
-                }
-                float d[2][4];
-                bool cand = false;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {  // both queries of the lane per packed instruction
-                    const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
-                    d[0][u] = dv.x; d[1][u] = dv.y;
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd_of(k, K - 1);
-                if (__any(cand)) {  // some lane may have to insert: rare once the lists have tightened
-                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
-                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
-                                                __float_as_uint(O.w)};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int pos = (m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32;
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const float du = d[k][u];
-                            if ((((unsigned long long)__float_as_uint(du) << 32) | os[u]) < kk[k][K - 1]) {
-                                bool dup = false;  // a seed met again by the sweep
-#pragma unroll
-                                for (int j = 0; j < K; ++j) dup |= kp[k][j] == pos;
-                                if (!dup) insert(k, du, os[u], pos);
-                            }
-                        }
-                    }
-                }
-            }
-         }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
-
-        bool redo = false;
-        if constexpr (VERIFY) {
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) bad |= qi[k] < N && cnt[k] != expect[k];
-            redo = __any(bad);
-            if (redo && lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
-        }
-        bool item_changed = false;
-        if (!redo) {
-        // Epilogue.  The plane (centroid, normal, is-it-planar) depends only on the ordered neighbour list -- map
-        // points, fixed for the align -- so when a query's list equals the last launch's, the cached plane is reused
-        // bit for bit and the fp64 covariance + Jacobi eigen-solve (dearer than the search itself) is skipped.  Near
-        // convergence almost no list changes; a wave pays for the solve only if one of its lanes needs it.
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = qi[k];
+    bool item_changed = false;
+    {
+            
             const bool in = i < N;
             const size_t ic = in ? (size_t)i : (size_t)(N - 1);
             int m = 0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) m += (kp[k][j] >= 0 && kd_of(k, j) < thr2) ? 1 : 0;  // sorted: the first m entries
+            for (int j = 0; j < K; ++j) m += (kp[j] >= 0 && kd[j] < thr2) ? 1 : 0;  // sorted: the first m entries
             bool same = use_seed != 0 && use_cache != 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const int now = j < m ? kp[k][j] : -1;
+                const int now = j < m ? kp[j] : -1;
                 if (use_seed) same &= knn_pos[ic * K + j] == now;
                 if (in) knn_pos[ic * K + j] = now;
             }
@@ -274,7 +105,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                     for (int j = 0; j < K; ++j) {
                         px[j] = py[j] = pz[j] = 0;
                         if (j < m) {
-                            px[j] = mp.sx[kp[k][j]]; py[j] = mp.sy[kp[k][j]]; pz[j] = mp.sz[kp[k][j]];
+                            px[j] = mp.sx[kp[j]]; py[j] = mp.sy[kp[j]]; pz[j] = mp.sz[kp[j]];
                             mean[0] += px[j]; mean[1] += py[j]; mean[2] += pz[j];
                         }
                     }
@@ -309,8 +140,8 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
             if (in) {
                 PlanePair pp = pl;
                 if (pl.valid) {
-                    const double dist = fabs(pl.n[0] * ((double)qx[k] - pl.c[0]) + pl.n[1] * ((double)qy[k] - pl.c[1]) +
-                                             pl.n[2] * ((double)qz[k] - pl.c[2]));
+                    const double dist = fabs(pl.n[0] * ((double)qx - pl.c[0]) + pl.n[1] * ((double)qy - pl.c[1]) +
+                                             pl.n[2] * ((double)qz - pl.c[2]));
                     if (dist > threshold) {
                         pp.valid = 0;
 #pragma unroll
@@ -319,10 +150,222 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                 }
                 out[ic] = pp;
             }
+    }
+    return item_changed;
+}
+
+// QL = queries per lane: 2 (items of 128 queries), or 1 (items of 64) when the cloud has no more 128-query items than the
+// launch has waves -- every wave then runs ONE item, the launch is as long as the heaviest of them, and halving the
+// items nearly halves it (an odometry-size scan pair: 120k points = 938 items of 128 on 3072 waves).
+template <int K, bool VERIFY, int QL>
+__global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                    const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
+                                                    float thr2, double threshold, double plane_eig_thr,
+                                                    PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
+                                                    int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
+                                                    int use_seed, int use_cache /*cached planes were decided with this launch's planeEigenThreshold*/,
+                                                    unsigned int* __restrict__ queue,
+                                                    unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
+                                                    unsigned int* __restrict__ changed_items,
+                                                    unsigned long long* __restrict__ staged_total, int lds_boxes,
+                                                    const int* __restrict__ item_order /*heaviest first, range boundaries behind it (k_order_items); may be null*/,
+                                                    unsigned int* __restrict__ item_cost /*cycles per item of this launch (full sweeps only)*/)
+{
+    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
+    __shared__ int s_list[4][kMaxList];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float(*sm)[64] = s_m[wave];
+    int* slist = s_list[wave];
+    // VERIFY = true (warm-started launches): all items; the sweep only COUNTS the points within each query's
+    //   K-th seed distance.  Count == number of seeds <=> the neighbour set is exactly the seeds (every seed lies
+    //   within that distance and is met once), so the sorted seed list IS the answer and no list is maintained
+    //   in the sweep.  Items with a lane whose count differs are queued in redo_list, untouched.
+    // VERIFY = false: the full sweep with sorted-list insertion -- over all items (first launch on a cloud pair:
+    //   redo_list == nullptr) or over the queued items only.
+    const bool from_list = !VERIFY && redo_list != nullptr;
+    if (from_list && *redo_count == 0u) return;  // nothing queued (uniform: before any barrier)
+    const lds_f32* lbox = (const lds_f32*)s_dyn;
+    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
+    constexpr int kQ = 64 * QL;  // queries per item
+    const int n_items = from_list ? (int)*redo_count : (N + kQ - 1) / kQ;
+    unsigned long long wave_staged = 0ull;
+    unsigned int wave_changed = 0u;  // items of this wave with a lane whose neighbour list differs from its seeds
+    // full sweeps are served heaviest item first inside each XCD's range (as k_nn_tiled: a launch is as long as its
+    // longest wave, and the dense regions' items take several times the median)
+    const int* order = from_list ? nullptr : item_order;
+    WaveQueue wq(queue, lane, n_items, order ? order + n_items : nullptr);
+    for (int raw = wq.first(); raw < n_items;) {
+        const int next_raw_v = wq.pop();
+        const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : (order ? __builtin_amdgcn_readfirstlane(order[raw]) : raw);
+        const unsigned long long t_item0 = (item_cost && !from_list) ? __builtin_amdgcn_s_memtime() : 0ull;
+
+        float qx[QL], qy[QL], qz[QL], reach[QL], kbound[QL];
+        // the K best of each query, sorted ascending by the packed key (d2 bits << 32 | original index): d2 >= 0, so the
+        // unsigned order of the key IS the lexicographic (d2, index) order -- one 64-bit compare per list step
+        unsigned long long kk[QL][K];
+        auto kd_of = [&](int k, int j) -> float { return __uint_as_float((unsigned int)(kk[k][j] >> 32)); };
+        int kp[QL][K];            // sorted-map positions
+        // insert (du, o, pos) into the sorted list of query k (caller has checked that it belongs there)
+        auto insert = [&](int k, float du, unsigned int o, int pos) {
+            kk[k][K - 1] = ((unsigned long long)__float_as_uint(du) << 32) | o; kp[k][K - 1] = pos;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                const bool sw = kk[k][j] < kk[k][j - 1];
+                if (!__any(sw)) break;  // every inserting lane has found its place (a new entry usually lands near the end)
+                const unsigned long long tk = kk[k][j]; const int tp = kp[k][j];
+                kk[k][j] = sw ? kk[k][j - 1] : tk; kp[k][j] = sw ? kp[k][j - 1] : tp;
+                kk[k][j - 1] = sw ? tk : kk[k][j - 1]; kp[k][j - 1] = sw ? tp : kp[k][j - 1];
+            }
+        };
+        int qi[QL];
+        float lx[QL], ly[QL], lz[QL];
+#pragma unroll
+        for (int k = 0; k < QL; ++k) {
+            qi[k] = item * kQ + k * 64 + lane;
+            const int ic = qi[k] < N ? qi[k] : N - 1;
+            lx[k] = slx[ic]; ly[k] = sly[ic]; lz[k] = slz[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < QL; ++k) {
+            xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) { kk[k][j] = (unsigned long long)__float_as_uint(thr2) << 32; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
+        }
+        if (use_seed) {
+            // warm start: the K neighbours of the last launch are exact candidates; with them in the list the
+            // reach is the K-th seed distance instead of the gate, and most tiles are never staged
+#pragma unroll
+            for (int k = 0; k < QL; ++k) {
+                const int ic = qi[k] < N ? qi[k] : N - 1;
+                int js[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) js[j] = knn_pos[(size_t)ic * K + j];
+                float gx[K], gy[K], gz[K];
+                unsigned int go[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int jc = js[j] >= 0 ? js[j] : 0;
+                    gx[j] = mp.sx[jc]; gy[j] = mp.sy[jc]; gz[j] = mp.sz[jc]; go[j] = (unsigned int)mp.perm[jc];
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float du = dist2(qx[k], qy[k], qz[k], gx[j], gy[j], gz[j]);
+                    if (js[j] >= 0 && du < thr2) insert(k, du, go[j], js[j]);  // distinct positions: no duplicates among the seeds
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QL; ++k) {
+            reach[k] = reach_of(kd_of(k, K - 1), qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
+            kbound[k] = kd_of(k, K - 1);  // the sweep's box tests read it LIVE: it shrinks as the list fills (below)
+            if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; kbound[k] = -1.0f; }  // padding lane
+        }
+        // VERIFY: tau = K-th seed distance (list full), else the largest float below gate^2 ("d2 < gate^2" as "<=")
+        float tau[QL];
+        int expect[QL], cnt[QL] = {};
+#pragma unroll
+        for (int k = 0; k < QL; ++k) {
+            int sds = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) sds += kp[k][j] >= 0 ? 1 : 0;
+            expect[k] = sds;
+            tau[k] = sds == K ? kd_of(k, K - 1) : __uint_as_float(__float_as_uint(thr2) - 1u);
+            if (VERIFY && qi[k] < N) kbound[k] = tau[k];
+        }
+
+        // distances of 4 staged points to the lane's queries: QL = 2 pairs the two queries per packed instruction, QL = 1
+        // pairs two points (each half the same IEEE sequence as the contract's dist2)
+        auto dist4 = [&](const float (&xs)[4], const float (&ys)[4], const float (&zs)[4], float (&d)[QL][4]) {
+            if constexpr (QL == 2) {
+                const v2f q2x = {qx[0], qx[1]}, q2y = {qy[0], qy[1]}, q2z = {qz[0], qz[1]};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const v2f dv = dist2_pk(q2x, q2y, q2z, xs[u], ys[u], zs[u]);
+                    d[0][u] = dv.x; d[1][u] = dv.y;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    const v2f mx = {xs[u], xs[u + 1]}, my = {ys[u], ys[u + 1]}, mz = {zs[u], zs[u + 1]};
+                    const v2f dv = dist2_pk2(qx[0], qy[0], qz[0], mx, my, mz);
+                    d[0][u] = dv.x; d[0][u + 1] = dv.y;
+                }
+            }
+        };
+        unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
+        unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
+        const unsigned long long n_staged = tiled_sweep<QL, !VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
+            for (int m = 0; m < nm; m += 4) {
+                const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+                const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+                const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
+                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                float d[QL][4];
+                dist4(xs, ys, zs, d);
+                if constexpr (VERIFY) {
+#pragma unroll
+                    for (int k = 0; k < QL; ++k)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cnt[k] += d[k][u] <= tau[k] ? 1 : 0;
+                    continue;
+                }
+                bool cand = false;
+#pragma unroll
+                for (int k = 0; k < QL; ++k) cand |= fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])) <= kd_of(k, K - 1);
+                if (__any(cand)) {  // some lane may have to insert: rare once the lists have tightened
+                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z),
+                                                __float_as_uint(O.w)};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int pos = (m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32;
+#pragma unroll
+                        for (int k = 0; k < QL; ++k) {
+                            const float du = d[k][u];
+                            if ((((unsigned long long)__float_as_uint(du) << 32) | os[u]) < kk[k][K - 1]) {
+                                bool dup = false;  // a seed met again by the sweep
+#pragma unroll
+                                for (int j = 0; j < K; ++j) dup |= kp[k][j] == pos;
+                                if (!dup) insert(k, du, os[u], pos);
+                            }
+                        }
+                    }
+                    // Live bound: tiles tested from here on meet the K-th distance found so far.  On uniform clouds the lists
+                    // tighten within the first tiles either way; on a spinning-lidar scan the gate ball of an unseeded query near
+                    // the sensor holds ~10^4 points, and a launch was as long as those few items (1.2 ms of a 120k-point pair).
+#pragma unroll
+                    for (int k = 0; k < QL; ++k)
+                        if (qi[k] < N) kbound[k] = kd_of(k, K - 1);
+                }
+            }
+         }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
+
+        bool redo = false;
+        if constexpr (VERIFY) {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < QL; ++k) bad |= qi[k] < N && cnt[k] != expect[k];
+            redo = __any(bad);
+            if (redo && lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
+        }
+        bool item_changed = false;
+        if (!redo) {
+        // Epilogue.  The plane (centroid, normal, is-it-planar) depends only on the ordered neighbour list -- map
+        // points, fixed for the align -- so when a query's list equals the last launch's, the cached plane is reused
+        // bit for bit and the fp64 covariance + Jacobi eigen-solve (dearer than the search itself) is skipped.  Near
+        // convergence almost no list changes; a wave pays for the solve only if one of its lanes needs it.
+#pragma unroll
+        for (int k = 0; k < QL; ++k) {
+            float kd[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) kd[j] = kd_of(k, j);
+            item_changed |= plane_epilogue<K>(mp, kp[k], kd, qx[k], qy[k], qz[k], qi[k], N, thr2, threshold, plane_eig_thr, out, cache, knn_pos,
+                                              use_seed, use_cache);
         }
         }  // (epilogue)
         wave_changed += item_changed ? 1u : 0u;
-        wave_staged += n_staged * 2;  // units of 64 (query, point) pairs
+        wave_staged += n_staged * QL;  // units of 64 (query, point) pairs
         if (item_cost && !from_list && lane == 0) {
             const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
             item_cost[item] = c > 0xffffffffull ? 0xffffffffu : (unsigned int)c;
