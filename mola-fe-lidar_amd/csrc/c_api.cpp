@@ -18,6 +18,7 @@
 #include "../../include/mola_icp_amd.h"
 #include "hip_backend.hpp"
 #include "icp_loop.hpp"
+#include "trace.hpp"
 #include "yaml_lite.hpp"
 
 namespace mola_icp_amd {
@@ -205,9 +206,13 @@ int align_host_clouds(mola_icp_handle* h, const float* fx, const float* fy, cons
     if (lease.rc) return lease.rc;
     HipWorkspace& ws = *lease.ws;
     std::memset(out, 0, sizeof *out);
+    TraceRange tr("mola_icp.align");   // = the reference's profiler entry "run_one_icp" (cpp:858)
     const double t0 = now_ms();
-    if ((rc = ws.set_map_host(fx, fy, fz, M))) { lease.rc = rc; return rc; }
-    if ((rc = ws.set_local_host(tx, ty, tz, N))) { lease.rc = rc; return rc; }
+    {
+        TraceRange tr_up("mola_icp.upload");
+        if ((rc = ws.set_map_host(fx, fy, fz, M))) { lease.rc = rc; return rc; }
+        if ((rc = ws.set_local_host(tx, ty, tz, N))) { lease.rc = rc; return rc; }
+    }
     ws.set_global_sizes(0, 0);
     ws.set_allreduce(nullptr, nullptr);
     const double t1 = now_ms();

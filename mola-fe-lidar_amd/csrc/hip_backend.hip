@@ -372,7 +372,10 @@ int HipWorkspace::shard_reach_box(const Mat4& T, double margin, double lo[3], do
 {
     int rc = init();
     if (rc) return rc;
-    if (N_ == 0) return fail(MOLA_ICP_E_BADARG, "no local cloud set");
+    if (N_ == 0) {  // an empty shard (more ranks than points) reaches nothing: an empty box, no map point kept
+        for (int a = 0; a < 3; ++a) { lo[a] = 1e30; hi[a] = -1e30; }
+        return MOLA_ICP_OK;
+    }
     if (!loc_bbox_valid_) {
         HIPCHK(hipSetDevice(device_));
         if ((rc = bbox_of(lx_, ly_, lz_, N_, loc_bbox_))) return rc;
@@ -1638,6 +1641,8 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         } else {
             const int shared = (same_map && lds_boxes) ? 1 : 0;
             const size_t lds = shared ? dyn_lds : 0;
+            int& fit_tiled_ = sc_.fit_tiled;
+            size_t& fit_tiled_lds_ = sc_.fit_tiled_lds;
             if (fit_tiled_ == 0 || fit_tiled_lds_ != lds) {  // persistent waves with fixed first entries: the whole grid must be resident
                 HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_tiled_, k_nn_tiled_batch<kCoopMaxBatch>, 256, lds));
                 fit_tiled_lds_ = lds;

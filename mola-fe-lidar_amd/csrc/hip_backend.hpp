@@ -66,6 +66,8 @@ struct BatchScratch {
     unsigned long long* stats_host = nullptr;   // pinned
     std::vector<void*> events;                  // hipEvent_t
     unsigned long long seq = 0;                 // read-back sequence numbers keep growing across uses
+    int fit_tiled = 0;                          // resident workgroups per CU of k_nn_tiled_batch (occupancy query, cached)
+    size_t fit_tiled_lds = 0;
     void release_all();
 };
 
@@ -248,8 +250,6 @@ class HipBatch final : public BatchStages {
     HipWorkspace& ws_;
     BatchScratch& sc_;           // the workspace's: buffers survive this object
     std::vector<BatchProblem> probs_;
-    int fit_tiled_ = 0;
-    size_t fit_tiled_lds_ = 0;
     size_t ev_used_ = 0;
     uint32_t nn_launches_ = 0;
     bool inited_ = false;

@@ -1,5 +1,6 @@
 // icp_loop.cpp -- see icp_loop.hpp.
 #include "icp_loop.hpp"
+#include "trace.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -105,6 +106,8 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     double plane_pairs = 0, plane_rmse = 0;
     double last_pacc[kNAccPlaneHost] = {};
     const double t0 = now_ms();
+    {
+    TraceRange tr_loop("mola_icp.iterations");
     for (; it < p.max_iterations; ++it) {
         const bool run_matcher =
             it >= p.run_from_iteration && (p.run_up_to_iteration == 0 || it <= p.run_up_to_iteration);
@@ -146,6 +149,7 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
         }
         Tprev = T;
     }
+    }
     if (term == MOLA_ICP_TERM_UNDEFINED) term = MOLA_ICP_TERM_MAX_ITERATIONS;
     const double t1 = now_ms();
 
@@ -153,6 +157,7 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     double quality = 0;
     if (p.skip_quality) quality = -1.0;
     else if (st.n_local_total() > 0 && st.n_map_total() > 0) {
+        TraceRange tr_q("mola_icp.quality");
         if ((rc = st.match(T, p.quality_threshold, p, nullptr))) return rc;
         double qacc[kNAcc];
         if ((rc = st.accumulate(p, T, 0, nullptr, nullptr, true, qacc))) return rc;

@@ -101,3 +101,21 @@ def test_device_pool_needs_a_gpu_or_fails_loudly(pkg):
     with pytest.raises(pkg.IcpError) as e:
         pkg.DevicePool()
     assert e.value.status == pkg._lib.E_NODEVICE
+
+
+def test_roctx_ranges_are_optional(pkg, monkeypatch):
+    """MOLA_ICP_ROCTX asks for named ranges around the stages (rocprofv3 --marker-trace); with or without the marker library
+    present the host loop behaves the same (run over caller-supplied stages: no GPU needed)"""
+    import subprocess
+    import sys
+    code = ("import importlib, numpy as np; pkg = importlib.import_module('mola-fe-lidar_amd');"
+            "p = pkg.Parameters(); p.max_iterations = 3;"
+            "acc = np.zeros(24); acc[0] = acc[16] = 3.0; acc[1:4] = 1.0; acc[4:7] = 1.5; acc[7] = acc[11] = acc[15] = 2.0;"
+            "r = pkg.run_loop(lambda T, thr: 3, lambda p_, T, s, cl, cg, rs: acc, np.eye(4), p, 3, 3);"
+            "print('ITS', r.nIterations)")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_extra in ({}, {"MOLA_ICP_ROCTX": "1"}):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "ITS" in out.stdout, out.stdout + out.stderr
