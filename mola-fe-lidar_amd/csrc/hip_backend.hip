@@ -846,27 +846,47 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
-    // persistent waves with a static first item: every block of the grid must be resident from the start
-    int& fit = fit_cache_[p.knn < 3 ? 2 : (p.knn > 8 ? 7 : (int)p.knn - 1)];   // slots 2..7: knn 3..8
-    size_t& fit_lds = fit_cache_lds_[p.knn < 3 ? 2 : (p.knn > 8 ? 7 : (int)p.knn - 1)];
-    if (fit == 0 || fit_lds != dyn_lds)
-    switch (p.knn) {  // (the verify flavour needs fewer registers than the insertion flavour)
-        case 3: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<3, false, 2>, 256, dyn_lds)); break;
-        case 4: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<4, false, 2>, 256, dyn_lds)); break;
-        case 5: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<5, false, 2>, 256, dyn_lds)); break;
-        case 6: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<6, false, 2>, 256, dyn_lds)); break;
-        case 7: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<7, false, 2>, 256, dyn_lds)); break;
-        default: HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_knn_planes<8, false, 2>, 256, dyn_lds)); break;
-    }
-    fit_lds = dyn_lds;
-    int grid = num_cus_ * (fit < 1 ? 1 : (fit > 3 ? 3 : fit));
-    // queries per lane: with no more 128-query items than waves every wave runs ONE item and the launch is as long as the
-    // heaviest: 64-query items (one query per lane) nearly halve it (MOLA_ICP_QPL forces either)
-    const size_t n128 = (N_ + kQPW - 1) / kQPW;
-    int ql = n128 <= (size_t)grid * 4 ? 1 : 2;
+    // Queries per lane: ONE (64-query items).  A lane's K-entry lists for two queries push the insertion flavour to 168
+    // VGPR + spills; with one query per lane there are none, items are twice as many and half as long -- better balance
+    // on large clouds (1M x 1M shipped pipeline 3090 -> 3370 it/s), and where a cloud has no more 128-query items than
+    // the launch has waves (an odometry-size pair) the launch, one item long, is nearly halved.  MOLA_ICP_QPL=2 forces
+    // 128-query items.
+    int ql = 1;
     if (g_knobs.qpl) ql = g_knobs.qpl;
+    // persistent waves with a static first item: every block of a grid must be resident from the start -- per flavour
+    // (the counting flavour holds ~100 VGPR, the insertion flavour ~140: the first fits four workgroups per CU)
+    const int kslot = p.knn < 3 ? 0 : (p.knn > 8 ? 5 : (int)p.knn - 3);
+    int& fit_ins = knn_fit_[ql - 1][0][kslot];
+    int& fit_ver = knn_fit_[ql - 1][1][kslot];
+    size_t& fit_lds = knn_fit_lds_[ql - 1][kslot];
+    if (fit_ins == 0 || fit_lds != dyn_lds) {
+#define MOLA_KNN_FIT(KK)                                                                                                   \
+    do {                                                                                                                   \
+        if (ql == 1) {                                                                                                     \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ins, k_knn_planes<KK, false, 1>, 256, dyn_lds));      \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ver, k_knn_planes<KK, true, 1>, 256, dyn_lds));       \
+        } else {                                                                                                           \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ins, k_knn_planes<KK, false, 2>, 256, dyn_lds));      \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ver, k_knn_planes<KK, true, 2>, 256, dyn_lds));       \
+        }                                                                                                                  \
+    } while (0)
+        switch (p.knn) {
+            case 3: MOLA_KNN_FIT(3); break;
+            case 4: MOLA_KNN_FIT(4); break;
+            case 5: MOLA_KNN_FIT(5); break;
+            case 6: MOLA_KNN_FIT(6); break;
+            case 7: MOLA_KNN_FIT(7); break;
+            default: MOLA_KNN_FIT(8); break;
+        }
+#undef MOLA_KNN_FIT
+        fit_lds = dyn_lds;
+    }
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    int grid = num_cus_ * clampi(fit_ins, 1, g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 3);
+    int grid_ver = num_cus_ * clampi(fit_ver, 1, g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 4);
     const int n_items = (int)((N_ + (size_t)(64 * ql) - 1) / (size_t)(64 * ql));
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
+    if (grid_ver > (n_items + 3) / 4) grid_ver = (n_items + 3) / 4;
     const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed) ? 1 : 0;
     // the cached plane of an unchanged neighbour list carries the planar / non-planar decision of the launch that
     // solved it: reusable only under the same planeEigenThreshold (the seeds themselves do not depend on it)
@@ -902,7 +922,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     // warm-started launches: the counting flavour over all items, then the insertion flavour over the items it
     // queued (counter[2] = their number); first launch on a cloud pair: the insertion flavour over all items
 #define MOLA_LAUNCH_KNN(KK, VER, QLL, QUEUE, LIST)                                                                        \
-    hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
+    hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL>), dim3(VER ? grid_ver : grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold,   \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
                        counter + 2, LIST, counter, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>())
