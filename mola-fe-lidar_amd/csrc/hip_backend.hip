@@ -972,6 +972,15 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
     HIPCHK(hipSetDevice(device_));
     if ((rc = plane_acc_.reserve(sizeof(double) * kNAccPlane * 514))) return rc;
     double* dacc = plane_acc_.as<double>() + (size_t)512 * kNAccPlane;
+    if (!plane_acc_host_) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&plane_acc_host_), sizeof(double) * (kNAccPlane + 4),
+                             hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(plane_acc_host_, 0, sizeof(double) * (kNAccPlane + 4));
+    }
+    // single GPU: the reduction writes the form (+ the changed-lists count) straight into the pinned block and then the
+    // sequence number the host spins on; sharded over RCCL the collective runs on the device block first
+    const bool direct = !comm_ && !g_knobs.no_direct_readback && !planes_empty_;
+    const unsigned long long seq = ++readback_seq_;
     if (planes_empty_) {
         HIPCHK(hipMemsetAsync(dacc, 0, sizeof(double) * (kNAccPlane + 1), stream_));
     } else {
@@ -982,7 +991,7 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
                            planes_.as<PlanePair>(), (int)N_, plane_acc_.as<double>());
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc,
-                           reinterpret_cast<const unsigned int*>(acc_dev_.as<double>() + kNAcc));
+                           reinterpret_cast<const unsigned int*>(acc_dev_.as<double>() + kNAcc), direct ? plane_acc_host_ : (double*)nullptr, seq);
         HIPCHK(hipGetLastError());
         counters_clean_ = true;
     }
@@ -994,18 +1003,14 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
         const int rc2 = rccl_allreduce_sum_f64(comm_, dacc, kNAccPlane, stream_);
         if (rc2) return rc2;
     }
-    if (!plane_acc_host_) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&plane_acc_host_), sizeof(double) * (kNAccPlane + 4),
-                             hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(plane_acc_host_, 0, sizeof(double) * (kNAccPlane + 4));
-    }
     if (g_knobs.no_direct_readback) {
         HIPCHK(hipMemcpyAsync(plane_acc_host_, dacc, sizeof(double) * (kNAccPlane + 1), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
-    } else {  // the form (+ the changed-lists count) into the pinned block, then the sequence number the host spins on
-        const unsigned long long seq = ++readback_seq_;
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, stream_, dacc, kNAccPlane + 1, plane_acc_host_, kNAccPlane + 2, seq);
-        HIPCHK(hipGetLastError());
+    } else {
+        if (!direct) {  // (after the collective, or an empty shard's zeros)
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, stream_, dacc, kNAccPlane + 1, plane_acc_host_, kNAccPlane + 2, seq);
+            HIPCHK(hipGetLastError());
+        }
         if ((rc = spin_for(reinterpret_cast<volatile unsigned long long*>(plane_acc_host_) + kNAccPlane + 2, seq))) return rc;
     }
     std::memcpy(acc, plane_acc_host_, sizeof(double) * kNAccPlane);

@@ -415,13 +415,17 @@ __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restri
 
 // fixed-order sum of [nblocks][n] partial rows (n <= 128): 8 slices of rows per accumulator with the loads of a
 // slice independent of each other, then the 8 slice sums in order.  Deterministic for a given nblocks.
+// host_out (pinned, may be null): the n sums + acc[n] written there too, then the sequence number in slot n + 2 -- the
+// hand-over k_publish would otherwise make in a launch of its own.
 __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
-                                                      double* __restrict__ acc, const unsigned int* __restrict__ counters)
+                                                      double* __restrict__ acc, const unsigned int* __restrict__ counters,
+                                                      double* __restrict__ host_out, unsigned long long seq)
 {
     // acc[n] = items of the plane matcher whose neighbour lists changed in this iteration (its next launch picks
     // the counting or the insertion flavour from it): counters[0] (insertion launch) + counters[2] (queued by verify)
     if (counters && threadIdx.x == 0) {
         acc[n] = (double)(counters[0] + counters[2]);
+        if (host_out) host_out[n] = acc[n];
         // ... and leave the matcher's counters (kept / redo / ticket, then the work-queue counters) zero for its next launch
         unsigned int* c = const_cast<unsigned int*>(counters);
         c[0] = c[1] = c[2] = c[3] = 0u;
@@ -446,6 +450,15 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
         double t = 0.0;
         for (int s2 = 0; s2 < 8; ++s2) t += sm[s2][k];
         acc[k] = t;
+        if (host_out) host_out[k] = t;
+    }
+    if (host_out) {  // publish: data first, then the sequence number the host spins on
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            reinterpret_cast<volatile unsigned long long*>(host_out)[n + 2] = seq;
+            __threadfence_system();
+        }
     }
 }
 
