@@ -122,9 +122,10 @@ def main():
         tl = torch.from_numpy(np.ascontiguousarray(l)).to(dev)
         n_shard = icp.set_local_shard(tl, rank, world)
         lo, hi = 0, n_shard                 # (queries_per_gpu below)
-        blo, bhi = icp.shard_reach_box(np.eye(4), GATE_M + 3.5)
+        slab_margin = GATE_M + 5.0      # gate + 0.54 m + 2.1 deg at up to 85 m from the origin (3.1 m) + slack
+        blo, bhi = icp.shard_reach_box(np.eye(4), slab_margin)
         kept = icp.set_map_slab(tg, blo, bhi)
-        slab = {"map_points_kept": kept, "map_points_total": M, "margin_m": GATE_M + 3.5}
+        slab = {"map_points_kept": kept, "map_points_total": M, "margin_m": slab_margin}
         del tl
     icp.set_global_sizes(N, M)
     allreduce_used = None
@@ -158,6 +159,21 @@ def main():
         torch.cuda.synchronize()
 
     T0 = np.eye(4)
+    if world > 1:
+        # The whole trajectory of the timed align must stay inside every rank's map slab (the matcher checks it at every
+        # pose; a violation on ANY rank reaches all of them through the all-reduce, so they fail -- and re-cut -- together).
+        # Rehearse the full run once per margin before anything is timed.
+        p.max_iterations = args.steps
+        for attempt in range(4):
+            try:
+                icp.align_resident(T0, p)
+                break
+            except pkg.IcpError as e:
+                if "map slab" not in str(e) or attempt == 3:
+                    raise
+                slab_margin *= 2.0
+                blo, bhi = icp.shard_reach_box(np.eye(4), slab_margin)
+                slab = {"map_points_kept": icp.set_map_slab(tg, blo, bhi), "map_points_total": M, "margin_m": slab_margin, "recut": attempt + 1}
     if args.warmup > 0:
         p.max_iterations = args.warmup
         icp.align_resident(T0, p)
@@ -195,14 +211,15 @@ def main():
                      "pairs_evaluated_per_query": pairs_exec / max(1, n_local),
                      "executed_tflops": tf_exe, "executed_frac_of_fp32_peak": tf_exe / PEAK_FP32_TFLOPS}
         if kern == "tiled":
-            # exact tile culling evaluates ~5e8 of the 1e12 pairs, so the flop view says little about the kernel;
-            # its compulsory traffic does: both sorted clouds once + the sorted pairing (position, index, d2 and the
-            # neighbour's coordinates -- next launch's seed and the accumulation's g) written
-            bytes_alg = 12.0 * n_local + 12.0 * M + 24.0 * n_local
+            # exact tile culling evaluates ~5e8 of the 1e12 pairs, so the flop view says little about the kernel; its
+            # compulsory traffic does.  SURVEY section 8(d): 12 N + 12 M (each cloud once) + 8 N (idx, d2 materialised).
+            # (The kernel also writes each neighbour's position and coordinates -- next launch's seeds, the accumulation's
+            # g -- and reads the seeds back: 16 N written + 16 N read on top, by design; `traffic` shows all of it.)
+            bytes_alg = 12.0 * n_local + 12.0 * M + 8.0 * n_local
             gbs = bytes_alg / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0
             return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                     "traffic": None, "kernel": "k_nn_tiled", "kernel_ms": nn_ms, "bytes_per_launch": bytes_alg,
-                    "culled": True, "flop_view": flop_view}
+                    "seed_bytes_per_launch_by_design": 32.0 * n_local, "culled": True, "flop_view": flop_view}
         return {"bound": "mfma", "achieved": tf_alg, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf_alg / PEAK_FP32_TFLOPS, "traffic": None, "kernel": "k_nn_" + kern, "kernel_ms": nn_ms,
                 "flops_per_launch": flops_alg, "culled": False,
