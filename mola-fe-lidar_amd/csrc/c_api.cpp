@@ -782,22 +782,71 @@ int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* 
             }
             return MOLA_ICP_OK;
         }
-        if ((rc = ws.set_map_host(fx, fy, fz, M))) { lease.rc = rc; return rc; }
-        if ((rc = ws.set_local_host(tx, ty, tz, N))) { lease.rc = rc; return rc; }
-        ws.set_global_sizes(0, 0);
-        ws.set_allreduce(nullptr, nullptr);
+        // Other pipelines (the shipped point-to-plane settings, tiny clouds): the pair is still uploaded and prepared ONCE;
+        // the attempts then run side by side on the handle's worker threads, a workspace and stream each, sharing the two
+        // prepared clouds (as concurrent mola_icp_align_cached calls would) -- at odometry sizes a launch leaves most of
+        // the GPU idle, so the streams overlap.  Each attempt is the stand-alone align, bit for bit.
+        auto map = h->take_cloud(), loc = h->take_cloud();
+        if ((rc = ws.build_cached(*map, fx, fy, fz, M))) { lease.rc = rc; return rc; }
+        if ((rc = ws.build_cached(*loc, tx, ty, tz, N))) { lease.rc = rc; return rc; }
         const double upload_ms = now_ms() - t0;
+        std::vector<mola_icp_result> res(n_init);
+        std::vector<int> rcs(n_init, MOLA_ICP_OK);
+        std::vector<std::string> errs(n_init);
+        auto attempt = [&](HipWorkspace& w, size_t k) {
+            std::memset(&res[k], 0, sizeof res[k]);
+            w.use_cached_map(map);
+            w.use_cached_local(loc);
+            w.set_global_sizes(0, 0);
+            w.set_allreduce(nullptr, nullptr);
+            rcs[k] = align_on(w, init_T + 16 * k, p, &res[k]);
+            if (rcs[k]) errs[k] = last_error();
+        };
+        if (n_init == 1) {
+            attempt(ws, 0);
+            if (rcs[0]) lease.rc = rcs[0];
+        } else {
+            std::mutex dm;
+            std::condition_variable dcv;
+            size_t pending = n_init - 1;
+            h->ensure_workers(std::min<size_t>(n_init - 1, 7));
+            for (size_t k = 1; k < n_init; ++k)
+                h->submit([&, k]() {
+                    rcs[k] = guarded([&]() -> int {
+                        Lease l2(h);
+                        if (l2.rc) return l2.rc;
+                        attempt(*l2.ws, k);
+                        l2.ws->use_cached_map(std::make_shared<SortedCloud>());   // (no reference kept in the pooled workspace)
+                        l2.ws->use_cached_local(std::make_shared<SortedCloud>());
+                        if (rcs[k]) l2.rc = rcs[k];
+                        return rcs[k];
+                    });
+                    if (rcs[k] && errs[k].empty()) errs[k] = last_error();
+                    {
+                        std::lock_guard<std::mutex> lk(dm);
+                        --pending;
+                    }
+                    dcv.notify_all();
+                });
+            attempt(ws, 0);   // this thread takes the first attempt
+            if (rcs[0]) lease.rc = rcs[0];
+            std::unique_lock<std::mutex> lk(dm);
+            dcv.wait(lk, [&]() { return pending == 0; });
+        }
+        ws.use_cached_map(std::make_shared<SortedCloud>());    // (drop this workspace's references before recycling the clouds)
+        ws.use_cached_local(std::make_shared<SortedCloud>());
+        for (size_t k = 0; k < n_init; ++k)
+            if (rcs[k]) { set_error(errs[k]); return rcs[k]; }
+        h->give_cloud(std::move(map));
+        h->give_cloud(std::move(loc));
         double best_q = 0.0;  // ICP_Output::goodness starts at .0 (LidarOdometry.h:130)
         for (size_t k = 0; k < n_init; ++k) {
-            mola_icp_result r;
-            std::memset(&r, 0, sizeof r);
-            if ((rc = align_on(ws, init_T + 16 * k, p, &r))) { lease.rc = rc; return rc; }
-            r.ms_upload = k == 0 ? upload_ms : 0.0;
-            if (out) out[k] = r;
-            if (r.quality > best_q) {
-                best_q = r.quality;
+            res[k].ms_upload = k == 0 ? upload_ms : 0.0;
+            if (out) out[k] = res[k];
+            if (res[k].quality > best_q) {
+                best_q = res[k].quality;
                 *best_index = (int)k;
-                if (best) *best = r;
+                if (best) *best = res[k];
             }
         }
         return MOLA_ICP_OK;
