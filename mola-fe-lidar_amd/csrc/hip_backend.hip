@@ -692,8 +692,8 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
         int& fit = fit_cache_[qpl == 2 ? 0 : 1];
         size_t& fit_lds = fit_cache_lds_[qpl == 2 ? 0 : 1];
         if (fit == 0 || fit_lds != dyn_lds) {
-            if (qpl == 2) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false, 2>, 256, dyn_lds));
-            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<false, 1>, 256, dyn_lds));
+            if (qpl == 2) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<2>, 256, dyn_lds));
+            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<1>, 256, dyn_lds));
             fit_lds = dyn_lds;
         }
         if (fit >= 1 && per_cu > fit) per_cu = fit;
@@ -735,25 +735,18 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     float* gs = ts_gs_.as<float>();
     const size_t gs_n = loc_sc_->padded;
     const float* sl = loc_sc_->sorted.as<float>();
-    if ((rc = redo_list_.reserve(sizeof(int) * cost_slots))) return rc;
     unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
     // counter[2] = redo count; tq = the fast pass's queue counters, tq + kQueues * kQueueStride the exact pass's
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
     unsigned long long* dbg = dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr;
-    // fast pass, then the exact pass over the items it queued (exact ties: duplicate points, lattices; usually
-    // none: a few waves that read the count and leave)
+    // one launch: an entry that meets an exact distance tie (duplicate points, lattices) is redone by its wave with the exact-key sweep
 #define MOLA_LAUNCH_TILED(QPL)                                                                                        \
     do {                                                                                                              \
-        hipLaunchKernelGGL((k_nn_tiled<false, QPL>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,  \
+        hipLaunchKernelGGL((k_nn_tiled<QPL>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,      \
                            sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),        \
-                           ts_idx_.as<int>(), ts_d2_.as<float>(), gs, gs + gs_n, gs + 2 * gs_n, order, item_cost_.as<unsigned int>(), tq, counter + 2, \
-                           redo_list_.as<int>(), staged, dbg, lds_boxes, wave_times_);                                \
+                           ts_idx_.as<int>(), ts_d2_.as<float>(), gs, gs + gs_n, gs + 2 * gs_n, order, item_cost_.as<unsigned int>(), tq, \
+                           staged, dbg, lds_boxes, wave_times_);                                                      \
         HIPCHK(hipGetLastError());                                                                                    \
-        hipLaunchKernelGGL((k_nn_tiled<true, QPL>), dim3(grid < 64 ? grid : 64), dim3(256), dyn_lds, stream_, sl,     \
-                           sl + loc_sc_->padded, sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2,                       \
-                           /*seed = fast pass's result*/ 1, ts_pos_.as<int>(), ts_idx_.as<int>(), ts_d2_.as<float>(), \
-                           gs, gs + gs_n, gs + 2 * gs_n, (const int*)nullptr, (unsigned int*)nullptr, tq + kQueues * kQueueStride, counter + 2,     \
-                           redo_list_.as<int>(), staged, dbg, lds_boxes, (unsigned long long*)nullptr);               \
     } while (0)
     if (qpl == 2) MOLA_LAUNCH_TILED(2);
     else MOLA_LAUNCH_TILED(1);

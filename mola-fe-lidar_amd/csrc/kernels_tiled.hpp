@@ -441,20 +441,20 @@ __device__ __forceinline__ void nn_visit_fast(float (*sm)[64], int nm, int jb0, 
     }
 }
 
-// EXACT = false: the fast sweep.  Per (query, kGroup = 8 points) only the group minimum meets the running best
+// Every entry runs the fast sweep: per (query, kGroup = 8 points) only the group minimum meets the running best
 //   (nn_visit_fast); the winning group is re-evaluated once at the end to recover the exact point and the
 //   lowest-original-index rule inside it.  If a second group reached the SAME minimum (exact ties: duplicate
-//   points, lattices) the entry is queued for the exact pass.
-// EXACT = true : the exact-key sweep over the queued entries: per-pair argmin on the packed key
-//   (d2 bits << 32 | original index), i.e. the full lexicographic rule.
-template <bool EXACT, int QPL>
+//   points, lattices) the wave redoes the entry at once with the exact-key sweep: per-pair argmin on the packed key
+//   (d2 bits << 32 | original index), i.e. the full lexicographic rule -- from the same seeds, nothing of the fast
+//   attempt having been written.  (A second launch over a list of tied entries, as in round 1, cost 5 us per
+//   iteration for a list that is almost always empty.)
+template <int QPL>
 __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
                                                   float* __restrict__ d2_s, float* __restrict__ gs_x, float* __restrict__ gs_y,
                                                   float* __restrict__ gs_z, const int* __restrict__ item_order,
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
-                                                  unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
                                                   unsigned long long* __restrict__ staged_total,
                                                   unsigned long long* __restrict__ dbg_stats, int lds_boxes,
                                                   unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
@@ -465,7 +465,6 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float(*sm)[64] = s_m[wave];
     int* slist = s_list[wave];
-    if (EXACT && *redo_count == 0u) return;  // the usual case: no exact ties in this launch (uniform: before any barrier)
     const lds_f32* lbox = (const lds_f32*)s_dyn;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
     // Entries of the work list.  QPL = 1: every entry is a 64-query item.  QPL = 2: an entry is a 128-query item (two
@@ -474,12 +473,11 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     // took 1.3x that share, and the launch is as long as its longest wave.
     const int n_items = (N + 64 * QPL - 1) / (64 * QPL);
     const int order_cap = QPL == 2 ? 2 * n_items : n_items;  // layout of item_order: entries, then kQueues + 1 boundaries, then the count
-    const int n_entries = EXACT ? (int)*redo_count : ((QPL == 2 && item_order) ? item_order[order_cap + kQueues + 1] : n_items);
+    const int n_entries = (QPL == 2 && item_order) ? item_order[order_cap + kQueues + 1] : n_items;
 
-    WaveQueue wq(queue, lane, n_entries, (!EXACT && item_order) ? item_order + order_cap : nullptr);  // boundaries follow the order
+    WaveQueue wq(queue, lane, n_entries, item_order ? item_order + order_cap : nullptr);  // boundaries follow the order
     auto lookup = [&](int raw) -> int {  // raw is wave-uniform; -1 = past the end
         if (raw >= n_entries) return -1;
-        if (EXACT) return redo_list[raw];
         return item_order ? item_order[raw] : raw;  // heaviest entries of the last launch first
     };
     unsigned long long wave_staged = 0ull;
@@ -488,13 +486,15 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     unsigned long long ph0 = 0ull, ph1 = 0ull, ph2 = 0ull, ph3 = 0ull, last_start = 0ull;
     unsigned int last_code = 0u;
     // one entry at the granularity QL (queries per lane); `item` counts in units of 64 * QL queries, `code` is the entry
-    // as listed (what the redo list and the cost record carry).  Returns the next entry's code.
-    auto run_item = [&](auto ql_tag, int item, int code) -> int {
+    // as listed (what the cost record carries).  EX = false: the fast attempt (pops the next entry behind its first loads);
+    // EX = true: the exact redo of the same entry (`next_in` = what the fast attempt popped).  Returns the next entry's code.
+    auto run_item = [&](auto& self, auto ql_tag, auto ex_tag, int item, int code, int next_in) -> int {
         constexpr int QL = decltype(ql_tag)::value;
+        constexpr bool EX = decltype(ex_tag)::value;
         constexpr int kQ = 64 * QL;
-        ++wave_items;
+        if (!EX) ++wave_items;
         const unsigned long long t_item0 = __builtin_amdgcn_s_memtime();
-        if (wave_times) { last_start = wall_clock64(); last_code = (unsigned int)code; }
+        if (wave_times && !EX) { last_start = wall_clock64(); last_code = (unsigned int)code; }
 
         float qx[QL], qy[QL], qz[QL], reach[QL];
         unsigned long long key[QL];  // EXACT: packed (d2, original index)
@@ -517,12 +517,12 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             if (use_seed) {
                 js[k] = pos_s[ic];
                 gsx[k] = gs_x[ic]; gsy[k] = gs_y[ic]; gsz[k] = gs_z[ic];
-                if (EXACT) gso[k] = (unsigned int)idx_s[ic];
+                if (EX) gso[k] = (unsigned int)idx_s[ic];
             }
         }
         // the next entry's pop goes out BEHIND these loads: memory results return in order, and a device-scope atomic
         // (slow, slower still in the burst at kernel start) ahead of them would sit on the prologue's critical path
-        const int next_raw_v = wq.pop();
+        const int next_raw_v = EX ? next_in : wq.pop();
 #pragma unroll
         for (int k = 0; k < QL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
 #pragma unroll
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             const float d = dist2(qx[k], qy[k], qz[k], gsx[k], gsy[k], gsz[k]);
             if (js[k] >= 0 && d < thr2) {  // warm start: last iteration's neighbour is an exact candidate
                 best[k] = d;
-                bpos[k] = EXACT ? js[k] : (js[k] & ~(kGroup - 1));
-                if (EXACT) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | gso[k];
+                bpos[k] = EX ? js[k] : (js[k] & ~(kGroup - 1));
+                if (EX) key[k] = ((unsigned long long)__float_as_uint(d) << 32) | gso[k];
             }
             reach[k] = reach_of(best[k], qx[k], qy[k], qz[k]);
             if (qi[k] >= N) {  // padding lane: reaches nothing, is never written
@@ -548,20 +548,20 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
         unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
         const unsigned long long t_sweep0 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
-        const unsigned long long n_staged = tiled_sweep<QL, EXACT>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
-            if constexpr (EXACT) nn_visit_exact<QL>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
+        const unsigned long long n_staged = tiled_sweep<QL, EX>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+            if constexpr (EX) nn_visit_exact<QL>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
             else nn_visit_fast<QL>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
         }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
         const unsigned long long t_sweep1 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
         // the popped entry has long arrived: its lookup (and a steal, if the segment is dry) overlaps the epilogue's loads
-        const int next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
+        const int next_item_v = EX ? next_in : lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
 
         bool any_tie = false;
         int rpos[QL], roi[QL];
         float rd[QL], wx[QL], wy[QL], wz[QL];  // (w*: the neighbour's coordinates, next launch's seed)
 #pragma unroll
         for (int k = 0; k < QL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; wx[k] = wy[k] = wz[k] = 0.f; }
-        if constexpr (EXACT) {
+        if constexpr (EX) {
 #pragma unroll
             for (int k = 0; k < QL; ++k) {
                 const float d = __uint_as_float((unsigned int)(key[k] >> 32));
@@ -616,20 +616,21 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             }
         }
 #pragma unroll
-        for (int k = 0; k < QL; ++k) {
-            if (qi[k] < N) {  // coalesced: the pairing stays in sorted query order
-                pos_s[qi[k]] = rpos[k];
-                idx_s[qi[k]] = rpos[k] >= 0 ? roi[k] : -1;
-                d2_s[qi[k]] = rd[k];
-                gs_x[qi[k]] = wx[k]; gs_y[qi[k]] = wy[k]; gs_z[qi[k]] = wz[k];
-                any_tie |= tie[k] >= 2;
+        for (int k = 0; k < QL; ++k) any_tie |= qi[k] < N && tie[k] >= 2;
+        const bool redo = !EX && __any(any_tie);  // (wave-uniform) an exact distance tie between two groups: nothing is written
+        if (!redo) {
+#pragma unroll
+            for (int k = 0; k < QL; ++k) {
+                if (qi[k] < N) {  // coalesced: the pairing stays in sorted query order
+                    pos_s[qi[k]] = rpos[k];
+                    idx_s[qi[k]] = rpos[k] >= 0 ? roi[k] : -1;
+                    d2_s[qi[k]] = rd[k];
+                    gs_x[qi[k]] = wx[k]; gs_y[qi[k]] = wy[k]; gs_z[qi[k]] = wz[k];
+                }
             }
         }
-        if (!EXACT && __any(any_tie)) {
-            if (lane == 0) redo_list[atomicAdd(redo_count, 1u)] = code;
-        }
         if (lane == 0) {
-            if (!EXACT) {
+            if (!EX && !redo) {
                 // (a deterministic proxy -- staged points -- orders no better than the measured cycles; without any
                 // order the kernel is 6 % slower)
                 const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
@@ -658,21 +659,25 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 rec[7] = t_end - t_sweep1;
             }
         }
-        if (wave_times && wave_items == 1u) {  // phases of the wave's first item (shader clock)
+        if (wave_times && wave_items == 1u && !EX) {  // phases of the wave's first item (shader clock)
             const unsigned long long t_end1 = __builtin_amdgcn_s_memtime();
             ph0 = t_sweep0 - t_item0; ph1 = t_sweep1 - t_sweep0; ph2 = t_end1 - t_sweep1; ph3 = n_staged;
         }
-        return __builtin_amdgcn_readfirstlane(next_item_v);
+        const int next_code = __builtin_amdgcn_readfirstlane(next_item_v);
+        if constexpr (!EX) {
+            if (redo) return self(self, ql_tag, std::true_type{}, item, code, next_code);
+        }
+        return next_code;
     };
     int code = __builtin_amdgcn_readfirstlane(lookup(wq.first()));
     while (code >= 0) {
         if constexpr (QPL == 2) {
             if (!(code & kHalfFlag)) {
-                code = run_item(std::integral_constant<int, 2>{}, code, code);
+                code = run_item(run_item, std::integral_constant<int, 2>{}, std::false_type{}, code, code, 0);
                 continue;
             }
         }
-        code = run_item(std::integral_constant<int, 1>{}, code & ~kHalfFlag, code);
+        code = run_item(run_item, std::integral_constant<int, 1>{}, std::false_type{}, code & ~kHalfFlag, code, 0);
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
     if (wave_times && lane == 0) {  // [start, end, items, first item: prologue, sweep, epilogue cycles, staged points] per wave

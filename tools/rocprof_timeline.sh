@@ -1,0 +1,28 @@
+#!/bin/bash
+# timeline of the headline iteration (1M x 1M, point-to-point): kernel start / duration / gap to the previous kernel
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_timeline; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cat > /tmp/tl.py <<PY
+import importlib, os, sys, numpy as np
+sys.path.insert(0, "$ROOT")
+pkg = importlib.import_module("mola-fe-lidar_amd"); synth = importlib.import_module("mola-fe-lidar_amd.synth")
+g, l, _ = synth.make_pair(1_000_000, 1_000_000, seed=42)
+icp = pkg.ICP(device=0); icp.set_map(g); icp.set_local(l)
+p = pkg.Parameters(); p.matcher_threshold, p.fixed_iterations, p.skip_quality, p.max_iterations = 1.0, 1, 1, 40
+icp.align_resident(np.eye(4), p); icp.align_resident(np.eye(4), p)
+PY
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 /tmp/tl.py > $OUT/trace.log 2>&1
+find $OUT/trace -name "*kernel_trace.csv" -exec cp {} $OUT/kernel_trace.csv \;
+python3 - <<PY
+import csv
+rows=[r for r in csv.DictReader(open("$OUT/kernel_trace.csv"))]
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+sel=rows[-24:]
+prev=None
+for r in sel:
+    s=int(r["Start_Timestamp"]); e=int(r["End_Timestamp"])
+    print("gap %6.1f us  run %7.1f us  %s" % ((s-prev)/1e3 if prev else 0, (e-s)/1e3, r["Kernel_Name"].split("(")[0].replace("void mola_icp_amd::","").replace("mola_icp_amd::","")[:40]))
+    prev=e
+PY
