@@ -381,15 +381,18 @@ def cpu_baseline(g, l, iters, flags):
              "kdtree_build_s": r["kdtree_build_s"], "host_cores_available": os.cpu_count(), "compiler_flags": flags}, r["T"])
 
 
-def _median_align(icp, g, l, T0, p, reps=3):
-    """wall time of `mola_icp_align` from host buffers (upload + sort + iterations + quality), median of `reps`"""
+def _median_align(icp, g, l, T0, p, reps=5):
+    """wall time of `mola_icp_align` from host buffers (upload + sort + iterations + quality): the median of `reps` runs
+    and THAT run's result (its prepare / loop / quality split)"""
     icp.align(g, l, T0, p)   # first call: allocations
-    ts, r = [], None
+    runs = []
     for _ in range(reps):
         t0 = time.perf_counter()
         r = icp.align(g, l, T0, p)
-        ts.append(time.perf_counter() - t0)
-    return float(np.median(ts)) * 1e3, r
+        runs.append((time.perf_counter() - t0, r))
+    runs.sort(key=lambda x: x[0])
+    t, r = runs[len(runs) // 2]
+    return t * 1e3, r
 
 
 def align_e2e(pkg, synth, icp, g1m, l1m, seed, with_cpu, cpu_flags):
