@@ -283,3 +283,24 @@ def test_loop_closure_montecarlo_10_guesses_at_100k(pkg, O, synth):
     rot, trans = O.pose_error(res[best].optimal_tf, ref["T"])
     assert res[best].nIterations == ref["n_iterations"] and rot < 1e-7 and trans < 1e-8
     icp.close()
+
+
+def test_cooperative_matcher_on_a_map_whose_box_levels_exceed_lds(pkg, O, synth):
+    """a small scan against a 4M-point map: one workgroup per item (k_nn_coop), the upper box levels read from global memory
+    (they do not fit the 40 KB LDS budget above ~3.4M points); unseeded and seeded launches, fused row sums"""
+    g, l, _ = synth.make_pair(20_011, 4_000_000, seed=77)
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    T = synth.pose_from_xyzypr(0.2, -0.1, 0.03, 0.01, 0.0, 0.002)
+    tree = O.KdTree(g)
+    p = p2p_params(pkg)
+    for Tk in (np.eye(4), T, T):        # unseeded, seeded after a pose step, seeded at the same pose
+        idx, d2, n = icp.match(Tk, 1.0, l.shape[1], pkg.NN_TILED)
+        oidx, od2, on = O.match(g, l, Tk, 1.0, tree)
+        assert n == on and np.array_equal(idx, oidx)
+        assert np.array_equal(d2[oidx >= 0], od2[oidx >= 0])
+        acc = icp.accumulate(p, Tk)
+        oacc = O.accumulate(g, l, oidx, od2, O.params_from_product(p), Tk)
+        np.testing.assert_allclose(acc, oacc, rtol=1e-10, atol=1e-6)
+    icp.close()
