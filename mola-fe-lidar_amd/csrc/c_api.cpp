@@ -595,38 +595,55 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const*
             if (pr->rc) pr->err = last_error();
             return pr;
         };
-        std::shared_ptr<Prepared> cur = together.empty() ? nullptr : prepare(0);
-        for (size_t ci = 0; ci + 1 < chunk_begin.size() && first_err.load() == MOLA_ICP_OK; ++ci) {
-            const size_t c0 = chunk_begin[ci], K = chunk_begin[ci + 1] - c0;
-            std::future<std::shared_ptr<Prepared>> next;
-            if (ci + 2 < chunk_begin.size()) {
-                auto task = std::make_shared<std::packaged_task<std::shared_ptr<Prepared>()>>([&prepare, ci]() { return prepare(ci + 1); });
-                next = task->get_future();
-                h->ensure_workers(1);
-                h->submit([task]() { (*task)(); });
+        // TWO lockstep loops side by side (chunks 0, 2, 4, ... and 1, 3, 5, ...), each with its own prepare-ahead: while one
+        // loop's host thread runs its dozen Horn solves and stall tests (the GPU would idle ~40 us of every ~185-us lockstep
+        // iteration), the other loop's launches run.  The persistent matcher has no inter-block dependencies, so two of them
+        // sharing the device is safe; each is a little slower, the pair is faster.
+        const size_t n_chunks = chunk_begin.size() - 1;
+        auto lane = [&](size_t first) {
+            if (first >= n_chunks) return;
+            std::shared_ptr<Prepared> cur = prepare(first);
+            for (size_t ci = first; ci < n_chunks; ci += 2) {
+                const size_t c0 = chunk_begin[ci], K = chunk_begin[ci + 1] - c0;
+                std::future<std::shared_ptr<Prepared>> next;
+                if (ci + 2 < n_chunks && first_err.load() == MOLA_ICP_OK) {
+                    auto task = std::make_shared<std::packaged_task<std::shared_ptr<Prepared>()>>([&prepare, ci]() { return prepare(ci + 2); });
+                    next = task->get_future();
+                    h->submit([task]() { (*task)(); });
+                }
+                if (cur->rc) {
+                    set_error(cur->err);
+                    record(cur->rc, together[c0]);
+                } else if (first_err.load() == MOLA_ICP_OK) {
+                    const int rc2 = guarded([&]() -> int {
+                        Lease lease(h);
+                        if (lease.rc) return lease.rc;
+                        std::vector<mola_icp_result> res(K);
+                        int rc3;
+                        if ((rc3 = run_batch_on(*lease.ws, cur->probs, cur->inits.data(), p, res.data()))) { lease.rc = rc3; return rc3; }
+                        for (size_t k = 0; k < K; ++k) {
+                            res[k].ms_upload = cur->upload_ms;  // the chunk's uploads + preparation (overlapped with the previous chunk's loop)
+                            out[together[c0 + k]] = res[k];
+                        }
+                        return MOLA_ICP_OK;
+                    });
+                    if (rc2) record(rc2, together[c0]);
+                }
+                for (BatchProblem& bp : cur->probs) { h->give_cloud(std::move(bp.map)); h->give_cloud(std::move(bp.loc)); }
+                cur = next.valid() ? next.get() : nullptr;   // (always collected: the worker references this frame)
+                if (!cur) break;
             }
-            if (cur->rc) {
-                set_error(cur->err);
-                record(cur->rc, together[c0]);
-            } else {
-                const int rc2 = guarded([&]() -> int {
-                    Lease lease(h);
-                    if (lease.rc) return lease.rc;
-                    std::vector<mola_icp_result> res(K);
-                    int rc3;
-                    if ((rc3 = run_batch_on(*lease.ws, cur->probs, cur->inits.data(), p, res.data()))) { lease.rc = rc3; return rc3; }
-                    for (size_t k = 0; k < K; ++k) {
-                        res[k].ms_upload = cur->upload_ms;  // the chunk's uploads + preparation (overlapped with the previous chunk's loop)
-                        out[together[c0 + k]] = res[k];
-                    }
-                    return MOLA_ICP_OK;
-                });
-                if (rc2) record(rc2, together[c0]);
-            }
-            for (BatchProblem& bp : cur->probs) { h->give_cloud(std::move(bp.map)); h->give_cloud(std::move(bp.loc)); }
-            cur = next.valid() ? next.get() : nullptr;   // (always collected: the worker references this frame)
+            if (cur) for (BatchProblem& bp : cur->probs) { h->give_cloud(std::move(bp.map)); h->give_cloud(std::move(bp.loc)); }
+        };
+        if (n_chunks >= 1) {
+            h->ensure_workers(n_chunks >= 2 ? 4 : 1);   // the second loop + a prepare-ahead each (+ the stream-per-pair jobs above)
+            std::promise<void> lane1_done;
+            std::future<void> lane1 = lane1_done.get_future();
+            if (n_chunks >= 2) h->submit([&]() { lane(1); lane1_done.set_value(); });
+            else lane1_done.set_value();
+            lane(0);
+            lane1.wait();
         }
-        if (cur) for (BatchProblem& bp : cur->probs) { h->give_cloud(std::move(bp.map)); h->give_cloud(std::move(bp.loc)); }
         {
             std::unique_lock<std::mutex> lk(done_mtx);
             done_cv.wait(lk, [&]() { return pending == 0; });
