@@ -56,6 +56,7 @@ struct Knobs {
     int coop = -1;             // MOLA_ICP_COOP (-1 = by cloud size, 0 = one item per wave, 1 = one item per block)
     int batch_tiled = -1;      // MOLA_ICP_BATCH_TILED (-1 = by item count; batched launches: 0 = k_nn_coop, 1 = k_nn_tiled_batch)
     bool no_split = false;     // MOLA_ICP_NO_SPLIT: never list a heavy 128-query item as its two halves
+    bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
 };
@@ -69,6 +70,7 @@ static Knobs read_knobs()
     k.batch_tiled = std::getenv("MOLA_ICP_BATCH_TILED") ? (geti("MOLA_ICP_BATCH_TILED") != 0 ? 1 : 0) : -1;
     k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
     k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
+    k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
     k.no_knn_seed = std::getenv("MOLA_ICP_NO_KNN_SEED") != nullptr;
     k.no_knn_verify = std::getenv("MOLA_ICP_NO_KNN_VERIFY") != nullptr;
     k.no_direct_readback = std::getenv("MOLA_ICP_NO_DIRECT_READBACK") != nullptr;
@@ -745,7 +747,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
         hipLaunchKernelGGL((k_nn_tiled<QPL>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,      \
                            sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),        \
                            ts_idx_.as<int>(), ts_d2_.as<float>(), gs, gs + gs_n, gs + 2 * gs_n, order, item_cost_.as<unsigned int>(), tq, \
-                           staged, dbg, lds_boxes, wave_times_);                                                      \
+                           staged, dbg, lds_boxes, wave_times_, g_knobs.early_pop ? 1 : 0);                            \
         HIPCHK(hipGetLastError());                                                                                    \
     } while (0)
     if (qpl == 2) MOLA_LAUNCH_TILED(2);
@@ -918,7 +920,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL>), dim3(VER ? grid_ver : grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold,   \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
-                       counter + 2, LIST, counter, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>())
+                       counter + 2, LIST, counter, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>(), g_knobs.early_pop ? 1 : 0)
 #define MOLA_LAUNCH_KNN_QL(KK, QLL)                                                                                  \
     do {                                                                                                             \
         if (verify) {                                                                                                \
@@ -1671,7 +1673,7 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
             if (grid > (total_items + 3) / 4) grid = (total_items + 3) / 4;
             HIPCHK(hipMemsetAsync(sc_.queue.p, 0, sizeof(unsigned int) * kQueues * kQueueStride, ws_.stream_));
             hipLaunchKernelGGL((k_nn_tiled_batch<kCoopMaxBatch>), dim3(grid), dim3(256), lds, ws_.stream_, b, bi, n, shared,
-                               sc_.queue.as<unsigned int>());
+                               sc_.queue.as<unsigned int>(), g_knobs.early_pop ? 1 : 0);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL((k_item_rows<kCoopMaxBatch>), dim3(max_items, n), dim3(256), 0, ws_.stream_, b);
             HIPCHK(hipGetLastError());

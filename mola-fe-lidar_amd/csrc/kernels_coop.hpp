@@ -563,9 +563,10 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
 // pose -- do not depend on which of the two matchers served it.
 template <int KMAX> struct NnBatchItems { int base[KMAX + 1]; };  // base[k] = first entry of problem k; base[n] = total
 
-template <bool EXACT>
+template <bool EXACT, class AfterSweep>
 __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist,
-                                                 float (*sm)[64], int lane, int item, unsigned long long& n_staged_out)
+                                                 float (*sm)[64], int lane, int item, unsigned long long& n_staged_out,
+                                                 AfterSweep&& after_sweep)
 {
     const int N = pb.N;
     const float thr2 = pb.thr2;
@@ -617,6 +618,7 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
         if constexpr (EXACT) nn_visit_exact<2>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
         else nn_visit_fast<2>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
     }, false, pa, pb2, pc, pd, pe, pf, pg);
+    after_sweep();
 
     bool any_tie = false;
 #pragma unroll
@@ -678,7 +680,8 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
 
 template <int KMAX>
 __global__ __launch_bounds__(256, 3) void k_nn_tiled_batch(const NnBatch<KMAX> batch, const NnBatchItems<KMAX> items, int n_problems,
-                                                           int shared_map_lds, unsigned int* __restrict__ queue)
+                                                           int shared_map_lds, unsigned int* __restrict__ queue,
+                                                           int early_pop /*tuning knob: reserve the next item at the START of this one*/)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
     __shared__ int s_list[4][kMaxList];
@@ -697,12 +700,17 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled_batch(const NnBatch<KMAX> b
         while (k + 1 < n_problems && raw >= items.base[k + 1]) ++k;  // (wave-uniform: scalar loop over <= KMAX entries)
         const NnProblem& pb = batch.p[k];
         const int item = raw - items.base[k];
-        const int next_raw_v = wq.pop();  // in flight during the item
+        // the next item is reserved LATE, behind the sweep (in flight during the epilogue): reserved at the start, an item was
+        // bound to a wave one whole item ahead of its execution and the launch's drain was two items long (see k_nn_tiled)
+        int next_raw_v = 0;
+        if (early_pop) next_raw_v = wq.pop();
+        else wq.hint();
         const TiledMap mp = pb.mp;
-        if (tiled_batch_item<false>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged)) {
+        if (tiled_batch_item<false>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged,
+                                    [&]() { if (!early_pop) next_raw_v = wq.pop(); })) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the redo reads this wave's own stores of a moment ago
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            (void)tiled_batch_item<true>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged);
+            (void)tiled_batch_item<true>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged, []() {});
         }
         raw = __builtin_amdgcn_readfirstlane(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
     }

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                                                     unsigned int* __restrict__ changed_items,
                                                     unsigned long long* __restrict__ staged_total, int lds_boxes,
                                                     const int* __restrict__ item_order /*heaviest first, range boundaries behind it (k_order_items); may be null*/,
-                                                    unsigned int* __restrict__ item_cost /*cycles per item of this launch (full sweeps only)*/)
+                                                    unsigned int* __restrict__ item_cost /*cycles per item of this launch (full sweeps only)*/,
+                                                    int early_pop /*tuning knob: reserve the next item at the START of this one*/)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
     __shared__ int s_list[4][kMaxList];
@@ -196,7 +197,11 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
     const int* order = from_list ? nullptr : item_order;
     WaveQueue wq(queue, lane, n_items, order ? order + n_items : nullptr);
     for (int raw = wq.first(); raw < n_items;) {
-        const int next_raw_v = wq.pop();
+        // the next item is reserved LATE (behind the sweep, ahead of the long epilogue): reserved at the start, an item was
+        // bound to a wave one whole item ahead of its execution and the launch's drain was two items long (see k_nn_tiled)
+        int next_raw_v = 0;
+        if (early_pop) next_raw_v = wq.pop();
+        else wq.hint();
         const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : (order ? __builtin_amdgcn_readfirstlane(order[raw]) : raw);
         const unsigned long long t_item0 = (item_cost && !from_list) ? __builtin_amdgcn_s_memtime() : 0ull;
 
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                 }
             }
          }, false, np_a, np_b, np_c, np_d, np_e, np_a, np_b);
+        if (!early_pop) next_raw_v = wq.pop();
 
         bool redo = false;
         if constexpr (VERIFY) {

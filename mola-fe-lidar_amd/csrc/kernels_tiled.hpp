@@ -314,33 +314,63 @@ __device__ __forceinline__ float reach_of(float best, float qx, float qy, float 
 //  - the first entry of every wave is fixed (its rank among the waves of its XCD): no atomics at kernel start;
 //  - the rest of a segment is handed out by its own counter (separate cache lines); a wave whose segment has run
 //    dry steals from the next ones.
-// Callers keep the next entry's pop in flight while the current item is processed.
+//  - a DRY segment is not popped again.  A failed pop is as dear as a successful one (a device-scope read-modify-write
+//    on one of 8 addresses, ~13 ns each, serialised), and at the end of a launch every wave used to walk all 8 dry
+//    counters before it left: 8 x 3072 failed pops against the ~6000 useful ones, all inside the drain -- the last
+//    entry of a wave "ran" 0.4 of the launch, most of it in that queue of atomics.  (Reading the counters first is no
+//    way out: coherent loads of those 8 hot lines serialise with the atomics -- measured, 135 -> 204 us.)  Instead the
+//    news travels IN the counters: bits 24..31 of every counter hold the set of segments known to be dry.  The wave
+//    whose pop is the FIRST to fail on segment c (its ticket equals the segment's size -- exactly one wave) ORs bit c
+//    into the other seven counters; every pop, successful or not, returns the set as of that moment, and a wave pops
+//    only segments outside the set it has seen.  A finishing wave pays one failed pop, not eight.
+// Callers reserve the next entry late (behind the epilogue's loads): see k_nn_tiled.
+constexpr int kQueueCountBits = 24;  // a counter = tickets handed out (low 24 bits: < 16M entries per segment) | dry set << 24
 struct WaveQueue {
     unsigned int* q;
     const int* seg;  // kQueues + 1 segment boundaries (k_order_items: equal COST per segment), or null: equal counts
-    int lane, n, tried;
+    int lane, n;
+    unsigned int dry;  // wave-uniform: bit c = segment c has nothing left to hand out
+    int cur;           // wave-uniform: the segment the pop in flight went to (-1: none was worth trying)
+    unsigned int seen; // lane 0: the dry set the pop in flight returned
     __device__ __forceinline__ WaveQueue(unsigned int* queue, int lane_, int n_entries, const int* seg_ = nullptr)
-        : q(queue), seg(seg_), lane(lane_), n(n_entries), tried(0) {}
+        : q(queue), seg(seg_), lane(lane_), n(n_entries), dry(0u), cur(-1), seen(0u) {}
     __device__ __forceinline__ int seg_begin(int c) const { return seg ? seg[c] : (int)(((long long)c * n) / kQueues); }
     __device__ __forceinline__ int n_static(int c) const  // waves of XCD c = fixed first entries of segment c
     {
         return (((int)gridDim.x + kQueues - 1 - c) / kQueues) * 4;
     }
     __device__ __forceinline__ int global_wave() const { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
+    __device__ __forceinline__ void hint() {}
     __device__ __forceinline__ int pop()  // the next entry (meaningful in lane 0; >= n: none there), still in flight
     {
-        const int c = ((int)blockIdx.x + tried) & (kQueues - 1);
-        int r = 0;
-        if (lane == 0) {
-            const int e = seg_begin(c) + n_static(c) + (int)atomicAdd(q + c * kQueueStride, 1u);
-            r = e < seg_begin(c + 1) ? e : 0x7fffffff;
+        // first segment not known to be dry, starting at this XCD's own
+        const unsigned int own = (unsigned int)blockIdx.x & (kQueues - 1);
+        const unsigned int open = ~dry & ((1u << kQueues) - 1u);
+        const unsigned int rot = ((open >> own) | (open << (kQueues - own))) & ((1u << kQueues) - 1u);
+        cur = rot ? (int)((own + (unsigned int)__builtin_ctz(rot)) & (kQueues - 1)) : -1;
+        int r = 0x7fffffff;
+        seen = 0u;
+        if (cur >= 0 && lane == 0) {
+            const unsigned int old = atomicAdd(q + cur * kQueueStride, 1u);
+            const int ticket = (int)(old & ((1u << kQueueCountBits) - 1u));
+            const int avail = seg_begin(cur + 1) - seg_begin(cur) - n_static(cur);  // entries this segment hands out
+            seen = old >> kQueueCountBits;
+            if (ticket < avail) r = seg_begin(cur) + n_static(cur) + ticket;
+            else if (ticket == (avail > 0 ? avail : 0)) seen |= 0x100u;  // the first pop to fail here: this wave tells the others
         }
         return r;
     }
-    __device__ __forceinline__ int settle(int raw)  // raw = readfirstlane(pop()): none there -> the other segments
+    __device__ __forceinline__ int settle(int raw)  // raw = readfirstlane(pop()): none there -> the segments still open
     {
-        while (raw >= n && ++tried < kQueues) raw = __builtin_amdgcn_readfirstlane(pop());
-        return raw;
+        for (;;) {
+            const unsigned int sn = (unsigned int)__builtin_amdgcn_readfirstlane((int)seen);
+            dry |= sn & ((1u << kQueues) - 1u);
+            if (raw < n || cur < 0) return raw;
+            dry |= 1u << cur;
+            if ((sn & 0x100u) && lane < kQueues && lane != cur)  // one vector atomic, nothing returned
+                atomicOr(q + lane * kQueueStride, 1u << (kQueueCountBits + cur));
+            raw = __builtin_amdgcn_readfirstlane(pop());
+        }
     }
     __device__ __forceinline__ int first()  // wave-uniform; >= n: nothing left anywhere
     {
@@ -457,7 +487,8 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                                                   unsigned int* __restrict__ item_cost, unsigned int* __restrict__ queue,
                                                   unsigned long long* __restrict__ staged_total,
                                                   unsigned long long* __restrict__ dbg_stats, int lds_boxes,
-                                                  unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
+                                                  unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/,
+                                                  int early_pop /*tuning knob: reserve the next entry at the START of this one*/)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
     __shared__ int s_list[4][kMaxList];
@@ -520,9 +551,13 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 if (EX) gso[k] = (unsigned int)idx_s[ic];
             }
         }
-        // the next entry's pop goes out BEHIND these loads: memory results return in order, and a device-scope atomic
-        // (slow, slower still in the burst at kernel start) ahead of them would sit on the prologue's critical path
-        const int next_raw_v = EX ? next_in : wq.pop();
+        // The next entry is reserved LATE -- behind the epilogue's loads, consumed after its stores.  Popping at the start of
+        // an entry (as this kernel did: the atomic's latency is then hidden for free) binds an entry to a wave one whole
+        // entry ahead of its execution: the queue ran dry at 0.55-0.6 of the launch while reserved entries still BEGAN at
+        // 0.8 of it -- the drain was two entries long instead of one.
+        int next_raw_v = 0;
+        if (!EX && early_pop) next_raw_v = wq.pop();  // (behind the loads above: memory results return in order)
+        else if (!EX) wq.hint();
 #pragma unroll
         for (int k = 0; k < QL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
 #pragma unroll
@@ -553,8 +588,8 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             else nn_visit_fast<QL>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
         }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
         const unsigned long long t_sweep1 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
-        // the popped entry has long arrived: its lookup (and a steal, if the segment is dry) overlaps the epilogue's loads
-        const int next_item_v = EX ? next_in : lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
+        int next_item_v = next_in;
+        if (!EX && early_pop) next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
 
         bool any_tie = false;
         int rpos[QL], roi[QL];
@@ -586,6 +621,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                     RP[k][c] = *reinterpret_cast<const int4*>(mp.perm + bp + 4 * c);
                 }
             }
+            if (!early_pop) next_raw_v = wq.pop();  // behind the loads above; the resolution below covers most of its latency
 #pragma unroll
             for (int k = 0; k < QL; ++k) {
                 unsigned int bo = 0xffffffffu;
@@ -663,6 +699,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
             const unsigned long long t_end1 = __builtin_amdgcn_s_memtime();
             ph0 = t_sweep0 - t_item0; ph1 = t_sweep1 - t_sweep0; ph2 = t_end1 - t_sweep1; ph3 = n_staged;
         }
+        if (!EX && !early_pop) next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
         const int next_code = __builtin_amdgcn_readfirstlane(next_item_v);
         if constexpr (!EX) {
             if (redo) return self(self, ql_tag, std::true_type{}, item, code, next_code);
