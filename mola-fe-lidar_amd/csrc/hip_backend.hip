@@ -56,6 +56,7 @@ struct Knobs {
     int coop = -1;             // MOLA_ICP_COOP (-1 = by cloud size, 0 = one item per wave, 1 = one item per block)
     int batch_tiled = -1;      // MOLA_ICP_BATCH_TILED (-1 = by item count; batched launches: 0 = k_nn_coop, 1 = k_nn_tiled_batch)
     bool no_split = false;     // MOLA_ICP_NO_SPLIT: never list a heavy 128-query item as its two halves
+    bool no_certify = false;   // MOLA_ICP_NO_CERTIFY: the point-to-plane matcher sweeps for every query at every launch
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
@@ -71,6 +72,7 @@ static Knobs read_knobs()
     k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
     k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
+    k.no_certify = std::getenv("MOLA_ICP_NO_CERTIFY") != nullptr;
     k.no_knn_seed = std::getenv("MOLA_ICP_NO_KNN_SEED") != nullptr;
     k.no_knn_verify = std::getenv("MOLA_ICP_NO_KNN_VERIFY") != nullptr;
     k.no_direct_readback = std::getenv("MOLA_ICP_NO_DIRECT_READBACK") != nullptr;
@@ -814,7 +816,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if ((rc = prepare_tiles())) return rc;
     if ((rc = prepare_queries())) return rc;
     if ((rc = planes_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
-    if ((rc = knn_pos_.reserve(sizeof(int) * loc_sc_->padded * 8))) return rc;
+    if ((rc = knn_pos_.reserve(sizeof(int) * loc_sc_->padded * 9))) return rc;  // lists of knn + 1 entries
+    if ((rc = knn_lb_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
     if ((rc = plane_cache_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
     PoseF P;
     for (int r = 0; r < 3; ++r) {
@@ -865,13 +868,13 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ver, k_knn_planes<KK, true, 2>, 256, dyn_lds));       \
         }                                                                                                                  \
     } while (0)
-        switch (p.knn) {
-            case 3: MOLA_KNN_FIT(3); break;
-            case 4: MOLA_KNN_FIT(4); break;
-            case 5: MOLA_KNN_FIT(5); break;
-            case 6: MOLA_KNN_FIT(6); break;
-            case 7: MOLA_KNN_FIT(7); break;
-            default: MOLA_KNN_FIT(8); break;
+        switch (p.knn) {  // (the kernels are instantiated on the list length: knn + 1)
+            case 3: MOLA_KNN_FIT(4); break;
+            case 4: MOLA_KNN_FIT(5); break;
+            case 5: MOLA_KNN_FIT(6); break;
+            case 6: MOLA_KNN_FIT(7); break;
+            case 7: MOLA_KNN_FIT(8); break;
+            default: MOLA_KNN_FIT(9); break;
         }
 #undef MOLA_KNN_FIT
         fit_lds = dyn_lds;
@@ -914,13 +917,24 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     }
     knn_cost_valid_ = true;
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
+    // certified lists (kernels_planes.hpp, KnnCert): the bound and the pose of the launch that wrote these seeds
+    KnnCert cert{};
+    for (int k = 0; k < 9; ++k) cert.Pprev.R[k] = knn_last_P_[k];
+    for (int k = 0; k < 3; ++k) cert.Pprev.t[k] = knn_last_P_[9 + k];
+    cert.lb = knn_lb_.as<float>();
+    cert.on = (knn_seed && !g_knobs.no_certify) ? 1 : 0;
+    cert.stats = profiling_ ? stats_.as<unsigned long long>() : nullptr;
+    // the lists' own gate (KnnCert): 1.1 x the matcher's; seeds kept under one gate are not reused under another
+    const float thr2x = g_knobs.no_certify ? thr2 : thr2 * 1.21f;
+    for (int k = 0; k < 9; ++k) knn_last_P_[k] = P.R[k];
+    for (int k = 0; k < 3; ++k) knn_last_P_[9 + k] = P.t[k];
     // warm-started launches: the counting flavour over all items, then the insertion flavour over the items it
     // queued (counter[2] = their number); first launch on a cloud pair: the insertion flavour over all items
 #define MOLA_LAUNCH_KNN(KK, VER, QLL, QUEUE, LIST)                                                                        \
     hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL>), dim3(VER ? grid_ver : grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
-                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, p.matcher_threshold, p.plane_eigen_threshold,   \
+                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold,   \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
-                       counter + 2, LIST, counter, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>(), g_knobs.early_pop ? 1 : 0)
+                       counter + 2, LIST, counter, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>(), g_knobs.early_pop ? 1 : 0, cert)
 #define MOLA_LAUNCH_KNN_QL(KK, QLL)                                                                                  \
     do {                                                                                                             \
         if (verify) {                                                                                                \
@@ -936,12 +950,12 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         else MOLA_LAUNCH_KNN_QL(KK, 2);                                                                              \
     } while (0)
     switch (p.knn) {
-        case 3: MOLA_LAUNCH_KNN_ALL(3); break;
-        case 4: MOLA_LAUNCH_KNN_ALL(4); break;
-        case 5: MOLA_LAUNCH_KNN_ALL(5); break;
-        case 6: MOLA_LAUNCH_KNN_ALL(6); break;
-        case 7: MOLA_LAUNCH_KNN_ALL(7); break;
-        default: MOLA_LAUNCH_KNN_ALL(8); break;
+        case 3: MOLA_LAUNCH_KNN_ALL(4); break;
+        case 4: MOLA_LAUNCH_KNN_ALL(5); break;
+        case 5: MOLA_LAUNCH_KNN_ALL(6); break;
+        case 6: MOLA_LAUNCH_KNN_ALL(7); break;
+        case 7: MOLA_LAUNCH_KNN_ALL(8); break;
+        default: MOLA_LAUNCH_KNN_ALL(9); break;
     }
 #undef MOLA_LAUNCH_KNN_ALL
 #undef MOLA_LAUNCH_KNN_QL

@@ -180,6 +180,8 @@ class HipWorkspace final : public Stages {
     DevBuf rows_;                     // k_nn_coop's fused stage-0 sums, one row of kNAcc doubles per 128-query item
     bool rows_valid_ = false;         // rows_ belongs to the pairing in place
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
+    DevBuf knn_lb_;   // per query: lower bound on the distance to every map point outside its stored neighbour list (KnnCert)
+    float knn_last_P_[12] = {};  // the pose of the launch that wrote knn_pos_ / knn_lb_ (PoseF: R row-major, then t)
     DevBuf planes_, knn_pos_, plane_acc_, plane_cache_;  // point-to-plane pairing (sorted query order) + its accumulators
     double* plane_acc_host_ = nullptr;
     bool planes_valid_ = false, planes_empty_ = false;

@@ -42,7 +42,6 @@ struct NnProblem {
     double* rows;                  // out: kNAcc unit-weight sums per item (fused stage-0 accumulation)
     unsigned long long* staged;    // statistics: kStatSlots counters on separate lines (units of 64 evaluated pairs)
 };
-constexpr int kStatSlots = 64, kStatStride = 16;  // (u64 units: one 128-byte line per slot)
 constexpr int kCoopMaxBatch = 12;                 // problems per launch (kernel arguments are limited to 4 KB; = kAccMaxBatch)
 template <int KMAX> struct NnBatch { NnProblem p[KMAX]; };
 
@@ -299,6 +298,7 @@ __device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledM
             reach[k] = -1.0f;
             best[k] = -1.0f;
             bpos[k] = -1;
+            key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (a padding lane loaded the last query's seed: the exact epilogue reads the point at bpos for any key below the gate)
         }
     }
     unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull};
@@ -609,6 +609,7 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
                 reach[k] = -1.0f;
                 best[k] = -1.0f;
                 bpos[k] = -1;
+                key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (a padding lane loaded the last query's seed: the exact epilogue reads the point at bpos for any key below the gate)
             }
         }
     }

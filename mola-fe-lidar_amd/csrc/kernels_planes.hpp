@@ -66,16 +66,19 @@ __device__ __forceinline__ void eig_sym3_dev(const double Cin[3][3], double ev[3
         for (int k = 0; k < 3; k++) V[r][k] = Vs[r][k];
 }
 
-// Epilogue of one query of the point-to-plane matcher (shared by k_knn_planes and k_knn_coop): kp / kd = its sorted
-// neighbour list (sorted-map positions, squared distances; -1 / gate^2 in the unused tail), (qx, qy, qz) the moved query.
-// Writes knn_pos (next launch's seeds), the plane of the list into `cache` when it had to be solved, the pairing into
-// `out`.  Returns whether SOME lane of the wave had to solve a plane (= the item's lists changed).
-template <int K>
-__device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&kp)[K], const float (&kd)[K], float qx, float qy, float qz,
+// Epilogue of one query of the point-to-plane matcher: kp / kd = its sorted neighbour list of KL = K + 1 entries (sorted-map
+// positions, squared distances; -1 / gate^2 in the unused tail), (qx, qy, qz) the moved query.  The plane is that of the
+// first K; the extra entry is only a seed -- it is what makes the list's last distance a lower bound on every point
+// OUTSIDE the K nearest (certified lists, k_knn_planes).  Writes knn_pos (next launch's seeds, KL per query), the plane of
+// the list into `cache` when it had to be solved, the pairing into `out`.  Returns whether SOME lane of the wave had to
+// solve a plane (= the item's lists changed).
+template <int KL>
+__device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&kp)[KL], const float (&kd)[KL], float qx, float qy, float qz,
                                                int i, int N, float thr2, double threshold, double plane_eig_thr,
                                                PlanePair* __restrict__ out, PlanePair* __restrict__ cache, int* __restrict__ knn_pos,
                                                int use_seed, int use_cache)
 {
+    constexpr int K = KL - 1;
     bool item_changed = false;
     {
             
@@ -83,13 +86,14 @@ __device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&k
             const size_t ic = in ? (size_t)i : (size_t)(N - 1);
             int m = 0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) m += (kp[j] >= 0 && kd[j] < thr2) ? 1 : 0;  // sorted: the first m entries
+            for (int j = 0; j < K; ++j) m += (kp[j] >= 0 && kd[j] < thr2) ? 1 : 0;  // sorted: the first m entries are inside the gate
+            // (the list may go on beyond the gate, up to the extended gate of k_knn_planes: seeds, never part of a plane)
             bool same = use_seed != 0 && use_cache != 0;
+            if (same) same = cache[ic].n_neigh == m;
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const int now = j < m ? kp[j] : -1;
-                if (use_seed) same &= knn_pos[ic * K + j] == now;
-                if (in) knn_pos[ic * K + j] = now;
+            for (int j = 0; j < KL; ++j) {
+                if (use_seed && j < K) same &= knn_pos[ic * KL + j] == kp[j];
+                if (in) knn_pos[ic * KL + j] = kp[j];
             }
             PlanePair pl;  // the plane of the list: valid = "is a plane" (before the query-distance test)
             pl.valid = 0; pl.n_neigh = m;
@@ -157,10 +161,38 @@ __device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&k
 // QL = queries per lane: 2 (items of 128 queries), or 1 (items of 64) when the cloud has no more 128-query items than the
 // launch has waves -- every wave then runs ONE item, the launch is as long as the heaviest of them, and halving the
 // items nearly halves it (an odometry-size scan pair: 120k points = 938 items of 128 on 3072 waves).
-template <int K, bool VERIFY, int QL>
-__global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+// CERTIFIED LISTS (temporal coherence, exact).  The point-to-plane loop converges in a handful of iterations and then
+// keeps launching the matcher at poses that hardly move; proving that a query's K nearest are still the same K is far
+// cheaper than sweeping for them.  The lists hold KL = K + 1 entries.  After a launch, every map point OUTSIDE a query's
+// stored list has d2 >= the list's last key (the sweep culls and rejects against exactly that value; gate^2 while the
+// list is not full): lb = its square root, rounded down, is a lower bound on the distance from the query (as that launch
+// transformed it) to every outside point.  The next launch moves the query by delta = |q - q_prev| (both transforms
+// recomputed here, bit for bit what the launches use), so every outside point is still >= lb - delta away (triangle
+// inequality).  The seeds are re-evaluated with the contract's arithmetic and sorted as always; if (lb - delta)^2 exceeds
+// the K-th seed's d2 -- margins for every rounding below -- no outside point can enter or tie with the first K: they ARE
+// the K nearest, in the right order (a swap with the K+1-th seed is inside the list).  Such a lane takes no part in the
+// sweep (no reach; it keeps evaluating what the others stage, which can only improve its K+1-th entry), an item whose
+// lanes are all certified skips the sweep, and lb - delta is stored as the new bound (a seed that left the gate joins
+// the outside at >= gate' >= lb).  THE LISTS' OWN GATE: a list that is not full bounds the outside only by the gate it was
+// swept with -- and with the matcher's gate itself there is no margin at all: a sparse region's queries (a spinning lidar's
+// far rings: fewer than K + 1 points within 0.7 m) would be swept over the whole gate ball at every launch, and they are
+// the heaviest items.  So the lists are kept over a slightly larger gate (gate' = 1.1 gate: thr2x); the plane uses the
+// entries inside the true gate among the first K, exactly as before (the list is sorted), and a short list certifies as
+// long as lb - delta stays beyond the true gate.  Rounding: the contract's d2 = D (1 + e), |e| <= 6u (u = 2^-24), so distances follow
+// from d2 within 3.1u; sqrtf within 2u; the products / differences below within u each; every factor (1 -+ 32u) leaves
+// several u to spare.
+struct KnnCert {
+    PoseF Pprev;  // the pose of the launch that wrote lb / the seeds
+    float* lb;    // per query (sorted order): read if `on`, always written
+    int on;       // lb and Pprev describe the seeds in knn_pos
+    unsigned long long* stats;  // diagnostics (slotted counters, may be null): [1] certified queries, [2] items that skipped the sweep
+};
+constexpr float kCertUp = 1.0f + 2.0e-6f, kCertDown = 1.0f - 2.0e-6f;  // ~ (1 +- 32u)
+
+template <int K /*list length: knn + 1*/, bool VERIFY, int QL>
+__global__ __launch_bounds__(256, (K <= 7 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
                                                     const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
-                                                    float thr2, double threshold, double plane_eig_thr,
+                                                    float thr2, float thr2x /*the lists' own gate^2 >= thr2 (see below)*/, double threshold, double plane_eig_thr,
                                                     PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
                                                     int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
                                                     int use_seed, int use_cache /*cached planes were decided with this launch's planeEigenThreshold*/,
@@ -170,7 +202,8 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
                                                     unsigned long long* __restrict__ staged_total, int lds_boxes,
                                                     const int* __restrict__ item_order /*heaviest first, range boundaries behind it (k_order_items); may be null*/,
                                                     unsigned int* __restrict__ item_cost /*cycles per item of this launch (full sweeps only)*/,
-                                                    int early_pop /*tuning knob: reserve the next item at the START of this one*/)
+                                                    int early_pop /*tuning knob: reserve the next item at the START of this one*/,
+                                                    KnnCert cert)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
     __shared__ int s_list[4][kMaxList];
@@ -192,6 +225,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
     const int n_items = from_list ? (int)*redo_count : (N + kQ - 1) / kQ;
     unsigned long long wave_staged = 0ull;
     unsigned int wave_changed = 0u;  // items of this wave with a lane whose neighbour list differs from its seeds
+    unsigned int wave_certified = 0u, wave_skipped = 0u;  // diagnostics
     // full sweeps are served heaviest item first inside each XCD's range (as k_nn_tiled: a launch is as long as its
     // longest wave, and the dense regions' items take several times the median)
     const int* order = from_list ? nullptr : item_order;
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         for (int k = 0; k < QL; ++k) {
             xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
 #pragma unroll
-            for (int j = 0; j < K; ++j) { kk[k][j] = (unsigned long long)__float_as_uint(thr2) << 32; kp[k][j] = -1; }  // sentinel: (gate^2, 0) never beaten by d2 >= gate^2
+            for (int j = 0; j < K; ++j) { kk[k][j] = (unsigned long long)__float_as_uint(thr2x) << 32; kp[k][j] = -1; }  // sentinel: (gate'^2, 0) never beaten by d2 >= gate'^2
         }
         if (use_seed) {
             // warm start: the K neighbours of the last launch are exact candidates; with them in the list the
@@ -256,16 +290,36 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
                     const float du = dist2(qx[k], qy[k], qz[k], gx[j], gy[j], gz[j]);
-                    if (js[j] >= 0 && du < thr2) insert(k, du, go[j], js[j]);  // distinct positions: no duplicates among the seeds
+                    if (js[j] >= 0 && du < thr2x) insert(k, du, go[j], js[j]);  // distinct positions: no duplicates among the seeds
                 }
             }
         }
+        unsigned long long cert_mask[QL];  // (wave-uniform) lanes whose first K entries are proven to be the K nearest
+        bool lane_open = false;
 #pragma unroll
         for (int k = 0; k < QL; ++k) {
-            reach[k] = reach_of(kd_of(k, K - 1), qx[k], qy[k], qz[k]);  // K-th best so far, or the gate while the list is not full
+            reach[k] = reach_of(kd_of(k, K - 1), qx[k], qy[k], qz[k]);  // last entry so far, or the gate while the list is not full
             kbound[k] = kd_of(k, K - 1);  // the sweep's box tests read it LIVE: it shrinks as the list fills (below)
+            bool certd = false;
+            if (cert.on && use_seed) {
+                const int ic = qi[k] < N ? qi[k] : N - 1;
+                float ox, oy, oz;
+                xform(cert.Pprev, lx[k], ly[k], lz[k], ox, oy, oz);  // where the launch that wrote lb had this query
+                const float delta = sqrtf(dist2(qx[k], qy[k], qz[k], ox, oy, oz)) * kCertUp + 1e-18f;
+                // every point outside the stored list is at least this far away now -- the seeds dropped above for lying beyond
+                // THIS launch's gate' have joined the outside (the gate may differ from the one lb was established under)
+                const float m = fminf((cert.lb[ic] - delta) * kCertDown, sqrtf(thr2x) * kCertDown);
+                const float mm = m * m * kCertDown;
+                // ... beyond the K-th nearest seed, or beyond the gate if fewer than K seeds are inside it
+                certd = qi[k] < N && m > 0.f && mm > fminf(kd_of(k, K - 2), thr2);
+                if (certd) cert.lb[ic] = m;
+            }
+            cert_mask[k] = __ballot(certd);
+            lane_open |= qi[k] < N && !certd;
+            if (certd) { reach[k] = -1.0f; kbound[k] = -1.0f; }   // no reach of its own (it keeps its query: the epilogue needs it)
             if (qi[k] >= N) { qx[k] = qy[k] = qz[k] = 1.0e18f; reach[k] = -1.0f; kbound[k] = -1.0f; }  // padding lane
         }
+        const bool skip_sweep = !__any(lane_open);  // every query of the item is certified
         // VERIFY: tau = K-th seed distance (list full), else the largest float below gate^2 ("d2 < gate^2" as "<=")
         float tau[QL];
         int expect[QL], cnt[QL] = {};
@@ -275,8 +329,8 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
 #pragma unroll
             for (int j = 0; j < K; ++j) sds += kp[k][j] >= 0 ? 1 : 0;
             expect[k] = sds;
-            tau[k] = sds == K ? kd_of(k, K - 1) : __uint_as_float(__float_as_uint(thr2) - 1u);
-            if (VERIFY && qi[k] < N) kbound[k] = tau[k];
+            tau[k] = sds == K ? kd_of(k, K - 1) : __uint_as_float(__float_as_uint(thr2x) - 1u);
+            if (VERIFY && qi[k] < N && !((cert_mask[k] >> lane) & 1ull)) kbound[k] = tau[k];
         }
 
         // distances of 4 staged points to the lane's queries: QL = 2 pairs the two queries per packed instruction, QL = 1
@@ -300,7 +354,7 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         };
         unsigned long long np_a = 0ull, np_b = 0ull;  // (profiling outputs of the sweep, unused here)
         unsigned int np_c = 0u, np_d = 0u, np_e = 0u;
-        const unsigned long long n_staged = tiled_sweep<QL, !VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
+        const unsigned long long n_staged = skip_sweep ? 0ull : tiled_sweep<QL, !VERIFY>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, kbound, [&](int nm, int jb0, int jb1) {
             for (int m = 0; m < nm; m += 4) {
                 const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
                 const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
@@ -351,12 +405,20 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         if constexpr (VERIFY) {
             bool bad = false;
 #pragma unroll
-            for (int k = 0; k < QL; ++k) bad |= qi[k] < N && cnt[k] != expect[k];
+            for (int k = 0; k < QL; ++k) bad |= qi[k] < N && !((cert_mask[k] >> lane) & 1ull) && cnt[k] != expect[k];
             redo = __any(bad);
             if (redo && lane == 0) redo_list[atomicAdd(redo_count, 1u)] = item;
         }
         bool item_changed = false;
         if (!redo) {
+        // the new lower bound of the lanes that were swept (a certified lane wrote its own above): every point outside the
+        // list has d2 >= the list's last key -- in the counting flavour: > tau, nothing but the seeds was counted inside it
+#pragma unroll
+        for (int k = 0; k < QL; ++k)
+            if (qi[k] < N && !((cert_mask[k] >> lane) & 1ull)) cert.lb[qi[k]] = sqrtf(VERIFY ? tau[k] : kd_of(k, K - 1)) * kCertDown;
+#pragma unroll
+        for (int k = 0; k < QL; ++k) wave_certified += (unsigned int)__popcll(cert_mask[k]);
+        wave_skipped += skip_sweep ? 1u : 0u;
         // Epilogue.  The plane (centroid, normal, is-it-planar) depends only on the ordered neighbour list -- map
         // points, fixed for the align -- so when a query's list equals the last launch's, the cached plane is reused
         // bit for bit and the fp64 covariance + Jacobi eigen-solve (dearer than the search itself) is skipped.  Near
@@ -379,6 +441,11 @@ __global__ __launch_bounds__(256, (K <= 6 ? 3 : 2)) void k_knn_planes(const floa
         raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v));
     }
     if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
+    if (cert.stats && lane == 0 && wave_certified) {
+        unsigned long long* st = cert.stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride;
+        atomicAdd(st + 1, (unsigned long long)wave_certified);
+        if (wave_skipped) atomicAdd(st + 2, (unsigned long long)wave_skipped);
+    }
     // (the verify flavour reports its queued items through redo_count; the queued-items launch must not count twice)
     if (!VERIFY && !from_list && lane == 0 && wave_changed) atomicAdd(changed_items, wave_changed);
 }
@@ -479,8 +546,8 @@ __global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict_
     out[o] = in[i];
     if (knn_idx && knn_pos)
         for (int j = 0; j < K; ++j) {
-            const int ps = knn_pos[(size_t)i * K + j];
-            knn_idx[(size_t)o * K + j] = ps >= 0 ? perm[ps] : -1;
+            const int ps = knn_pos[(size_t)i * (K + 1) + j];  // (stored lists hold one entry more than knn, and may go on beyond the gate)
+            knn_idx[(size_t)o * K + j] = (j < in[i].n_neigh && ps >= 0) ? perm[ps] : -1;
         }
 }
 

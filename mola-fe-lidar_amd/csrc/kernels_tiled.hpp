@@ -70,6 +70,7 @@ constexpr size_t kMaxLdsBoxBytes = 40 * 1024;  // upper box levels kept in LDS u
 constexpr size_t kDbgItems = 1u << 17;  // MOLA_ICP_DEBUG_STATS: per-item records for clouds up to 16M points
 constexpr int kQueues = 8, kQueueStride = 32;  // work-queue counters, one 128-byte line each
 constexpr int kMaxList = 64;   // super-tiles collected before their tiles are streamed
+constexpr int kStatSlots = 64, kStatStride = 16;  // slotted statistics counters (u64 units: one 128-byte line per slot)
 constexpr int kHalfFlag = 0x40000000;  // work-list entry = one 64-query half of a 128-query item (id = 2 * item + half)
 
 // LDS copy of the two upper box levels (one per workgroup): [6][n_top] then [6][n_super] floats.  The upper
@@ -577,6 +578,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                 reach[k] = -1.0f;
                 best[k] = -1.0f;
                 bpos[k] = -1;
+                key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (a padding lane loaded the last query's seed: the exact epilogue reads the point at bpos for any key below the gate)
             }
         }
 

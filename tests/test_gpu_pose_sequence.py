@@ -1,0 +1,171 @@
+"""-m gpu: the warm-started tiled matcher over SEQUENCES of launches on the same clouds.  Every launch seeds the next one
+(neighbour positions and coordinates kept on the device), so a wrong seed, a stale bound or a padding lane's leftovers
+would only show a launch or two later: every launch of a pose sequence must give the oracle's indices and d2 bit for bit
+-- through poses that converge, jump, change the gate between launches (as the quality pass does), meet exact ties and
+queries without any neighbour.  (Written for an experiment that kept per-query lower bounds between launches -- see
+DESIGN.md 'measured and dropped'; the sequences found a latent out-of-bounds read of the exact redo's padding lanes.)"""
+import numpy as np
+import pytest
+
+from tests.helpers import p2p_params
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_QPL", "MOLA_ICP_NO_CERTIFY")
+
+
+def _env(pkg, monkeypatch, **kv):
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in kv.items():
+        monkeypatch.setenv(k, v)
+    pkg._lib.lib().mola_icp_debug_reload_env()
+
+
+def _pose_sequence(synth, n_steps, seed):
+    """identity -> towards the ground truth in shrinking steps (an ICP-like trajectory), then a jump, then tiny steps again"""
+    tgt = np.array([0.50, 0.20, 0.05, np.deg2rad(2.0), np.deg2rad(0.5), np.deg2rad(0.3)])
+    rng = np.random.default_rng(seed)
+    x = np.zeros(6)
+    out = []
+    for i in range(n_steps):
+        if i == n_steps // 2:
+            x = x + np.array([0.3, -0.2, 0.05, 0.01, 0.0, 0.0])          # a jump: bounds must fail, not lie
+        elif i == n_steps // 2 + 1:
+            x = x - np.array([0.3, -0.2, 0.05, 0.01, 0.0, 0.0])
+        else:
+            x = x + 0.5 * (tgt - x) + rng.normal(0, 1.0, 6) * np.array([1e-4, 1e-4, 1e-4, 1e-6, 1e-6, 1e-6]) * (0.7 ** i)
+        out.append(synth.pose_from_xyzypr(*x))
+    return out
+
+
+@pytest.mark.parametrize("coop", ["0", "1"])
+@pytest.mark.parametrize("qpl", ["1", "2"])
+def test_every_launch_of_a_pose_sequence_is_the_oracles(pkg, O, synth, small_scene, monkeypatch, qpl, coop):
+    _env(pkg, monkeypatch, MOLA_ICP_COOP=coop, MOLA_ICP_QPL=qpl)
+    try:
+        icp = pkg.ICP(device=0)
+        icp.set_profiling(True)
+        for N, M, seed in ((30011, 20011, 3), (9000, 60000, 4)):
+            g, l, _ = synth.make_pair(N, M, seed=seed, scene=small_scene)
+            # a tenth of the scan far outside the map: queries without any neighbour
+            l = l.copy()
+            l[2, : N // 10] += 50.0
+            kd = O.KdTree(g)
+            icp.set_map(g)
+            icp.set_local(l)
+            for i, T in enumerate(_pose_sequence(synth, 16, seed)):
+                thr = 0.7 if i % 5 else 0.45          # the gate changes between launches (as the quality pass does)
+                idx, d2, n = icp.match(T, thr, N, pkg.NN_TILED)
+                oidx, od2, on = O.match(g, l, T, thr, kd)
+                assert n == on, (i, n, on)
+                assert np.array_equal(idx, oidx), f"launch {i}: {(idx != oidx).sum()} of {N} NN indices differ"
+                k = oidx >= 0
+                assert np.array_equal(d2[k], od2[k]), f"launch {i}: d2 differs"
+        icp.close()
+    finally:
+        _env(pkg, monkeypatch)
+
+
+@pytest.mark.parametrize("coop", ["0", "1"])
+def test_ties_and_duplicates_over_a_sequence(pkg, O, monkeypatch, coop):
+    """a lattice with every map point duplicated: exact ties everywhere (the exact redo runs seeded from the second launch
+    on, its last item with padding lanes); the lowest original index must win at every pose"""
+    _env(pkg, monkeypatch, MOLA_ICP_COOP=coop)
+    try:
+        ax = np.arange(12, dtype=np.float32)
+        g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij")).reshape(3, -1)
+        g = np.ascontiguousarray(np.concatenate([g, g], axis=1))
+        l = np.ascontiguousarray((g[:, :1500] + np.float32(0.5)).astype(np.float32))
+        icp = pkg.ICP(device=0)
+        icp.set_map(g)
+        icp.set_local(l)
+        kd = O.KdTree(g)
+        for i in range(6):
+            T = np.eye(4)
+            T[:3, 3] = [1e-3 * i, 0, 0] if i < 4 else [0.25, 0.25, 0.0]   # off the symmetric spot, then back onto another one
+            idx, d2, n = icp.match(T, 2.0, l.shape[1], pkg.NN_TILED)
+            oidx, od2, on = O.match(g, l, T, 2.0, kd)
+            assert n == on and np.array_equal(idx, oidx) and np.array_equal(d2[oidx >= 0], od2[oidx >= 0]), i
+        icp.close()
+    finally:
+        _env(pkg, monkeypatch)
+
+
+# ---- the point-to-plane matcher: certified neighbour lists (kernels_planes.hpp, KnnCert) ----------------------------------
+def _p2pl_sequence(synth, n_steps):
+    """towards a pose in halving steps (Gauss-Newton-like: the steps vanish quickly, most lists certify), a jump in the
+    middle (nothing may certify wrongly), then vanishing steps again and two launches at the very same pose"""
+    tgt = np.array([0.30, -0.15, 0.04, np.deg2rad(1.5), np.deg2rad(-0.4), np.deg2rad(0.25)])
+    x = np.zeros(6)
+    out = []
+    for i in range(n_steps):
+        if i == n_steps // 2:
+            x = x + np.array([0.2, 0.1, -0.03, 0.01, 0.0, 0.0])
+        elif i == n_steps // 2 + 1:
+            x = x - np.array([0.2, 0.1, -0.03, 0.01, 0.0, 0.0])
+        elif i < n_steps - 1:
+            x = x + 0.6 * (tgt - x)
+        out.append(synth.pose_from_xyzypr(*x))
+    return out
+
+
+@pytest.mark.parametrize("knn", [3, 6, 8])
+@pytest.mark.parametrize("qpl", ["1", "2"])
+def test_every_launch_of_a_plane_matcher_sequence_is_the_oracles(pkg, O, synth, monkeypatch, knn, qpl):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _env(pkg, monkeypatch, MOLA_ICP_QPL=qpl)
+    try:
+        scene = synth.Scene(scene_seed=3, half=12.0, wall_y=5.0, wall_h=4.0, n_boxes=8)
+        g, l, _ = synth.make_pair(12000, 10000, seed=11, scene=scene)
+        l = l.copy()
+        l[2, :700] += 30.0                      # queries without any neighbour inside the gate
+        l[0, 700:1400] += 0.55                  # ... and a band whose lists are short / change with the pose
+        kd = O.KdTree(g)
+        p = pkg.Parameters.load_from_file(os.path.join(root, "params", "icp-settings-regular.yaml"))
+        p.knn = knn
+        icp = pkg.ICP(device=0)
+        icp.set_profiling(True)
+        icp.set_map(g)
+        icp.set_local(l)
+        for i, T in enumerate(_p2pl_sequence(synth, 14)):
+            p.matcher_threshold = 0.7 if i % 4 else 0.5        # the gate changes between launches
+            valid, cen, nor, kidx, n = icp.match_planes(T, p, l.shape[1])
+            ov, oc, on, ok, onum = O.match_point2plane(g, l, T, p.matcher_threshold, p.plane_eigen_threshold, knn, kd)
+            assert np.array_equal(kidx, ok), f"launch {i}: {(kidx != ok).any(1).sum()} of {len(ok)} neighbour lists differ"
+            assert np.array_equal(valid, ov) and n == onum, i
+            k = ov.astype(bool)
+            np.testing.assert_allclose(cen[k], oc[k], atol=1e-12)
+            np.testing.assert_allclose(np.abs((nor[k] * on[k]).sum(1)), 1.0, atol=1e-9)
+        icp.close()
+    finally:
+        _env(pkg, monkeypatch)
+
+
+@pytest.mark.parametrize("n,m", [(120_000, 100_000), (1_000_000, 1_000_000)])
+def test_shipped_align_does_not_depend_on_certified_lists(pkg, synth, monkeypatch, n, m):
+    """icp-settings-regular.yaml, 14 fixed iterations + the quality pass: bit-identical pose, pair count and quality with the
+    lower bounds on and off (any differing list of any iteration moves the fp64 sums) -- and far fewer evaluated pairs"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g, l, _ = synth.make_pair(n, m, seed=13)
+    res = {}
+    try:
+        for mode in ("on", "off"):
+            _env(pkg, monkeypatch, **({"MOLA_ICP_NO_CERTIFY": "1"} if mode == "off" else {}))
+            icp = pkg.ICP(device=0)
+            icp.set_profiling(True)
+            icp.set_map(g)
+            icp.set_local(l)
+            p = pkg.Parameters.load_from_file(os.path.join(root, "params", "icp-settings-regular.yaml"))
+            p.max_iterations, p.fixed_iterations = 14, 1
+            res[mode] = icp.align_resident(np.eye(4), p)
+            icp.close()
+        a, b = res["on"], res["off"]
+        assert a.nIterations == b.nIterations == 14
+        assert np.array_equal(a.optimal_tf, b.optimal_tf)
+        assert a.n_pairs == b.n_pairs and a.quality == b.quality
+        assert a.nn_pairs_evaluated < 0.75 * b.nn_pairs_evaluated, (a.nn_pairs_evaluated, b.nn_pairs_evaluated)
+    finally:
+        _env(pkg, monkeypatch)
