@@ -891,7 +891,19 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int plane_cache_ok = (knn_seed && planes_eig_thr_ == p.plane_eigen_threshold) ? 1 : 0;
     // the counting flavour pays off when few items will need the insertion flavour afterwards: judged by the
     // number of items whose lists changed in the previous iteration (read back with its accumulators)
-    const bool verify = knn_seed && knn_changed_items_ >= 0.0 && knn_changed_items_ < 0.3 * (double)n_items &&
+    // ... and only inside a converging sequence of poses: the first launch of another align on the same clouds starts far from
+    // where the last one ended -- every list changes, the counting pass (0.27 ms at C3) would queue every item.  Judged by the
+    // pose step against the previous one (a heuristic: rotation weighed with a 30 m lever; results do not depend on it).
+    double step = 0.0;
+    {
+        double dr = 0.0, dt = 0.0;
+        for (int k = 0; k < 9; ++k) { const double d = (double)P.R[k] - (double)knn_last_P_[k]; dr += d * d; }
+        for (int k = 0; k < 3; ++k) { const double d = (double)P.t[k] - (double)knn_last_P_[9 + k]; dt += d * d; }
+        step = std::sqrt(dt) + 30.0 * std::sqrt(dr);
+    }
+    const bool converging = step <= 4.0 * knn_last_step_ + 1e-9;
+    knn_last_step_ = knn_seed ? step : 1e30;   // (after an unseeded launch any step counts as "converging")
+    const bool verify = knn_seed && knn_changed_items_ >= 0.0 && knn_changed_items_ < 0.3 * (double)n_items && converging &&
                         !g_knobs.no_knn_verify;
     knn_changed_items_ = -1.0;  // consumed: only an accumulate_planes() after this launch renews it
     if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;

@@ -181,6 +181,7 @@ class HipWorkspace final : public Stages {
     bool rows_valid_ = false;         // rows_ belongs to the pairing in place
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
     DevBuf knn_lb_;   // per query: lower bound on the distance to every map point outside its stored neighbour list (KnnCert)
+    double knn_last_step_ = 1e30;   // size of the pose step between the last two launches of the plane matcher (flavour heuristic)
     float knn_last_P_[12] = {};  // the pose of the launch that wrote knn_pos_ / knn_lb_ (PoseF: R row-major, then t)
     DevBuf planes_, knn_pos_, plane_acc_, plane_cache_;  // point-to-plane pairing (sorted query order) + its accumulators
     double* plane_acc_host_ = nullptr;

@@ -155,7 +155,9 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
         if (host_out) host_out[threadIdx.x] = t;  // straight into the host's pinned block: no copy engine, no extra launch gap
     }
     if (host_out) {  // publish: data first, then the sequence number the host spins on
-        __threadfence_system();
+        // (only the waves that wrote to the host block fence at system scope: the fence is an L2 write-back per wave, and
+        //  twelve waves doing it one after another was most of this kernel)
+        if (threadIdx.x < ((kNAcc + 63) / 64) * 64) __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
             reinterpret_cast<volatile unsigned long long*>(host_out)[kNAcc + 6] = seq;  // (slots 24..29 serve other read-backs)

@@ -13,7 +13,7 @@ namespace mola_icp_amd {
 // Jacobi eigen-decomposition -> plane iff e0 <= planeEigenThreshold * e2, normal = eigenvector of e0,
 // pairing iff |n.(q - mean)| <= distanceThreshold.  [EXT-recalled mp2p_icp behaviour; restated in the
 // CPU checker with the same operation order.]
-struct PlanePair {      // one per query, sorted query order
+struct PlanePair {      // one per query, sorted query order  (padding it to 64 bytes / 16-byte loads was measured: no gain)
     double c[3];        // plane centroid
     double n[3];        // unit normal
     int valid, n_neigh;
@@ -461,27 +461,41 @@ __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restri
     double acc[kNAccPlane];
 #pragma unroll
     for (int k = 0; k < kNAccPlane; ++k) acc[k] = 0.0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
-        const PlanePair pp = pairs[i];
-        if (!pp.valid) continue;
-        const double l[3] = {slx[i], sly[i], slz[i]};
-        double phi[12];
+    // 92 fp64 accumulators leave one wave per SIMD: nothing hides a load but the thread's own next element -- fetched while
+    // this one is accumulated (same order of additions: 20 -> ~12 us at 1M)
+    const int stride = (int)gridDim.x * 256;
+    int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    PlanePair pp{};
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    bool have = i < N;
+    if (have) { pp = pairs[i]; l0 = slx[i]; l1 = sly[i]; l2 = slz[i]; }
+    while (have) {
+        const int inext = i + stride;
+        const bool hn = inext < N;
+        PlanePair pn{};
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+        if (hn) { pn = pairs[inext]; n0 = slx[inext]; n1 = sly[inext]; n2 = slz[inext]; }
+        if (pp.valid) {
+            const double l[3] = {l0, l1, l2};
+            double phi[12];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < 3; ++r) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) phi[3 * r + c] = pp.n[r] * l[c];
-            phi[9 + r] = pp.n[r];
+                for (int c = 0; c < 3; ++c) phi[3 * r + c] = pp.n[r] * l[c];
+                phi[9 + r] = pp.n[r];
+            }
+            const double d = pp.n[0] * pp.c[0] + pp.n[1] * pp.c[1] + pp.n[2] * pp.c[2];
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 12; ++a)
+#pragma unroll
+                for (int b = a; b < 12; ++b) acc[q++] += phi[a] * phi[b];
+#pragma unroll
+            for (int a = 0; a < 12; ++a) acc[78 + a] += phi[a] * d;
+            acc[90] += d * d;
+            acc[91] += 1.0;
         }
-        const double d = pp.n[0] * pp.c[0] + pp.n[1] * pp.c[1] + pp.n[2] * pp.c[2];
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 12; ++a)
-#pragma unroll
-            for (int b = a; b < 12; ++b) acc[q++] += phi[a] * phi[b];
-#pragma unroll
-        for (int a = 0; a < 12; ++a) acc[78 + a] += phi[a] * d;
-        acc[90] += d * d;
-        acc[91] += 1.0;
+        pp = pn; l0 = n0; l1 = n1; l2 = n2; have = hn; i = inext;
     }
     block_sum_256<kNAccPlane>(acc, partials + (size_t)blockIdx.x * kNAccPlane);  // fixed order
 }
@@ -510,6 +524,13 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
     double v = 0.0;
     if (k < n) {
         int b = sl;
+        for (; b + 120 < nblocks; b += 128) {  // sixteen rows in flight (a thread's rows are a chain of dependent round trips otherwise: 12.6 -> ~5 us at 512 rows)
+            double a[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] = partials[(size_t)(b + 8 * u) * n + k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v += a[u];
+        }
         for (; b + 24 < nblocks; b += 32) {  // four rows in flight
             const double a0 = partials[(size_t)b * n + k], a1 = partials[(size_t)(b + 8) * n + k];
             const double a2 = partials[(size_t)(b + 16) * n + k], a3 = partials[(size_t)(b + 24) * n + k];
@@ -526,7 +547,7 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
         if (host_out) host_out[k] = t;
     }
     if (host_out) {  // publish: data first, then the sequence number the host spins on
-        __threadfence_system();
+        if (threadIdx.x < 128) __threadfence_system();  // (the waves that wrote to the host block: see reduce_rows)
         __syncthreads();
         if (threadIdx.x == 0) {
             reinterpret_cast<volatile unsigned long long*>(host_out)[n + 2] = seq;
