@@ -739,7 +739,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     float* gs = ts_gs_.as<float>();
     const size_t gs_n = loc_sc_->padded;
     const float* sl = loc_sc_->sorted.as<float>();
-    unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
+    unsigned long long* staged = profiling_ ? stats_.as<unsigned long long>() : nullptr;  // evaluated pairs, slotted (statistics only)
     // counter[2] = redo count; tq = the fast pass's queue counters, tq + kQueues * kQueueStride the exact pass's
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
     unsigned long long* dbg = dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr;
@@ -840,7 +840,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if (profiling_) HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     const float* sl = loc_sc_->sorted.as<float>();
     const TiledMap mp = tiled_map();
-    unsigned long long* staged = reinterpret_cast<unsigned long long*>(acc_dev_.as<double>() + kNAcc + 4);
+    unsigned long long* staged = profiling_ ? stats_.as<unsigned long long>() : nullptr;  // evaluated pairs, slotted (statistics only)
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
@@ -946,7 +946,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL>), dim3(VER ? grid_ver : grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold,   \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
-                       counter + 2, LIST, counter, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>(), g_knobs.early_pop ? 1 : 0, cert)
+                       counter + 2, LIST, ((QUEUE) == tq ? tq + kQueues * kQueueStride : tq) + 1, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>(), g_knobs.early_pop ? 1 : 0, cert)
 #define MOLA_LAUNCH_KNN_QL(KK, QLL)                                                                                  \
     do {                                                                                                             \
         if (verify) {                                                                                                \

@@ -440,14 +440,16 @@ __global__ __launch_bounds__(256, (K <= 7 ? 3 : 2)) void k_knn_planes(const floa
         }
         raw = wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v));
     }
-    if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
+    if (lane == 0 && wave_staged && staged_total)  // (statistics, slotted, only when the caller profiles: see k_nn_tiled)
+        atomicAdd(staged_total + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, wave_staged);
     if (cert.stats && lane == 0 && wave_certified) {
         unsigned long long* st = cert.stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride;
         atomicAdd(st + 1, (unsigned long long)wave_certified);
         if (wave_skipped) atomicAdd(st + 2, (unsigned long long)wave_skipped);
     }
     // (the verify flavour reports its queued items through redo_count; the queued-items launch must not count twice)
-    if (!VERIFY && !from_list && lane == 0 && wave_changed) atomicAdd(changed_items, wave_changed);
+    // (8 slots on separate lines -- word 1 of the OTHER launch's queue lines: one address would see 3072 end-of-wave atomics)
+    if (!VERIFY && !from_list && lane == 0 && wave_changed) atomicAdd(changed_items + (size_t)(blockIdx.x & (kQueues - 1)) * kQueueStride, wave_changed);
 }
 
 // the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
@@ -511,7 +513,10 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
     // acc[n] = items of the plane matcher whose neighbour lists changed in this iteration (its next launch picks
     // the counting or the insertion flavour from it): counters[0] (insertion launch) + counters[2] (queued by verify)
     if (counters && threadIdx.x == 0) {
-        acc[n] = (double)(counters[0] + counters[2]);
+        unsigned int ch = counters[0] + counters[2];
+        unsigned int* slots = const_cast<unsigned int*>(counters) + 16 + 1;  // word 1 of the 2 x kQueues queue lines (queues start 8 doubles on)
+        for (int q = 0; q < 2 * kQueues; ++q) { ch += slots[q * kQueueStride]; slots[q * kQueueStride] = 0u; }
+        acc[n] = (double)ch;
         if (host_out) host_out[n] = acc[n];
         // ... and leave the matcher's counters (kept / redo / ticket, then the work-queue counters) zero for its next launch
         unsigned int* c = const_cast<unsigned int*>(counters);

@@ -718,7 +718,10 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         }
         code = run_item(run_item, std::integral_constant<int, 1>{}, std::false_type{}, code & ~kHalfFlag, code, 0);
     }
-    if (lane == 0 && wave_staged) atomicAdd(staged_total, wave_staged);
+    // (statistics, only when the caller profiles: slotted -- 3072 end-of-wave atomics on ONE address arrive at about the
+    //  rate the memory side retires them, ~13 ns each, and the launch cannot end before the last one has landed)
+    if (lane == 0 && wave_staged && staged_total)
+        atomicAdd(staged_total + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, wave_staged);
     if (wave_times && lane == 0) {  // [start, end, items, first item: prologue, sweep, epilogue cycles, staged points] per wave
         unsigned long long* w = wave_times + 8 * (size_t)wq.global_wave();
         w[0] = t_wave0; w[1] = wall_clock64(); w[2] = wave_items | ((unsigned long long)last_code << 32); w[3] = ph0; w[4] = ph1; w[5] = ph2; w[6] = ph3;
