@@ -57,6 +57,7 @@ struct Knobs {
     int batch_tiled = -1;      // MOLA_ICP_BATCH_TILED (-1 = by item count; batched launches: 0 = k_nn_coop, 1 = k_nn_tiled_batch)
     bool no_split = false;     // MOLA_ICP_NO_SPLIT: never list a heavy 128-query item as its two halves
     bool no_certify = false;   // MOLA_ICP_NO_CERTIFY: the point-to-plane matcher sweeps for every query at every launch
+    double split_share = 0.55; // MOLA_ICP_SPLIT_SHARE: a 128-query item dearer than this share of a wave's fair share is listed as its two halves
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
@@ -72,6 +73,7 @@ static Knobs read_knobs()
     k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
     k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
+    if (const char* e = std::getenv("MOLA_ICP_SPLIT_SHARE")) { const double v = std::atof(e); if (v > 0.01 && v < 100.0) k.split_share = v; }
     k.no_certify = std::getenv("MOLA_ICP_NO_CERTIFY") != nullptr;
     k.no_knn_seed = std::getenv("MOLA_ICP_NO_KNN_SEED") != nullptr;
     k.no_knn_verify = std::getenv("MOLA_ICP_NO_KNN_VERIFY") != nullptr;
@@ -676,20 +678,18 @@ TiledMap HipWorkspace::tiled_map() const
 
 int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsigned int* counter)
 {
-    // blocks per CU, measured at C3: 2 -> 0.159 ms, 3 -> 0.150, 4 -> 0.156
-    int per_cu = g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 3;  // tuning knob
+    // Items of 64 queries (one per lane; the packed math pairs map points), four workgroups per CU: measured at every size
+    // once the end-of-wave statistics atomics were out of the way (they had hidden it) -- 1M x 1M: 64-query items 4 / 3 per
+    // CU 105-108 / 112-114 us, 128-query items (heavy ones listed as halves) 123-125 us; 2M x 2M 188 / 206 / 214 us;
+    // 1M vs a 10M-point map 277 / 293 / 413 us.  Smaller items evaluate fewer pairs per query (309 vs 420: a tile staged
+    // for a wave is evaluated by ALL its queries) and balance better (5 per wave); the 118-VGPR one-query body fits four
+    // waves per SIMD (five with spills: no gain).  MOLA_ICP_QPL=2 / MOLA_ICP_BLOCKS_PER_CU bring the older form back.
+    int qpl = g_knobs.qpl ? g_knobs.qpl : 1;
+    int per_cu = g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : (qpl == 1 ? 4 : 3);  // tuning knob
     const TiledMap mp = tiled_map();
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
-    // Queries per lane.  2 (items of 128 queries) amortises the per-item box scan best.  When 128-query items
-    // would give every persistent wave between one and two items -- the launch is then two items long for a
-    // work of one and a bit -- items of 64 queries (1 per lane; the packed math pairs map points instead) balance
-    // better: measured at 500k queries 0.128 -> 0.105 ms.  Below one item per wave the launch is one item long
-    // either way and the larger items do less total work (250k: 0.083 vs 0.091 ms).
-    const size_t n128 = (N_ + kQPW - 1) / kQPW, slots = (size_t)num_cus_ * per_cu * 4;
-    int qpl = (n128 >= slots && n128 < 2 * slots) ? 1 : 2;
-    if (g_knobs.qpl) qpl = g_knobs.qpl;  // tuning knob
     const int n_items = (int)((N_ + (size_t)(64 * qpl) - 1) / (size_t)(64 * qpl));
     {   // persistent waves with a static first item: every block of the grid must be resident from the start
         // (the query is a runtime call of tens of microseconds on the launch path: once per kernel flavour and LDS size)
@@ -720,7 +720,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
         if (!order_valid_ || launches_since_order_ >= plan_interval_) {
             if (qpl == 2)
                 hipLaunchKernelGGL(k_order_entries, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
-                                   g_knobs.no_split ? 1 : grid * 4, item_order_.as<int>());
+                                   g_knobs.no_split ? 1 : (int)((double)(grid * 4) * 0.55 / g_knobs.split_share), item_order_.as<int>());
             else
                 hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, item_cost_.as<unsigned int>(), n_items,
                                    item_order_.as<int>());
@@ -757,6 +757,9 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
 #undef MOLA_LAUNCH_TILED
     cost_valid_ = true;
     rows_valid_ = false;
+    // (no item rows here: k_accumulate sums the pairing.  A batched problem's rows are summed in another order, so beyond the
+    //  cooperative kernel's range -- 131k queries -- a batched result equals its stand-alone align to ~1e-12, not bit for bit;
+    //  writing the rows here too was measured: +4 us per iteration at 200k, +10 at 390k, the reduction of 3000 rows)
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
 }
@@ -1282,7 +1285,9 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         const bool use_seed = seed_valid_ && pairing_sorted_ && !g_knobs.no_warm_start;
         // fewer 128-query items than persistent wave slots: the launch would be one item long -> one WORKGROUP per item
         const size_t n128 = (N_ + kQPW - 1) / kQPW;
-        const bool coop = g_knobs.coop >= 0 ? g_knobs.coop != 0 : n128 <= (size_t)num_cus_ * 3 * 4;
+        // (crossover measured with the 64-query persistent kernel, us per ICP iteration cooperative / persistent: 50k 34 / 42,
+        //  100k 41 / 43, 150k 50 / 47, 200k 58 / 50, 390k 93 / 65)
+        const bool coop = g_knobs.coop >= 0 ? g_knobs.coop != 0 : n128 <= (size_t)num_cus_ * 4;
         const int rc = coop ? launch_coop(P, thr2, use_seed) : launch_tiled(P, thr2, use_seed, counter);
         if (rc) return rc;
         last_kernel_ = MOLA_ICP_NN_TILED;
@@ -1635,7 +1640,7 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         NnBatchItems<kCoopMaxBatch> bi;
         std::memset(&b, 0, sizeof b);
         std::memset(&bi, 0, sizeof bi);
-        int n = 0, max_items = 0, total_items = 0;
+        int n = 0, max_items = 0, total_items = 0, total_items_t = 0;
         size_t max_box_bytes = 0;
         bool same_map = true;
         const SortedCloud* first_map = nullptr;
@@ -1663,11 +1668,13 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
             pb.rows = bf.rows.as<double>();
             pb.staged = sc_.stats.as<unsigned long long>();
             bf.seed_valid = true;
-            const int items = (int)((pr.loc->n + kQPW - 1) / kQPW);
+            const int items = (int)((pr.loc->n + kQPW - 1) / kQPW);   // 128-query items: the cooperative kernel's, and the rows'
             if (items > max_items) max_items = items;
-            bi.base[n - 1] = total_items;
+            const int items_t = (int)((pr.loc->n + 63) / 64);         // 64-query items: the persistent batched matcher's
+            bi.base[n - 1] = total_items_t;
             total_items += items;
-            bi.base[n] = total_items;
+            total_items_t += items_t;
+            bi.base[n] = total_items_t;
             if (!first_map) first_map = pr.map.get();
             same_map = same_map && pr.map.get() == first_map;
             const size_t bb = sizeof(float) * 6u * ((size_t)pb.mp.n_top + (size_t)pb.mp.n_super);
@@ -1690,15 +1697,15 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
             int& fit_tiled_ = sc_.fit_tiled;
             size_t& fit_tiled_lds_ = sc_.fit_tiled_lds;
             if (fit_tiled_ == 0 || fit_tiled_lds_ != lds) {  // persistent waves with fixed first entries: the whole grid must be resident
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_tiled_, k_nn_tiled_batch<kCoopMaxBatch>, 256, lds));
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_tiled_, (k_nn_tiled_batch<kCoopMaxBatch, 1>), 256, lds));
                 fit_tiled_lds_ = lds;
             }
-            int per_cu = g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 3;
+            int per_cu = g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 4;   // (64-query items, four workgroups per CU: see launch_tiled)
             if (fit_tiled_ >= 1 && per_cu > fit_tiled_) per_cu = fit_tiled_;
             int grid = ws_.num_cus_ * per_cu;
-            if (grid > (total_items + 3) / 4) grid = (total_items + 3) / 4;
+            if (grid > (total_items_t + 3) / 4) grid = (total_items_t + 3) / 4;
             HIPCHK(hipMemsetAsync(sc_.queue.p, 0, sizeof(unsigned int) * kQueues * kQueueStride, ws_.stream_));
-            hipLaunchKernelGGL((k_nn_tiled_batch<kCoopMaxBatch>), dim3(grid), dim3(256), lds, ws_.stream_, b, bi, n, shared,
+            hipLaunchKernelGGL((k_nn_tiled_batch<kCoopMaxBatch, 1>), dim3(grid), dim3(256), lds, ws_.stream_, b, bi, n, shared,
                                sc_.queue.as<unsigned int>(), g_knobs.early_pop ? 1 : 0);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL((k_item_rows<kCoopMaxBatch>), dim3(max_items, n), dim3(256), 0, ws_.stream_, b);

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
 // pose -- do not depend on which of the two matchers served it.
 template <int KMAX> struct NnBatchItems { int base[KMAX + 1]; };  // base[k] = first entry of problem k; base[n] = total
 
-template <bool EXACT, class AfterSweep>
+template <int QL, bool EXACT, class AfterSweep>
 __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist,
                                                  float (*sm)[64], int lane, int item, unsigned long long& n_staged_out,
                                                  AfterSweep&& after_sweep)
@@ -571,16 +571,16 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
     const int N = pb.N;
     const float thr2 = pb.thr2;
     const PoseF P = pb.P;
-    int qi[2], js[2];
-    float qx[2], qy[2], qz[2], reach[2], best[2];
-    unsigned long long key[2];
-    int bpos[2], tie[2] = {0, 0};
+    int qi[QL], js[QL];
+    float qx[QL], qy[QL], qz[QL], reach[QL], best[QL];
+    unsigned long long key[QL];
+    int bpos[QL], tie[QL] = {};
     {
-        float lx[2], ly[2], lz[2], gsx[2], gsy[2], gsz[2];
-        unsigned int gso[2] = {0u, 0u};
+        float lx[QL], ly[QL], lz[QL], gsx[QL], gsy[QL], gsz[QL];
+        unsigned int gso[QL] = {};
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            qi[k] = item * kQPW + k * 64 + lane;
+        for (int k = 0; k < QL; ++k) {
+            qi[k] = item * (64 * QL) + k * 64 + lane;
             if (qi[k] >= N) qi[k] = N;  // padding lane
             const int ic = qi[k] < N ? qi[k] : N - 1;
             lx[k] = pb.slx[ic]; ly[k] = pb.sly[ic]; lz[k] = pb.slz[ic];
@@ -592,7 +592,7 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
             }
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < QL; ++k) {
             xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
             key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);
             best[k] = thr2;
@@ -615,15 +615,15 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
     }
     unsigned long long pa = 0ull, pb2 = 0ull, pf = 0ull, pg = 0ull;
     unsigned int pc = 0u, pd = 0u, pe = 0u;
-    n_staged_out += tiled_sweep<2, EXACT>(mp, lbox, use_lbox, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
-        if constexpr (EXACT) nn_visit_exact<2>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
-        else nn_visit_fast<2>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
+    n_staged_out += tiled_sweep<QL, EXACT>(mp, lbox, use_lbox, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+        if constexpr (EXACT) nn_visit_exact<QL>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
+        else nn_visit_fast<QL>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
     }, false, pa, pb2, pc, pd, pe, pf, pg);
     after_sweep();
 
     bool any_tie = false;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < QL; ++k) {
         int rpos = -1, roi = -1;
         float rd = thr2, wx = 0.f, wy = 0.f, wz = 0.f;
         if constexpr (EXACT) {
@@ -679,7 +679,7 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
     return !EXACT && __any(any_tie);
 }
 
-template <int KMAX>
+template <int KMAX, int QL /*queries per lane: items of 64 * QL queries (1: as k_nn_tiled's default, four workgroups per CU)*/>
 __global__ __launch_bounds__(256, 3) void k_nn_tiled_batch(const NnBatch<KMAX> batch, const NnBatchItems<KMAX> items, int n_problems,
                                                            int shared_map_lds, unsigned int* __restrict__ queue,
                                                            int early_pop /*tuning knob: reserve the next item at the START of this one*/)
@@ -707,16 +707,16 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled_batch(const NnBatch<KMAX> b
         if (early_pop) next_raw_v = wq.pop();
         else wq.hint();
         const TiledMap mp = pb.mp;
-        if (tiled_batch_item<false>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged,
+        if (tiled_batch_item<QL, false>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged,
                                     [&]() { if (!early_pop) next_raw_v = wq.pop(); })) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the redo reads this wave's own stores of a moment ago
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            (void)tiled_batch_item<true>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged, []() {});
+            (void)tiled_batch_item<QL, true>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged, []() {});
         }
         raw = __builtin_amdgcn_readfirstlane(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
     }
     if (lane == 0 && wave_staged)
-        atomicAdd(batch.p[0].staged + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, wave_staged * 2ull);
+        atomicAdd(batch.p[0].staged + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, wave_staged * (unsigned long long)QL);
 }
 
 // one workgroup per (item, problem): the item's row of unit-weight sums from the stored pairing -- k_nn_coop's fused rows
