@@ -1372,7 +1372,7 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
         unsigned int* hc = reinterpret_cast<unsigned int*>(acc_host_ + kNAcc);
         if (pairing_sorted_) {  // the tiled kernels do not count: do it now
             HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream_));
-            hipLaunchKernelGGL(k_count_kept, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, ts_idx_.as<int>(),
+            hipLaunchKernelGGL(k_count_kept, dim3((unsigned)std::min<size_t>((N_ + 255) / 256, 256)), dim3(256), 0, stream_, ts_idx_.as<int>(),
                                (int)N_, counter);
             HIPCHK(hipGetLastError());
         }
