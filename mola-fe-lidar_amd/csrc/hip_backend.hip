@@ -114,6 +114,9 @@ HipWorkspace::~HipWorkspace()
     if (!inited_) return;
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
+    if (ev_order_a_) (void)hipEventDestroy(ev_order_a_);
+    if (ev_order_b_) (void)hipEventDestroy(ev_order_b_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
     shard_idx_.release(); slab_orig_.release(); stage_in_.release();
@@ -152,6 +155,9 @@ int HipWorkspace::init()
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     own_stream_ = true;
+    HIPCHK(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_order_a_, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_order_b_, hipEventDisableTiming));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * (kNAcc + 8), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(acc_host_, 0, sizeof(double) * (kNAcc + 8));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocDefault));
@@ -669,6 +675,28 @@ void HipWorkspace::use_cached_local(const std::shared_ptr<SortedCloud>& sc)
     knn_seed_valid_ = false;
 }
 
+int HipWorkspace::order_begin()
+{
+    HIPCHK(hipEventRecord(ev_order_a_, stream_));
+    HIPCHK(hipStreamWaitEvent(aux_stream_, ev_order_a_, 0));
+    return MOLA_ICP_OK;
+}
+int HipWorkspace::order_end()
+{
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_order_b_, aux_stream_));
+    order_pending_ = true;
+    return MOLA_ICP_OK;
+}
+int HipWorkspace::order_join()
+{
+    if (order_pending_) {
+        HIPCHK(hipStreamWaitEvent(stream_, ev_order_b_, 0));
+        order_pending_ = false;
+    }
+    return MOLA_ICP_OK;
+}
+
 TiledMap HipWorkspace::tiled_map() const
 {
     const float* sx = map_sc_->sorted.as<float>();
@@ -714,6 +742,7 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     }
     if ((rc = item_order_.reserve(sizeof(int) * (cost_slots + kQueues + 2)))) return rc;  // + the range boundaries + the entry count
     const int* order = nullptr;
+    if ((rc = order_join())) return rc;   // a re-sort launched behind the last matcher launch (below)
     if (cost_valid_ && !g_knobs.no_lpt) {
         // the cost profile drifts slowly with the pose: re-sort at launch 1, 2, 4, 8 after the clouds were set,
         // then every 16th; the order is reused in between
@@ -756,6 +785,21 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     else MOLA_LAUNCH_TILED(1);
 #undef MOLA_LAUNCH_TILED
     cost_valid_ = true;
+    // the NEXT launch's re-sort, if one is due: now, on the side stream -- it reads this launch's costs and runs beside the
+    // accumulation and the host's turn-around instead of in front of the next matcher launch
+    if (!g_knobs.no_lpt && (!order_valid_ || launches_since_order_ >= plan_interval_)) {
+        if ((rc = order_begin())) return rc;
+        if (qpl == 2)
+            hipLaunchKernelGGL(k_order_entries, dim3(1), dim3(1024), 0, aux_stream_, item_cost_.as<unsigned int>(), n_items,
+                               g_knobs.no_split ? 1 : (int)((double)(grid * 4) * 0.55 / g_knobs.split_share), item_order_.as<int>());
+        else
+            hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, aux_stream_, item_cost_.as<unsigned int>(), n_items,
+                               item_order_.as<int>());
+        if ((rc = order_end())) return rc;
+        plan_interval_ = order_valid_ ? (plan_interval_ < 16 ? plan_interval_ * 2 : 16) : 1;
+        order_valid_ = true;
+        launches_since_order_ = 0;
+    }
     rows_valid_ = false;
     // (no item rows here: k_accumulate sums the pairing.  A batched problem's rows are summed in another order, so beyond the
     //  cooperative kernel's range -- 131k queries -- a batched result equals its stand-alone align to ~1e-12, not bit for bit;
@@ -918,6 +962,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     }
     if ((rc = knn_order_.reserve(sizeof(int) * ((size_t)n_items + kQueues + 1)))) return rc;
     const int* knn_order = nullptr;
+    if ((rc = order_join())) return rc;   // a re-sort launched behind the last launch (below)
     // (with at most one item per wave there is nothing to balance, and heavy-first would put the heaviest four on ONE CU)
     if (knn_cost_valid_ && !g_knobs.no_lpt && n_items > grid * 4) {
         if (!knn_order_valid_ || knn_launches_since_order_ >= knn_plan_interval_) {
@@ -979,6 +1024,15 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if (profiling_) {
         HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
         ev_used_ += 2;
+    }
+    // the next launch's re-sort, if one is due, on the side stream (see launch_tiled)
+    if (!g_knobs.no_lpt && n_items > grid * 4 && (!knn_order_valid_ || knn_launches_since_order_ >= knn_plan_interval_)) {
+        if ((rc = order_begin())) return rc;
+        hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, aux_stream_, knn_cost_.as<unsigned int>(), n_items, knn_order_.as<int>());
+        if ((rc = order_end())) return rc;
+        knn_plan_interval_ = knn_order_valid_ ? (knn_plan_interval_ < 16 ? knn_plan_interval_ * 2 : 16) : 1;
+        knn_order_valid_ = true;
+        knn_launches_since_order_ = 0;
     }
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;

@@ -199,6 +199,14 @@ class HipWorkspace final : public Stages {
     DevBuf knn_cost_, knn_order_;     // ... of the kNN (point-to-plane) kernels' full sweeps
     bool knn_cost_valid_ = false, knn_order_valid_ = false;
     int knn_plan_interval_ = 1, knn_launches_since_order_ = 0;
+    // the work lists are re-sorted on a side stream, behind the matcher launch whose costs they read and beside the
+    // accumulation that follows it (a single-block 22-30 us kernel otherwise on the next matcher's critical path)
+    hipStream_t aux_stream_ = nullptr;
+    hipEvent_t ev_order_a_ = nullptr, ev_order_b_ = nullptr;
+    bool order_pending_ = false;
+    int order_begin();   // aux_stream_ waits for what stream_ holds so far
+    int order_end();     // ... and the next matcher launch will wait for what aux_stream_ holds
+    int order_join();    // (called by that launch)
     bool cost_valid_ = false, order_valid_ = false;
     unsigned int launches_since_order_ = 0, plan_interval_ = 1;
     int fit_cache_[8] = {};            // resident blocks per CU of the tiled kernels (0 = not queried yet)
