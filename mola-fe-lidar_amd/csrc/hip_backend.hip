@@ -58,6 +58,7 @@ struct Knobs {
     bool no_split = false;     // MOLA_ICP_NO_SPLIT: never list a heavy 128-query item as its two halves
     bool no_certify = false;   // MOLA_ICP_NO_CERTIFY: the point-to-plane matcher sweeps for every query at every launch
     double split_share = 0.55; // MOLA_ICP_SPLIT_SHARE: a 128-query item dearer than this share of a wave's fair share is listed as its two halves
+    int knn_coop = -1;         // MOLA_ICP_KNN_COOP (-1 = by cloud size, 0 = k_knn_planes, 1 = k_knn_coop: one workgroup per item)
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
@@ -73,6 +74,7 @@ static Knobs read_knobs()
     k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
     k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
+    k.knn_coop = std::getenv("MOLA_ICP_KNN_COOP") ? (geti("MOLA_ICP_KNN_COOP") != 0 ? 1 : 0) : -1;
     if (const char* e = std::getenv("MOLA_ICP_SPLIT_SHARE")) { const double v = std::atof(e); if (v > 0.01 && v < 100.0) k.split_share = v; }
     k.no_certify = std::getenv("MOLA_ICP_NO_CERTIFY") != nullptr;
     k.no_knn_seed = std::getenv("MOLA_ICP_NO_KNN_SEED") != nullptr;
@@ -1009,6 +1011,25 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         if (ql == 1) MOLA_LAUNCH_KNN_QL(KK, 1);                                                                      \
         else MOLA_LAUNCH_KNN_QL(KK, 2);                                                                              \
     } while (0)
+    // Odometry-size clouds: fewer 64-query items than wave slots -- a persistent launch is one item per wave and as long as its
+    // slowest item; one WORKGROUP per item instead (k_knn_coop: four waves deal the tiles, lists merged through LDS).
+    const int n_items64 = (int)((N_ + 63) / 64);   // (the cooperative kernel's items hold 64 queries whatever MOLA_ICP_QPL says)
+    const bool knn_coop = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 3 * 4;
+#define MOLA_LAUNCH_KNN_COOP(KK)                                                                                       \
+    hipLaunchKernelGGL((k_knn_coop<KK>), dim3(n_items64), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,       \
+                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold, \
+                       planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, \
+                       tq + kQueues * kQueueStride + 1, staged, lds_boxes, cert)
+    if (knn_coop) {
+        switch (p.knn) {
+            case 3: MOLA_LAUNCH_KNN_COOP(4); break;
+            case 4: MOLA_LAUNCH_KNN_COOP(5); break;
+            case 5: MOLA_LAUNCH_KNN_COOP(6); break;
+            case 6: MOLA_LAUNCH_KNN_COOP(7); break;
+            case 7: MOLA_LAUNCH_KNN_COOP(8); break;
+            default: MOLA_LAUNCH_KNN_COOP(9); break;
+        }
+    } else
     switch (p.knn) {
         case 3: MOLA_LAUNCH_KNN_ALL(4); break;
         case 4: MOLA_LAUNCH_KNN_ALL(5); break;
@@ -1017,6 +1038,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         case 7: MOLA_LAUNCH_KNN_ALL(8); break;
         default: MOLA_LAUNCH_KNN_ALL(9); break;
     }
+#undef MOLA_LAUNCH_KNN_COOP
 #undef MOLA_LAUNCH_KNN_ALL
 #undef MOLA_LAUNCH_KNN_QL
 #undef MOLA_LAUNCH_KNN

@@ -3,6 +3,7 @@
 // launched from there).  Numeric contract and data layout: hip_backend.hip / DESIGN.md.
 #pragma once
 #include "kernels_tiled.hpp"
+#include "kernels_coop.hpp"
 
 namespace mola_icp_amd {
 
@@ -450,6 +451,170 @@ __global__ __launch_bounds__(256, (K <= 7 ? 3 : 2)) void k_knn_planes(const floa
     // (the verify flavour reports its queued items through redo_count; the queued-items launch must not count twice)
     // (8 slots on separate lines -- word 1 of the OTHER launch's queue lines: one address would see 3072 end-of-wave atomics)
     if (!VERIFY && !from_list && lane == 0 && wave_changed) atomicAdd(changed_items + (size_t)(blockIdx.x & (kQueues - 1)) * kQueueStride, wave_changed);
+}
+
+// ---- k_knn_coop: the plane matcher for ODOMETRY-SIZE clouds -- one workgroup per 64-query item -----------------------------
+// With <= ~0.2M queries k_knn_planes has fewer items than wave slots: a launch is one item per wave and as long as its
+// slowest item -- a lone wave walking a chain of dependent round trips and, for an unseeded or far-moved query of a
+// spinning lidar's dense core, thousands of points (a KITTI-like 120k-point pair: 75-310 us per launch against 41 us for
+// a point-to-point iteration at that size).  Here the four waves of a workgroup hold the SAME 64 queries and deal the
+// candidate tiles among themselves exactly as k_nn_coop does (coop_sweep: wave 0 walks the upper box levels into the shared
+// list, wave w owns the tiles t of super-tile S with (t + S) % 4 == w).  Every wave keeps its own sorted list of K entries,
+// seeded alike; its bound -- the last key of ITS list -- is never below the final one (a list over fewer points), so a
+// tile its owner culls holds nothing that belongs in the merged list.  The three other lists go through LDS, wave 0 merges
+// them into its own (seeds are in all four: dropped by position) and runs the epilogue.  Same lists, same planes, same
+// certified-list logic (KnnCert) as k_knn_planes: results are identical.
+template <int K /*list length: knn + 1*/>
+__global__ __launch_bounds__(256, 3) void k_knn_coop(const float* __restrict__ slx, const float* __restrict__ sly, const float* __restrict__ slz,
+                                                     int N, TiledMap mp, PoseF P, float thr2, float thr2x, double threshold, double plane_eig_thr,
+                                                     PlanePair* __restrict__ out, PlanePair* __restrict__ cache, int* __restrict__ knn_pos,
+                                                     int use_seed, int use_cache, unsigned int* __restrict__ changed_items /*8 slots*/,
+                                                     unsigned long long* __restrict__ staged_total /*slotted, may be null*/, int lds_boxes,
+                                                     KnnCert cert)
+{
+    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
+    __shared__ int s_list[kMaxList];
+    __shared__ float s_wbox[6];
+    __shared__ int s_ctl[4];
+    __shared__ unsigned long long s_mk[kCoopParts - 1][K][64];
+    __shared__ int s_mpos[kCoopParts - 1][K][64];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = (int)blockIdx.x;
+    const lds_f32* lbox = (const lds_f32*)s_dyn;
+    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
+
+    unsigned long long kk[K];
+    int kp[K];
+    auto kd_of = [&](int j) -> float { return __uint_as_float((unsigned int)(kk[j] >> 32)); };
+    auto insert = [&](float du, unsigned int o, int pos) {
+        kk[K - 1] = ((unsigned long long)__float_as_uint(du) << 32) | o; kp[K - 1] = pos;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            const bool sw = kk[j] < kk[j - 1];
+            if (!__any(sw)) break;
+            const unsigned long long tk = kk[j]; const int tp = kp[j];
+            kk[j] = sw ? kk[j - 1] : tk; kp[j] = sw ? kp[j - 1] : tp;
+            kk[j - 1] = sw ? tk : kk[j - 1]; kp[j - 1] = sw ? tp : kp[j - 1];
+        }
+    };
+    const int qi = item * 64 + lane;
+    const int ic = qi < N ? qi : N - 1;
+    const float lx = slx[ic], ly = sly[ic], lz = slz[ic];
+    float qx, qy, qz;
+    xform(P, lx, ly, lz, qx, qy, qz);
+#pragma unroll
+    for (int j = 0; j < K; ++j) { kk[j] = (unsigned long long)__float_as_uint(thr2x) << 32; kp[j] = -1; }
+    if (use_seed) {
+        int js[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) js[j] = knn_pos[(size_t)ic * K + j];
+        float gx[K], gy[K], gz[K];
+        unsigned int go[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int jc = js[j] >= 0 ? js[j] : 0;
+            gx[j] = mp.sx[jc]; gy[j] = mp.sy[jc]; gz[j] = mp.sz[jc]; go[j] = (unsigned int)mp.perm[jc];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float du = dist2(qx, qy, qz, gx[j], gy[j], gz[j]);
+            if (js[j] >= 0 && du < thr2x) insert(du, go[j], js[j]);
+        }
+    }
+    // certified lists (KnnCert): every wave derives the same verdicts from the same data -- which is why NOTHING is written
+    // (bounds, seeds, planes: wave 0, in the epilogue) before every wave has read its part: the barrier below
+    bool certd = false;
+    float lb_new = 0.f;
+    if (cert.on && use_seed) {
+        float ox, oy, oz;
+        xform(cert.Pprev, lx, ly, lz, ox, oy, oz);
+        const float delta = sqrtf(dist2(qx, qy, qz, ox, oy, oz)) * kCertUp + 1e-18f;
+        const float m = fminf((cert.lb[ic] - delta) * kCertDown, sqrtf(thr2x) * kCertDown);
+        const float mm = m * m * kCertDown;
+        certd = qi < N && m > 0.f && mm > fminf(kd_of(K - 2), thr2);
+        lb_new = m;
+    }
+    const unsigned long long cert_mask = __ballot(certd);
+    const bool skip_sweep = !__any(qi < N && !certd);
+    __syncthreads();
+    float q2x[2] = {qx, 1.0e18f}, q2y[2] = {qy, 1.0e18f}, q2z[2] = {qz, 1.0e18f};
+    float reach2[2] = {reach_of(kd_of(K - 1), qx, qy, qz), -1.0f};
+    float kb2[2] = {kd_of(K - 1), -1.0f};
+    if (certd) { reach2[0] = -1.0f; kb2[0] = -1.0f; }
+    if (qi >= N) { q2x[0] = q2y[0] = q2z[0] = 1.0e18f; reach2[0] = -1.0f; kb2[0] = -1.0f; }
+    unsigned long long n_staged = 0ull;
+    if (!skip_sweep) {   // (workgroup-uniform: the barriers inside are met by all four waves)
+        unsigned long long pc[4] = {};
+        unsigned int pn[3] = {};
+        float(*sm)[64] = s_m[wave];
+        n_staged = coop_sweep<true>(mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, lane, wave, sm, q2x, q2y, q2z, reach2, kb2, [&](int nm, int jb0, int jb1) {
+            for (int m = 0; m < nm; m += 4) {
+                const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
+                const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
+                const float4 Z = *reinterpret_cast<const float4*>(&sm[2][m]);
+                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                float d[4];
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    const v2f mx = {xs[u], xs[u + 1]}, my = {ys[u], ys[u + 1]}, mz = {zs[u], zs[u + 1]};
+                    const v2f dv = dist2_pk2(q2x[0], q2y[0], q2z[0], mx, my, mz);
+                    d[u] = dv.x; d[u + 1] = dv.y;
+                }
+                const bool cand = fminf(fminf(d[0], d[1]), fminf(d[2], d[3])) <= kd_of(K - 1);
+                if (__any(cand)) {
+                    const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
+                    const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z), __float_as_uint(O.w)};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int pos = (m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32;
+                        if ((((unsigned long long)__float_as_uint(d[u]) << 32) | os[u]) < kk[K - 1]) {
+                            bool dup = false;  // a seed met again by the sweep
+#pragma unroll
+                            for (int j = 0; j < K; ++j) dup |= kp[j] == pos;
+                            if (!dup) insert(d[u], os[u], pos);
+                        }
+                    }
+                    if (qi < N && !certd) kb2[0] = kd_of(K - 1);   // live bound (see k_knn_planes)
+                }
+            }
+        }, false, pc, pn);
+        // merge: the other three waves' lists through LDS into wave 0's
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) { s_mk[wave - 1][j][lane] = kk[j]; s_mpos[wave - 1][j][lane] = kp[j]; }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 0; w < kCoopParts - 1; ++w) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const unsigned long long ck = s_mk[w][j][lane];
+                    const int cp = s_mpos[w][j][lane];
+                    bool take = cp >= 0 && ck < kk[K - 1];
+#pragma unroll
+                    for (int i = 0; i < K; ++i) take &= kp[i] != cp;
+                    if (__any(take)) {
+                        if (take) insert(__uint_as_float((unsigned int)(ck >> 32)), (unsigned int)(ck & 0xffffffffu), cp);
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0 && n_staged && staged_total)   // (each wave its own tiles: units of 64 pairs, one query per lane)
+        atomicAdd(staged_total + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, n_staged);
+    if (wave != 0) return;   // (no barrier below)
+    if (qi < N) cert.lb[qi] = certd ? lb_new : sqrtf(kd_of(K - 1)) * kCertDown;
+    float kd[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) kd[j] = kd_of(j);
+    const bool changed = plane_epilogue<K>(mp, kp, kd, qx, qy, qz, qi, N, thr2, threshold, plane_eig_thr, out, cache, knn_pos, use_seed, use_cache);
+    if (lane == 0 && changed) atomicAdd(changed_items + (size_t)(blockIdx.x & (kQueues - 1)) * kQueueStride, 1u);
+    if (cert.stats && lane == 0 && cert_mask) {
+        unsigned long long* st = cert.stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride;
+        atomicAdd(st + 1, (unsigned long long)__popcll(cert_mask));
+        if (skip_sweep) atomicAdd(st + 2, 1ull);
+    }
 }
 
 // the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
