@@ -11,7 +11,7 @@ from tests.helpers import p2p_params
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
-KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_QPL", "MOLA_ICP_NO_CERTIFY")
+KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_QPL", "MOLA_ICP_NO_CERTIFY", "MOLA_ICP_KNN_COOP")
 
 
 def _env(pkg, monkeypatch, **kv):
@@ -111,11 +111,16 @@ def _p2pl_sequence(synth, n_steps):
 
 
 @pytest.mark.parametrize("knn", [3, 6, 8])
-@pytest.mark.parametrize("qpl", ["1", "2"])
-def test_every_launch_of_a_plane_matcher_sequence_is_the_oracles(pkg, O, synth, monkeypatch, knn, qpl):
+@pytest.mark.parametrize("flavour", ["coop", "persistent-1", "persistent-2"])
+def test_every_launch_of_a_plane_matcher_sequence_is_the_oracles(pkg, O, synth, monkeypatch, knn, flavour):
+    """k_knn_coop (one workgroup per item: the default at this size) and k_knn_planes (persistent waves, 64- and 128-query
+    items, counting + insertion flavours) are the same matcher"""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    _env(pkg, monkeypatch, MOLA_ICP_QPL=qpl)
+    if flavour == "coop":
+        _env(pkg, monkeypatch, MOLA_ICP_KNN_COOP="1")
+    else:
+        _env(pkg, monkeypatch, MOLA_ICP_KNN_COOP="0", MOLA_ICP_QPL=flavour[-1])
     try:
         scene = synth.Scene(scene_seed=3, half=12.0, wall_y=5.0, wall_h=4.0, n_boxes=8)
         g, l, _ = synth.make_pair(12000, 10000, seed=11, scene=scene)
