@@ -453,9 +453,9 @@ def config3_batch(pkg, synth, icp, n_pairs, with_cpu, cpu_flags):
     pairs = [synth.make_pair(100_000, 100_000, seed=100 + s)[:2] for s in range(n_pairs)]
     p = pkg.Parameters()
     p.matcher_threshold, p.max_iterations, p.min_abs_step_trans, p.min_abs_step_rot = GATE_M, 100, 5e-5, 1e-5
-    # warm-up: the batch scratch of a full 12-problem chunk, and the GPU's clocks (this leg follows seconds of CPU-only work: timed
-    # right after a 2-pair warm-up it read 507 pairs/s in the full run against 750 on its own)
-    for _ in range(3):
+    # warm-up: the batch scratch of a full 12-problem chunk, and the GPU's clocks (this leg follows seconds of CPU-only work)
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < 0.8:   # (the GPU has idled through seconds of CPU legs: 570 pairs/s behind a 60-ms warm-up, 900 without the CPU legs)
         icp.align_batch(pairs[:min(n_pairs, 12)], [np.eye(4)] * min(n_pairs, 12), p)
     t0 = time.perf_counter()
     res = icp.align_batch(pairs, [np.eye(4)] * n_pairs, p)
