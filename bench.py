@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--device-warmup-aligns", type=int, default=60,
+                    help="untimed repetitions of the K-step align before the W warm-up steps (GPU clocks; 0 = none)")
     ap.add_argument("--n-local", type=int, default=1_000_000)
     ap.add_argument("--n-map", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=42)
@@ -174,6 +176,13 @@ def main():
                 slab_margin *= 2.0
                 blo, bhi = icp.shard_reach_box(np.eye(4), slab_margin)
                 slab = {"map_points_kept": icp.set_map_slab(tg, blo, bhi), "map_points_total": M, "margin_m": slab_margin, "recut": attempt + 1}
+    # Device warm-up (untimed, the same count on every rank): the GPU has idled through seconds of host-side cloud
+    # generation and its clocks take a few hundred milliseconds of work to settle -- behind 3 warm-up steps alone the
+    # matcher launch read 106.5 us, behind 300 of them 100.1 us.  Then the W warm-up steps the caller asked for.
+    if args.device_warmup_aligns > 0:
+        p.max_iterations = args.steps
+        for _ in range(args.device_warmup_aligns):
+            icp.align_resident(T0, p)
     if args.warmup > 0:
         p.max_iterations = args.warmup
         icp.align_resident(T0, p)
@@ -242,6 +251,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "device_warmup": {"aligns": args.device_warmup_aligns, "steps_each": args.steps, "note": "untimed, before the W warm-up steps: GPU clocks"},
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
@@ -385,6 +395,9 @@ def _median_align(icp, g, l, T0, p, reps=5):
     """wall time of `mola_icp_align` from host buffers (upload + sort + iterations + quality): the median of `reps` runs
     and THAT run's result (its prepare / loop / quality split)"""
     icp.align(g, l, T0, p)   # first call: allocations
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < 0.3:   # (the GPU idles through the CPU checker's seconds before every leg but the first: clocks)
+        icp.align(g, l, T0, p)
     runs = []
     for _ in range(reps):
         t0 = time.perf_counter()
