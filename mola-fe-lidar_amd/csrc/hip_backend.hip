@@ -726,8 +726,8 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
         int& fit = fit_cache_[qpl == 2 ? 0 : 1];
         size_t& fit_lds = fit_cache_lds_[qpl == 2 ? 0 : 1];
         if (fit == 0 || fit_lds != dyn_lds) {
-            if (qpl == 2) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<2>, 256, dyn_lds));
-            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_nn_tiled<1>, 256, dyn_lds));
+            if (qpl == 2) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (k_nn_tiled<2, true>), 256, dyn_lds));
+            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (k_nn_tiled<1, true>), 256, dyn_lds));   // (the diagnostic build: the larger one)
             fit_lds = dyn_lds;
         }
         if (fit >= 1 && per_cu > fit) per_cu = fit;
@@ -775,16 +775,17 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
     unsigned long long* dbg = dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr;
     // one launch: an entry that meets an exact distance tie (duplicate points, lattices) is redone by its wave with the exact-key sweep
-#define MOLA_LAUNCH_TILED(QPL)                                                                                        \
+#define MOLA_LAUNCH_TILED(QPL, DIAG)                                                                                  \
     do {                                                                                                              \
-        hipLaunchKernelGGL((k_nn_tiled<QPL>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,      \
+        hipLaunchKernelGGL((k_nn_tiled<QPL, DIAG>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, \
                            sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),        \
                            ts_idx_.as<int>(), ts_d2_.as<float>(), gs, gs + gs_n, gs + 2 * gs_n, order, item_cost_.as<unsigned int>(), tq, \
                            staged, dbg, lds_boxes, wave_times_, g_knobs.early_pop ? 1 : 0);                            \
         HIPCHK(hipGetLastError());                                                                                    \
     } while (0)
-    if (qpl == 2) MOLA_LAUNCH_TILED(2);
-    else MOLA_LAUNCH_TILED(1);
+    const bool diag = dbg != nullptr || wave_times_ != nullptr;
+    if (qpl == 2) { if (diag) MOLA_LAUNCH_TILED(2, true); else MOLA_LAUNCH_TILED(2, false); }
+    else { if (diag) MOLA_LAUNCH_TILED(1, true); else MOLA_LAUNCH_TILED(1, false); }
 #undef MOLA_LAUNCH_TILED
     cost_valid_ = true;
     // the NEXT launch's re-sort, if one is due: now, on the side stream -- it reads this launch's costs and runs beside the
@@ -845,7 +846,8 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
-    hipLaunchKernelGGL((k_nn_coop<1>), dim3(n_items), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
+    if (wave_times_) hipLaunchKernelGGL((k_nn_coop<1, true>), dim3(n_items), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
+    else hipLaunchKernelGGL((k_nn_coop<1, false>), dim3(n_items), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
     HIPCHK(hipGetLastError());
     wave_times_coop_ = true;
     rows_valid_ = true;

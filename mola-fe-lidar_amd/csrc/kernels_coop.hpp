@@ -456,7 +456,7 @@ __device__ __forceinline__ void item_row_sum(double (*s_acc)[128], bool paired, 
     }
 }
 
-template <int KMAX>
+template <int KMAX, bool DIAG = false /*per-wave phase records (MOLA_ICP_DEBUG_STATS=2); compiled out of the launch path: see k_nn_tiled*/>
 __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, int lds_boxes,
                                                     unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
 {
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
     const TiledMap mp = pb.mp;
     const PoseF P = pb.P;
     const lds_f32* lbox = (const lds_f32*)s_dyn;
-    const bool prof = wave_times != nullptr;
+    const bool prof = DIAG && wave_times != nullptr;
     const unsigned long long t_wave0 = prof ? wall_clock64() : 0ull;  // 100 MHz, the same on every XCD
     const unsigned long long c0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 

@@ -479,7 +479,9 @@ __device__ __forceinline__ void nn_visit_fast(float (*sm)[64], int nm, int jb0, 
 //   (d2 bits << 32 | original index), i.e. the full lexicographic rule -- from the same seeds, nothing of the fast
 //   attempt having been written.  (A second launch over a list of tied entries, as in round 1, cost 5 us per
 //   iteration for a list that is almost always empty.)
-template <int QPL>
+// DIAG = false (the launch path): the per-phase / per-wave diagnostics are compiled out -- as run-time branches that never fire
+// they still held 90 scalar registers' worth of spills and five VGPRs: 101 -> 94 us at C3.
+template <int QPL, bool DIAG>
 __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     __shared__ int s_list[4][kMaxList];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (!DIAG) { dbg_stats = nullptr; wave_times = nullptr; }  // (constants from here on: the diagnostics fold away)
     float(*sm)[64] = s_m[wave];
     int* slist = s_list[wave];
     const lds_f32* lbox = (const lds_f32*)s_dyn;
