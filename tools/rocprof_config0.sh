@@ -10,7 +10,7 @@ import csv
 rows=[r for r in csv.DictReader(open("$OUT/kernel_trace.csv"))]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # the last resident 8-iteration run: the final ~60 kernels
-sel=[r for r in rows if any(k in r["Kernel_Name"] for k in ("k_knn_planes","k_accumulate_planes","k_reduce_rows","k_publish","k_order"))]
+sel=[r for r in rows if any(k in r["Kernel_Name"] for k in ("k_knn","k_accumulate_planes","k_reduce_rows","k_publish","k_order"))]
 t0=None
 for r in sel[-40:]:
     s=int(r["Start_Timestamp"]); e=int(r["End_Timestamp"])
