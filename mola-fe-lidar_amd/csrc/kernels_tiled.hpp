@@ -140,9 +140,10 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
             const v2f D = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
             return __any(D.x <= bound2[0] || D.y <= bound2[1]);
         } else {
-            const float ax = fmaxf(fmaxf(m0 - qx[0], qx[0] - m3), 0.f);
-            const float ay = fmaxf(fmaxf(m1 - qy[0], qy[0] - m4), 0.f);
-            const float az = fmaxf(fmaxf(m2 - qz[0], qz[0] - m5), 0.f);
+            // (q - clamp(q, lo, hi), as above: two instructions per axis instead of four -- this one-query form is the default now)
+            const float ax = qx[0] - __builtin_amdgcn_fmed3f(qx[0], m0, m3);
+            const float ay = qy[0] - __builtin_amdgcn_fmed3f(qy[0], m1, m4);
+            const float az = qz[0] - __builtin_amdgcn_fmed3f(qz[0], m2, m5);
             return __any(fmaf(az, az, fmaf(ay, ay, ax * ax)) <= bound2[0]);
         }
     };
