@@ -846,8 +846,8 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
-    if (wave_times_) hipLaunchKernelGGL((k_nn_coop<1, true>), dim3(n_items), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
-    else hipLaunchKernelGGL((k_nn_coop<1, false>), dim3(n_items), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
+    if (wave_times_) hipLaunchKernelGGL((k_nn_coop<1, true>), dim3(xcd_grid(n_items)), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
+    else hipLaunchKernelGGL((k_nn_coop<1, false>), dim3(xcd_grid(n_items)), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
     HIPCHK(hipGetLastError());
     wave_times_coop_ = true;
     rows_valid_ = true;
@@ -1018,7 +1018,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int n_items64 = (int)((N_ + 63) / 64);   // (the cooperative kernel's items hold 64 queries whatever MOLA_ICP_QPL says)
     const bool knn_coop = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 3 * 4;
 #define MOLA_LAUNCH_KNN_COOP(KK)                                                                                       \
-    hipLaunchKernelGGL((k_knn_coop<KK>), dim3(n_items64), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,       \
+    hipLaunchKernelGGL((k_knn_coop<KK>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold, \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, \
                        tq + kQueues * kQueueStride + 1, staged, lds_boxes, cert)
@@ -1766,7 +1766,7 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         // rows (k_item_rows: the same sums, bit for bit).  MOLA_ICP_BATCH_TILED=0|1 forces either.
         const bool tiled = g_knobs.batch_tiled >= 0 ? g_knobs.batch_tiled != 0 : total_items >= 2 * 1024;
         if (!tiled) {
-            hipLaunchKernelGGL((k_nn_coop<kCoopMaxBatch>), dim3(max_items, n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
+            hipLaunchKernelGGL((k_nn_coop<kCoopMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
                                (unsigned long long*)nullptr);
             HIPCHK(hipGetLastError());
         } else {

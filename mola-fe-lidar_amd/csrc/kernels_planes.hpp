@@ -480,7 +480,8 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const float* __restrict__ s
     __shared__ int s_mpos[kCoopParts - 1][K][64];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int item = (int)blockIdx.x;
+    const int item = xcd_item((int)blockIdx.x, (N + 63) / 64);
+    if (item * 64 >= N) return;  // (the grid is rounded up to whole XCD ranges; uniform: before any barrier)
     const lds_f32* lbox = (const lds_f32*)s_dyn;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
 

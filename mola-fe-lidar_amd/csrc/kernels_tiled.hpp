@@ -71,7 +71,18 @@ constexpr size_t kDbgItems = 1u << 17;  // MOLA_ICP_DEBUG_STATS: per-item record
 constexpr int kQueues = 8, kQueueStride = 32;  // work-queue counters, one 128-byte line each
 constexpr int kMaxList = 64;   // super-tiles collected before their tiles are streamed
 constexpr int kStatSlots = 64, kStatStride = 16;  // slotted statistics counters (u64 units: one 128-byte line per slot)
-constexpr int kHalfFlag = 0x40000000;  // work-list entry = one 64-query half of a 128-query item (id = 2 * item + half)
+constexpr int kHalfFlag = 0x40000000;
+
+// One workgroup per item (the cooperative kernels): workgroups are dealt to the 8 XCDs round-robin (XCD = blockIdx & 7), so
+// item = blockIdx would send every XCD over the whole cloud -- each of the 8 L2s ends up holding all of it.  Item ranges
+// instead: XCD c takes the items [c * per, (c + 1) * per), contiguous = neighbours in space, and its L2 holds an eighth of the
+// clouds (what the persistent kernels' per-XCD segments do).  The grid is rounded up to 8 * per workgroups; >= n_items: none.
+__device__ __forceinline__ int xcd_item(int block, int n_items)
+{
+    const int per = (n_items + 7) >> 3, r = block >> 3;
+    return r < per ? (block & 7) * per + r : n_items;   // (a grid sized for a larger problem of the batch: nothing for this one)
+}
+__host__ __device__ __forceinline__ int xcd_grid(int n_items) { return ((n_items + 7) >> 3) << 3; }  // work-list entry = one 64-query half of a 128-query item (id = 2 * item + half)
 
 // LDS copy of the two upper box levels (one per workgroup): [6][n_top] then [6][n_super] floats.  The upper
 // levels of the scan then cost LDS reads instead of dependent global round trips.
