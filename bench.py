@@ -202,10 +202,14 @@ def main():
     # executed-pair counters -- come from an IDENTICAL repetition right after the timed region: the two event packets per
     # launch cost ~8 us per iteration, which the timed region does not pay (mola_icp_set_profiling, off by default).
     icp.set_profiling(True)
-    res_prof = icp.align_resident(T0, p)
-    barrier()
+    profs = []
+    for _ in range(3):   # (three repetitions, the median one is reported: one in six single repetitions read 25-30 % high on this pool)
+        profs.append(icp.align_resident(T0, p))
+        barrier()
     icp.set_profiling(False)
-    assert np.array_equal(res_prof.optimal_tf, res.optimal_tf)
+    profs.sort(key=lambda r: r.ms_nn_kernel)
+    res_prof = profs[1]
+    assert all(np.array_equal(r.optimal_tf, res.optimal_tf) for r in profs)
 
     # dominant kernel: the NN matcher; duration from HIP events on the kernel's own stream
     def roofline_of(r, n_local):
@@ -236,6 +240,7 @@ def main():
                 "flop_view": flop_view}
 
     roof = roofline_of(res_prof, hi - lo)
+    roof["kernel_ms_repetitions"] = [r.ms_nn_kernel / max(1, r.n_nn_launches) for r in profs]   # (sorted; kernel_ms = the median)
     if world == 1:
         roof.update(_recorded_counters(roof["kernel"], N, M))
     if world > 1:
