@@ -24,12 +24,13 @@ def test_tiled_matcher_finishes_in_every_flavour(pkg, synth, monkeypatch, n, m):
     ps.fixed_iterations, ps.skip_quality, ps.max_iterations = 1, 1, 3
     ref = ref_s = None
     flavours = [{}, {"MOLA_ICP_QPL": "1"}, {"MOLA_ICP_QPL": "2"}, {"MOLA_ICP_NO_WARM_START": "1"}, {"MOLA_ICP_NO_LPT": "1"},
-                {"MOLA_ICP_QPL": "1", "MOLA_ICP_NO_WARM_START": "1"}, {"MOLA_ICP_BLOCKS_PER_CU": "2"}]
+                {"MOLA_ICP_QPL": "1", "MOLA_ICP_NO_WARM_START": "1"}, {"MOLA_ICP_BLOCKS_PER_CU": "2"}, {"MOLA_ICP_EARLY_POP": "1"},
+                {"MOLA_ICP_QPL": "2", "MOLA_ICP_NO_SPLIT": "1"}]
     if n <= 400_000:
         flavours += [{"MOLA_ICP_COOP": "1"}, {"MOLA_ICP_COOP": "0"}]
     try:
         for env in flavours:
-            for k in ("MOLA_ICP_QPL", "MOLA_ICP_NO_WARM_START", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU", "MOLA_ICP_COOP"):
+            for k in ("MOLA_ICP_QPL", "MOLA_ICP_NO_WARM_START", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU", "MOLA_ICP_COOP", "MOLA_ICP_EARLY_POP", "MOLA_ICP_NO_SPLIT"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -56,6 +57,6 @@ def test_tiled_matcher_finishes_in_every_flavour(pkg, synth, monkeypatch, n, m):
                     assert np.array_equal(rs.optimal_tf, ref_s.optimal_tf), env
             icp.close()
     finally:
-        for k in ("MOLA_ICP_QPL", "MOLA_ICP_NO_WARM_START", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU", "MOLA_ICP_COOP"):
+        for k in ("MOLA_ICP_QPL", "MOLA_ICP_NO_WARM_START", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU", "MOLA_ICP_COOP", "MOLA_ICP_EARLY_POP", "MOLA_ICP_NO_SPLIT"):
             monkeypatch.delenv(k, raising=False)
         pkg._lib.lib().mola_icp_debug_reload_env()
