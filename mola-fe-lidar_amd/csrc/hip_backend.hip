@@ -59,6 +59,7 @@ struct Knobs {
     bool no_certify = false;   // MOLA_ICP_NO_CERTIFY: the point-to-plane matcher sweeps for every query at every launch
     double split_share = 0.55; // MOLA_ICP_SPLIT_SHARE: a 128-query item dearer than this share of a wave's fair share is listed as its two halves
     int knn_coop = -1;         // MOLA_ICP_KNN_COOP (-1 = by cloud size, 0 = k_knn_planes, 1 = k_knn_coop: one workgroup per item)
+    bool planes_valu = false;  // MOLA_ICP_PLANES_VALU: the plane form accumulated by k_accumulate_planes (VALU) instead of the fp64-MFMA kernel
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
@@ -74,6 +75,7 @@ static Knobs read_knobs()
     k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
     k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
+    k.planes_valu = std::getenv("MOLA_ICP_PLANES_VALU") != nullptr;
     k.knn_coop = std::getenv("MOLA_ICP_KNN_COOP") ? (geti("MOLA_ICP_KNN_COOP") != 0 ? 1 : 0) : -1;
     if (const char* e = std::getenv("MOLA_ICP_SPLIT_SHARE")) { const double v = std::atof(e); if (v > 0.01 && v < 100.0) k.split_share = v; }
     k.no_certify = std::getenv("MOLA_ICP_NO_CERTIFY") != nullptr;
@@ -1089,8 +1091,12 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
         int nblocks = (int)((N_ + 255) / 256);
         if (nblocks > 512) nblocks = 512;
         const float* sl = loc_sc_->sorted.as<float>();
-        hipLaunchKernelGGL(k_accumulate_planes, dim3(nblocks), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
-                           planes_.as<PlanePair>(), (int)N_, plane_acc_.as<double>());
+        if (g_knobs.planes_valu)
+            hipLaunchKernelGGL(k_accumulate_planes, dim3(nblocks), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
+                               planes_.as<PlanePair>(), (int)N_, plane_acc_.as<double>());
+        else
+            hipLaunchKernelGGL(k_accumulate_planes_mfma, dim3(nblocks), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded,
+                               planes_.as<PlanePair>(), (int)N_, plane_acc_.as<double>());
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(1024), 0, stream_, plane_acc_.as<double>(), nblocks, kNAccPlane, dacc,
                            reinterpret_cast<const unsigned int*>(acc_dev_.as<double>() + kNAcc), direct ? plane_acc_host_ : (double*)nullptr, seq);

@@ -183,7 +183,7 @@ class HipWorkspace final : public Stages {
     DevBuf knn_lb_;   // per query: lower bound on the distance to every map point outside its stored neighbour list (KnnCert)
     double knn_last_step_ = 1e30;   // size of the pose step between the last two launches of the plane matcher (flavour heuristic)
     float knn_last_P_[12] = {};  // the pose of the launch that wrote knn_pos_ / knn_lb_ (PoseF: R row-major, then t)
-    DevBuf planes_, knn_pos_, plane_acc_, plane_cache_;  // point-to-plane pairing (sorted query order) + its accumulators
+    DevBuf planes_, knn_pos_, plane_acc_, plane_cache_;  // point-to-plane pairing (sorted query order; knn_pos_: knn + 1 positions per query) + its accumulators
     double* plane_acc_host_ = nullptr;
     bool planes_valid_ = false, planes_empty_ = false;
     int planes_knn_ = 0;

@@ -705,7 +705,6 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled_batch(const NnBatch<KMAX> b
         // bound to a wave one whole item ahead of its execution and the launch's drain was two items long (see k_nn_tiled)
         int next_raw_v = 0;
         if (early_pop) next_raw_v = wq.pop();
-        else wq.hint();
         const TiledMap mp = pb.mp;
         if (tiled_batch_item<QL, false>(pb, mp, lbox, shared_map_lds != 0, slist, sm, lane, item, wave_staged,
                                     [&]() { if (!early_pop) next_raw_v = wq.pop(); })) {

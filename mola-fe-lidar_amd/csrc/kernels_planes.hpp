@@ -236,7 +236,6 @@ __global__ __launch_bounds__(256, (K <= 7 ? 3 : 2)) void k_knn_planes(const floa
         // bound to a wave one whole item ahead of its execution and the launch's drain was two items long (see k_nn_tiled)
         int next_raw_v = 0;
         if (early_pop) next_raw_v = wq.pop();
-        else wq.hint();
         const int item = from_list ? __builtin_amdgcn_readfirstlane(redo_list[raw]) : (order ? __builtin_amdgcn_readfirstlane(order[raw]) : raw);
         const unsigned long long t_item0 = (item_cost && !from_list) ? __builtin_amdgcn_s_memtime() : 0ull;
 
@@ -666,6 +665,75 @@ __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restri
         pp = pn; l0 = n0; l1 = n1; l2 = n2; have = hn; i = inext;
     }
     block_sum_256<kNAccPlane>(acc, partials + (size_t)blockIdx.x * kNAccPlane);  // fixed order
+}
+
+// The same sums on the matrix cores.  With v = [phi (12), d, 1, 0, 0] per pairing, the whole form is ONE symmetric 16 x 16 matrix
+// D = sum v v^T  (A = D[a][b], b = D[a][12], c0 = D[12][12], count = D[13][13]) -- a rank-4 update per v_mfma_f64_16x16x4_f64:
+// lane l supplies v_{l & 15} of pairing (l >> 4) of a chunk of four, and since A[i][k] = B[k][i] here the SAME register is both
+// operands.  A wave writes its 64 pairings' vectors to LDS ([pairing][16] doubles, padded rows), reads them back one f64 per lane
+// per chunk, and keeps D in the accumulator (4 f64 per lane: col = lane & 15, row = (lane >> 4) + 4 r) across all its batches: no
+// per-thread accumulators at all (k_accumulate_planes holds 92 of them -- 184 VGPRs, one wave per SIMD -- which is what made a
+// bandwidth-sized kernel latency-bound: 19 us at 1M, 9.7 us at 120k).  The four waves' matrices are added in wave order and the row
+// is written in k_accumulate_planes' layout.  Deterministic (fixed order for a given grid); differs from the VALU form by summation
+// order only.
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kPhiStride = 18;   // doubles per pairing in LDS: 16 + 2 (rows 144 bytes apart: 16-byte aligned, banks spread)
+__global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                                const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
+                                                                int N, double* __restrict__ partials)
+{
+    __shared__ __attribute__((aligned(16))) double s_v[4][64 * kPhiStride];   // per wave: the vectors of its 64 pairings
+    __shared__ double s_d[4][256];                                             // per wave: its 16 x 16 result
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* sv = s_v[wave];
+    v4d D = {0.0, 0.0, 0.0, 0.0};
+    const int n_batches = (N + 63) / 64, n_waves = (int)gridDim.x * 4;
+    // (a wave's batches are a chain of round trips otherwise -- 2 waves per SIMD at 1M: the next batch is fetched while this one runs)
+    int bt = (int)blockIdx.x * 4 + wave;
+    PlanePair pp{};
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    if (bt < n_batches && bt * 64 + lane < N) { const int i = bt * 64 + lane; pp = pairs[i]; l0 = slx[i]; l1 = sly[i]; l2 = slz[i]; }
+    for (; bt < n_batches; bt += n_waves) {
+        const int bn = bt + n_waves;
+        PlanePair pn{};
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+        if (bn < n_batches && bn * 64 + lane < N) { const int i = bn * 64 + lane; pn = pairs[i]; n0 = slx[i]; n1 = sly[i]; n2 = slz[i]; }
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.0;
+        if (pp.valid) {   // (a lane past the end holds a zero pairing: valid = 0)
+            const double l[3] = {l0, l1, l2};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[3 * r + c] = pp.n[r] * l[c];
+                v[9 + r] = pp.n[r];
+            }
+            v[12] = pp.n[0] * pp.c[0] + pp.n[1] * pp.c[1] + pp.n[2] * pp.c[2];
+            v[13] = 1.0;
+        }
+        pp = pn; l0 = n0; l1 = n1; l2 = n2;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) *reinterpret_cast<double2*>(&sv[lane * kPhiStride + k]) = double2{v[k], v[k + 1]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const double a = sv[(4 * c + (lane >> 4)) * kPhiStride + (lane & 15)];
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, D, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();   // the vectors are rewritten by the next batch
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_d[wave][((lane >> 4) + 4 * r) * 16 + (lane & 15)] = D[r];
+    __syncthreads();
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const double t = ((s_d[0][threadIdx.x] + s_d[1][threadIdx.x]) + s_d[2][threadIdx.x]) + s_d[3][threadIdx.x];
+    double* out = partials + (size_t)blockIdx.x * kNAccPlane;
+    if (row <= col && col < 12) out[row * 12 - row * (row - 1) / 2 + (col - row)] = t;   // upper triangle, row-major (a <= b)
+    else if (col == 12 && row < 12) out[78 + row] = t;
+    else if (col == 12 && row == 12) out[90] = t;
+    else if (col == 13 && row == 13) out[91] = t;
 }
 
 // fixed-order sum of [nblocks][n] partial rows (n <= 128): 8 slices of rows per accumulator with the loads of a

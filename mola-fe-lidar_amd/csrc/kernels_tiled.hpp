@@ -353,7 +353,6 @@ struct WaveQueue {
         return (((int)gridDim.x + kQueues - 1 - c) / kQueues) * 4;
     }
     __device__ __forceinline__ int global_wave() const { return (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); }
-    __device__ __forceinline__ void hint() {}
     __device__ __forceinline__ int pop()  // the next entry (meaningful in lane 0; >= n: none there), still in flight
     {
         // first segment not known to be dry, starting at this XCD's own
@@ -573,7 +572,6 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         // 0.8 of it -- the drain was two entries long instead of one.
         int next_raw_v = 0;
         if (!EX && early_pop) next_raw_v = wq.pop();  // (behind the loads above: memory results return in order)
-        else if (!EX) wq.hint();
 #pragma unroll
         for (int k = 0; k < QL; ++k) xform(P, lx[k], ly[k], lz[k], qx[k], qy[k], qz[k]);
 #pragma unroll
