@@ -324,6 +324,10 @@ int mola_icp_match_planes(mola_icp_handle* h, const double T[16], const mola_icp
 
 /* ---- host-side math (no GPU needed) ------------------------------------ */
 #define MOLA_ICP_NACC_PLANES 92
+/* the quadratic form of the stored plane pairing (after mola_icp_match_planes), for parity tests: 78 terms of the upper
+ * triangle of sum(phi phi^T) row-major (a <= b), phi = [n (x) l, n]; 12 of sum(phi d), d = n.c; sum(d^2); the pairing count --
+ * what Solver_GaussNewton (icpreg:23-26) iterates on.  No all-reduce is applied here. */
+int mola_icp_accumulate_planes(mola_icp_handle* h, double acc_out[MOLA_ICP_NACC_PLANES]);
 /* Gauss-Newton (mp2p_icp::Solver_GaussNewton, icpreg:23-26) on the point-to-plane cost given as the quadratic
  * form x^T A x - 2 b^T x + c0 in x = [R row-major, t]: acc = A's upper triangle (78, row-major a<=b), b (12),
  * c0, pair count.  This is what the loop runs after the single device accumulation pass. */

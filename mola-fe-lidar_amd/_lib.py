@@ -200,6 +200,7 @@ SIGNATURES = {
     "mola_icp_accumulate": (C.c_int, [_H, C.POINTER(CParams), _DP, C.c_int, _DP, _DP, C.c_int, _DP]),
     "mola_icp_match_planes": (C.c_int, [_H, _DP, C.POINTER(CParams), C.POINTER(C.c_uint8), _DP, _DP, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_uint64)]),
+    "mola_icp_accumulate_planes": (C.c_int, [_H, _DP]),
     "mola_icp_solve_gauss_newton_planes": (C.c_int, [_DP, _DP, C.c_uint32, _DP, _DP, C.POINTER(C.c_uint32)]),
     "mola_icp_solve_horn": (C.c_int, [_DP, _DP, _DP, _DP]),
     "mola_icp_stall_deltas": (C.c_int, [_DP, _DP, _DP, _DP]),

@@ -1113,6 +1113,15 @@ int mola_icp_match_planes(mola_icp_handle* h, const double T[16], const mola_icp
     });
 }
 
+int mola_icp_accumulate_planes(mola_icp_handle* h, double acc_out[MOLA_ICP_NACC_PLANES])
+{
+    return guarded([&]() -> int {
+        if (!h || !acc_out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        return h->resident->accumulate_planes(acc_out);
+    });
+}
+
 int mola_icp_solve_gauss_newton_planes(const double acc[MOLA_ICP_NACC_PLANES], const double T0[16],
                                        uint32_t max_iterations, double T_out[16], double* final_cost,
                                        uint32_t* iterations_done)

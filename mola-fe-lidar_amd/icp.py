@@ -496,6 +496,12 @@ class ICP:
                                               _dp(cen), _dp(nor), kidx.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
         return valid[:n_local], cen[:n_local], nor[:n_local], kidx[:n_local], n.value
 
+    def accumulate_planes(self) -> np.ndarray:
+        """the 92-term quadratic form of the stored plane pairing (after match_planes)"""
+        acc = np.zeros(92)
+        L.check(L.lib().mola_icp_accumulate_planes(self._h, _dp(acc)))
+        return acc
+
     def accumulate(self, params: Parameters, Tcur, stage: int = 0, cl=None, cg=None, reset_outliers: bool = True):
         T = _pose16(Tcur)
         acc = np.empty(L.NACC)

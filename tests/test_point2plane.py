@@ -151,6 +151,34 @@ def test_plane_cache_follows_plane_eigen_threshold(pkg, O, pair):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
+def test_plane_form_accumulators_equal_numpy(pkg, pair, synth, monkeypatch, kernel):
+    """the 92-term quadratic form from the device (k_accumulate_planes_mfma: one 16 x 16 fp64 MFMA accumulation; or the VALU
+    kernel behind MOLA_ICP_PLANES_VALU) against numpy on the same pairing: every term, at a ragged size and at 300k"""
+    if kernel == "valu":
+        monkeypatch.setenv("MOLA_ICP_PLANES_VALU", "1")
+    pkg._lib.lib().mola_icp_debug_reload_env()
+    try:
+        p = pkg.Parameters.load_from_file(REGULAR)
+        icp = pkg.ICP(device=0)
+        g0, l0, _ = pair
+        g1, l1, _ = synth.make_pair(300_007, 250_001, seed=5)
+        for g, l in ((g0, l0[:, :9973]), (g1, l1)):
+            icp.set_map(g)
+            icp.set_local(np.ascontiguousarray(l))
+            T = pkg.pose_from_xyzypr([0.05, -0.02, 0.01, 0.004, 0.001, -0.002])
+            valid, cen, nor, _, n = icp.match_planes(T, p, l.shape[1])
+            acc = icp.accumulate_planes()
+            ref = _form_from_pairing(l, valid, cen, nor)
+            assert acc[91] == ref[91] == n and n > 0.5 * l.shape[1]
+            np.testing.assert_allclose(acc, ref, rtol=1e-10, atol=1e-7 * max(1.0, np.abs(ref).max() * 1e-6))
+        icp.close()
+    finally:
+        monkeypatch.delenv("MOLA_ICP_PLANES_VALU", raising=False)
+        pkg._lib.lib().mola_icp_debug_reload_env()
+
+
+@pytest.mark.gpu
 def test_plane_accumulators_shard_sum(pkg, pair):
     """query shards run one after another: summed plane forms == the un-sharded form (what RCCL reduces)"""
     import importlib
