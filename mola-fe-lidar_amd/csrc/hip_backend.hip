@@ -909,16 +909,19 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int kslot = p.knn < 3 ? 0 : (p.knn > 8 ? 5 : (int)p.knn - 3);
     int& fit_ins = knn_fit_[ql - 1][0][kslot];
     int& fit_ver = knn_fit_[ql - 1][1][kslot];
+    int& fit_ins4 = knn_fit_[ql - 1][2][kslot];
     size_t& fit_lds = knn_fit_lds_[ql - 1][kslot];
     if (fit_ins == 0 || fit_lds != dyn_lds) {
 #define MOLA_KNN_FIT(KK)                                                                                                   \
     do {                                                                                                                   \
         if (ql == 1) {                                                                                                     \
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ins, k_knn_planes<KK, false, 1>, 256, dyn_lds));      \
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ver, k_knn_planes<KK, true, 1>, 256, dyn_lds));       \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ins, (k_knn_planes<KK, false, 1>), 256, dyn_lds));    \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ver, (k_knn_planes<KK, true, 1>), 256, dyn_lds));     \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ins4, (k_knn_planes<KK, false, 1, true>), 256, dyn_lds)); \
         } else {                                                                                                           \
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ins, k_knn_planes<KK, false, 2>, 256, dyn_lds));      \
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ver, k_knn_planes<KK, true, 2>, 256, dyn_lds));       \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ins, (k_knn_planes<KK, false, 2>), 256, dyn_lds));    \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_ver, (k_knn_planes<KK, true, 2>), 256, dyn_lds));     \
+            fit_ins4 = fit_ins;   /* (two queries per lane: no dense build) */                                              \
         }                                                                                                                  \
     } while (0)
         switch (p.knn) {  // (the kernels are instantiated on the list length: knn + 1)
@@ -935,9 +938,11 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
     int grid = num_cus_ * clampi(fit_ins, 1, g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 3);
     int grid_ver = num_cus_ * clampi(fit_ver, 1, g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 4);
+    int grid4 = num_cus_ * clampi(fit_ins4, 1, g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : 4);   // seeded insertion launches (DENSE build)
     const int n_items = (int)((N_ + (size_t)(64 * ql) - 1) / (size_t)(64 * ql));
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     if (grid_ver > (n_items + 3) / 4) grid_ver = (n_items + 3) / 4;
+    if (grid4 > (n_items + 3) / 4) grid4 = (n_items + 3) / 4;
     const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed) ? 1 : 0;
     // the cached plane of an unchanged neighbour list carries the planar / non-planar decision of the launch that
     // solved it: reusable only under the same planeEigenThreshold (the seeds themselves do not depend on it)
@@ -996,8 +1001,9 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     for (int k = 0; k < 3; ++k) knn_last_P_[9 + k] = P.t[k];
     // warm-started launches: the counting flavour over all items, then the insertion flavour over the items it
     // queued (counter[2] = their number); first launch on a cloud pair: the insertion flavour over all items
-#define MOLA_LAUNCH_KNN(KK, VER, QLL, QUEUE, LIST)                                                                        \
-    hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL>), dim3(VER ? grid_ver : grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
+#define MOLA_LAUNCH_KNN(KK, VER, QLL, QUEUE, LIST) MOLA_LAUNCH_KNN_D(KK, VER, QLL, false, QUEUE, LIST)
+#define MOLA_LAUNCH_KNN_D(KK, VER, QLL, DENSE, QUEUE, LIST)                                                               \
+    hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL, DENSE>), dim3(VER ? grid_ver : (DENSE ? grid4 : grid)), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold,   \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
                        counter + 2, LIST, ((QUEUE) == tq ? tq + kQueues * kQueueStride : tq) + 1, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>(), g_knobs.early_pop ? 1 : 0, cert)
@@ -1005,7 +1011,10 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     do {                                                                                                             \
         if (verify) {                                                                                                \
             MOLA_LAUNCH_KNN(KK, true, QLL, tq, redo_list_.as<int>());                                                \
-            MOLA_LAUNCH_KNN(KK, false, QLL, tq + kQueues * kQueueStride, redo_list_.as<int>());                      \
+            if (QLL == 1) MOLA_LAUNCH_KNN_D(KK, false, 1, true, tq + kQueues * kQueueStride, redo_list_.as<int>());   \
+            else MOLA_LAUNCH_KNN(KK, false, QLL, tq + kQueues * kQueueStride, redo_list_.as<int>());                 \
+        } else if (knn_seed && QLL == 1) {   /* seeded: the dense build, four workgroups per CU */                   \
+            MOLA_LAUNCH_KNN_D(KK, false, 1, true, tq, (int*)nullptr);                                                \
         } else {                                                                                                     \
             MOLA_LAUNCH_KNN(KK, false, QLL, tq, (int*)nullptr);                                                      \
         }                                                                                                            \
@@ -1046,6 +1055,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 #undef MOLA_LAUNCH_KNN_ALL
 #undef MOLA_LAUNCH_KNN_QL
 #undef MOLA_LAUNCH_KNN
+#undef MOLA_LAUNCH_KNN_D
     HIPCHK(hipGetLastError());
     if (profiling_) {
         HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));

@@ -194,7 +194,7 @@ class HipWorkspace final : public Stages {
     unsigned long long* stats_host_ = nullptr;  // pinned
     DevBuf redo_list_;                // work items with exact distance ties: redone with the full lexicographic key
     DevBuf item_cost_, item_order_;   // per work item: cycles in the last launch -> heavy-first order of the next
-    int knn_fit_[2][2][6] = {};       // resident workgroups per CU of k_knn_planes<K, flavour, QL> (occupancy queries, cached)
+    int knn_fit_[2][3][6] = {};       // resident workgroups per CU of k_knn_planes<K, flavour, QL> (insertion, counting, dense insertion; occupancy queries, cached)
     size_t knn_fit_lds_[2][6] = {};
     DevBuf knn_cost_, knn_order_;     // ... of the kNN (point-to-plane) kernels' full sweeps
     bool knn_cost_valid_ = false, knn_order_valid_ = false;

@@ -190,8 +190,11 @@ struct KnnCert {
 };
 constexpr float kCertUp = 1.0f + 2.0e-6f, kCertDown = 1.0f - 2.0e-6f;  // ~ (1 +- 32u)
 
-template <int K /*list length: knn + 1*/, bool VERIFY, int QL>
-__global__ __launch_bounds__(256, (K <= 7 ? 3 : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+// DENSE = true: the same kernel compiled for four workgroups per CU (128 VGPRs, ~20 spilled) -- the SEEDED insertion launches gain
+// more from the fourth wave per SIMD than they lose to the spills (C3: 521 / 561 / 303 / 194 us -> 458 / 489 / 257 / 143); the
+// unseeded launch, where every lane is inserting, does not (554 -> 610 us) and keeps the spill-free build at three.
+template <int K /*list length: knn + 1*/, bool VERIFY, int QL, bool DENSE = false>
+__global__ __launch_bounds__(256, (K <= 7 ? (DENSE ? 4 : 3) : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
                                                     const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
                                                     float thr2, float thr2x /*the lists' own gate^2 >= thr2 (see below)*/, double threshold, double plane_eig_thr,
                                                     PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
