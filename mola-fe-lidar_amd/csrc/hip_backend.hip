@@ -1027,7 +1027,9 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     // Odometry-size clouds: fewer 64-query items than wave slots -- a persistent launch is one item per wave and as long as its
     // slowest item; one WORKGROUP per item instead (k_knn_coop: four waves deal the tiles, lists merged through LDS).
     const int n_items64 = (int)((N_ + 63) / 64);   // (the cooperative kernel's items hold 64 queries whatever MOLA_ICP_QPL says)
-    const bool knn_coop = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 3 * 4;
+    // (crossover, ms per 8-iteration align cooperative / persistent -- uniform synthetic clouds: 60k 0.54 / 0.67, 120k 0.83 / 0.78,
+    //  160k 1.02 / 0.84, 200k 1.21 / 0.92; a KITTI-like 120k scan pair, dense near the sensor: 1.76 / 1.96.  Up to 131k queries.)
+    const bool knn_coop = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8;
 #define MOLA_LAUNCH_KNN_COOP(KK)                                                                                       \
     hipLaunchKernelGGL((k_knn_coop<KK>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold, \
