@@ -1,0 +1,74 @@
+"""-m gpu: randomised parity -- random cloud sizes (1 ... 40k, the awkward ones over-represented), gates, 5-launch pose
+sequences, queries without neighbours, duplicated map points, and a random kernel flavour per case (cooperative / persistent
+matchers, 64- / 128-query items, queue knobs, blocks per CU): every launch of the NN matcher and of the plane matcher against the
+CPU oracle, bit for bit.  80 cases here (seconds); MOLA_ICP_FUZZ_CASES / MOLA_ICP_FUZZ_SEED run more (860 cases were run on the
+round's final kernels)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_KNN_COOP", "MOLA_ICP_QPL", "MOLA_ICP_EARLY_POP", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU")
+
+
+def test_random_cases_equal_the_oracle(pkg, O, synth):
+    n_cases = int(os.environ.get("MOLA_ICP_FUZZ_CASES", "80"))
+    rng = np.random.default_rng(int(os.environ.get("MOLA_ICP_FUZZ_SEED", "1")))
+    scene = synth.Scene(scene_seed=3, half=12.0, wall_y=5.0, wall_h=4.0, n_boxes=8)
+    p2pl = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-regular.yaml"))
+    saved = {k: os.environ.get(k) for k in KNOBS}
+    failures = []
+    try:
+        for case in range(n_cases):
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            env = {"MOLA_ICP_COOP": str(rng.integers(0, 2)), "MOLA_ICP_KNN_COOP": str(rng.integers(0, 2)), "MOLA_ICP_QPL": str(rng.integers(1, 3))}
+            if rng.random() < 0.2:
+                env["MOLA_ICP_EARLY_POP"] = "1"
+            if rng.random() < 0.2:
+                env["MOLA_ICP_NO_LPT"] = "1"
+            if rng.random() < 0.3:
+                env["MOLA_ICP_BLOCKS_PER_CU"] = str(rng.integers(1, 5))
+            os.environ.update(env)
+            pkg._lib.lib().mola_icp_debug_reload_env()
+            N = int(rng.choice([1, 63, 64, 65, 127, 129, 1000, 4097, 9000, 20000, 33333]) if rng.random() < 0.5 else rng.integers(1, 40000))
+            M = int(rng.choice([1, 17, 64, 2047, 2049, 10000, 30000]) if rng.random() < 0.5 else rng.integers(1, 40000))
+            g, l, _ = synth.make_pair(N, M, seed=int(rng.integers(1, 10**6)), scene=scene)
+            if rng.random() < 0.3 and N > 10:
+                l = l.copy()
+                l[2, : N // 7] += 40.0          # queries without neighbours
+            if rng.random() < 0.2 and M > 10:
+                g = np.ascontiguousarray(np.concatenate([g, g[:, : M // 3]], axis=1))   # duplicated map points: exact ties
+            kd = O.KdTree(g)
+            icp = pkg.ICP(device=0)
+            icp.set_map(g)
+            icp.set_local(l)
+            x = np.zeros(6)
+            knn = int(rng.integers(3, 9))
+            p2pl.knn = knn
+            for launch in range(5):
+                x = x + rng.normal(0, 1, 6) * np.array([0.2, 0.2, 0.05, 0.02, 0.005, 0.005]) * (0.3 ** launch if rng.random() < 0.7 else 1.0)
+                T = synth.pose_from_xyzypr(*x)
+                thr = float(rng.choice([0.3, 0.5, 0.7, 1.0]))
+                idx, d2, n = icp.match(T, thr, N, pkg.NN_TILED)
+                oidx, od2, on = O.match(g, l, T, thr, kd)
+                if n != on or not np.array_equal(idx, oidx) or not np.array_equal(d2[oidx >= 0], od2[oidx >= 0]):
+                    failures.append(f"case {case} launch {launch}: NN mismatch N={N} M={g.shape[1]} thr={thr} env={env}")
+                if g.shape[1] >= 3:
+                    p2pl.matcher_threshold = thr
+                    valid, cen, nor, kidx, npl = icp.match_planes(T, p2pl, N)
+                    ov, oc, onn, okn, onum = O.match_point2plane(g, l, T, thr, p2pl.plane_eigen_threshold, knn, kd)
+                    if npl != onum or not np.array_equal(kidx, okn) or not np.array_equal(valid, ov):
+                        failures.append(f"case {case} launch {launch}: plane mismatch N={N} M={g.shape[1]} knn={knn} thr={thr} env={env}")
+            icp.close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        pkg._lib.lib().mola_icp_debug_reload_env()
+    assert not failures, failures[:5]
