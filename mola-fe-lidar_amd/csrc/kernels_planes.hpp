@@ -739,8 +739,8 @@ __global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __r
     else if (col == 13 && row == 13) out[91] = t;
 }
 
-// fixed-order sum of [nblocks][n] partial rows (n <= 128): 8 slices of rows per accumulator with the loads of a
-// slice independent of each other, then the 8 slice sums in order.  Deterministic for a given nblocks.
+// fixed-order sum of [nblocks][n] partial rows (n even, <= 128): 22 slices of rows per accumulator pair with the loads of a
+// slice independent of each other, then the 22 slice sums in order.  Deterministic for a given nblocks.
 // host_out (pinned, may be null): the n sums + acc[n] written there too, then the sequence number in slot n + 2 -- the
 // hand-over k_publish would otherwise make in a launch of its own.
 __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
@@ -761,30 +761,33 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
     }
     if (counters && threadIdx.x >= 32 && threadIdx.x < 32 + 2 * kQueues)
         const_cast<unsigned int*>(counters)[16 + (threadIdx.x - 32) * kQueueStride] = 0u;  // (queues start 8 doubles on)
-    __shared__ double sm[8][128];
-    const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
-    double v = 0.0;
-    if (k < n) {
+    // 22 slices of rows x 46 column PAIRS (n = 92: a thread adds two accumulators per 16-byte load): 1012 of the 1024 threads busy and
+    // 23 rows per thread at 512 rows, where 8 slices x 128 columns left a quarter of the block idle and 64 rows per thread
+    constexpr int kSl = 22;
+    __shared__ double sm[kSl][128];
+    const int half = n >> 1;                       // (n is even: 92)
+    const int kp = threadIdx.x % half, sl = threadIdx.x / half;
+    double v0 = 0.0, v1 = 0.0;
+    if (sl < kSl) {
         int b = sl;
-        for (; b + 120 < nblocks; b += 128) {  // sixteen rows in flight (a thread's rows are a chain of dependent round trips otherwise: 12.6 -> ~5 us at 512 rows)
-            double a[16];
+        for (; b + 15 * kSl < nblocks; b += 16 * kSl) {  // sixteen rows in flight
+            double2 a[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a[u] = partials[(size_t)(b + 8 * u) * n + k];
+            for (int u = 0; u < 16; ++u) a[u] = *reinterpret_cast<const double2*>(partials + (size_t)(b + kSl * u) * n + 2 * kp);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v += a[u];
+            for (int u = 0; u < 16; ++u) { v0 += a[u].x; v1 += a[u].y; }
         }
-        for (; b + 24 < nblocks; b += 32) {  // four rows in flight
-            const double a0 = partials[(size_t)b * n + k], a1 = partials[(size_t)(b + 8) * n + k];
-            const double a2 = partials[(size_t)(b + 16) * n + k], a3 = partials[(size_t)(b + 24) * n + k];
-            v += a0; v += a1; v += a2; v += a3;
+        for (; b < nblocks; b += kSl) {
+            const double2 a = *reinterpret_cast<const double2*>(partials + (size_t)b * n + 2 * kp);
+            v0 += a.x; v1 += a.y;
         }
-        for (; b < nblocks; b += 8) v += partials[(size_t)b * n + k];
+        sm[sl][2 * kp] = v0; sm[sl][2 * kp + 1] = v1;
     }
-    sm[sl][k] = v;
     __syncthreads();
-    if (sl == 0 && k < n) {
+    const int k = threadIdx.x;
+    if (k < n) {
         double t = 0.0;
-        for (int s2 = 0; s2 < 8; ++s2) t += sm[s2][k];
+        for (int s2 = 0; s2 < kSl; ++s2) t += sm[s2][k];
         acc[k] = t;
         if (host_out) host_out[k] = t;
     }
