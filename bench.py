@@ -74,6 +74,11 @@ def main():
     ap.add_argument("--batch-pairs", type=int, default=64, help="pairs of the configs[3] leg (0 = skip)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU
+        # (and never will): N FRESH children, one per rank, do -- see _self_launch.
+        raise SystemExit(_self_launch(args))
+
     import torch
     import torch.distributed as dist
 
@@ -81,8 +86,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree "
+                         f"(python bench.py --gpus {args.gpus} launches its own ranks)")
+    n_dev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if world > n_dev and not args.share_gpu:
+        # fewer devices than ranks (a 1-GPU box rehearsing the N>1 path): the ranks share what is there, gloo carries the
+        # all-reduce -- the line says so (config.parallelism, "ranks_share_gpus"); it is not a scaling measurement
+        if rank == 0:
+            print(f"[bench] {world} ranks on {n_dev} visible GPU(s): sharing them (--share-gpu)", file=sys.stderr, flush=True)
+        args.share_gpu = True
     if args.share_gpu:
         local_rank = local_rank % max(1, torch.cuda.device_count())
         args.allreduce = "hook"
@@ -131,11 +143,13 @@ def main():
         del tl
     icp.set_global_sizes(N, M)
     allreduce_used = None
+    rccl_nranks = None
     if use_dist:
         allreduce_used = args.allreduce
         if args.allreduce == "rccl":
             try:
                 icp.comm_init()
+                rccl_nranks = icp.comm_nranks()   # what RCCL itself reports (ncclCommCount)
             except Exception as e:  # keep the run alive: torch.distributed carries the 24 doubles instead
                 print(f"[bench] native RCCL communicator failed on rank {rank} ({e}); using the torch.distributed hook",
                       file=sys.stderr, flush=True)
@@ -147,6 +161,7 @@ def main():
             if allreduce_used == "rccl":
                 icp.comm_destroy()
             allreduce_used = "hook"
+            rccl_nranks = None
             icp.set_allreduce(sharded.make_allreduce(device=dev))
 
     p = pkg.Parameters()
@@ -267,6 +282,7 @@ def main():
                                f"iterations, point-to-point NN (gate {GATE_M} m) + Horn, seed {args.seed}",
                    "n_local": N, "n_map": M, "gate_m": GATE_M, "queries_per_gpu": hi - lo,
                    "parallelism": (f"query-shard x{world}, {allreduce_used} all-reduce" if use_dist else "single GPU"),
+                   "ranks_share_gpus": bool(args.share_gpu and world > 1), "rccl_nranks": rccl_nranks,
                    "nn_kernel": roof["kernel"], "map_slab_rank0": slab},
         "roofline": roof,
         "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(res.optimal_tf, T_gt))),
@@ -335,6 +351,47 @@ def main():
         ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio: the JSON must be the LAST line
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh child processes of this script, one
+    per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would), BEFORE
+    anything in this process has touched the GPU -- a process that has initialised HIP is never re-executed.  Rank 0's
+    stdout is this process's stdout (the ONE JSON line); the other ranks' stdout goes to stderr.  Any rank failing -> the
+    others are stopped (by their exact PIDs) and the exit code is non-zero."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env0 = dict(os.environ)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
+    env0["MASTER_ADDR"] = "127.0.0.1"
+    env0["MASTER_PORT"] = str(port)
+    env0["WORLD_SIZE"] = str(args.gpus)
+    env0["LOCAL_WORLD_SIZE"] = str(args.gpus)
+    procs = []
+    for r in range(args.gpus):
+        env = dict(env0)
+        env["RANK"] = env["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(args.gpus))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with code {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                for o in sorted(alive):
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def kernel_sources_sha1():

@@ -186,6 +186,9 @@ int mola_icp_set_allreduce(mola_icp_handle* h, mola_icp_allreduce_fn fn, void* u
 int mola_icp_comm_set_library(const char* path);
 int mola_icp_comm_unique_id(uint8_t id_out[128]);
 int mola_icp_comm_init(mola_icp_handle* h, const uint8_t id[128], int nranks, int rank);
+/* the size RCCL itself reports for this handle's communicator (ncclCommCount): what a launcher prints to show the
+ * collective really spans the ranks it started */
+int mola_icp_comm_nranks(mola_icp_handle* h, int* nranks_out);
 int mola_icp_comm_destroy(mola_icp_handle* h);
 
 /* ---- the hot path ------------------------------------------------------ */

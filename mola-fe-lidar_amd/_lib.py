@@ -167,6 +167,7 @@ SIGNATURES = {
     "mola_icp_comm_set_library": (C.c_int, [C.c_char_p]),
     "mola_icp_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "mola_icp_comm_init": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "mola_icp_comm_nranks": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "mola_icp_comm_destroy": (C.c_int, [_H]),
     "mola_icp_align": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, _FP, _FP, _FP, C.c_size_t, _DP,
                                  C.POINTER(CParams), C.POINTER(CResult)]),

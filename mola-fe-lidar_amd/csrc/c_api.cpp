@@ -122,6 +122,17 @@ double now_ms()
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// Runs `f` when the scope dies, by return or by exception: every frame below that hands references to itself to worker
+// threads waits for those workers through one of these, so no worker ever writes into a frame that has been unwound.
+template <class F> struct AtScopeExit {
+    F f;
+    explicit AtScopeExit(F&& fn) : f(std::move(fn)) {}
+    AtScopeExit(const AtScopeExit&) = delete;
+    AtScopeExit& operator=(const AtScopeExit&) = delete;
+    ~AtScopeExit() { f(); }
+};
+template <class F> AtScopeExit<F> at_scope_exit(F&& f) { return AtScopeExit<F>(std::move(f)); }
+
 template <class F> int guarded(F&& f)
 {
     try {
@@ -483,6 +494,16 @@ int mola_icp_comm_init(mola_icp_handle* h, const uint8_t id[128], int nranks, in
     });
 }
 
+int mola_icp_comm_nranks(mola_icp_handle* h, int* nranks_out)
+{
+    return guarded([&]() -> int {
+        if (!h || !nranks_out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        if (!h->comm) return fail(MOLA_ICP_E_BADARG, "no communicator: call mola_icp_comm_init first");
+        return rccl_comm_count(h->comm, nranks_out);
+    });
+}
+
 int mola_icp_comm_destroy(mola_icp_handle* h)
 {
     return guarded([&]() -> int {
@@ -539,21 +560,35 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const*
         // the stream-per-pair jobs run on the pool while this thread drives the lockstep chunks
         std::mutex done_mtx;
         std::condition_variable done_cv;
-        size_t pending = apart.size();
+        size_t pending = 0;   // jobs on the pool that reference this frame
+        // (declared before the first submit: whatever throws below, the frame outlives its jobs)
+        auto wait_jobs = at_scope_exit([&]() {
+            std::unique_lock<std::mutex> lk(done_mtx);
+            done_cv.wait(lk, [&]() { return pending == 0; });
+        });
+        auto submit_counted = [&](std::function<void()> job) {   // the job must end with job_done()
+            { std::lock_guard<std::mutex> lk(done_mtx); ++pending; }
+            try {
+                h->submit(std::move(job));
+            } catch (...) {
+                { std::lock_guard<std::mutex> lk(done_mtx); --pending; }
+                throw;
+            }
+        };
+        auto job_done = [&]() {
+            { std::lock_guard<std::mutex> lk(done_mtx); --pending; }
+            done_cv.notify_all();
+        };
         if (!apart.empty()) {
             h->ensure_workers(apart.size() < 8 ? apart.size() : 8);
             for (size_t i : apart)
-                h->submit([&, i]() {
+                submit_counted([&, i]() {
                     const int rc2 = guarded([&]() -> int {
                         return align_host_clouds(h, fx[i], fy[i], fz[i], M[i], tx[i], ty[i], tz[i], N[i], init_T + 16 * i, p,
                                                  &out[i]);
                     });
                     if (rc2) record(rc2, i);
-                    {
-                        std::lock_guard<std::mutex> lk(done_mtx);
-                        --pending;
-                    }
-                    done_cv.notify_all();
+                    job_done();
                 });
         }
         // Lockstep chunks, software-pipelined: while chunk c iterates on this thread, chunk c+1's clouds are uploaded and
@@ -600,16 +635,21 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const*
         // iteration), the other loop's launches run.  The persistent matcher has no inter-block dependencies, so two of them
         // sharing the device is safe; each is a little slower, the pair is faster.
         const size_t n_chunks = chunk_begin.size() - 1;
-        auto lane = [&](size_t first) {
+        // A lane never lets an exception out (it may run on a thread of its own) and never leaves a prepare-ahead task
+        // behind: the task references this frame, so its future is always collected -- also when the loop body throws.
+        auto lane_body = [&](size_t first) {
             if (first >= n_chunks) return;
             std::shared_ptr<Prepared> cur = prepare(first);
             for (size_t ci = first; ci < n_chunks; ci += 2) {
                 const size_t c0 = chunk_begin[ci], K = chunk_begin[ci + 1] - c0;
                 std::future<std::shared_ptr<Prepared>> next;
+                auto collect = at_scope_exit([&]() { if (next.valid()) next.wait(); });
                 if (ci + 2 < n_chunks && first_err.load() == MOLA_ICP_OK) {
                     auto task = std::make_shared<std::packaged_task<std::shared_ptr<Prepared>()>>([&prepare, ci]() { return prepare(ci + 2); });
                     next = task->get_future();
-                    h->submit([task]() { (*task)(); });
+                    // the prepare-ahead runs on a pool worker; it waits for nothing on the pool (no job of this library
+                    // blocks on another pool job: lane 1 below has a thread of its own), so it always gets its turn
+                    try { h->submit([task]() { (*task)(); }); } catch (...) { (*task)(); }
                 }
                 if (cur->rc) {
                     set_error(cur->err);
@@ -635,15 +675,24 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const*
             }
             if (cur) for (BatchProblem& bp : cur->probs) { h->give_cloud(std::move(bp.map)); h->give_cloud(std::move(bp.loc)); }
         };
+        auto lane = [&](size_t first) {
+            const int rc2 = guarded([&]() -> int { lane_body(first); return MOLA_ICP_OK; });
+            if (rc2) record(rc2, first < n_chunks ? together[chunk_begin[first]] : 0);
+        };
         if (n_chunks >= 1) {
-            h->ensure_workers(n_chunks >= 2 ? 4 : 1);   // the second loop + a prepare-ahead each (+ the stream-per-pair jobs above)
-            std::promise<void> lane1_done;
-            std::future<void> lane1 = lane1_done.get_future();
-            if (n_chunks >= 2) h->submit([&]() { lane(1); lane1_done.set_value(); });
-            else lane1_done.set_value();
+            h->ensure_workers(n_chunks >= 2 ? 2 : 1);   // a prepare-ahead per loop (+ the stream-per-pair jobs above)
+            // The second loop runs on a thread of ITS OWN, not on the pool: it blocks on prepare-ahead tasks that sit in the
+            // pool's queue -- as a pool job it could occupy the very worker its task needs (several concurrent batch calls
+            // on one handle filled every worker with a waiting lane: nothing ever ran the tasks).
+            std::thread lane1;
+            auto join_lane1 = at_scope_exit([&]() { if (lane1.joinable()) lane1.join(); });
+            bool lane1_inline = false;
+            if (n_chunks >= 2) {
+                try { lane1 = std::thread([&]() { lane(1); }); } catch (const std::system_error&) { lane1_inline = true; }
+            }
             lane(0);
-            lane1.wait();
-        }
+            if (lane1_inline) lane(1);
+        }   // (lane 1 joined here)
         {
             std::unique_lock<std::mutex> lk(done_mtx);
             done_cv.wait(lk, [&]() { return pending == 0; });
@@ -825,9 +874,15 @@ int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* 
         } else {
             std::mutex dm;
             std::condition_variable dcv;
-            size_t pending = n_init - 1;
+            size_t pending = 0;   // jobs on the pool that reference this frame: it outlives them whatever throws below
+            auto wait_jobs = at_scope_exit([&]() {
+                std::unique_lock<std::mutex> lk(dm);
+                dcv.wait(lk, [&]() { return pending == 0; });
+            });
             h->ensure_workers(std::min<size_t>(n_init - 1, 7));
-            for (size_t k = 1; k < n_init; ++k)
+            for (size_t k = 1; k < n_init; ++k) {
+                { std::lock_guard<std::mutex> lk(dm); ++pending; }
+                try {
                 h->submit([&, k]() {
                     rcs[k] = guarded([&]() -> int {
                         Lease l2(h);
@@ -845,6 +900,11 @@ int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* 
                     }
                     dcv.notify_all();
                 });
+                } catch (...) {
+                    { std::lock_guard<std::mutex> lk(dm); --pending; }
+                    throw;
+                }
+            }
             attempt(ws, 0);   // this thread takes the first attempt
             if (rcs[0]) lease.rc = rcs[0];
             std::unique_lock<std::mutex> lk(dm);

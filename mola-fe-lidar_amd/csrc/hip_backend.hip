@@ -344,7 +344,7 @@ int HipWorkspace::set_local_shard(const float* x, const float* y, const float* z
         if ((rc = bbox_of(fx, fy, fz, n_total, bbox))) return rc;
         const size_t padded = (n_total + kQPW - 1) / kQPW * kQPW;
         if ((rc = sorted.reserve(sizeof(float) * 3 * padded))) return rc;
-        if ((rc = perm.reserve(sizeof(int) * padded))) return rc;
+        if ((rc = perm.reserve(sizeof(int) * padded))) { sorted.release(); return rc; }   // (an OOM path: leak nothing)
         if ((rc = morton_sort_points(stream_, fx, fy, fz, n_total, padded, bbox, sort_scratch_, sorted.as<float>(), perm.as<int>()))) {
             sorted.release(); perm.release();
             return rc;
@@ -645,9 +645,11 @@ int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, 
     gx_ = sc.x; gy_ = sc.y; gz_ = sc.z; M_ = n;
     sc.ready = false;
     rc = n ? prepare_tiles() : MOLA_ICP_OK;
-    if (!rc) HIPCHK(hipStreamSynchronize(stream_));
+    // (the workspace's own map is put back BEFORE any return: map_sc_ aliases the caller's cloud through a no-op deleter)
+    const hipError_t es = rc ? hipSuccess : hipStreamSynchronize(stream_);
     map_sc_ = keep_sc;
     gx_ = kx; gy_ = ky; gz_ = kz; M_ = kM;
+    if (es != hipSuccess) return fail(es == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("build_cached: ") + hipGetErrorString(es));
     return rc;
 }
 

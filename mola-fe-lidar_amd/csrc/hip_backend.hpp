@@ -24,6 +24,7 @@ int rccl_set_library(const char* path);
 int rccl_unique_id(RcclUniqueId* id);
 int rccl_comm_init(void** comm, int nranks, const RcclUniqueId& id, int rank);
 int rccl_allreduce_sum_f64(void* comm, double* dev_buf, size_t n, hipStream_t stream);
+int rccl_comm_count(void* comm, int* nranks);   // what RCCL itself reports for the communicator
 int rccl_comm_destroy(void* comm);
 
 void reload_env_knobs();  // re-reads the MOLA_ICP_* diagnostic variables (tests); they are otherwise read once per process

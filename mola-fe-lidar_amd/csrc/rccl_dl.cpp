@@ -17,6 +17,7 @@ struct RcclApi {
     int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi g_api;
@@ -41,6 +42,7 @@ int load_locked()
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy)
         return fail(MOLA_ICP_E_COMM, "the RCCL library lacks a required symbol");
@@ -88,6 +90,13 @@ int rccl_allreduce_sum_f64(void* comm, double* dev_buf, size_t n, hipStream_t st
 {
     const int r = g_api.AllReduce(dev_buf, dev_buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, stream);
     return r ? rccl_fail("ncclAllReduce", r) : MOLA_ICP_OK;
+}
+
+int rccl_comm_count(void* comm, int* nranks)
+{
+    if (!comm || !g_api.CommCount) return fail(MOLA_ICP_E_COMM, "no RCCL communicator (or the library lacks ncclCommCount)");
+    const int r = g_api.CommCount(comm, nranks);
+    return r ? rccl_fail("ncclCommCount", r) : MOLA_ICP_OK;
 }
 
 int rccl_comm_destroy(void* comm)

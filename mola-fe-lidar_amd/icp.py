@@ -464,6 +464,12 @@ class ICP:
         ident = (C.c_uint8 * 128)(*got[:128])
         L.check(L.lib().mola_icp_comm_init(self._h, ident, world, rank))
 
+    def comm_nranks(self) -> int:
+        """the size RCCL itself reports for the communicator (ncclCommCount)"""
+        n = C.c_int(0)
+        L.check(L.lib().mola_icp_comm_nranks(self._h, C.byref(n)))
+        return int(n.value)
+
     def comm_destroy(self):
         L.check(L.lib().mola_icp_comm_destroy(self._h))
 

@@ -128,6 +128,15 @@ class ShardedICP:
             return self.icp.align_resident(init_guess, params)
         import torch
         import torch.distributed as dist
+        # the slab is cut around the pose the align STARTS from: a guess that differs from the one set_clouds() saw would
+        # begin outside the slab and only recover by doubling a margin centred on the stale pose (re-upload + re-sort each time)
+        from .icp import _pose16
+        T0 = _pose16(init_guess).reshape(4, 4)
+        map_pc, local_full, cut_at = self._full
+        cut_T = np.eye(4) if cut_at is None else np.asarray(cut_at, dtype=np.float64).reshape(4, 4)
+        if not np.array_equal(T0, cut_T):
+            self._full = (map_pc, local_full, T0)
+            self._cut_slab()
         for _ in range(6):
             res, left = None, 0
             try:

@@ -1,0 +1,68 @@
+"""`python bench.py --gpus N` launches its own ranks (SURVEY.md §8 row e: the driver's N>1 command has no launcher in front
+of it on some paths).  CPU: the launcher starts N fresh children and reports a failing rank with a non-zero exit.
+GPU (one device): two ranks sharing the GPU through the self-launch path, and the one-rank distributed path with the
+native RCCL communicator on and off."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "4", "--warmup", "1", "--device-warmup-aligns", "1", "--n-local", "60000", "--n-map", "70000",
+         "--cpu-baseline-iters", "0", "--shipped-iters", "0", "--dense-iters", "0", "--e2e", "0", "--batch-pairs", "0"]
+
+
+def _run(extra, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + SMALL, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_self_launch_reports_a_failing_rank(pkg):
+    import ctypes
+    n = ctypes.c_int(0)
+    pkg._lib.lib().mola_icp_device_count(ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present: the ranks would run")
+    r = _run(["--gpus", "2"], timeout=300)
+    assert r.returncode != 0
+    assert "exited with code" in r.stderr and "stopping the other ranks" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]   # no JSON line from a failed job
+
+
+@pytest.mark.gpu
+def test_two_self_launched_ranks_share_the_gpu():
+    r = _run(["--gpus", "2"])    # fewer devices than ranks: the ranks share the GPU (gloo + the host hook), said in the line
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0
+    assert j["config"]["ranks_share_gpus"] is True and "query-shard x2" in j["config"]["parallelism"]
+    assert j["config"]["queries_per_gpu"] in (30000,)
+    r1 = _run(["--gpus", "1"])
+    j1 = _json_line(r1.stdout)
+    # same job: the two-rank pose is the one-rank pose (fp64 sums in another order)
+    assert abs(j["pose_err_vs_gt"]["rot_rad"] - j1["pose_err_vs_gt"]["rot_rad"]) < 1e-9
+    assert abs(j["pose_err_vs_gt"]["trans_m"] - j1["pose_err_vs_gt"]["trans_m"]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("allreduce", ["rccl", "hook"])
+def test_one_rank_distributed_path_rccl_on_and_off(allreduce):
+    r = _run(["--gpus", "1", "--force-dist", "--allreduce", allreduce])
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 1
+    assert allreduce in j["config"]["parallelism"]
+    if allreduce == "rccl":
+        assert j["config"]["rccl_nranks"] == 1     # what ncclCommCount reports
+    else:
+        assert j["config"]["rccl_nranks"] is None
