@@ -328,6 +328,14 @@ def main():
         from oracle import oracle as O
         cpu_flags = O.use_native()   # -O3 -march=native, built on this machine
         out["cpu_baseline"], ref_T = cpu_baseline(g, l, args.cpu_baseline_iters, cpu_flags)
+        # a real mp2p_icp on this box?  (expected absent: reported either way; if it is there and the harness builds, IT is
+        # the CPU baseline -- kind "reference" -- and the oracle's leg stays beside it as `cpu_baseline_port`)
+        out["reference_probe"] = _probe_reference()
+        ref_leg = _reference_baseline(out["reference_probe"], g, l, args.cpu_baseline_iters)
+        if ref_leg is not None:
+            out["cpu_baseline_port"] = out["cpu_baseline"]
+            out["cpu_baseline"], T_ref_real = ref_leg
+            out["oracle_vs_reference_pose"] = dict(zip(("rot_rad", "trans_m"), _pose_err(ref_T, T_ref_real)))
         # pose parity on the same pair: GPU vs the CPU oracle after the same number of iterations (the timed run did
         # args.steps iterations; the pairings are bit-identical per iteration, so the first iterations are the same ones)
         p.max_iterations = args.cpu_baseline_iters
@@ -438,6 +446,79 @@ def _pose_err(T, Tref):
     dR = Tref[:3, :3].T @ T[:3, :3]
     c = float(np.clip((np.trace(dR) - 1) / 2, -1, 1))
     return float(np.arccos(c)), float(np.linalg.norm(T[:3, 3] - Tref[:3, 3]))
+
+
+def _probe_reference():
+    """SURVEY section 8(c), last row / 8(d)(iii): is a REAL mp2p_icp (the third-party library the reference calls at
+    src/LidarOdometry.cpp:869-871 and requires at CMakeLists.txt:23) installed on the box this runs on?  It is the only
+    thing that could pin the oracle.  Looks for the Python module, the shared library and the CMake package in the
+    usual prefixes; builds oracle/ref_probe/mp2p_icp_time.cpp against it when headers and library are there.  Never
+    raises; returns a small report (found / where / harness path or why not)."""
+    import glob
+    import shutil
+    import subprocess
+    rep = {"found": False}
+    try:
+        import importlib.util
+        if importlib.util.find_spec("mp2p_icp") is not None:
+            rep["python_module"] = True
+    except Exception:
+        pass
+    prefixes = [p for p in (os.environ.get("CMAKE_PREFIX_PATH", "").split(":") + ["/usr", "/usr/local", "/opt/ros/*", os.path.expanduser("~/.local")]) if p]
+    libs, cfgs, incs = [], [], []
+    for pre in prefixes:
+        for pp in glob.glob(pre):   # fixed, shallow patterns only (a recursive walk of /usr takes for ever)
+            for sub in ("lib", "lib64", "lib/x86_64-linux-gnu"):
+                libs += glob.glob(os.path.join(pp, sub, "libmp2p_icp.so*"))
+                for cm in ("cmake/mp2p_icp", "mp2p_icp/cmake"):
+                    cfgs += glob.glob(os.path.join(pp, sub, cm, "mp2p_icp*onfig.cmake"))
+            cfgs += glob.glob(os.path.join(pp, "share", "mp2p_icp", "cmake", "mp2p_icp*onfig.cmake"))
+            incs += glob.glob(os.path.join(pp, "include", "mp2p_icp", "ICP.h")) + glob.glob(os.path.join(pp, "include", "*", "mp2p_icp", "ICP.h"))
+    if libs or cfgs or rep.get("python_module"):
+        rep.update(found=True, libraries=libs[:3], cmake_packages=cfgs[:3], headers=incs[:1])
+    if libs and incs and shutil.which("g++"):
+        src = os.path.join(ROOT, "oracle", "ref_probe", "mp2p_icp_time.cpp")
+        out = os.path.join(ROOT, "oracle", "_ref", "mp2p_icp_time")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        inc = os.path.dirname(os.path.dirname(incs[0]))
+        cmd = ["g++", "-O2", "-std=c++17", src, "-o", out, "-I", inc, "-L", os.path.dirname(libs[0]), "-lmp2p_icp",
+               "-lmrpt-maps", "-lmrpt-obs", "-lmrpt-poses", "-lmrpt-math", "-lmrpt-containers", "-lmrpt-rtti", "-lmrpt-serialization", "-lmrpt-core", "-lmrpt-system",
+               "-Wl,-rpath," + os.path.dirname(libs[0])]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            rep["harness"] = out if r.returncode == 0 else None
+            if r.returncode != 0:
+                rep["harness_build_error"] = r.stderr[-400:]
+        except Exception as e:  # noqa: BLE001
+            rep["harness_build_error"] = str(e)
+    return rep
+
+
+def _reference_baseline(rep, g, l, iters):
+    """times the real mp2p_icp through oracle/_ref/mp2p_icp_time (see _probe_reference); None if that is not possible"""
+    import subprocess
+    import tempfile
+    if not rep.get("harness"):
+        return None
+    try:
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            np.array([g.shape[1], l.shape[1]], dtype=np.uint64).tofile(f)
+            np.ascontiguousarray(g.T, dtype=np.float32).tofile(f)
+            np.ascontiguousarray(l.T, dtype=np.float32).tofile(f)
+            path = f.name
+        r = subprocess.run([rep["harness"], path, str(iters), str(GATE_M)], capture_output=True, text=True, timeout=900)
+        os.unlink(path)
+        if r.returncode != 0:
+            return None
+        kv = r.stdout.strip()
+        n = int(kv.split("iterations=")[1].split()[0])
+        s = float(kv.split("seconds=")[1].split()[0])
+        T = np.array([float(v) for v in kv.split("T=")[1].split("quality=")[0].split()]).reshape(4, 4)
+        return ({"value": n / s, "unit": "iterations/s", "cores": 1, "kind": "reference",
+                 "sample": f"{n} fixed iterations of the same pair through the installed mp2p_icp (kd-tree build inside the time)",
+                 "host_cores_available": os.cpu_count()}, T)
+    except Exception:
+        return None
 
 
 def cpu_baseline(g, l, iters, flags):
