@@ -43,10 +43,20 @@ def test_1m_x_1m_properties(pkg, O, synth, big, kern):
     dd = q[:, kk].astype(np.float64) - g[:, idx[kk]].astype(np.float64)
     np.testing.assert_allclose((dd * dd).sum(0), d2[kk], rtol=1e-5, atol=1e-9)
     assert (d2[kk] < np.float32(1.0)).all() and int(kk.sum()) == n
-    # (4) linearity of the accumulators: sum over two halves == whole
+    # (4) linearity of the accumulators: the sums over two halves of the scan (each its own set_local + match +
+    #     accumulate) add up to the whole scan's -- same pairings, fp64 sums in another order: 1e-12
     p = p2p_params(pkg)
     whole = icp.accumulate(p, np.eye(4))
     assert whole[16] == n
+    half = l.shape[1] // 2 + 12345          # (an uneven cut: neither half is a whole number of items)
+    parts = np.zeros(24)
+    for lo_, hi_ in ((0, half), (half, l.shape[1])):
+        icp.set_local(np.ascontiguousarray(l[:, lo_:hi_]))
+        i_h, d_h, n_h = icp.match(np.eye(4), 1.0, hi_ - lo_, kern)
+        assert np.array_equal(i_h, idx[lo_:hi_]) and np.array_equal(d_h, d2[lo_:hi_])
+        parts += icp.accumulate(p, np.eye(4))
+    np.testing.assert_allclose(parts, whole, rtol=1e-12, atol=1e-7)
+    assert parts[16] == whole[16]
     icp.close()
 
 
@@ -191,6 +201,54 @@ def test_config5_10m_map_sequential_shards(pkg, O, synth):
         tot += icp.accumulate(p, np.eye(4))
     np.testing.assert_allclose(tot, full, rtol=1e-12, atol=1e-6)
     icp.close()
+
+
+def test_config5_sharded_align_10_iterations(pkg, O, synth):
+    """BASELINE configs[4] as an ALIGN: 10M-point map, 1M queries, 8 query shards (the device's own Hilbert cut, as the
+    8 ranks would hold them) run one after another on this one GPU inside every iteration -- each shard's matcher at
+    the current pose, its accumulators summed over the shards (the sum RCCL performs over xGMI), fed back through the
+    product's own loop (mola_icp_run_loop: Horn, stall test, quality).  The pose after 10 iterations equals the
+    un-sharded align's to fp64 summation order."""
+    g, l, _ = synth.make_pair(1_000_000, 10_000_000, seed=7)
+    W = 8
+    p = p2p_params(pkg, max_iterations=10, fixed_iterations=1)
+    whole = pkg.ICP(device=0)
+    whole.set_map(g)
+    whole.set_local(l)
+    ref = whole.align_resident(np.eye(4), p)
+    whole.close()
+    assert ref.nIterations == 10
+    ranks = []
+    seen = np.zeros(l.shape[1], dtype=np.int32)
+    for r in range(W):                       # every "rank": the whole map resident, its shard of the scan
+        icp = pkg.ICP(device=0)
+        icp.set_map(g)
+        n_r = icp.set_local_shard(l, r, W)
+        seen[icp.local_shard_indices()] += 1
+        ranks.append((icp, n_r))
+    assert np.all(seen == 1) and sum(n for _, n in ranks) == l.shape[1]
+    state = {}
+
+    def match_fn(T, thr):
+        state["T"], state["thr"] = T, thr
+        tot = 0
+        for icp, n_r in ranks:
+            tot += icp.match(T, thr, n_r, copy=False)[2]
+        return tot
+
+    def accumulate_fn(pp, T, stage, cl, cg, reset):
+        acc = np.zeros(24)
+        for icp, _ in ranks:                 # the all-reduce, as a loop over the shards
+            acc += icp.accumulate(pp, T, stage, cl, cg, reset)
+        return acc
+
+    res = pkg.run_loop(match_fn, accumulate_fn, np.eye(4), p, l.shape[1], g.shape[1])
+    assert res.nIterations == 10 and res.terminationReason == ref.terminationReason
+    rot, trans = O.pose_error(res.optimal_tf, ref.optimal_tf)
+    assert rot < 1e-10 and trans < 1e-10, (rot, trans)
+    assert res.n_pairs == ref.n_pairs and res.quality == pytest.approx(ref.quality, abs=1e-12)
+    for icp, _ in ranks:
+        icp.close()
 
 
 def test_config4_64_pairs_of_100k_batch_and_device_pool(pkg, O, synth):

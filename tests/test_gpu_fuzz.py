@@ -73,3 +73,67 @@ def test_random_cases_equal_the_oracle(pkg, O, synth):
                 os.environ[k] = v
         pkg._lib.lib().mola_icp_debug_reload_env()
     assert not failures, failures[:5]
+
+
+def test_large_random_cases_equal_the_oracle_on_a_sample(pkg, O, synth):
+    """300k ... 900k points: every persistent wave takes SEVERAL entries from the work queue (segments, steals, dry-set bits,
+    heavy-first orders, redo of tied items) -- the sizes where the hand-rolled queue matters.  Random sizes, gates, 4-launch
+    pose sequences and queue knobs; every launch of the NN matcher and of the plane matcher against the oracle's exact
+    kd-tree on every 20th query, bit for bit; the reported pair counts against the whole returned pairing."""
+    n_cases = int(os.environ.get("MOLA_ICP_FUZZ_LARGE_CASES", "6"))
+    rng = np.random.default_rng(int(os.environ.get("MOLA_ICP_FUZZ_SEED", "1")) + 77)
+    p2pl = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-regular.yaml"))
+    saved = {k: os.environ.get(k) for k in KNOBS}
+    failures = []
+    try:
+        for case in range(n_cases):
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            env = {"MOLA_ICP_QPL": str(rng.integers(1, 3))}
+            if rng.random() < 0.3:
+                env["MOLA_ICP_EARLY_POP"] = "1"
+            if rng.random() < 0.3:
+                env["MOLA_ICP_NO_LPT"] = "1"
+            if rng.random() < 0.5:
+                env["MOLA_ICP_BLOCKS_PER_CU"] = str(rng.integers(1, 5))
+            os.environ.update(env)
+            pkg._lib.lib().mola_icp_debug_reload_env()
+            N = int(rng.integers(300_000, 900_001))
+            M = int(rng.integers(300_000, 900_001))
+            g, l, _ = synth.make_pair(N, M, seed=int(rng.integers(1, 10**6)))
+            if rng.random() < 0.5:
+                l = l.copy()
+                l[2, : N // 9] += 40.0          # queries without neighbours
+            if rng.random() < 0.5:
+                g = np.ascontiguousarray(np.concatenate([g, g[:, : M // 5]], axis=1))   # duplicated map points: exact ties -> redone items
+            kd = O.KdTree(g)
+            sel = np.arange(int(rng.integers(0, 20)), N, 20)
+            ls = np.ascontiguousarray(l[:, sel])
+            icp = pkg.ICP(device=0)
+            icp.set_map(g)
+            icp.set_local(l)
+            x = np.zeros(6)
+            knn = int(rng.integers(3, 9))
+            p2pl.knn = knn
+            for launch in range(4):
+                x = x + rng.normal(0, 1, 6) * np.array([0.2, 0.2, 0.05, 0.02, 0.005, 0.005]) * (0.3 ** launch if rng.random() < 0.7 else 1.0)
+                T = synth.pose_from_xyzypr(*x)
+                thr = float(rng.choice([0.5, 0.7, 1.0]))
+                idx, d2, n = icp.match(T, thr, N, pkg.NN_TILED)
+                oidx, od2, _ = O.match(g, ls, T, thr, kd)
+                if not np.array_equal(idx[sel], oidx) or not np.array_equal(d2[sel][oidx >= 0], od2[oidx >= 0]) or n != int((idx >= 0).sum()):
+                    failures.append(f"case {case} launch {launch}: NN mismatch N={N} M={g.shape[1]} thr={thr} env={env}")
+                p2pl.matcher_threshold = thr
+                valid, cen, nor, kidx, npl = icp.match_planes(T, p2pl, N)
+                ov, oc, onn, okn, _ = O.match_point2plane(g, ls, T, thr, p2pl.plane_eigen_threshold, knn, kd)
+                if not np.array_equal(kidx[sel], okn) or not np.array_equal(valid[sel], ov) or npl != int(valid.sum()):
+                    failures.append(f"case {case} launch {launch}: plane mismatch N={N} M={g.shape[1]} knn={knn} thr={thr} env={env}")
+            icp.close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        pkg._lib.lib().mola_icp_debug_reload_env()
+    assert not failures, failures[:5]
