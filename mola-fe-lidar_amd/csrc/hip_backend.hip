@@ -61,6 +61,7 @@ struct Knobs {
     int knn_coop = -1;         // MOLA_ICP_KNN_COOP (-1 = by cloud size, 0 = k_knn_planes, 1 = k_knn_coop: one workgroup per item)
     bool planes_valu = false;  // MOLA_ICP_PLANES_VALU: the plane form accumulated by k_accumulate_planes (VALU) instead of the fp64-MFMA kernel
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
+    bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
 };
@@ -75,6 +76,7 @@ static Knobs read_knobs()
     k.no_lpt = std::getenv("MOLA_ICP_NO_LPT") != nullptr;
     k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
+    k.no_fused_rows = std::getenv("MOLA_ICP_NO_FUSED_ROWS") != nullptr;
     k.planes_valu = std::getenv("MOLA_ICP_PLANES_VALU") != nullptr;
     k.knn_coop = std::getenv("MOLA_ICP_KNN_COOP") ? (geti("MOLA_ICP_KNN_COOP") != 0 ? 1 : 0) : -1;
     if (const char* e = std::getenv("MOLA_ICP_SPLIT_SHARE")) { const double v = std::atof(e); if (v > 0.01 && v < 100.0) k.split_share = v; }
@@ -130,6 +132,8 @@ HipWorkspace::~HipWorkspace()
     ts_pos_.release(); ts_idx_.release(); ts_d2_.release(); ts_gs_.release(); rows_.release(); item_cost_.release(); item_order_.release(); redo_list_.release(); knn_cost_.release(); knn_order_.release();
     planes_.release(); knn_pos_.release(); plane_acc_.release(); plane_cache_.release();
     if (plane_acc_host_) (void)hipHostFree(plane_acc_host_);
+    if (item_part_host_) (void)hipHostFree(item_part_host_);
+    item_part_.release();
     sort_scratch_.release();
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
@@ -778,13 +782,20 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     // counter[2] = redo count; tq = the fast pass's queue counters, tq + kQueues * kQueueStride the exact pass's
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
     unsigned long long* dbg = dbg_stats_ && !wave_times_ ? dbg_stats_ : nullptr;
+    // 64-query items: the unit-weight sums of every item are formed in the matcher's epilogue (item_row_mfma) -- the first
+    // accumulation pass of the iteration is then a row reduction, no second pass over the pairing
+    double* item_rows = nullptr;
+    if (qpl == 1 && !g_knobs.no_fused_rows) {
+        if ((rc = rows_.reserve(sizeof(double) * kNAcc * (size_t)n_items))) return rc;
+        item_rows = rows_.as<double>();
+    }
     // one launch: an entry that meets an exact distance tie (duplicate points, lattices) is redone by its wave with the exact-key sweep
 #define MOLA_LAUNCH_TILED(QPL, DIAG)                                                                                  \
     do {                                                                                                              \
         hipLaunchKernelGGL((k_nn_tiled<QPL, DIAG>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, \
                            sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),        \
                            ts_idx_.as<int>(), ts_d2_.as<float>(), gs, gs + gs_n, gs + 2 * gs_n, order, item_cost_.as<unsigned int>(), tq, \
-                           staged, dbg, lds_boxes, wave_times_, g_knobs.early_pop ? 1 : 0);                            \
+                           staged, dbg, lds_boxes, wave_times_, g_knobs.early_pop ? 1 : 0, item_rows);                 \
         HIPCHK(hipGetLastError());                                                                                    \
     } while (0)
     const bool diag = dbg != nullptr || wave_times_ != nullptr;
@@ -807,10 +818,11 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
         order_valid_ = true;
         launches_since_order_ = 0;
     }
-    rows_valid_ = false;
-    // (no item rows here: k_accumulate sums the pairing.  A batched problem's rows are summed in another order, so beyond the
-    //  cooperative kernel's range -- 131k queries -- a batched result equals its stand-alone align to ~1e-12, not bit for bit;
-    //  writing the rows here too was measured: +4 us per iteration at 200k, +10 at 390k, the reduction of 3000 rows)
+    rows_valid_ = item_rows != nullptr;
+    rows_count_ = n_items;
+    rows_items_ = true;
+    // (A batched problem's rows are summed in another order, so beyond the cooperative kernel's range -- 131k queries -- a
+    //  batched result equals its stand-alone align to ~1e-12, not bit for bit.)
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
 }
@@ -855,6 +867,8 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
     HIPCHK(hipGetLastError());
     wave_times_coop_ = true;
     rows_valid_ = true;
+    rows_count_ = n_items;
+    rows_items_ = false;
     return MOLA_ICP_OK;
 }
 
@@ -1564,9 +1578,36 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     // the first pass of an iteration after a cooperative match: the matcher already summed the unit-weight terms per item
     const bool fused = pairing_sorted_ && rows_valid_ && stage == 0 && reset_outliers;
     const double* rows = partials_.as<double>();
-    if (fused) {
+    if (fused && rows_items_) {
+        // k_nn_tiled's item rows (thousands): G blocks sum a slice each; on a single GPU they publish their G rows to the
+        // pinned block themselves and THIS thread adds them in order -- else the one-block reduction below takes the G rows
+        const int G = std::max(1, std::min(kItemRedBlocks, (rows_count_ + 63) / 64));
+        if ((rc = item_part_.reserve(sizeof(double) * kNAcc * kItemRedBlocks))) return rc;
+        if (!item_part_host_) {
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&item_part_host_), sizeof(double) * 32 * kItemRedBlocks, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(item_part_host_, 0, sizeof(double) * 32 * kItemRedBlocks);
+        }
+        const bool direct_items = !comm_ && !g_knobs.no_direct_readback;
+        const unsigned long long seq_i = ++readback_seq_;
+        hipLaunchKernelGGL(k_reduce_items, dim3(G), dim3(kNAcc * kRedSlices), 0, stream_, rows_.as<double>(), rows_count_, item_part_.as<double>(),
+                           direct_items ? item_part_host_ : (double*)nullptr, seq_i, acc_dev_.as<double>());
+        HIPCHK(hipGetLastError());
+        counters_clean_ = true;
+        if (direct_items) {
+            for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
+            for (int g = 0; g < G; ++g) {
+                const double* row = item_part_host_ + 32 * (size_t)g;
+                if ((rc = spin_for(reinterpret_cast<volatile unsigned long long*>(const_cast<double*>(row)) + kNAcc + 6, seq_i))) return rc;
+                for (int k = 0; k < kNAcc; ++k) acc[k] += row[k];
+            }
+            if (ar_fn_ && slab_violation_) acc[16] = std::nan("");  // the hook's sum carries it to every rank (allreduce below)
+            return MOLA_ICP_OK;
+        }
+        rows = item_part_.as<double>();
+        nblocks = G;
+    } else if (fused) {
         rows = rows_.as<double>();
-        nblocks = (int)((N_ + kQPW - 1) / kQPW);
+        nblocks = rows_count_;
     } else {
         hipLaunchKernelGGL(k_accumulate, dim3(nblocks), dim3(kAccThreads), 0, stream_, a, partials_.as<double>());
         HIPCHK(hipGetLastError());

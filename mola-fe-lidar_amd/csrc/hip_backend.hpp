@@ -180,6 +180,10 @@ class HipWorkspace final : public Stages {
     DevBuf ts_gs_;                    // ... and each neighbour's coordinates (3 x padded floats): next launch's seeds, accumulate's g
     DevBuf rows_;                     // k_nn_coop's fused stage-0 sums, one row of kNAcc doubles per 128-query item
     bool rows_valid_ = false;         // rows_ belongs to the pairing in place
+    int rows_count_ = 0;              // ... and holds this many rows
+    bool rows_items_ = false;         // ... written by k_nn_tiled (one per 64-query item: thousands -> k_reduce_items first)
+    DevBuf item_part_;                // k_reduce_items' partial rows
+    double* item_part_host_ = nullptr;  // pinned: the same, 32 doubles apart, each with its sequence flag
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
     DevBuf knn_lb_;   // per query: lower bound on the distance to every map point outside its stored neighbour list (KnnCert)
     double knn_last_step_ = 1e30;   // size of the pose step between the last two launches of the plane matcher (flavour heuristic)

@@ -178,6 +178,25 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const do
         reinterpret_cast<unsigned int*>(acc + kNAcc + 8)[(threadIdx.x - 32) * kQueueStride] = 0u;
 }
 
+// The persistent matcher's item rows (item_row_mfma: one row per 64-query item, 15 625 of them at 1M queries): block g of G
+// sums the rows [g n / G, (g + 1) n / G) in reduce_rows' fixed order into row g of `part` (stride kNAcc) and, single GPU,
+// publishes it at host_out + 32 g with its own sequence flag -- the host adds the G rows in order itself (a second,
+// one-block launch for a few dozen rows would cost more than the sums).  Block 0 also leaves the matcher's counters zero.
+constexpr int kItemRedBlocks = 32;
+__global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_items(const double* __restrict__ rows, int n_rows, double* __restrict__ part,
+                                                                     double* __restrict__ host_out /*pinned, may be null*/,
+                                                                     unsigned long long seq, double* __restrict__ counters_block /*acc_dev_*/)
+{
+    const int g = (int)blockIdx.x, G = (int)gridDim.x;
+    const int lo = (int)(((long long)g * n_rows) / G), hi = (int)(((long long)(g + 1) * n_rows) / G);
+    reduce_rows(rows + (size_t)lo * kNAcc, hi - lo, part + (size_t)g * kNAcc, host_out ? host_out + 32 * (size_t)g : (double*)nullptr, seq);
+    if (g == 0) {  // (as k_reduce_partials: the matcher's kept / redo counters and its work-queue counters)
+        if (threadIdx.x == kNAcc) { counters_block[kNAcc] = 0.0; counters_block[kNAcc + 1] = 0.0; }
+        if (threadIdx.x >= 32 && threadIdx.x < 32 + 2 * kQueues)
+            reinterpret_cast<unsigned int*>(counters_block + kNAcc + 8)[(threadIdx.x - 32) * kQueueStride] = 0u;
+    }
+}
+
 // K problems: block y reduces problem y's rows into acc + 32 y and publishes them at host_out + 32 y (flag in slot 30
 // of that stride)
 struct ReduceBatch {

@@ -483,6 +483,77 @@ __device__ __forceinline__ void nn_visit_fast(float (*sm)[64], int nm, int jb0, 
     }
 }
 
+// Row a8 fused into the persistent matcher: the 24 unit-weight sums of ONE 64-query item on the fp64 matrix cores.
+// With u = [m, m l] and v = [m, g] per pairing (m = 1 if the query has a neighbour inside the gate, else 0) the sums
+// W, sum l, sum g, sum l g^T are the 4 x 4 matrix sum u v^T; sum l l^T and sum d2 come out of a second one,
+// u' = [m l, m d2], v' = [m l, m].  v_mfma_f64_4x4x4_4b_f64 adds FOUR such 4 x 4 products over four pairings each per
+// instruction: lane L supplies A[block (L >> 2) & 3][row L & 3][k = L >> 4] and B[block][k][column L & 3], lane d receives
+// D[block (d >> 2) & 3][row d >> 4][column d & 3] (layout probed on gfx950: tools/microbench/mfma_f64_4x4_layout.hip) --
+// 16 pairings per instruction, 2 x 4 instructions per item on a pipe the matcher leaves idle, instead of a second pass
+// over the pairing (k_accumulate: 10.7 us at 1M queries).  The lanes' pairings are transposed through the wave's staging
+// area (free in the epilogue; 32 records of 8 floats at a time), the four blocks are added in block order and lanes
+// 0..23 write the item's row: every row depends on its item's pairing only -- not on which wave ran it, nor when -- so
+// the fixed-order row reduction that follows (k_reduce_items) keeps the accumulators bitwise reproducible.  The products
+// of two fp32 values are exact in fp64; the sums differ from k_accumulate's by their order only.
+__device__ __forceinline__ void item_row_mfma(float* __restrict__ smf /*256 floats of wave-private LDS*/, int lane, bool paired,
+                                              float l0, float l1, float l2, float g0, float g1, float g2, float d2,
+                                              double* __restrict__ row)
+{
+    const float m = paired ? 1.0f : 0.0f;
+    const float r[8] = {m, paired ? l0 : 0.0f, paired ? l1 : 0.0f, paired ? l2 : 0.0f,
+                        paired ? g0 : 0.0f, paired ? g1 : 0.0f, paired ? g2 : 0.0f, paired ? d2 : 0.0f};
+    // record [m, m lx, m ly, m lz, gx, gy, gz, m d2] of pairing 16 t + 4 block + k (within a half of 32 pairings)
+    const int e = lane & 3, rec = (((lane >> 2) & 3) << 2) + (lane >> 4);
+    const int oA = rec * 8 + e;                     // u  = [m, l]
+    const int oB = rec * 8 + (e ? 3 + e : 0);       // v  = [m, g]
+    const int oA2 = rec * 8 + (e < 3 ? 1 + e : 7);  // u' = [l, d2]
+    const int oB2 = rec * 8 + (e < 3 ? 1 + e : 0);  // v' = [l, m]
+    double D1 = 0.0, D2 = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the reads of the previous half / the sweep's last pass are done)
+        if ((lane >> 5) == h) {
+            // (plain float stores, the type the reads below use: a float4 store and float loads of the same words are
+            //  "no alias" to the compiler, and a release fence alone lets it hoist the loads above the stores -- it did)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) smf[(lane & 31) * 8 + q] = r[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const double a = (double)smf[oA + 128 * t], b = (double)smf[oB + 128 * t];
+            const double a2 = (double)smf[oA2 + 128 * t], b2 = (double)smf[oB2 + 128 * t];
+            D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, D1, 0, 0, 0);
+            D2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, b2, D2, 0, 0, 0);
+        }
+    }
+    // the four blocks, added in block order; D element (block, i, j) sits in lane 16 i + 4 block + j
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double* sd = reinterpret_cast<double*>(smf);
+    sd[lane] = D1;
+    sd[64 + lane] = D2;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 24) {
+        // the accumulator block's layout (kNAcc): W, sum l (3), sum g (3), sum l g^T (9, row-major), n, sum d2, sum l l^T (00 01 02 11 12 22)
+        int src;
+        if (lane == 0 || lane == 16) src = 0;                                  // D1(0,0): W = n for unit weights
+        else if (lane < 4) src = 16 * lane;                                    // D1(i,0): sum l
+        else if (lane < 7) src = lane - 3;                                     // D1(0,j): sum g
+        else if (lane < 16) src = 16 * (1 + (lane - 7) / 3) + 1 + (lane - 7) % 3;   // D1(i,j): sum l g^T
+        else if (lane == 17) src = 64 + 51;                                    // D2(3,3): sum d2
+        else if (lane < 21) src = 64 + (lane - 18);                            // D2(0,j): l0 l0, l0 l1, l0 l2
+        else if (lane < 23) src = 64 + 16 + 1 + (lane - 21);                   // D2(1,1), D2(1,2)
+        else src = 64 + 32 + 2;                                                // D2(2,2)
+        row[lane] = ((sd[src] + sd[src + 4]) + sd[src + 8]) + sd[src + 12];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the staging area goes back to the sweep
+}
+
 // Every entry runs the fast sweep: per (query, kGroup = 8 points) only the group minimum meets the running best
 //   (nn_visit_fast); the winning group is re-evaluated once at the end to recover the exact point and the
 //   lowest-original-index rule inside it.  If a second group reached the SAME minimum (exact ties: duplicate
@@ -502,7 +573,8 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                                                   unsigned long long* __restrict__ staged_total,
                                                   unsigned long long* __restrict__ dbg_stats, int lds_boxes,
                                                   unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/,
-                                                  int early_pop /*tuning knob: reserve the next entry at the START of this one*/)
+                                                  int early_pop /*tuning knob: reserve the next entry at the START of this one*/,
+                                                  double* __restrict__ item_rows /*QPL = 1: one row of kNAcc unit-weight sums per item (item_row_mfma); may be null*/)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
     __shared__ int s_list[4][kMaxList];
@@ -611,6 +683,15 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         float rd[QL], wx[QL], wy[QL], wz[QL];  // (w*: the neighbour's coordinates, next launch's seed)
 #pragma unroll
         for (int k = 0; k < QL; ++k) { rpos[k] = -1; roi[k] = -1; rd[k] = thr2; wx[k] = wy[k] = wz[k] = 0.f; }
+        // fused accumulation (item_row_mfma): the query's own coordinates again -- re-read here, in flight with the
+        // epilogue's other loads, rather than held in three registers through the sweep
+        float al0 = 0.f, al1 = 0.f, al2 = 0.f;
+        if constexpr (QPL == 1 && QL == 1) {
+            if (item_rows) {
+                const int ic = qi[0] < N ? qi[0] : N - 1;
+                al0 = slx[ic]; al1 = sly[ic]; al2 = slz[ic];
+            }
+        }
         if constexpr (EX) {
 #pragma unroll
             for (int k = 0; k < QL; ++k) {
@@ -678,6 +759,11 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
                     d2_s[qi[k]] = rd[k];
                     gs_x[qi[k]] = wx[k]; gs_y[qi[k]] = wy[k]; gs_z[qi[k]] = wz[k];
                 }
+            }
+            if constexpr (QPL == 1 && QL == 1) {
+                if (item_rows)   // (wave-uniform)
+                    item_row_mfma(&sm[0][0], lane, qi[0] < N && rpos[0] >= 0, al0, al1, al2, wx[0], wy[0], wz[0], rd[0],
+                                  item_rows + (size_t)item * kNAcc);
             }
         }
         if (lane == 0) {
