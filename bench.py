@@ -317,10 +317,24 @@ def main():
         icp.set_profiling(True)
         rs = icp.align_resident(T0, ps)
         icp.set_profiling(False)
+        k_ms = rs.ms_nn_kernel / max(1, rs.n_nn_launches)
+        # the plane matcher against the HBM roofline: DESIGN section 4's bytes per launch -- both sorted clouds once, and per
+        # query the plane pairing written (56 B) + its cached twin (56 B), the K + 1 seed positions read and written back
+        # (4 (K + 1) B) and the certified bound (4 B): 12 N + 12 M + (112 + 4 (K + 1) + 4) N
+        bytes_alg = 12.0 * N + 12.0 * M + (112.0 + 4.0 * (int(ps.knn) + 1) + 4.0) * N
+        pairs_exec = rs.nn_pairs_evaluated / max(1, rs.n_nn_launches)
+        roof_s = {"bound": "hbm", "achieved": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                  "kernel": "k_knn_planes", "kernel_ms": k_ms, "bytes_per_launch": bytes_alg,
+                  "note": f"average over the {rs.n_nn_launches} matcher launches of the {args.shipped_iters}-iteration run (unseeded, seeded-insertion, "
+                          "certified / counting launches: profiles/r03 breaks them out)",
+                  "pairs_evaluated_per_query": pairs_exec / max(1, N),
+                  "executed_tflops": 8.0 * pairs_exec / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0}
+        roof_s["frac"] = roof_s["achieved"] / PEAK_HBM_GBS
+        roof_s.update(_recorded_counters("k_knn_planes", N, M))
         out["shipped_point2plane_gn"] = {"value": args.shipped_iters / ts, "unit": "iterations/s",
                                          "iterations": args.shipped_iters, "knn": int(ps.knn),
                                          "gate_m": float(ps.matcher_threshold),
-                                         "kernel_ms": rs.ms_nn_kernel / max(1, rs.n_nn_launches), "pairs": int(rs.n_pairs),
+                                         "kernel_ms": k_ms, "pairs": int(rs.n_pairs), "roofline": roof_s,
                                          "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(rs.optimal_tf, T_gt)))}
 
     cpu_flags = None
@@ -349,6 +363,10 @@ def main():
         out["align_e2e"] = align_e2e(pkg, synth, icp, g, l, args.seed, args.cpu_baseline_iters > 0, cpu_flags)
     if extras and args.batch_pairs > 0:
         out["config3_batch"] = config3_batch(pkg, synth, icp, args.batch_pairs, args.cpu_baseline_iters > 0, cpu_flags)
+        # ... and the same 64 pairs through the settings the reference's nearby / loop-closure checks actually load
+        # (params/icp-settings-loop-closure.yaml = Point2Plane + Gauss-Newton): the lockstep device batch since round 3
+        out["config3_batch_shipped"] = config3_batch(pkg, synth, icp, args.batch_pairs, False, cpu_flags, shipped=True)
+        out["loop_closure_montecarlo"] = montecarlo_leg(pkg, synth, icp)
 
     if use_dist:
         if allreduce_used == "rccl":
@@ -603,12 +621,42 @@ def align_e2e(pkg, synth, icp, g1m, l1m, seed, with_cpu, cpu_flags):
     return out
 
 
-def config3_batch(pkg, synth, icp, n_pairs, with_cpu, cpu_flags):
+def montecarlo_leg(pkg, synth, icp, n_guesses=10, n=100_000):
+    """row f2 (src/LidarOdometry.cpp:767-788): 10 perturbed guesses on one 100k x 100k pair through `align_multi_init`, host
+    buffers in -- the point-to-point pipeline and the reference's own loop-closure settings (Point2Plane + Gauss-Newton)"""
+    g, l, _ = synth.make_pair(n, n, seed=42)
+    rng = np.random.default_rng(7)
+    guesses = []
+    for _ in range(n_guesses):
+        d = rng.normal(0, 1, 4) * np.array([0.3, 0.3, 0.3, np.deg2rad(2.0)])
+        guesses.append(synth.pose_from_xyzypr(d[0], d[1], d[2], d[3], 0, 0))
+    out = {"workload": f"{n_guesses} guesses (sigma 0.3 m / 2 deg) on one {n} x {n} pair, <= 100 its with the stall test, host buffers in"}
+    p2p = pkg.Parameters()
+    p2p.matcher_threshold, p2p.max_iterations, p2p.min_abs_step_trans, p2p.min_abs_step_rot = GATE_M, 100, 5e-5, 1e-5
+    shipped = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-loop-closure.yaml"))
+    for name, p in (("point_to_point", p2p), ("shipped_loop_closure_yaml", shipped)):
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 0.3:
+            icp.align_multi_init(g, l, guesses, p)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            res, best = icp.align_multi_init(g, l, guesses, p)
+            ts.append(time.perf_counter() - t0)
+        out[name] = {"ms": float(np.median(ts)) * 1e3, "iterations": [int(r.nIterations) for r in res], "best": int(best)}
+    return out
+
+
+def config3_batch(pkg, synth, icp, n_pairs, with_cpu, cpu_flags, shipped=False):
     """configs[3] on ONE GPU: independent 100k x 100k pairs (seeds 100...), <= 100 iterations with the stall test, through
-    `align_batch`; and SURVEY §8(d)(ii)'s all-core CPU leg: max(2, nproc/2) threads, one pair each (cpp:94-96)."""
+    `align_batch`; and SURVEY §8(d)(ii)'s all-core CPU leg: max(2, nproc/2) threads, one pair each (cpp:94-96).
+    shipped=True: the same pairs through params/icp-settings-loop-closure.yaml (Point2Plane + Gauss-Newton)."""
     pairs = [synth.make_pair(100_000, 100_000, seed=100 + s)[:2] for s in range(n_pairs)]
-    p = pkg.Parameters()
-    p.matcher_threshold, p.max_iterations, p.min_abs_step_trans, p.min_abs_step_rot = GATE_M, 100, 5e-5, 1e-5
+    if shipped:
+        p = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-loop-closure.yaml"))
+    else:
+        p = pkg.Parameters()
+        p.matcher_threshold, p.max_iterations, p.min_abs_step_trans, p.min_abs_step_rot = GATE_M, 100, 5e-5, 1e-5
     # warm-up: the batch scratch of a full 12-problem chunk, and the GPU's clocks (this leg follows seconds of CPU-only work)
     tw = time.perf_counter()
     while time.perf_counter() - tw < 0.8:   # (the GPU has idled through seconds of CPU legs: 570 pairs/s behind a 60-ms warm-up, 900 without the CPU legs)
@@ -617,7 +665,8 @@ def config3_batch(pkg, synth, icp, n_pairs, with_cpu, cpu_flags):
     res = icp.align_batch(pairs, [np.eye(4)] * n_pairs, p)
     dt = time.perf_counter() - t0
     its = int(sum(r.nIterations for r in res))
-    out = {"workload": f"{n_pairs} independent 100k x 100k pairs (seeds 100..{99 + n_pairs}), point-to-point + Horn, <= 100 its, "
+    out = {"workload": f"{n_pairs} independent 100k x 100k pairs (seeds 100..{99 + n_pairs}), "
+                       + ("Point2Plane knn 6 + Gauss-Newton (icp-settings-loop-closure.yaml)" if shipped else "point-to-point + Horn") + ", <= 100 its, "
                        "host buffers in (uploads and sorts inside the time)",
            "gpu": {"pairs_per_s": n_pairs / dt, "iterations_per_s": its / dt, "ms": dt * 1e3, "iterations_total": its,
                    "n_gpus": 1, "note": "one MI355X; the 8-GPU form deals the pairs round-robin (mola_icp_pool_*), no collective"}}

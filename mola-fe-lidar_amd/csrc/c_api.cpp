@@ -235,9 +235,15 @@ int align_host_clouds(mola_icp_handle* h, const float* fx, const float* fy, cons
 
 // Would a stand-alone align of this problem run the tiled matcher (sorted pairing)?  Only then is the batched path
 // (k_nn_coop + batched accumulation) bit-identical to it: the dense kernels sum the pairing in another order.
+// The shipped point-to-plane pipeline (params/icp-settings-loop-closure.yaml:23-39 -- what the reference's own nearby / loop-closure
+// checks run, src/LidarOdometry.cpp:704-741, 767-788) always works on the tiled structures and its lists are exact whatever
+// kernel computes them: batched = stand-alone at every size.  Its quality pass runs the point-to-point matcher, whose batched
+// form counts the same pairings (an integer) as any of the stand-alone kernels.
 bool batch_eligible(const mola_icp_params& p, size_t N, size_t M)
 {
-    if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD || N == 0 || M == 0) return false;
+    if (N == 0 || M == 0) return false;
+    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) return true;
+    if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD) return false;
     if (p.nn_kernel == MOLA_ICP_NN_TILED) return true;
     return p.nn_kernel == MOLA_ICP_NN_AUTO && N >= 8192 && M >= 8192;
 }

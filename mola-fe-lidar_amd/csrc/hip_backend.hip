@@ -1047,11 +1047,20 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     //  160k 1.02 / 0.84, 200k 1.21 / 0.92; a KITTI-like 120k scan pair, dense near the sensor: 1.76 / 1.96.  Up to 131k queries.)
     const bool knn_coop = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8;
 #define MOLA_LAUNCH_KNN_COOP(KK)                                                                                       \
-    hipLaunchKernelGGL((k_knn_coop<KK>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, \
-                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold, \
-                       planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, \
-                       tq + kQueues * kQueueStride + 1, staged, lds_boxes, cert)
+    hipLaunchKernelGGL((k_knn_coop<KK, 1>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, kb, thr2, thr2x,    \
+                       p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, cert.stats)
     if (knn_coop) {
+        KnnBatch<1> kb;
+        KnnProblem& kp = kb.p[0];
+        kp.slx = sl; kp.sly = sl + loc_sc_->padded; kp.slz = sl + 2 * loc_sc_->padded;
+        kp.N = (int)N_;
+        kp.mp = mp;
+        kp.P = P;
+        kp.Pprev = cert.Pprev;
+        kp.out = planes_.as<PlanePair>(); kp.cache = plane_cache_.as<PlanePair>(); kp.knn_pos = knn_pos_.as<int>();
+        kp.lb = cert.lb;
+        kp.use_seed = knn_seed; kp.use_cache = plane_cache_ok; kp.cert_on = cert.on;
+        kp.changed_items = tq + kQueues * kQueueStride + 1;
         switch (p.knn) {
             case 3: MOLA_LAUNCH_KNN_COOP(4); break;
             case 4: MOLA_LAUNCH_KNN_COOP(5); break;
@@ -1695,9 +1704,14 @@ static TiledMap tiled_map_of(const SortedCloud& sc)
 
 void BatchScratch::release_all()
 {
-    for (BatchBuffers& b : bufs) { b.pos.release(); b.idx.release(); b.d2.release(); b.gs.release(); b.rows.release(); b.outlier.release(); b.partials.release(); }
+    for (BatchBuffers& b : bufs) {
+        b.pos.release(); b.idx.release(); b.d2.release(); b.gs.release(); b.rows.release(); b.outlier.release(); b.partials.release();
+        b.planes.release(); b.plane_cache.release(); b.knn_pos.release(); b.knn_lb.release(); b.plane_partials.release();
+    }
     bufs.clear();
-    acc_dev.release(); stats.release(); queue.release();
+    acc_dev.release(); stats.release(); queue.release(); plane_acc_dev.release();
+    if (plane_acc_host) (void)hipHostFree(plane_acc_host);
+    plane_acc_host = nullptr; plane_acc_host_problems = 0;
     if (acc_host) (void)hipHostFree(acc_host);
     if (stats_host) (void)hipHostFree(stats_host);
     acc_host = nullptr; stats_host = nullptr; acc_host_problems = 0;
@@ -1932,6 +1946,173 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
         volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(sc_.acc_host + 32 * (size_t)k) + kNAcc + 6;
         if ((rc = ws_.spin_for(flag, seq))) return rc;
         for (int c = 0; c < kNAcc; ++c) acc[k][c] = sc_.acc_host[32 * (size_t)k + c];
+    }
+    return MOLA_ICP_OK;
+}
+
+// ---- the shipped pipeline, batched (row f3 in the lockstep loop) ----------------------------------------------------
+int HipBatch::init_planes(int knn)
+{
+    int rc = init();
+    if (rc) return rc;
+    if (planes_inited_) return MOLA_ICP_OK;
+    HIPCHK(hipSetDevice(ws_.device_));
+    const size_t K = probs_.size();
+    for (size_t k = 0; k < K; ++k) {
+        const BatchProblem& pr = probs_[k];
+        Buffers& b = sc_.bufs[k];
+        b.knn_seed_valid = false;   // (a reused buffer holds another problem's lists)
+        b.planes_valid = false;
+        b.planes_knn = knn;
+        b.planes_eig_thr = -1.0;
+        if (pr.loc->n == 0 || pr.map->n == 0) continue;
+        const size_t np = pr.loc->padded;
+        if ((rc = b.planes.reserve(sizeof(PlanePair) * np))) return rc;
+        if ((rc = b.plane_cache.reserve(sizeof(PlanePair) * np))) return rc;
+        if ((rc = b.knn_pos.reserve(sizeof(int) * np * 9))) return rc;   // lists of knn + 1 entries
+        if ((rc = b.knn_lb.reserve(sizeof(float) * np))) return rc;
+        if ((rc = b.plane_partials.reserve(sizeof(double) * kNAccPlane * 512))) return rc;
+    }
+    if ((rc = sc_.plane_acc_dev.reserve(sizeof(double) * kPlaneAccStride * (K ? K : 1)))) return rc;
+    if (sc_.plane_acc_host_problems < (K ? K : 1)) {
+        if (sc_.plane_acc_host) (void)hipHostFree(sc_.plane_acc_host);
+        sc_.plane_acc_host = nullptr;
+        const size_t cap = (K ? K : 1) < 16 ? 16 : (K ? K : 1);
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sc_.plane_acc_host), sizeof(double) * kPlaneAccStride * cap, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(sc_.plane_acc_host, 0, sizeof(double) * kPlaneAccStride * cap);
+        sc_.plane_acc_host_problems = cap;
+    }
+    planes_inited_ = true;
+    return MOLA_ICP_OK;
+}
+
+// One k_knn_coop launch per chunk of up to kKnnMaxBatch active problems (blockIdx.y = problem): per problem the kernel, the
+// seeds, the certified lists and the plane cache of HipWorkspace::match_planes' cooperative path -- the lists are exact and the
+// planes a function of the lists, so every problem's pairing is the one its stand-alone align computes, whichever kernel that uses.
+int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_params& p)
+{
+    if (p.knn < 3 || p.knn > 8) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 8] in this build");
+    int rc = init_planes((int)p.knn);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ws_.device_));
+    const float thr2 = (float)(p.matcher_threshold * p.matcher_threshold);
+    const float thr2x = g_knobs.no_certify ? thr2 : thr2 * 1.21f;   // the lists' own gate (KnnCert)
+    while (sc_.events.size() < ev_used_ + 2) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        sc_.events.push_back(e);
+    }
+    ++nn_launches_;
+    if (ws_.profiling_) HIPCHK(hipEventRecord(static_cast<hipEvent_t>(sc_.events[ev_used_]), ws_.stream_));
+    const int K = (int)probs_.size();
+    for (int k0 = 0; k0 < K;) {
+        KnnBatch<kKnnMaxBatch> kb;
+        std::memset(&kb, 0, sizeof kb);
+        int n = 0, max_items = 0;
+        size_t max_box_bytes = 0;
+        for (; k0 < K && n < kKnnMaxBatch; ++k0) {
+            if (!active[k0]) continue;
+            const BatchProblem& pr = probs_[(size_t)k0];
+            Buffers& bf = sc_.bufs[(size_t)k0];
+            if (pr.loc->n == 0 || pr.map->n == 0) return fail(MOLA_ICP_E_INTERNAL, "empty problem in a batched match");
+            KnnProblem& kp = kb.p[n++];
+            const float* sl = pr.loc->sorted.as<float>();
+            kp.slx = sl; kp.sly = sl + pr.loc->padded; kp.slz = sl + 2 * pr.loc->padded;
+            kp.N = (int)pr.loc->n;
+            kp.mp = tiled_map_of(*pr.map);
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) kp.P.R[3 * r + c] = (float)T[k0](r, c);
+                kp.P.t[r] = (float)T[k0](r, 3);
+            }
+            for (int q = 0; q < 9; ++q) kp.Pprev.R[q] = bf.knn_last_P[q];
+            for (int q = 0; q < 3; ++q) kp.Pprev.t[q] = bf.knn_last_P[9 + q];
+            kp.out = bf.planes.as<PlanePair>(); kp.cache = bf.plane_cache.as<PlanePair>(); kp.knn_pos = bf.knn_pos.as<int>();
+            kp.lb = bf.knn_lb.as<float>();
+            const int seed = (bf.knn_seed_valid && bf.planes_knn == (int)p.knn && !g_knobs.no_knn_seed) ? 1 : 0;
+            kp.use_seed = seed;
+            kp.use_cache = (seed && bf.planes_eig_thr == p.plane_eigen_threshold) ? 1 : 0;
+            kp.cert_on = (seed && !g_knobs.no_certify) ? 1 : 0;
+            kp.changed_items = nullptr;   // (only the persistent kernel's counting flavour reads the count)
+            for (int q = 0; q < 9; ++q) bf.knn_last_P[q] = kp.P.R[q];
+            for (int q = 0; q < 3; ++q) bf.knn_last_P[9 + q] = kp.P.t[q];
+            bf.knn_seed_valid = true;
+            bf.planes_valid = true;
+            bf.planes_knn = (int)p.knn;
+            bf.planes_eig_thr = p.plane_eigen_threshold;
+            const int items = (int)((pr.loc->n + 63) / 64);
+            if (items > max_items) max_items = items;
+            const size_t bb = sizeof(float) * 6u * ((size_t)kp.mp.n_top + (size_t)kp.mp.n_super);
+            if (bb > max_box_bytes) max_box_bytes = bb;
+        }
+        if (n == 0) break;
+        const int lds_boxes = max_box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
+        const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
+        unsigned long long* staged = ws_.profiling_ ? sc_.stats.as<unsigned long long>() : nullptr;
+#define MOLA_LAUNCH_KNN_COOP_B(KK)                                                                                          \
+    hipLaunchKernelGGL((k_knn_coop<KK, kKnnMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, kb, thr2, thr2x, \
+                       p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, (unsigned long long*)nullptr)
+        switch (p.knn) {
+            case 3: MOLA_LAUNCH_KNN_COOP_B(4); break;
+            case 4: MOLA_LAUNCH_KNN_COOP_B(5); break;
+            case 5: MOLA_LAUNCH_KNN_COOP_B(6); break;
+            case 6: MOLA_LAUNCH_KNN_COOP_B(7); break;
+            case 7: MOLA_LAUNCH_KNN_COOP_B(8); break;
+            default: MOLA_LAUNCH_KNN_COOP_B(9); break;
+        }
+#undef MOLA_LAUNCH_KNN_COOP_B
+        HIPCHK(hipGetLastError());
+    }
+    if (ws_.profiling_) {
+        HIPCHK(hipEventRecord(static_cast<hipEvent_t>(sc_.events[ev_used_ + 1]), ws_.stream_));
+        ev_used_ += 2;
+    }
+    return MOLA_ICP_OK;
+}
+
+// The plane form of every active problem: per problem k_accumulate_planes_mfma's partition and k_reduce_rows' order (same bits
+// as the stand-alone accumulate_planes), one launch each over the chunk, one pinned read-back per problem.
+int HipBatch::accumulate_planes(const uint8_t* active, double (*acc)[kNAccPlaneHost])
+{
+    int rc = init();
+    if (rc) return rc;
+    if (!planes_inited_) return fail(MOLA_ICP_E_BADARG, "batched accumulate_planes() before match_planes()");
+    HIPCHK(hipSetDevice(ws_.device_));
+    const int K = (int)probs_.size();
+    const unsigned long long seq = ++sc_.seq;
+    int n_active = 0;
+    for (int k0 = 0; k0 < K;) {
+        PlaneAccBatch ab;
+        std::memset(&ab, 0, sizeof ab);
+        int n = 0, max_blocks = 0;
+        for (; k0 < K && n < kKnnMaxBatch; ++k0) {
+            if (!active[k0]) continue;
+            const BatchProblem& pr = probs_[(size_t)k0];
+            Buffers& bf = sc_.bufs[(size_t)k0];
+            if (!bf.planes_valid) return fail(MOLA_ICP_E_BADARG, "batched accumulate_planes() before match_planes()");
+            const float* sl = pr.loc->sorted.as<float>();
+            int nblocks = (int)((pr.loc->n + 255) / 256);
+            if (nblocks > 512) nblocks = 512;
+            ab.slx[n] = sl; ab.sly[n] = sl + pr.loc->padded; ab.slz[n] = sl + 2 * pr.loc->padded;
+            ab.pairs[n] = bf.planes.as<PlanePair>();
+            ab.partials[n] = bf.plane_partials.as<double>();
+            ab.N[n] = (int)pr.loc->n; ab.nblocks[n] = nblocks; ab.slot[n] = k0;
+            if (nblocks > max_blocks) max_blocks = nblocks;
+            ++n;
+        }
+        if (n == 0) break;
+        n_active += n;
+        hipLaunchKernelGGL(k_accumulate_planes_mfma_batch, dim3(max_blocks, n), dim3(256), 0, ws_.stream_, ab);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_reduce_rows_batch, dim3(n), dim3(1024), 0, ws_.stream_, ab, kNAccPlane, sc_.plane_acc_dev.as<double>(),
+                           sc_.plane_acc_host, seq);
+        HIPCHK(hipGetLastError());
+    }
+    if (n_active == 0) return MOLA_ICP_OK;
+    for (int k = 0; k < K; ++k) {
+        if (!active[k]) continue;
+        const double* hb = sc_.plane_acc_host + (size_t)kPlaneAccStride * (size_t)k;
+        if ((rc = ws_.spin_for(reinterpret_cast<volatile unsigned long long*>(const_cast<double*>(hb)) + kNAccPlane + 2, seq))) return rc;
+        std::memcpy(acc[k], hb, sizeof(double) * kNAccPlane);
     }
     return MOLA_ICP_OK;
 }

@@ -58,12 +58,21 @@ struct BatchBuffers {
     DevBuf pos, idx, d2, gs, rows, outlier, partials;
     bool seed_valid = false, outliers_dirty = false;
     size_t outlier_cleared_for = 0;
+    // the point-to-plane pipeline's per-problem state (K guesses on one cloud pair share the clouds, never these)
+    DevBuf planes, plane_cache, knn_pos, knn_lb, plane_partials;
+    bool knn_seed_valid = false, planes_valid = false;
+    int planes_knn = 0;
+    double planes_eig_thr = -1.0;
+    float knn_last_P[12] = {};
 };
 struct BatchScratch {
     std::vector<BatchBuffers> bufs;
     DevBuf acc_dev, stats, queue;
     double* acc_host = nullptr;                 // pinned: 32 doubles per problem (24 sums, flag in slot 30)
     size_t acc_host_problems = 0;
+    DevBuf plane_acc_dev;                       // 96 doubles per problem: the 92-term plane form
+    double* plane_acc_host = nullptr;           // pinned: the same, sequence flag in slot 94
+    size_t plane_acc_host_problems = 0;
     unsigned long long* stats_host = nullptr;   // pinned
     std::vector<void*> events;                  // hipEvent_t
     unsigned long long seq = 0;                 // read-back sequence numbers keep growing across uses
@@ -254,10 +263,14 @@ class HipBatch final : public BatchStages {
     HipBatch(HipWorkspace& ws, std::vector<BatchProblem> probs);
     ~HipBatch() override;
     int init();  // per-problem pairing buffers, pinned read-back block
+    int init_planes(int knn);  // ... and the point-to-plane pipeline's (on its first use)
     int size() const override { return (int)probs_.size(); }
     int match(const uint8_t* active, const Mat4* T, double threshold, const mola_icp_params& p) override;
     int accumulate(const uint8_t* active, const mola_icp_params& p, const Mat4* Tcur, int stage, const double (*cl)[3],
                    const double (*cg)[3], bool reset_outliers, double (*acc)[kNAcc]) override;
+    // row f3, batched: the plane matcher (k_knn_coop, blockIdx.y = problem) and the plane form of every active problem
+    int match_planes(const uint8_t* active, const Mat4* T, const mola_icp_params& p) override;
+    int accumulate_planes(const uint8_t* active, double (*acc)[kNAccPlaneHost]) override;
     uint64_t n_local_total(int k) const override { return probs_[(size_t)k].loc->n; }
     uint64_t n_map_total(int k) const override { return probs_[(size_t)k].map->n; }
     // statistics of the matcher launches since init(): total HIP-event time, launches, evaluated pairs (whole batch)
@@ -270,7 +283,7 @@ class HipBatch final : public BatchStages {
     std::vector<BatchProblem> probs_;
     size_t ev_used_ = 0;
     uint32_t nn_launches_ = 0;
-    bool inited_ = false;
+    bool inited_ = false, planes_inited_ = false;
 };
 
 }  // namespace mola_icp_amd

@@ -191,20 +191,21 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
 {
     int rc = validate_params(p);
     if (rc) return rc;
-    if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD)
-        return fail(MOLA_ICP_E_UNSUPPORTED, "the batched loop runs the point-to-point pipeline only");
+    const bool planes = p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE;
     const int K = st.size();
     if (K <= 0) return MOLA_ICP_OK;
     struct State {
         Mat4 T, Tprev;
         uint32_t term = MOLA_ICP_TERM_UNDEFINED, its = 0;
         double last_acc[kNAcc] = {};
+        double last_pacc[kNAccPlaneHost] = {};   // row f3: the last linearisation's quadratic form
+        double plane_pairs = 0, plane_rmse = 0;
         bool have_solution = false, done = false;
     };
     std::vector<State> s((size_t)K);
     std::vector<Mat4> Tn((size_t)K), Tcur((size_t)K);
     std::vector<uint8_t> active((size_t)K), sub((size_t)K);
-    std::vector<double> accv((size_t)K * kNAcc), clv((size_t)K * 3), cgv((size_t)K * 3);
+    std::vector<double> accv((size_t)K * kNAcc), clv((size_t)K * 3), cgv((size_t)K * 3), paccv;
     auto acc = reinterpret_cast<double(*)[kNAcc]>(accv.data());
     auto cl = reinterpret_cast<double(*)[3]>(clv.data());
     auto cg = reinterpret_cast<double(*)[3]>(cgv.data());
@@ -223,6 +224,37 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
             Tn[k] = s[k].T;
         }
         if (!any(active)) break;
+        if (planes) {
+            // row f3, batched: plane pairings -> ONE accumulation pass per problem (the quadratic form of its cost) -> K host
+            // Gauss-Newton solves -- per problem exactly run_icp_loop's point-to-plane branch
+            if ((rc = st.match_planes(active.data(), Tcur.data(), p))) return rc;
+            if (paccv.empty()) paccv.resize((size_t)K * kNAccPlaneHost);
+            auto pacc = reinterpret_cast<double(*)[kNAccPlaneHost]>(paccv.data());
+            if ((rc = st.accumulate_planes(active.data(), pacc))) return rc;
+            for (int k = 0; k < K; ++k) {
+                if (!active[k]) continue;
+                const double pairs_global = pacc[k][91];
+                if (!(pairs_global > 0)) { s[k].term = MOLA_ICP_TERM_NO_PAIRINGS; s[k].its = it; s[k].done = true; continue; }
+                double cost = 0;
+                if (!solve_gauss_newton_planes(pacc[k], s[k].T, p.solver_max_iterations, Tn[k], &cost)) {
+                    s[k].term = MOLA_ICP_TERM_SOLVER_ERROR; s[k].its = it; s[k].done = true;
+                    continue;
+                }
+                s[k].plane_pairs = pairs_global;
+                s[k].plane_rmse = std::sqrt((cost > 0 ? cost : 0.0) / pairs_global);
+                std::memcpy(s[k].last_pacc, pacc[k], sizeof s[k].last_pacc);
+                s[k].have_solution = true;
+                s[k].T = Tn[k];
+                double d_xyz, d_rot;
+                stall_deltas(s[k].T, s[k].Tprev, d_xyz, d_rot);
+                if (!p.fixed_iterations && std::fabs(d_xyz) < p.min_abs_step_trans && std::fabs(d_rot) < p.min_abs_step_rot) {
+                    s[k].term = MOLA_ICP_TERM_STALLED; s[k].its = it + 1; s[k].done = true;
+                    continue;
+                }
+                s[k].Tprev = s[k].T;
+            }
+            continue;
+        }
         if ((rc = st.match(active.data(), Tcur.data(), p.matcher_threshold, p))) return rc;
         // solve_on_pairing, batched
         if ((rc = st.accumulate(active.data(), p, Tcur.data(), 0, nullptr, nullptr, true, acc))) return rc;
@@ -296,9 +328,15 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
         o.quality = quality[k];
         o.n_iterations = s[k].its;
         o.termination = s[k].term;
-        o.n_pairs = s[k].have_solution ? (uint64_t)s[k].last_acc[16] : 0;
-        o.rmse = (s[k].have_solution && s[k].last_acc[16] > 0) ? std::sqrt(s[k].last_acc[17] / s[k].last_acc[16]) : 0.0;
-        if (!s[k].have_solution || !pose_covariance(s[k].last_acc, s[k].T, o.cov)) std::memset(o.cov, 0, sizeof o.cov);
+        if (planes) {
+            o.n_pairs = s[k].have_solution ? (uint64_t)s[k].plane_pairs : 0;
+            o.rmse = s[k].have_solution ? s[k].plane_rmse : 0.0;   // rms point-to-plane distance at the last linearisation
+            if (!s[k].have_solution || !pose_covariance_planes(s[k].last_pacc, s[k].T, o.cov)) std::memset(o.cov, 0, sizeof o.cov);
+        } else {
+            o.n_pairs = s[k].have_solution ? (uint64_t)s[k].last_acc[16] : 0;
+            o.rmse = (s[k].have_solution && s[k].last_acc[16] > 0) ? std::sqrt(s[k].last_acc[17] / s[k].last_acc[16]) : 0.0;
+            if (!s[k].have_solution || !pose_covariance(s[k].last_acc, s[k].T, o.cov)) std::memset(o.cov, 0, sizeof o.cov);
+        }
         o.ms_iterations = t1 - t0;   // the whole batch's loop / quality pass (the problems ran together)
         o.ms_quality = t2 - t1;
     }

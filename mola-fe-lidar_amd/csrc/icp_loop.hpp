@@ -49,7 +49,7 @@ struct Stages {
     virtual uint64_t n_map_total() const = 0;
 };
 
-// K independent point-to-point problems advanced in lockstep, every stage ONE batched launch over the problems still
+// K independent problems (point-to-point + Horn, or the shipped point-to-plane + Gauss-Newton pipeline) advanced in lockstep, every stage ONE batched launch over the problems still
 // iterating: the loop-closure Monte-Carlo (K initial poses on one cloud pair, src/LidarOdometry.cpp:767-788) and the
 // nearby-keyframe batch (K pairs, cpp:704-741).  `active[k] != 0` selects the problems a call works on.
 struct BatchStages {
@@ -58,10 +58,22 @@ struct BatchStages {
     virtual int match(const uint8_t* active, const Mat4* T, double threshold, const mola_icp_params& p) = 0;
     virtual int accumulate(const uint8_t* active, const mola_icp_params& p, const Mat4* Tcur, int stage,
                            const double (*cl)[3], const double (*cg)[3], bool reset_outliers, double (*acc)[kNAcc]) = 0;
+    // row f3 (point-to-plane + Gauss-Newton), batched: plane pairings of the active problems at their poses, then the
+    // quadratic form of each one's cost.  Default: not available.
+    virtual int match_planes(const uint8_t* active, const Mat4* T, const mola_icp_params& p)
+    {
+        (void)active; (void)T; (void)p;
+        return fail(MOLA_ICP_E_UNSUPPORTED, "these batched stages do not provide the point-to-plane matcher");
+    }
+    virtual int accumulate_planes(const uint8_t* active, double (*acc)[kNAccPlaneHost])
+    {
+        (void)active; (void)acc;
+        return fail(MOLA_ICP_E_UNSUPPORTED, "these batched stages do not provide the point-to-plane matcher");
+    }
     virtual uint64_t n_local_total(int k) const = 0;
     virtual uint64_t n_map_total(int k) const = 0;
 };
-// Per problem the same sequence of operations as run_icp_loop (point-to-point pipeline): results are bit-identical to
+// Per problem the same sequence of operations as run_icp_loop (either pipeline): results are bit-identical to
 // K separate runs over stages that compute the same sums.  out = K results.
 int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params& p, mola_icp_result* out);
 

@@ -466,13 +466,31 @@ __global__ __launch_bounds__(256, (K <= 7 ? (DENSE ? 4 : 3) : 2)) void k_knn_pla
 // tile its owner culls holds nothing that belongs in the merged list.  The three other lists go through LDS, wave 0 merges
 // them into its own (seeds are in all four: dropped by position) and runs the epilogue.  Same lists, same planes, same
 // certified-list logic (KnnCert) as k_knn_planes: results are identical.
-template <int K /*list length: knn + 1*/>
-__global__ __launch_bounds__(256, 3) void k_knn_coop(const float* __restrict__ slx, const float* __restrict__ sly, const float* __restrict__ slz,
-                                                     int N, TiledMap mp, PoseF P, float thr2, float thr2x, double threshold, double plane_eig_thr,
-                                                     PlanePair* __restrict__ out, PlanePair* __restrict__ cache, int* __restrict__ knn_pos,
-                                                     int use_seed, int use_cache, unsigned int* __restrict__ changed_items /*8 slots*/,
+// One problem of a (possibly batched) k_knn_coop launch: K initial poses on one cloud pair (the loop-closure Monte-Carlo,
+// src/LidarOdometry.cpp:767-788) or K different pairs (the nearby-keyframe checks, cpp:704-741) share one launch through
+// blockIdx.y, as the NN matcher's problems do in k_nn_coop -- the reference's own nearby / loop-closure settings select
+// THIS matcher (params/icp-settings-loop-closure.yaml:33-39).
+struct KnnProblem {
+    const float *slx, *sly, *slz;   // Hilbert-sorted local cloud (queries)
+    int N;
+    TiledMap mp;                    // Hilbert-sorted map + box levels
+    PoseF P;                        // this launch's pose
+    PoseF Pprev;                    // the pose of the launch that wrote lb / the seeds (KnnCert)
+    PlanePair* out;                 // the plane pairing, sorted query order
+    PlanePair* cache;               // the plane of each query's stored list
+    int* knn_pos;                   // N x K: in = last launch's neighbours (use_seed), out = this launch's
+    float* lb;                      // per query: lower bound on the distance to every point outside its list (KnnCert)
+    int use_seed, use_cache, cert_on;
+    unsigned int* changed_items;    // 8 slots, kQueueStride words apart: items whose lists changed
+};
+constexpr int kKnnMaxBatch = 12;    // problems per launch (kernel arguments are limited to 4 KB; = kCoopMaxBatch)
+template <int KMAX> struct KnnBatch { KnnProblem p[KMAX]; };
+static_assert(sizeof(KnnBatch<kKnnMaxBatch>) <= 3900, "KnnBatch must fit the kernel-argument segment");
+
+template <int K /*list length: knn + 1*/, int KMAX /*problems per launch: blockIdx.y*/>
+__global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch, float thr2, float thr2x, double threshold, double plane_eig_thr,
                                                      unsigned long long* __restrict__ staged_total /*slotted, may be null*/, int lds_boxes,
-                                                     KnnCert cert)
+                                                     unsigned long long* __restrict__ cert_stats /*diagnostics, may be null*/)
 {
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
     __shared__ int s_list[kMaxList];
@@ -482,8 +500,25 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const float* __restrict__ s
     __shared__ int s_mpos[kCoopParts - 1][K][64];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const KnnProblem& pb = batch.p[KMAX == 1 ? 0 : blockIdx.y];
+    const int N = pb.N;
     const int item = xcd_item((int)blockIdx.x, (N + 63) / 64);
-    if (item * 64 >= N) return;  // (the grid is rounded up to whole XCD ranges; uniform: before any barrier)
+    if (item * 64 >= N) return;  // (the grid is rounded up to whole XCD ranges / sized for the batch's largest problem; uniform: before any barrier)
+    const TiledMap mp = pb.mp;
+    const PoseF P = pb.P;
+    const float* __restrict__ slx = pb.slx;
+    const float* __restrict__ sly = pb.sly;
+    const float* __restrict__ slz = pb.slz;
+    PlanePair* __restrict__ out = pb.out;
+    PlanePair* __restrict__ cache = pb.cache;
+    int* __restrict__ knn_pos = pb.knn_pos;
+    const int use_seed = pb.use_seed, use_cache = pb.use_cache;
+    unsigned int* __restrict__ changed_items = pb.changed_items;
+    KnnCert cert;
+    cert.Pprev = pb.Pprev;
+    cert.lb = pb.lb;
+    cert.on = pb.cert_on;
+    cert.stats = cert_stats;
     const lds_f32* lbox = (const lds_f32*)s_dyn;
     if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
 
@@ -612,7 +647,7 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const float* __restrict__ s
 #pragma unroll
     for (int j = 0; j < K; ++j) kd[j] = kd_of(j);
     const bool changed = plane_epilogue<K>(mp, kp, kd, qx, qy, qz, qi, N, thr2, threshold, plane_eig_thr, out, cache, knn_pos, use_seed, use_cache);
-    if (lane == 0 && changed) atomicAdd(changed_items + (size_t)(blockIdx.x & (kQueues - 1)) * kQueueStride, 1u);
+    if (lane == 0 && changed && changed_items) atomicAdd(changed_items + (size_t)(blockIdx.x & (kQueues - 1)) * kQueueStride, 1u);   // (batched launches do not count)
     if (cert.stats && lane == 0 && cert_mask) {
         unsigned long long* st = cert.stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride;
         atomicAdd(st + 1, (unsigned long long)__popcll(cert_mask));
@@ -681,18 +716,20 @@ __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restri
 // order only.
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kPhiStride = 18;   // doubles per pairing in LDS: 16 + 2 (rows 144 bytes apart: 16-byte aligned, banks spread)
-__global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __restrict__ slx, const float* __restrict__ sly,
-                                                                const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
-                                                                int N, double* __restrict__ partials)
+// block `bx` of `nblocks` over one problem's plane pairing -> one row of the form (the summation order depends on (N, nblocks)
+// only: the single-problem and the batched launch produce the same bits)
+__device__ __forceinline__ void accumulate_planes_mfma_rows(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                            const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
+                                                            int N, int bx, int nblocks, double* __restrict__ partials)
 {
     __shared__ __attribute__((aligned(16))) double s_v[4][64 * kPhiStride];   // per wave: the vectors of its 64 pairings
     __shared__ double s_d[4][256];                                             // per wave: its 16 x 16 result
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* sv = s_v[wave];
     v4d D = {0.0, 0.0, 0.0, 0.0};
-    const int n_batches = (N + 63) / 64, n_waves = (int)gridDim.x * 4;
+    const int n_batches = (N + 63) / 64, n_waves = nblocks * 4;
     // (a wave's batches are a chain of round trips otherwise -- 2 waves per SIMD at 1M: the next batch is fetched while this one runs)
-    int bt = (int)blockIdx.x * 4 + wave;
+    int bt = bx * 4 + wave;
     PlanePair pp{};
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
     if (bt < n_batches && bt * 64 + lane < N) { const int i = bt * 64 + lane; pp = pairs[i]; l0 = slx[i]; l1 = sly[i]; l2 = slz[i]; }
@@ -732,20 +769,43 @@ __global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __r
     __syncthreads();
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
     const double t = ((s_d[0][threadIdx.x] + s_d[1][threadIdx.x]) + s_d[2][threadIdx.x]) + s_d[3][threadIdx.x];
-    double* out = partials + (size_t)blockIdx.x * kNAccPlane;
+    double* out = partials + (size_t)bx * kNAccPlane;
     if (row <= col && col < 12) out[row * 12 - row * (row - 1) / 2 + (col - row)] = t;   // upper triangle, row-major (a <= b)
     else if (col == 12 && row < 12) out[78 + row] = t;
     else if (col == 12 && row == 12) out[90] = t;
     else if (col == 13 && row == 13) out[91] = t;
 }
 
+__global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                                const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
+                                                                int N, double* __restrict__ partials)
+{
+    accumulate_planes_mfma_rows(slx, sly, slz, pairs, N, (int)blockIdx.x, (int)gridDim.x, partials);
+}
+
+// K problems in one launch (grid = (max rows, K)): per problem the SAME partition as its own k_accumulate_planes_mfma launch
+struct PlaneAccBatch {
+    const float* slx[kKnnMaxBatch];
+    const float* sly[kKnnMaxBatch];
+    const float* slz[kKnnMaxBatch];
+    const PlanePair* pairs[kKnnMaxBatch];
+    double* partials[kKnnMaxBatch];
+    int N[kKnnMaxBatch], nblocks[kKnnMaxBatch], slot[kKnnMaxBatch];
+};
+__global__ __launch_bounds__(256) void k_accumulate_planes_mfma_batch(const PlaneAccBatch b)
+{
+    const int y = (int)blockIdx.y, nb = b.nblocks[y];
+    if ((int)blockIdx.x >= nb) return;
+    accumulate_planes_mfma_rows(b.slx[y], b.sly[y], b.slz[y], b.pairs[y], b.N[y], (int)blockIdx.x, nb, b.partials[y]);
+}
+
 // fixed-order sum of [nblocks][n] partial rows (n even, <= 128): 22 slices of rows per accumulator pair with the loads of a
 // slice independent of each other, then the 22 slice sums in order.  Deterministic for a given nblocks.
 // host_out (pinned, may be null): the n sums + acc[n] written there too, then the sequence number in slot n + 2 -- the
 // hand-over k_publish would otherwise make in a launch of its own.
-__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
-                                                      double* __restrict__ acc, const unsigned int* __restrict__ counters,
-                                                      double* __restrict__ host_out, unsigned long long seq)
+__device__ __forceinline__ void reduce_rows_wide(const double* __restrict__ partials, int nblocks, int n,
+                                                 double* __restrict__ acc, const unsigned int* __restrict__ counters,
+                                                 double* __restrict__ host_out, unsigned long long seq)
 {
     // acc[n] = items of the plane matcher whose neighbour lists changed in this iteration (its next launch picks
     // the counting or the insertion flavour from it): counters[0] (insertion launch) + counters[2] (queued by verify)
@@ -799,6 +859,23 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
             __threadfence_system();
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
+                                                      double* __restrict__ acc, const unsigned int* __restrict__ counters,
+                                                      double* __restrict__ host_out, unsigned long long seq)
+{
+    reduce_rows_wide(partials, nblocks, n, acc, counters, host_out, seq);
+}
+
+// K problems: block y sums problem y's rows (the same order as its own k_reduce_rows launch) into acc + kPlaneAccStride * slot and
+// publishes them at host_out + kPlaneAccStride * slot (sequence flag in slot n + 2 of that stride)
+constexpr int kPlaneAccStride = 96;
+__global__ __launch_bounds__(1024) void k_reduce_rows_batch(const PlaneAccBatch b, int n, double* __restrict__ acc,
+                                                            double* __restrict__ host_out, unsigned long long seq)
+{
+    const int y = (int)blockIdx.x, sl = b.slot[y];
+    reduce_rows_wide(b.partials[y], b.nblocks[y], n, acc + (size_t)kPlaneAccStride * sl, nullptr, host_out + (size_t)kPlaneAccStride * sl, seq);
 }
 
 // plane pairing in sorted query order -> original order (tests / callers that want the pairing)
