@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOLA_ICP_ABI_VERSION 2
+#define MOLA_ICP_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -69,6 +69,31 @@ enum {
     MOLA_ICP_NN_TILED = 3   /* exact VALU brute force over the Hilbert-sorted map tiles a query group can reach */
 };
 
+/* Further entries of the `matchers:` / `solvers:` sequences -- "a sequence of one or more" pairs of class + params
+ * (params/icp-settings-regular.yaml:28-31), which is what runFromIteration / runUpToIteration (icpreg:38-39) exist for.
+ * Entry 0 of each sequence lives in the flat fields of mola_icp_params; entries 1.. here.  Semantics ([EXT-recalled]
+ * mp2p_icp: a matcher outside its iteration range contributes no pairings; the solvers are tried in order):
+ *   - at iteration `it` the ACTIVE matcher is the one whose [runFromIteration, runUpToIteration (0 = no limit)] holds it;
+ *     none active = no pairings (terminates as NoPairings), as with a single entry;
+ *   - two matchers active in the SAME iteration would feed mixed pairings to one solve: MOLA_ICP_E_UNSUPPORTED, named;
+ *   - the solver of an iteration is the first `solvers:` entry whose range holds it (entries without a range: always).
+ * Typical use: point-to-point + Horn for the first iterations, then point-to-plane + Gauss-Newton. */
+#define MOLA_ICP_MAX_EXTRA_STAGES 3
+typedef struct mola_icp_matcher_entry {
+    int32_t  matcher_class;              /* MOLA_ICP_MATCHER_*                       */
+    double   matcher_threshold;          /* threshold / distanceThreshold [m]        */
+    double   plane_eigen_threshold;      /* planeEigenThreshold                      */
+    uint32_t knn;                        /* knn                                      */
+    uint32_t run_from_iteration;         /* runFromIteration                         */
+    uint32_t run_up_to_iteration;        /* runUpToIteration (0 = no limit)          */
+} mola_icp_matcher_entry;
+typedef struct mola_icp_solver_entry {
+    int32_t  solver_class;               /* MOLA_ICP_SOLVER_*                        */
+    uint32_t solver_max_iterations;      /* params.maxIterations (Gauss-Newton)      */
+    uint32_t run_from_iteration;         /* runFromIteration                         */
+    uint32_t run_up_to_iteration;        /* runUpToIteration (0 = no limit)          */
+} mola_icp_solver_entry;
+
 /* ---- per-call parameters == mp2p_icp::Parameters + the per-object pipeline
  *      settings the YAML carries (params/icp-settings-regular.yaml:10-46).
  *      Replaces `mp2p_icp::Parameters` (include/mola-fe-lidar/LidarOdometry.h:99,123). */
@@ -95,6 +120,13 @@ typedef struct mola_icp_params {
     int32_t  fixed_iterations;           /* !=0: never stop on the stall test (benchmarks) */
     int32_t  nn_kernel;                  /* MOLA_ICP_NN_*                                */
     int32_t  skip_quality;               /* !=0: skip the quality pass, quality = -1 (benchmarks) */
+    /* matchers[1..] / solvers[1..] of the YAML sequences (see mola_icp_matcher_entry); 0 = the single-entry pipelines above */
+    uint32_t solver_run_from_iteration;  /* solvers[0].params.runFromIteration (absent: 0)          */
+    uint32_t solver_run_up_to_iteration; /* solvers[0].params.runUpToIteration (absent / 0: no limit) */
+    uint32_t n_extra_matchers;
+    uint32_t n_extra_solvers;
+    mola_icp_matcher_entry extra_matchers[MOLA_ICP_MAX_EXTRA_STAGES];
+    mola_icp_solver_entry  extra_solvers[MOLA_ICP_MAX_EXTRA_STAGES];
 } mola_icp_params;
 
 /* ---- result == the fields of mp2p_icp::Results that the reference consumes

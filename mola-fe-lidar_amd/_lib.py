@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmola_icp_amd.so")
 
 NACC = 24
-ABI_VERSION = 2   # MOLA_ICP_ABI_VERSION of include/mola_icp_amd.h
+ABI_VERSION = 3   # MOLA_ICP_ABI_VERSION of include/mola_icp_amd.h
 
 OK = 0
 E_BADARG, E_CONFIG, E_HIP, E_OOM, E_NODEVICE, E_UNSUPPORTED, E_COMM, E_INTERNAL = -1, -2, -3, -4, -5, -6, -7, -8
@@ -20,6 +20,19 @@ MATCHER_POINTS_DISTANCE_THRESHOLD, MATCHER_POINT2PLANE = 0, 1
 SOLVER_HORN, SOLVER_GAUSS_NEWTON = 0, 1
 QUALITY_PAIRED_RATIO = 0
 NN_AUTO, NN_VALU, NN_MFMA, NN_TILED = 0, 1, 2, 3
+
+
+MAX_EXTRA_STAGES = 3
+
+
+class CMatcherEntry(C.Structure):
+    _fields_ = [("matcher_class", C.c_int32), ("matcher_threshold", C.c_double), ("plane_eigen_threshold", C.c_double),
+                ("knn", C.c_uint32), ("run_from_iteration", C.c_uint32), ("run_up_to_iteration", C.c_uint32)]
+
+
+class CSolverEntry(C.Structure):
+    _fields_ = [("solver_class", C.c_int32), ("solver_max_iterations", C.c_uint32), ("run_from_iteration", C.c_uint32),
+                ("run_up_to_iteration", C.c_uint32)]
 
 
 class CParams(C.Structure):
@@ -45,6 +58,12 @@ class CParams(C.Structure):
         ("fixed_iterations", C.c_int32),
         ("nn_kernel", C.c_int32),
         ("skip_quality", C.c_int32),
+        ("solver_run_from_iteration", C.c_uint32),
+        ("solver_run_up_to_iteration", C.c_uint32),
+        ("n_extra_matchers", C.c_uint32),
+        ("n_extra_solvers", C.c_uint32),
+        ("extra_matchers", CMatcherEntry * MAX_EXTRA_STAGES),
+        ("extra_solvers", CSolverEntry * MAX_EXTRA_STAGES),
     ]
 
 

@@ -62,15 +62,56 @@ static void require(const YamlNode& cfg, const char* key)
     if (!cfg.is_map() || !cfg.has(key)) throw std::runtime_error(std::string("Missing YAML required entry `") + key + "`");
 }
 
-static const YamlNode& first_of_seq(const YamlNode& n, const char* what)
+// entry i of a `solvers:` / `matchers:` / `quality:` sequence ("a sequence of one or more" {class, params}: icpreg:28-31)
+static const YamlNode& entry_of_seq(const YamlNode& n, const char* what, size_t i, size_t max_entries)
 {
     if (!n.is_seq() || n.seq.empty())
         throw std::runtime_error(std::string("`") + what + "` must be a non-empty sequence of {class, params}");
-    if (n.seq.size() > 1)
-        throw std::runtime_error(std::string("`") + what + "`: this build runs exactly one entry per pipeline stage");
-    const YamlNode& e = n.seq[0];
-    if (!e.is_map() || !e.has("class")) throw std::runtime_error(std::string("`") + what + "[0]` lacks a `class`");
+    if (n.seq.size() > max_entries)
+        throw std::runtime_error(std::string("`") + what + "`: at most " + std::to_string(max_entries) + (max_entries == 1 ? " entry" : " entries") +
+                                 " in this build (" + std::to_string(n.seq.size()) + " given)");
+    const YamlNode& e = n.seq[i];
+    if (!e.is_map() || !e.has("class"))
+        throw std::runtime_error(std::string("`") + what + "[" + std::to_string(i) + "]` lacks a `class`");
     return e;
+}
+
+static void parse_solver(const YamlNode& s, int32_t& cls_out, uint32_t& max_its, uint32_t& from, uint32_t& upto)
+{
+    const std::string cls = s.at("class").as_string();
+    if (cls == "mp2p_icp::Solver_Horn") cls_out = MOLA_ICP_SOLVER_HORN;
+    else if (cls == "mp2p_icp::Solver_GaussNewton") cls_out = MOLA_ICP_SOLVER_GAUSS_NEWTON;
+    else throw std::runtime_error("solver class=`" + cls + "` is a non-registered class. Known: "
+                                  "`mp2p_icp::Solver_Horn`, `mp2p_icp::Solver_GaussNewton`.");
+    if (auto* sp = s.find("params")) {
+        if (auto* n = sp->find("maxIterations")) max_its = (uint32_t)n->as_int();
+        if (auto* n = sp->find("runFromIteration")) from = (uint32_t)n->as_int();
+        if (auto* n = sp->find("runUpToIteration")) upto = (uint32_t)n->as_int();
+    }
+}
+
+static void parse_matcher(const YamlNode& m, int32_t& cls_out, double& thr, double& eig, uint32_t& knn, uint32_t& from, uint32_t& upto)
+{
+    const std::string cls = m.at("class").as_string();
+    const YamlNode* mp = m.find("params");
+    if (cls == "mp2p_icp::Matcher_Points_DistanceThreshold") {
+        cls_out = MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD;
+        if (mp)
+            if (auto* n = mp->find("threshold")) thr = n->as_double();
+    } else if (cls == "mp2p_icp::Matcher_Point2Plane") {
+        cls_out = MOLA_ICP_MATCHER_POINT2PLANE;
+        if (mp) {
+            if (auto* n = mp->find("distanceThreshold")) thr = n->as_double();
+            if (auto* n = mp->find("planeEigenThreshold")) eig = n->as_double();
+            if (auto* n = mp->find("knn")) knn = (uint32_t)n->as_int();
+        }
+    } else
+        throw std::runtime_error("matcher class=`" + cls + "` is a non-registered class. Known: "
+                                 "`mp2p_icp::Matcher_Points_DistanceThreshold`, `mp2p_icp::Matcher_Point2Plane`.");
+    if (mp) {
+        if (auto* n = mp->find("runFromIteration")) from = (uint32_t)n->as_int();
+        if (auto* n = mp->find("runUpToIteration")) upto = (uint32_t)n->as_int();
+    }
 }
 
 void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p)
@@ -116,40 +157,32 @@ void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p)
     }
 
     {
-        const YamlNode& s = first_of_seq(cfg.at("solvers"), "solvers");
-        const std::string cls = s.at("class").as_string();
-        if (cls == "mp2p_icp::Solver_Horn") p.solver_class = MOLA_ICP_SOLVER_HORN;
-        else if (cls == "mp2p_icp::Solver_GaussNewton") p.solver_class = MOLA_ICP_SOLVER_GAUSS_NEWTON;
-        else throw std::runtime_error("solver class=`" + cls + "` is a non-registered class. Known: "
-                                      "`mp2p_icp::Solver_Horn`, `mp2p_icp::Solver_GaussNewton`.");
-        if (auto* sp = s.find("params"))
-            if (auto* n = sp->find("maxIterations")) p.solver_max_iterations = (uint32_t)n->as_int();
-    }
-    {
-        const YamlNode& m = first_of_seq(cfg.at("matchers"), "matchers");
-        const std::string cls = m.at("class").as_string();
-        const YamlNode* mp = m.find("params");
-        if (cls == "mp2p_icp::Matcher_Points_DistanceThreshold") {
-            p.matcher_class = MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD;
-            if (mp)
-                if (auto* n = mp->find("threshold")) p.matcher_threshold = n->as_double();
-        } else if (cls == "mp2p_icp::Matcher_Point2Plane") {
-            p.matcher_class = MOLA_ICP_MATCHER_POINT2PLANE;
-            if (mp) {
-                if (auto* n = mp->find("distanceThreshold")) p.matcher_threshold = n->as_double();
-                if (auto* n = mp->find("planeEigenThreshold")) p.plane_eigen_threshold = n->as_double();
-                if (auto* n = mp->find("knn")) p.knn = (uint32_t)n->as_int();
-            }
-        } else
-            throw std::runtime_error("matcher class=`" + cls + "` is a non-registered class. Known: "
-                                     "`mp2p_icp::Matcher_Points_DistanceThreshold`, `mp2p_icp::Matcher_Point2Plane`.");
-        if (mp) {
-            if (auto* n = mp->find("runFromIteration")) p.run_from_iteration = (uint32_t)n->as_int();
-            if (auto* n = mp->find("runUpToIteration")) p.run_up_to_iteration = (uint32_t)n->as_int();
+        const YamlNode& seq = cfg.at("solvers");
+        parse_solver(entry_of_seq(seq, "solvers", 0, 1 + MOLA_ICP_MAX_EXTRA_STAGES), p.solver_class, p.solver_max_iterations,
+                     p.solver_run_from_iteration, p.solver_run_up_to_iteration);
+        p.n_extra_solvers = (uint32_t)seq.seq.size() - 1;
+        for (uint32_t i = 0; i < p.n_extra_solvers; ++i) {
+            mola_icp_solver_entry& e = p.extra_solvers[i];
+            e = mola_icp_solver_entry{};
+            parse_solver(entry_of_seq(seq, "solvers", i + 1, 1 + MOLA_ICP_MAX_EXTRA_STAGES), e.solver_class, e.solver_max_iterations,
+                         e.run_from_iteration, e.run_up_to_iteration);
         }
     }
     {
-        const YamlNode& q = first_of_seq(cfg.at("quality"), "quality");
+        const YamlNode& seq = cfg.at("matchers");
+        parse_matcher(entry_of_seq(seq, "matchers", 0, 1 + MOLA_ICP_MAX_EXTRA_STAGES), p.matcher_class, p.matcher_threshold,
+                      p.plane_eigen_threshold, p.knn, p.run_from_iteration, p.run_up_to_iteration);
+        p.n_extra_matchers = (uint32_t)seq.seq.size() - 1;
+        for (uint32_t i = 0; i < p.n_extra_matchers; ++i) {
+            mola_icp_matcher_entry& e = p.extra_matchers[i];
+            e = mola_icp_matcher_entry{};
+            e.matcher_threshold = 0.50; e.plane_eigen_threshold = 0.07; e.knn = 6;   // (the defaults of entry 0: params_default)
+            parse_matcher(entry_of_seq(seq, "matchers", i + 1, 1 + MOLA_ICP_MAX_EXTRA_STAGES), e.matcher_class, e.matcher_threshold,
+                          e.plane_eigen_threshold, e.knn, e.run_from_iteration, e.run_up_to_iteration);
+        }
+    }
+    {
+        const YamlNode& q = entry_of_seq(cfg.at("quality"), "quality", 0, 1);
         const std::string cls = q.at("class").as_string();
         if (cls != "mp2p_icp::QualityEvaluator_PairedRatio")
             throw std::runtime_error("quality class=`" + cls + "` is a non-registered class. Known: "

@@ -26,7 +26,83 @@ int fail(int code, const std::string& msg)
     return code;
 }
 
+namespace {
+bool in_range(uint32_t it, uint32_t from, uint32_t upto) { return it >= from && (upto == 0 || it <= upto); }
+
+// the one-matcher / one-solver parameter set an iteration runs with (entry k of `matchers:`, entry j of `solvers:`)
+mola_icp_params with_entries(const mola_icp_params& p, int k, int j)
+{
+    mola_icp_params e = p;
+    if (k > 0) {
+        const mola_icp_matcher_entry& m = p.extra_matchers[k - 1];
+        e.matcher_class = m.matcher_class; e.matcher_threshold = m.matcher_threshold; e.plane_eigen_threshold = m.plane_eigen_threshold;
+        e.knn = m.knn; e.run_from_iteration = m.run_from_iteration; e.run_up_to_iteration = m.run_up_to_iteration;
+    }
+    if (j > 0) {
+        const mola_icp_solver_entry& sv = p.extra_solvers[j - 1];
+        e.solver_class = sv.solver_class; e.solver_max_iterations = sv.solver_max_iterations;
+        e.solver_run_from_iteration = sv.run_from_iteration; e.solver_run_up_to_iteration = sv.run_up_to_iteration;
+    }
+    e.n_extra_matchers = 0;
+    e.n_extra_solvers = 0;
+    return e;
+}
+int validate_single(const mola_icp_params& p);
+}  // namespace
+
+// The `matchers:` / `solvers:` entries in force at iteration `it` as a single-entry parameter set (see mola_icp_matcher_entry).
+// Returns false when no matcher's range holds the iteration (no pairings).  An iteration no solver's range holds keeps the
+// LAST solver listed ([EXT] mp2p_icp tries its solvers in order; a pipeline without any solver for an iteration cannot solve).
+bool stage_params(const mola_icp_params& p, uint32_t it, mola_icp_params& eff)
+{
+    int k_act = -1;
+    for (int k = 0; k <= (int)p.n_extra_matchers && k <= MOLA_ICP_MAX_EXTRA_STAGES; ++k) {
+        const uint32_t from = k ? p.extra_matchers[k - 1].run_from_iteration : p.run_from_iteration;
+        const uint32_t upto = k ? p.extra_matchers[k - 1].run_up_to_iteration : p.run_up_to_iteration;
+        if (in_range(it, from, upto)) { k_act = k; break; }
+    }
+    if (k_act < 0) return false;
+    int j_act = (int)p.n_extra_solvers;
+    for (int j = 0; j <= (int)p.n_extra_solvers && j <= MOLA_ICP_MAX_EXTRA_STAGES; ++j) {
+        const uint32_t from = j ? p.extra_solvers[j - 1].run_from_iteration : p.solver_run_from_iteration;
+        const uint32_t upto = j ? p.extra_solvers[j - 1].run_up_to_iteration : p.solver_run_up_to_iteration;
+        if (in_range(it, from, upto)) { j_act = j; break; }
+    }
+    eff = with_entries(p, k_act, j_act);
+    return true;
+}
+
 int validate_params(const mola_icp_params& p)
+{
+    if (p.n_extra_matchers > MOLA_ICP_MAX_EXTRA_STAGES || p.n_extra_solvers > MOLA_ICP_MAX_EXTRA_STAGES)
+        return fail(MOLA_ICP_E_BADARG, "n_extra_matchers / n_extra_solvers exceed MOLA_ICP_MAX_EXTRA_STAGES");
+    if (p.n_extra_matchers == 0 && p.n_extra_solvers == 0) return validate_single(p);
+    // several entries: no two matchers may be active in one iteration (mixed pairings in one solve are not run), and every
+    // (matcher, solver) combination an iteration can meet must be a pipeline this build runs
+    const uint32_t n_it = p.max_iterations < 4096 ? p.max_iterations : 4096;   // (ranges beyond are checked when met)
+    for (uint32_t it = 0; it < n_it; ++it) {
+        int active = 0;
+        for (int k = 0; k <= (int)p.n_extra_matchers; ++k) {
+            const uint32_t from = k ? p.extra_matchers[k - 1].run_from_iteration : p.run_from_iteration;
+            const uint32_t upto = k ? p.extra_matchers[k - 1].run_up_to_iteration : p.run_up_to_iteration;
+            active += in_range(it, from, upto) ? 1 : 0;
+        }
+        if (active > 1)
+            return fail(MOLA_ICP_E_UNSUPPORTED, "matchers: " + std::to_string(active) + " entries are active in iteration " + std::to_string(it) +
+                                                    " (overlapping runFromIteration / runUpToIteration ranges): pairings of several matchers in "
+                                                    "one solve are not run by this build -- give the entries disjoint iteration ranges");
+        mola_icp_params eff;
+        if (stage_params(p, it, eff)) {
+            const int rc = validate_single(eff);
+            if (rc) return rc;
+        }
+    }
+    if (n_it == 0) return validate_single(with_entries(p, 0, 0));
+    return MOLA_ICP_OK;
+}
+
+namespace {
+int validate_single(const mola_icp_params& p)
 {
     if (!(p.matcher_threshold > 0) || !std::isfinite(p.matcher_threshold))
         return fail(MOLA_ICP_E_BADARG, "matcher threshold must be a positive finite distance");
@@ -55,6 +131,7 @@ int validate_params(const mola_icp_params& p)
     if (p.quality_class != MOLA_ICP_QUALITY_PAIRED_RATIO) return fail(MOLA_ICP_E_BADARG, "unknown quality_class");
     return MOLA_ICP_OK;
 }
+}  // namespace
 
 // One solver invocation on the stored pairing (row a8 + a9).
 //  unweighted: acc0 -> Horn.
@@ -93,10 +170,14 @@ static int solve_on_pairing(Stages& st, const mola_icp_params& p, const Mat4& Tc
     return MOLA_ICP_OK;
 }
 
-int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_icp_result* out)
+int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mola_icp_result* out)
 {
-    int rc = validate_params(p);
+    int rc = validate_params(p_all);
     if (rc) return rc;
+    mola_icp_params p = p_all;          // the single-entry set of the current iteration (stage_params)
+    p.n_extra_matchers = p.n_extra_solvers = 0;
+    const bool staged = p_all.n_extra_matchers != 0 || p_all.n_extra_solvers != 0;
+    bool last_planes = p_all.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE;   // which pipeline fed the last solve
     Mat4 T = init, Tprev = init;
     uint32_t term = MOLA_ICP_TERM_UNDEFINED;
     uint32_t it = 0;
@@ -109,12 +190,18 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     {
     TraceRange tr_loop("mola_icp.iterations");
     for (; it < p.max_iterations; ++it) {
-        const bool run_matcher =
-            it >= p.run_from_iteration && (p.run_up_to_iteration == 0 || it <= p.run_up_to_iteration);
+        bool run_matcher;
+        if (staged) {
+            run_matcher = stage_params(p_all, it, p);
+            if (run_matcher && (rc = validate_params(p))) return rc;   // (an iteration beyond the range validate_params walked)
+        } else {
+            run_matcher = it >= p.run_from_iteration && (p.run_up_to_iteration == 0 || it <= p.run_up_to_iteration);
+        }
         if (!run_matcher || st.n_local_total() == 0 || st.n_map_total() == 0) {
             term = MOLA_ICP_TERM_NO_PAIRINGS;
             break;
         }
+        last_planes = p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE;
         Mat4 Tn = T;
         double pairs_global = 0;
         bool solver_error = false;
@@ -171,7 +258,7 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_ic
     out->quality = quality;
     out->n_iterations = it;
     out->termination = term;
-    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) {
+    if (last_planes) {
         out->n_pairs = have_solution ? (uint64_t)plane_pairs : 0;
         out->rmse = have_solution ? plane_rmse : 0.0;   // rms point-to-plane distance at the last linearisation
         if (!have_solution || !pose_covariance_planes(last_pacc, T, out->cov)) std::memset(out->cov, 0, sizeof out->cov);
@@ -191,6 +278,8 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
 {
     int rc = validate_params(p);
     if (rc) return rc;
+    if (p.n_extra_matchers != 0 || p.n_extra_solvers != 0)
+        return fail(MOLA_ICP_E_UNSUPPORTED, "the batched loop runs single-entry `matchers:` / `solvers:` pipelines (staged pipelines: align the pairs one by one)");
     const bool planes = p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE;
     const int K = st.size();
     if (K <= 0) return MOLA_ICP_OK;

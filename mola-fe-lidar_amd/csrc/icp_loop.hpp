@@ -82,5 +82,8 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
 int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_icp_result* out);
 
 int validate_params(const mola_icp_params& p);
+// the single-entry parameter set in force at iteration `it` of a staged pipeline (include/mola_icp_amd.h: mola_icp_matcher_entry);
+// false: no matcher's range holds the iteration
+bool stage_params(const mola_icp_params& p, uint32_t it, mola_icp_params& eff);
 
 }  // namespace mola_icp_amd
