@@ -820,9 +820,6 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     }
     rows_valid_ = item_rows != nullptr;
     rows_count_ = n_items;
-    rows_items_ = true;
-    // (A batched problem's rows are summed in another order, so beyond the cooperative kernel's range -- 131k queries -- a
-    //  batched result equals its stand-alone align to ~1e-12, not bit for bit.)
     HIPCHK(hipGetLastError());
     return MOLA_ICP_OK;
 }
@@ -835,8 +832,8 @@ int HipWorkspace::fill_nn_problem(const PoseF& P, float thr2, bool use_seed, NnP
     if ((rc = ts_idx_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
     if ((rc = ts_d2_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
     if ((rc = ts_gs_.reserve(sizeof(float) * 3 * loc_sc_->padded))) return rc;
-    const size_t n_items = (N_ + kQPW - 1) / kQPW;
-    if ((rc = rows_.reserve(sizeof(double) * kNAcc * n_items))) return rc;
+    const size_t n_rows = (N_ + 63) / 64;   // one row per 64 queries
+    if ((rc = rows_.reserve(sizeof(double) * kNAcc * n_rows))) return rc;
     const float* sl = loc_sc_->sorted.as<float>();
     pb.slx = sl; pb.sly = sl + loc_sc_->padded; pb.slz = sl + 2 * loc_sc_->padded;
     pb.N = (int)N_;
@@ -867,8 +864,7 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
     HIPCHK(hipGetLastError());
     wave_times_coop_ = true;
     rows_valid_ = true;
-    rows_count_ = n_items;
-    rows_items_ = false;
+    rows_count_ = (int)((N_ + 63) / 64);
     return MOLA_ICP_OK;
 }
 
@@ -1587,10 +1583,10 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     // the first pass of an iteration after a cooperative match: the matcher already summed the unit-weight terms per item
     const bool fused = pairing_sorted_ && rows_valid_ && stage == 0 && reset_outliers;
     const double* rows = partials_.as<double>();
-    if (fused && rows_items_) {
-        // k_nn_tiled's item rows (thousands): G blocks sum a slice each; on a single GPU they publish their G rows to the
-        // pinned block themselves and THIS thread adds them in order -- else the one-block reduction below takes the G rows
-        const int G = std::max(1, std::min(kItemRedBlocks, (rows_count_ + 63) / 64));
+    if (fused) {
+        // the matchers' item rows (one per 64 queries: thousands): G blocks sum a slice each; on a single GPU they publish their G
+        // rows to the pinned block themselves and THIS thread adds them in order -- else the one-block reduction below takes them
+        const int G = item_red_blocks(rows_count_);
         if ((rc = item_part_.reserve(sizeof(double) * kNAcc * kItemRedBlocks))) return rc;
         if (!item_part_host_) {
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&item_part_host_), sizeof(double) * 32 * kItemRedBlocks, hipHostMallocMapped | hipHostMallocCoherent));
@@ -1614,9 +1610,6 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         }
         rows = item_part_.as<double>();
         nblocks = G;
-    } else if (fused) {
-        rows = rows_.as<double>();
-        nblocks = rows_count_;
     } else {
         hipLaunchKernelGGL(k_accumulate, dim3(nblocks), dim3(kAccThreads), 0, stream_, a, partials_.as<double>());
         HIPCHK(hipGetLastError());
@@ -1709,7 +1702,9 @@ void BatchScratch::release_all()
         b.planes.release(); b.plane_cache.release(); b.knn_pos.release(); b.knn_lb.release(); b.plane_partials.release();
     }
     bufs.clear();
-    acc_dev.release(); stats.release(); queue.release(); plane_acc_dev.release();
+    acc_dev.release(); stats.release(); queue.release(); plane_acc_dev.release(); item_part_dev.release();
+    if (item_part_host) (void)hipHostFree(item_part_host);
+    item_part_host = nullptr; item_part_host_problems = 0;
     if (plane_acc_host) (void)hipHostFree(plane_acc_host);
     plane_acc_host = nullptr; plane_acc_host_problems = 0;
     if (acc_host) (void)hipHostFree(acc_host);
@@ -1750,7 +1745,7 @@ int HipBatch::init()
         if ((rc = b.idx.reserve(sizeof(int) * np))) return rc;
         if ((rc = b.d2.reserve(sizeof(float) * np))) return rc;
         if ((rc = b.gs.reserve(sizeof(float) * 3 * np))) return rc;
-        if ((rc = b.rows.reserve(sizeof(double) * kNAcc * (np / kQPW)))) return rc;
+        if ((rc = b.rows.reserve(sizeof(double) * kNAcc * (np / 64)))) return rc;   // one row per 64 queries
         if ((rc = b.outlier.reserve(pr.loc->n))) return rc;
         if ((rc = b.partials.reserve(sizeof(double) * kNAcc * kAccMaxBlocks))) return rc;
     }
@@ -1768,6 +1763,15 @@ int HipBatch::init()
     }
     if (!sc_.stats_host)
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sc_.stats_host), sizeof(unsigned long long) * kStatSlots * kStatStride, hipHostMallocDefault));
+    if ((rc = sc_.item_part_dev.reserve(sizeof(double) * kNAcc * kItemRedBlocks * (K ? K : 1)))) return rc;
+    if (sc_.item_part_host_problems < (K ? K : 1)) {
+        if (sc_.item_part_host) (void)hipHostFree(sc_.item_part_host);
+        sc_.item_part_host = nullptr;
+        const size_t cap = (K ? K : 1) < 16 ? 16 : (K ? K : 1);
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sc_.item_part_host), sizeof(double) * 32 * kItemRedBlocks * cap, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(sc_.item_part_host, 0, sizeof(double) * 32 * kItemRedBlocks * cap);
+        sc_.item_part_host_problems = cap;
+    }
     inited_ = true;
     return MOLA_ICP_OK;
 }
@@ -1837,8 +1841,8 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         const int lds_boxes = max_box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
         const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
         // Few items: latency counts -> one WORKGROUP per item (k_nn_coop, rows fused).  Many (a dozen 100k-point problems
-        // are ~10^4): issue slots count -> the persistent one-wave-per-item matcher over all problems' items, then the
-        // rows (k_item_rows: the same sums, bit for bit).  MOLA_ICP_BATCH_TILED=0|1 forces either.
+        // are ~10^4): issue slots count -> the persistent one-wave-per-item matcher over all problems' items (rows fused too:
+        // the same sums, bit for bit).  MOLA_ICP_BATCH_TILED=0|1 forces either.
         const bool tiled = g_knobs.batch_tiled >= 0 ? g_knobs.batch_tiled != 0 : total_items >= 2 * 1024;
         if (!tiled) {
             hipLaunchKernelGGL((k_nn_coop<kCoopMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
@@ -1861,8 +1865,6 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
             hipLaunchKernelGGL((k_nn_tiled_batch<kCoopMaxBatch, 1>), dim3(grid), dim3(256), lds, ws_.stream_, b, bi, n, shared,
                                sc_.queue.as<unsigned int>(), g_knobs.early_pop ? 1 : 0);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL((k_item_rows<kCoopMaxBatch>), dim3(max_items, n), dim3(256), 0, ws_.stream_, b);
-            HIPCHK(hipGetLastError());
         }
     }
     if (ws_.profiling_) {
@@ -1882,7 +1884,45 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
     HIPCHK(hipSetDevice(ws_.device_));
     const int K = (int)probs_.size();
     const unsigned long long seq = ++sc_.seq;
-    const bool fused = stage == 0 && reset_outliers;  // (every batched match is a cooperative one: its rows are in place)
+    const bool fused = stage == 0 && reset_outliers;  // (every batched match writes its item rows)
+    if (fused) {
+        // per problem the partition and the order of HipWorkspace::accumulate's k_reduce_items + host sum: the same bits
+        for (int k0 = 0; k0 < K;) {
+            ReduceItemsBatch rb;
+            std::memset(&rb, 0, sizeof rb);
+            int n = 0;
+            for (; k0 < K && n < kAccMaxBatch; ++k0) {
+                if (!active[k0]) continue;
+                Buffers& bf = sc_.bufs[(size_t)k0];
+                if (!bf.seed_valid) return fail(MOLA_ICP_E_BADARG, "batched accumulate() before match()");
+                const size_t N = probs_[(size_t)k0].loc->n;
+                if (bf.outliers_dirty || bf.outlier_cleared_for != N) {
+                    HIPCHK(hipMemsetAsync(bf.outlier.p, 0, N, ws_.stream_));
+                    bf.outliers_dirty = false;
+                    bf.outlier_cleared_for = N;
+                }
+                rb.rows[n] = bf.rows.as<double>();
+                rb.n_rows[n] = (int)((N + 63) / 64);
+                rb.slot[n] = k0;
+                ++n;
+            }
+            if (n == 0) break;
+            hipLaunchKernelGGL(k_reduce_items_batch, dim3(kItemRedBlocks, n), dim3(kNAcc * kRedSlices), 0, ws_.stream_, rb,
+                               sc_.item_part_dev.as<double>(), sc_.item_part_host, seq);
+            HIPCHK(hipGetLastError());
+        }
+        for (int k = 0; k < K; ++k) {
+            if (!active[k]) continue;
+            const int G = item_red_blocks((int)((probs_[(size_t)k].loc->n + 63) / 64));
+            for (int c = 0; c < kNAcc; ++c) acc[k][c] = 0.0;
+            for (int g = 0; g < G; ++g) {
+                const double* row = sc_.item_part_host + 32 * ((size_t)kItemRedBlocks * (size_t)k + (size_t)g);
+                if ((rc = ws_.spin_for(reinterpret_cast<volatile unsigned long long*>(const_cast<double*>(row)) + kNAcc + 6, seq))) return rc;
+                for (int c = 0; c < kNAcc; ++c) acc[k][c] += row[c];
+            }
+        }
+        return MOLA_ICP_OK;
+    }
     int n_active = 0;
     for (int k0 = 0; k0 < K;) {
         AccBatch ab;
@@ -1923,19 +1963,16 @@ int HipBatch::accumulate(const uint8_t* active, const mola_icp_params& p, const 
                 for (int c = 0; c < 3; ++c) a.R[3 * r + c] = Tcur[k0](r, c);
             ab.nblocks[n] = nblocks;
             ab.partials[n] = bf.partials.as<double>();
-            // the first pass of an iteration: k_nn_coop already summed the unit-weight terms per item (rows)
-            rb.partials[n] = fused ? bf.rows.as<double>() : bf.partials.as<double>();
-            rb.nblocks[n] = fused ? (int)((N + kQPW - 1) / kQPW) : nblocks;
+            rb.partials[n] = bf.partials.as<double>();
+            rb.nblocks[n] = nblocks;
             rb.slot[n] = k0;
             if (nblocks > max_blocks) max_blocks = nblocks;
             ++n;
         }
         if (n == 0) break;
         n_active += n;
-        if (!fused) {
-            hipLaunchKernelGGL(k_accumulate_batch, dim3(max_blocks, n), dim3(kAccThreads), 0, ws_.stream_, ab);
-            HIPCHK(hipGetLastError());
-        }
+        hipLaunchKernelGGL(k_accumulate_batch, dim3(max_blocks, n), dim3(kAccThreads), 0, ws_.stream_, ab);
+        HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_reduce_partials_batch, dim3(n), dim3(kNAcc * kRedSlices), 0, ws_.stream_, rb, sc_.acc_dev.as<double>(),
                            sc_.acc_host, seq);
         HIPCHK(hipGetLastError());

@@ -70,6 +70,9 @@ struct BatchScratch {
     DevBuf acc_dev, stats, queue;
     double* acc_host = nullptr;                 // pinned: 32 doubles per problem (24 sums, flag in slot 30)
     size_t acc_host_problems = 0;
+    DevBuf item_part_dev;                       // k_reduce_items_batch: 32 partial rows per problem
+    double* item_part_host = nullptr;           // pinned: the same, 32 doubles apart, each with its sequence flag
+    size_t item_part_host_problems = 0;
     DevBuf plane_acc_dev;                       // 96 doubles per problem: the 92-term plane form
     double* plane_acc_host = nullptr;           // pinned: the same, sequence flag in slot 94
     size_t plane_acc_host_problems = 0;
@@ -187,10 +190,9 @@ class HipWorkspace final : public Stages {
     DevBuf sort_scratch_;
     DevBuf ts_pos_, ts_idx_, ts_d2_;  // the tiled matcher's pairing, in SORTED query order
     DevBuf ts_gs_;                    // ... and each neighbour's coordinates (3 x padded floats): next launch's seeds, accumulate's g
-    DevBuf rows_;                     // k_nn_coop's fused stage-0 sums, one row of kNAcc doubles per 128-query item
+    DevBuf rows_;                     // the matchers' fused stage-0 sums, one row of kNAcc doubles per 64 queries (item_row_mfma)
     bool rows_valid_ = false;         // rows_ belongs to the pairing in place
     int rows_count_ = 0;              // ... and holds this many rows
-    bool rows_items_ = false;         // ... written by k_nn_tiled (one per 64-query item: thousands -> k_reduce_items first)
     DevBuf item_part_;                // k_reduce_items' partial rows
     double* item_part_host_ = nullptr;  // pinned: the same, 32 doubles apart, each with its sequence flag
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in

@@ -197,6 +197,28 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_items(const doubl
     }
 }
 
+// ... and for K problems in one launch (grid = (kItemRedBlocks, K)): per problem the partition and the order of its own
+// k_reduce_items launch (the G rows land at host_out + 32 (kItemRedBlocks slot + g), each with its sequence flag)
+__host__ __device__ __forceinline__ int item_red_blocks(int n_rows)
+{
+    const int g = (n_rows + 63) / 64;
+    return g < 1 ? 1 : (g > kItemRedBlocks ? kItemRedBlocks : g);
+}
+struct ReduceItemsBatch {
+    const double* rows[kAccMaxBatch];
+    int n_rows[kAccMaxBatch];
+    int slot[kAccMaxBatch];
+};
+__global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_items_batch(const ReduceItemsBatch b, double* __restrict__ part,
+                                                                           double* __restrict__ host_out, unsigned long long seq)
+{
+    const int y = (int)blockIdx.y, g = (int)blockIdx.x, n_rows = b.n_rows[y], G = item_red_blocks(n_rows);
+    if (g >= G) return;
+    const int lo = (int)(((long long)g * n_rows) / G), hi = (int)(((long long)(g + 1) * n_rows) / G);
+    const size_t o = (size_t)kItemRedBlocks * (size_t)b.slot[y] + (size_t)g;
+    reduce_rows(b.rows[y] + (size_t)lo * kNAcc, hi - lo, part + o * kNAcc, host_out + 32 * o, seq);
+}
+
 // K problems: block y reduces problem y's rows into acc + 32 y and publishes them at host_out + 32 y (flag in slot 30
 // of that stride)
 struct ReduceBatch {

@@ -415,47 +415,6 @@ __device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledM
     return redo;
 }
 
-// The terms of k_accumulate's stage 0 for one pairing (w = 1), summed over an item's 128 pairings in a fixed order: the
-// threads of waves 0/1 hold one pairing each (`paired`, l, g, d2; zeros elsewhere); twelve terms per round go through LDS
-// ([term][pairing]), 16 threads per term add 8 entries each in index order, then a 16-wide shuffle tree.  All 256 threads
-// of the workgroup must call.  Shared by k_nn_coop (fused) and k_item_rows (after the batched persistent matcher): the
-// two produce the same bits.
-__device__ __forceinline__ void item_row_sum(double (*s_acc)[128], bool paired, float al0, float al1, float al2, float ag0, float ag1,
-                                             float ag2, float ad, double* __restrict__ row)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double m = paired ? 1.0 : 0.0;
-    const double l0 = m * al0, l1 = m * al1, l2 = m * al2, g0 = ag0, g1 = ag1, g2 = ag2;
-    const int term = threadIdx.x >> 4, sub = threadIdx.x & 15;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (wave < 2) {
-            const int q = wave * 64 + lane;
-            if (r == 0) {
-                s_acc[0][q] = m; s_acc[1][q] = l0; s_acc[2][q] = l1; s_acc[3][q] = l2;
-                s_acc[4][q] = m * g0; s_acc[5][q] = m * g1; s_acc[6][q] = m * g2;
-                s_acc[7][q] = l0 * g0; s_acc[8][q] = l0 * g1; s_acc[9][q] = l0 * g2;
-                s_acc[10][q] = l1 * g0; s_acc[11][q] = l1 * g1;
-            } else {
-                s_acc[0][q] = l1 * g2; s_acc[1][q] = l2 * g0; s_acc[2][q] = l2 * g1; s_acc[3][q] = l2 * g2;
-                s_acc[4][q] = m; s_acc[5][q] = m * (double)ad;
-                s_acc[6][q] = l0 * al0; s_acc[7][q] = l0 * al1; s_acc[8][q] = l0 * al2;
-                s_acc[9][q] = l1 * al1; s_acc[10][q] = l1 * al2; s_acc[11][q] = l2 * al2;
-            }
-        }
-        __syncthreads();
-        double t = 0.0;
-        if (term < 12) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t += s_acc[term][sub + 16 * j];
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) t += __shfl_down(t, off, 16);
-        if (term < 12 && sub == 0) row[12 * r + term] = t;
-        __syncthreads();
-    }
-}
-
 template <int KMAX, bool DIAG = false /*per-wave phase records (MOLA_ICP_DEBUG_STATS=2); compiled out of the launch path: see k_nn_tiled*/>
 __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, int lds_boxes,
                                                     unsigned long long* __restrict__ wave_times /*diagnostics, usually null*/)
@@ -466,7 +425,6 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
     __shared__ int s_ctl[2];                          // [0] entries in s_list
     __shared__ unsigned int s_mg[kCoopParts][6][64];  // per wave: its partial result for the 128 queries
     __shared__ unsigned int s_flag[4];                // [0..1] tie seen by finishing wave 0/1, [2] staged points
-    __shared__ double s_acc[12][128];                 // fused accumulation: 12 terms x 128 pairings per round
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float(*sm)[64] = s_m[wave];
@@ -522,11 +480,14 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
     }
 
     // ---- the pairing (sorted query order, coalesced) and the item's row of unit-weight sums ----
-    float al0 = 0.f, al1 = 0.f, al2 = 0.f, ag0 = 0.f, ag1 = 0.f, ag2 = 0.f, ad = 0.f;
-    bool paired = false;
-    if (wave < 2) {
+    // Rows of 64 queries, formed by the finishing wave itself on the fp64 matrix cores (item_row_mfma, kernels_tiled.hpp): the
+    // SAME row, bit for bit, that k_nn_tiled / k_nn_tiled_batch write for these 64 queries -- a problem's accumulators, and its
+    // pose, do not depend on which matcher served it, at any size.  No workgroup barrier: waves 2 / 3 are done.
+    if (wave < 2 && (2 * item + wave) * 64 < N) {   // (wave-uniform; a half that is all padding has no row)
         const int k = wave;
         const int fqi = k ? qi[1] : qi[0];
+        float al0 = 0.f, al1 = 0.f, al2 = 0.f;
+        bool paired = false;
         if (fqi < N) {
             pb.pos_s[fqi] = res.rpos;
             pb.idx_s[fqi] = res.rpos >= 0 ? res.roi : -1;
@@ -534,10 +495,9 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
             pb.gsx[fqi] = res.gx; pb.gsy[fqi] = res.gy; pb.gsz[fqi] = res.gz;
             paired = res.rpos >= 0;
             al0 = pb.slx[fqi]; al1 = pb.sly[fqi]; al2 = pb.slz[fqi];  // (re-read: cheaper than six registers held through the sweep)
-            ag0 = res.gx; ag1 = res.gy; ag2 = res.gz; ad = res.rd;
         }
+        item_row_mfma(&sm[0][0], lane, paired, al0, al1, al2, res.gx, res.gy, res.gz, res.rd, pb.rows + (size_t)(2 * item + wave) * kNAcc);
     }
-    item_row_sum(s_acc, paired, al0, al1, al2, ag0, ag1, ag2, ad, pb.rows + (size_t)item * kNAcc);
 
     if (prof && lane == 0 && blockIdx.y == 0 && blockIdx.x * 4 + wave < 8192) {
         // [start, end (wall clock)], then shader cycles: setup (round trip A + boxes -> LDS), sweep, wait for the other
@@ -558,9 +518,9 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
 // persistent one-wave-per-item matcher of kernels_tiled.hpp over the items of ALL problems (entry -> problem by the
 // prefix sums `item_base`): same sweep, same visitors, same tie rule; a wave that meets an exact distance tie redoes
 // its item with the exact-key visitor at once.  The upper box levels come from the LDS copy only if every problem
-// shares ONE map (`shared_map`: the loop-closure Monte-Carlo), else from global memory.  k_item_rows then writes the
-// per-item rows of unit-weight sums exactly as k_nn_coop does (item_row_sum), so a problem's accumulators -- and its
-// pose -- do not depend on which of the two matchers served it.
+// shares ONE map (`shared_map`: the loop-closure Monte-Carlo), else from global memory.  Every item's row of unit-weight
+// sums is formed in the epilogue exactly as k_nn_coop and k_nn_tiled form it (item_row_mfma: the same bits for the same 64
+// queries), so a problem's accumulators -- and its pose -- do not depend on which of the matchers served it.
 template <int KMAX> struct NnBatchItems { int base[KMAX + 1]; };  // base[k] = first entry of problem k; base[n] = total
 
 template <int QL, bool EXACT, class AfterSweep>
@@ -622,6 +582,8 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
     after_sweep();
 
     bool any_tie = false;
+    int f_pos = -1;                                    // (QL = 1: the lane's result, for the item's row)
+    float f_d = 0.f, f_gx = 0.f, f_gy = 0.f, f_gz = 0.f;
 #pragma unroll
     for (int k = 0; k < QL; ++k) {
         int rpos = -1, roi = -1;
@@ -675,8 +637,17 @@ __device__ __forceinline__ bool tiled_batch_item(const NnProblem& pb, const Tile
             pb.gsx[qi[k]] = wx; pb.gsy[qi[k]] = wy; pb.gsz[qi[k]] = wz;
             any_tie |= tie[k] >= 2;
         }
+        if constexpr (QL == 1) { f_pos = rpos; f_d = rd; f_gx = wx; f_gy = wy; f_gz = wz; }
     }
-    return !EXACT && __any(any_tie);
+    const bool redo = !EXACT && __any(any_tie);
+    if constexpr (QL == 1) {
+        if (!redo) {   // (wave-uniform; a tied item's row is written by its exact redo) -- the item's row of unit-weight sums
+            const int ic = qi[0] < N ? qi[0] : N - 1;
+            item_row_mfma(&sm[0][0], lane, qi[0] < N && f_pos >= 0, pb.slx[ic], pb.sly[ic], pb.slz[ic], f_gx, f_gy, f_gz, f_d,
+                          pb.rows + (size_t)item * kNAcc);
+        }
+    }
+    return redo;
 }
 
 template <int KMAX, int QL /*queries per lane: items of 64 * QL queries (1: as k_nn_tiled's default, four workgroups per CU)*/>
@@ -716,29 +687,6 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled_batch(const NnBatch<KMAX> b
     }
     if (lane == 0 && wave_staged)
         atomicAdd(batch.p[0].staged + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, wave_staged * (unsigned long long)QL);
-}
-
-// one workgroup per (item, problem): the item's row of unit-weight sums from the stored pairing -- k_nn_coop's fused rows
-template <int KMAX>
-__global__ __launch_bounds__(256) void k_item_rows(const NnBatch<KMAX> batch)
-{
-    __shared__ double s_acc[12][128];
-    const NnProblem& pb = batch.p[KMAX == 1 ? 0 : blockIdx.y];
-    const int item = (int)blockIdx.x;
-    if (item * kQPW >= pb.N) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float al0 = 0.f, al1 = 0.f, al2 = 0.f, ag0 = 0.f, ag1 = 0.f, ag2 = 0.f, ad = 0.f;
-    bool paired = false;
-    if (wave < 2) {
-        const int q = item * kQPW + wave * 64 + lane;
-        if (q < pb.N) {
-            paired = pb.pos_s[q] >= 0;
-            al0 = pb.slx[q]; al1 = pb.sly[q]; al2 = pb.slz[q];
-            ag0 = pb.gsx[q]; ag1 = pb.gsy[q]; ag2 = pb.gsz[q];
-            ad = pb.d2_s[q];
-        }
-    }
-    item_row_sum(s_acc, paired, al0, al1, al2, ag0, ag1, ag2, ad, pb.rows + (size_t)item * kNAcc);
 }
 
 }  // namespace mola_icp_amd

@@ -43,10 +43,10 @@ def test_tiled_matcher_finishes_in_every_flavour(pkg, synth, monkeypatch, n, m):
             if ref is None:
                 ref = r
             else:   # exact NN: the pairing cannot depend on the item flavour, the queue order or the seeds
-                if env.get("MOLA_ICP_COOP") is None and env.get("MOLA_ICP_QPL") != "2":
+                if env.get("MOLA_ICP_QPL") != "2":   # (cooperative or persistent: the same rows of 64 queries, bit for bit)
                     assert np.array_equal(r.optimal_tf, ref.optimal_tf), env
-                else:   # (the cooperative kernel sums its rows in another order, and so does k_accumulate behind the 128-query
-                        #  items -- the 64-query items' sums are formed in the matcher's epilogue: same pairing, last-bit differences)
+                else:   # (k_accumulate behind the 128-query items sums the pairing in another order than the 64-query items'
+                        #  rows, which are formed in the matcher's epilogue: same pairing, last-bit differences)
                     np.testing.assert_allclose(r.optimal_tf, ref.optimal_tf, rtol=0, atol=1e-12)
                 assert r.n_pairs == ref.n_pairs
             if "MOLA_ICP_QPL" not in env and "MOLA_ICP_COOP" not in env and n <= 1_000_000:   # the kNN flavours share the queue code
