@@ -1,9 +1,15 @@
 #!/bin/bash
-# A/B of environment knobs on ONE box, alternating, N rounds: bash tools/gpu_ab.sh "A=1" "MOLA_ICP_NO_SPLIT=1" ...
-R=${ROUNDS:-3}
-for r in $(seq 1 $R); do
-  for kv in "$@"; do
-    env $kv python bench.py --cpu-baseline-iters 0 --dense-iters 0 --shipped-iters 0 --e2e 0 --batch-pairs 0 2>/dev/null | tail -n1 | python -c "
-import json,sys; d=json.load(sys.stdin); print('round $r', '$kv', 'value %.0f it/s  kernel %.1f us  pairs/query %.0f' % (d['value'], d['roofline']['kernel_ms']*1e3, d['roofline']['flop_view']['pairs_evaluated_per_query']))"
-  done
-done
+# round 3: A/B of one environment knob on the headline bench (no CPU legs):  tools/gpu_r3_ab.sh <tag> <KNOB=1> [more bench args]
+tag=$1; knob=$2; shift 2
+mkdir -p gpurun_out/$tag
+Q="--cpu-baseline-iters 0 --e2e 0 --batch-pairs 0 --dense-iters 0"
+python bench.py $Q "$@" > gpurun_out/$tag/default.json 2> gpurun_out/$tag/default.err || exit 1
+env $knob python bench.py $Q "$@" > gpurun_out/$tag/knob.json 2> gpurun_out/$tag/knob.err || exit 1
+python bench.py $Q "$@" > gpurun_out/$tag/default2.json 2> gpurun_out/$tag/default2.err || exit 1
+python - <<PY
+import json
+for n in ("default", "knob", "default2"):
+    j = json.load(open("gpurun_out/$tag/%s.json" % n))
+    s = j.get("shipped_point2plane_gn", {})
+    print(n, "it/s %.0f  ms/step %.4f  matcher ms %.4f  shipped it/s %.0f" % (j["value"], j["ms_per_step"], j["roofline"]["kernel_ms"], s.get("value", 0)))
+PY
