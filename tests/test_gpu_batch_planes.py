@@ -85,3 +85,35 @@ def test_nearby_keyframe_pairs_shipped_settings_batch(pkg, O, synth):
         for k in range(2):
             _same(rb[k], icp.align(pairs[k][0], pairs[k][1], inits[k], q))
     icp.close()
+
+
+def test_concurrent_batch_calls_on_one_handle_finish(pkg, synth):
+    """mola_icp_align_batch used to run its second lockstep loop as a job on the handle's fixed-size worker pool, where
+    it blocked on prepare-ahead tasks queued to the same pool -- several concurrent calls with 4+ chunks each could fill every
+    worker with a waiting loop.  Six threads, 40 pairs each (4 chunks), one handle: all must return, each result equal to the
+    single-threaded batch's."""
+    import threading
+    pairs = [synth.make_pair(9_000 + 300 * k, 10_000, seed=500 + k)[:2] for k in range(40)]
+    p = pkg.Parameters()
+    p.matcher_threshold, p.max_iterations, p.min_abs_step_trans, p.min_abs_step_rot = 1.0, 30, 5e-5, 1e-5
+    icp = pkg.ICP(device=0)
+    ref = icp.align_batch(pairs, [np.eye(4)] * len(pairs), p)
+    out, errs = [None] * 6, []
+
+    def work(i):
+        try:
+            out[i] = icp.align_batch(pairs, [np.eye(4)] * len(pairs), p)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a concurrent align_batch call never returned"
+    assert not errs, errs
+    for res in out:
+        for r, s in zip(res, ref):
+            assert r.nIterations == s.nIterations and np.array_equal(r.optimal_tf, s.optimal_tf)
+    icp.close()
