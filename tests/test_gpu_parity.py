@@ -524,9 +524,12 @@ def test_native_rccl_single_rank(pkg, icp, golden):
     h.set_local(l)
     p = p2p_params(pkg, max_iterations=30)
     plain = h.align_resident(np.eye(4), p)
+    with pytest.raises(pkg.IcpError, match="no communicator"):   # nothing to report before mola_icp_comm_init
+        h.comm_nranks()
     ident = (ctypes.c_uint8 * 128)()
     L.check(L.lib().mola_icp_comm_unique_id(ident))
     L.check(L.lib().mola_icp_comm_init(h._h, ident, 1, 0))
+    assert h.comm_nranks() == 1                # what RCCL itself reports (ncclCommCount)
     with pytest.raises(pkg.IcpError):      # a second communicator on the same handle is refused
         L.check(L.lib().mola_icp_comm_init(h._h, ident, 1, 0))
     r = h.align_resident(np.eye(4), p)
