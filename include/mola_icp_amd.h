@@ -232,8 +232,13 @@ int mola_icp_align(mola_icp_handle* h,
                    const float* to_x, const float* to_y, const float* to_z, size_t N,
                    const double init_T[16], const mola_icp_params* p, mola_icp_result* out);
 
-/* Loop-closure / nearby-KF batch (src/LidarOdometry.cpp:704-741, 767-788):
- * n_pairs independent problems, stream-per-pair on this handle's device.
+/* Loop-closure / nearby-KF batch (src/LidarOdometry.cpp:704-741, 767-788): n_pairs independent problems on this
+ * handle's device.  Pairs advance in LOCKSTEP, a dozen at a time -- every stage of an iteration is one launch over the
+ * pairs still iterating -- for both single-entry pipelines: point-to-point + Horn and the reference's own nearby /
+ * loop-closure settings, Matcher_Point2Plane + Solver_GaussNewton (params/icp-settings-loop-closure.yaml:23-39); the
+ * next chunk's uploads and preparation overlap the current chunk's loop.  Pairs the lockstep path does not serve (tiny
+ * clouds under the dense NN kernels, staged multi-entry pipelines) run stream-per-pair on the handle's worker threads.
+ * Every result equals the pair's stand-alone mola_icp_align, bit for bit.
  * Arrays of per-pair pointers/sizes; init_T = n_pairs x 16; out = n_pairs results. */
 int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs,
                          const float* const* from_x, const float* const* from_y, const float* const* from_z,
@@ -265,7 +270,9 @@ int mola_icp_pool_align_batch(mola_icp_pool* pool, size_t n_pairs,
 /* Loop-closure Monte-Carlo (src/LidarOdometry.cpp:767-788): the SAME pair aligned from n_init initial
  * poses (init_T = n_init x 16), keeping the attempt with the highest goodness (strictly greater, i.e. the
  * first best, as `if (this_icp_out.goodness > icp_out.goodness)` cpp:785).  The clouds are uploaded and
- * prepared once.  out = n_init results (may be NULL), *best_index = winner, -1 if every goodness is 0. */
+ * prepared once and the guesses are a batch dimension on the device (lockstep, as mola_icp_align_batch; each attempt
+ * bit-equal to a stand-alone align from that guess).  out = n_init results (may be NULL), *best_index = winner, -1 if
+ * every goodness is 0. */
 int mola_icp_align_multi_init(mola_icp_handle* h,
                               const float* from_x, const float* from_y, const float* from_z, size_t M,
                               const float* to_x, const float* to_y, const float* to_z, size_t N,
