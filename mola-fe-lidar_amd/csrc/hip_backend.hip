@@ -1240,7 +1240,7 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
         HIPCHK(hipStreamSynchronize(stream_));
         HIPCHK(hipMemcpy(w.data(), wave_times_, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t1 = 0ull;
-        std::vector<unsigned long long> ends, pro, swp, epi, stg, setup, mwait, starts, entered, tiles, supers, boxwait, tiletest, stagec, visitc;
+        std::vector<unsigned long long> ends, pro, swp, epi, stg, setup, mwait, starts, entered, tiles, supers, boxwait, tiletest, stagec, visitc, fillw, fill0;
         for (size_t i = 0; i < 8192; ++i)
             if (w[8 * i + 1]) {
                 t0 = std::min(t0, w[8 * i]); t1 = std::max(t1, w[8 * i + 1]); ends.push_back(w[8 * i + 1]);
@@ -1250,6 +1250,7 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
                     auto hi = [&](int k) { return w[8 * i + k] >> 32; };
                     setup.push_back(lo(2)); pro.push_back(hi(2)); swp.push_back(lo(3)); mwait.push_back(hi(3)); epi.push_back(lo(4));
                     boxwait.push_back(hi(4)); tiletest.push_back(lo(5)); stagec.push_back(hi(5)); visitc.push_back(lo(6));
+                    ((i & 3) == 0 ? fill0 : fillw).push_back(hi(6));   // wave 0 walks the upper box levels, the others wait for it
                     stg.push_back(w[8 * i + 7] & 0xffffull);
                     entered.push_back((w[8 * i + 7] >> 16) & 0xffffull); tiles.push_back((w[8 * i + 7] >> 32) & 0xffffull);
                     supers.push_back(w[8 * i + 7] >> 48);
@@ -1311,6 +1312,9 @@ int HipWorkspace::collect_stats(double* ms_total, uint32_t* launches, uint32_t* 
                                      "own tile tests %llu / %llu / %llu\n",
                              med(supers, 0.5), med(supers, 0.9), med(supers, 1.0), med(entered, 0.5), med(entered, 0.9), med(entered, 1.0),
                              med(tiles, 0.5), med(tiles, 0.9), med(tiles, 1.0));
+                if (!fill0.empty() && !fillw.empty())
+                    std::fprintf(stderr, "[mola_icp debug]   list fill + barrier (median / p90 / max cycles): wave 0 (the walk over the upper box levels) %llu / %llu / %llu, waves 1-3 (waiting for it) %llu / %llu / %llu\n",
+                                 med(fill0, 0.5), med(fill0, 0.9), med(fill0, 1.0), med(fillw, 0.5), med(fillw, 0.9), med(fillw, 1.0));
                 std::fprintf(stderr, "[mola_icp debug]   inside the sweep (median / p90 / max cycles): tile-box wait %llu / %llu / %llu, tile tests + passes %llu / %llu / %llu, "
                                      "of which staging (wait for points) %llu / %llu / %llu, distance passes %llu / %llu / %llu\n",
                              med(boxwait, 0.5), med(boxwait, 0.9), med(boxwait, 1.0), med(tiletest, 0.5), med(tiletest, 0.9), med(tiletest, 1.0),

@@ -64,10 +64,10 @@ struct CoopResult {
 //     exactly cullable for every query, so the merged result is exact.
 template <bool NEED_PERM, class Visit>
 __device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* s_list,
-                                                         float* s_wbox, int* s_ctl, int lane, int part, float (*sm)[64],
+                                                         float* s_wbox, int* s_ctl, int* s_tick /*kMaxList tickets*/, int lane, int part, float (*sm)[64],
                                                          const float (&qx)[2], const float (&qy)[2], const float (&qz)[2],
                                                          const float (&reach)[2], const float (&bound2)[2], Visit&& visit,
-                                                         bool prof, unsigned long long (&pc)[4], unsigned int (&pn)[3])
+                                                         bool prof, unsigned long long (&pc)[5], unsigned int (&pn)[3])
 {
     unsigned long long n_staged = 0;
     // squared distance from each query to the box vs its live bound (see tiled_sweep::any_reach: exact, no margins)
@@ -197,12 +197,16 @@ __device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, con
     };
 
     bool have_w = part == 0;
+    (void)part;
     for (;;) {
+        const unsigned long long tf0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
         if (part == 0) {
             const int n = fill_list();
             if (lane == 0) s_ctl[0] = n;
+            s_tick[lane] = 0;   // (kMaxList = 64 = one per lane) every listed super-tile's candidate tiles are dealt from ticket 0
         }
         __syncthreads();
+        if (prof) pc[4] += __builtin_amdgcn_s_memtime() - tf0;   // wave 0: the walk over the upper box levels; the others: waiting for it
         const int n_list = s_ctl[0];  // (workgroup-uniform)
         if (n_list == 0) break;
         if (!have_w) {
@@ -225,14 +229,25 @@ __device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, con
                 n0 = mp.tbox[ti]; n1 = mp.tbox[mp.n_tiles_p + ti]; n2 = mp.tbox[2 * mp.n_tiles_p + ti];
                 n3 = mp.tbox[3 * mp.n_tiles_p + ti]; n4 = mp.tbox[4 * mp.n_tiles_p + ti]; n5 = mp.tbox[5 * mp.n_tiles_p + ti];
             }
-            unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
-                                               b4 >= w.lo[1] && b5 >= w.lo[2]);
-            cand &= 0x1111111111111111ull << ((part - Sc) & 3);  // this wave's tiles of the super-tile
+            // The candidate tiles of this super-tile (the same set in all four waves: same boxes, same wave box) are dealt by
+            // TICKET: a wave takes the next one nobody has taken (one LDS atomic), whichever it is.  A static deal -- tile t to
+            // wave (t + S) % 4, rounds 1-2 -- left the waves up to 3x apart (own tile tests 4 / 7 / 31 per wave at 100k x 100k)
+            // and the item as long as its slowest wave.  Still exact: every tile has ONE taker, and a tile its taker's live
+            // bounds cannot reach holds nothing that beats the final ones either.
+            const unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
+                                                     b4 >= w.lo[1] && b5 >= w.lo[2]);
+            const int n_cand = __popcll(cand);
+            const bool my_bit = (cand >> lane) & 1ull;
+            const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(cand >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)cand, 0u));
             const unsigned long long tb1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-            auto next_tile = [&]() -> int {  // next own candidate some query still reaches (live bound), or -1
-                while (cand) {
-                    const int t = __builtin_ctzll(cand);
-                    cand &= cand - 1;
+            bool dry = n_cand == 0;
+            auto next_tile = [&]() -> int {  // the next candidate nobody has taken that some query still reaches (live bound), or -1
+                while (!dry) {
+                    int tk = 0;
+                    if (lane == 0) tk = atomicAdd(&s_tick[e], 1);
+                    tk = __builtin_amdgcn_readfirstlane(tk);
+                    if (tk >= n_cand) { dry = true; break; }
+                    const int t = __builtin_ctzll(__ballot(my_bit && my_rank == tk));
                     if (prof) pn[2] += 1;
                     if (any_reach(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
                                   bcast_lane(b4, t), bcast_lane(b5, t)))
@@ -253,8 +268,8 @@ __device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, con
             }
             if (prof) { const unsigned long long tb2 = __builtin_amdgcn_s_memtime(); pc[2] += tb1 - tb0; pc[3] += tb2 - tb1; pn[1] += 1; }
         }
-        __syncthreads();  // the shared list is rewritten from here on
-        if (n_list < kMaxList) break;  // the scan of the upper levels has ended
+        if (n_list < kMaxList) break;  // the scan of the upper levels has ended (no barrier: nothing shared is rewritten any more)
+        __syncthreads();  // the shared list and its tickets are rewritten from here on
     }
     if (pend_a >= 0) compute_pending(-1, -1);
     return n_staged;
@@ -265,7 +280,7 @@ __device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, con
 // Returns (workgroup-uniform) whether some query met an exact distance tie the fast visitor cannot resolve.
 template <bool EXACT>
 __device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledMap& mp, const lds_f32* lbox, bool lds_boxes, int* s_list,
-                                               float* s_wbox, int* s_ctl,
+                                               float* s_wbox, int* s_ctl, int* s_tick,
                                                float (*sm)[64], unsigned int (*s_mg)[6][64], unsigned int* s_flag, int lane,
                                                int wave, const float (&qx)[2], const float (&qy)[2], const float (&qz)[2],
                                                const int (&qi)[2], const int (&js)[2],
@@ -301,10 +316,10 @@ __device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledM
             key[k] = ((unsigned long long)__float_as_uint(thr2) << 32);  // (a padding lane loaded the last query's seed: the exact epilogue reads the point at bpos for any key below the gate)
         }
     }
-    unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long pc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     unsigned int pn[3] = {0u, 0u, 0u};
     const unsigned long long n_staged = coop_sweep<EXACT>(
-        mp, lbox, lds_boxes, s_list, s_wbox, s_ctl, lane, wave, sm, qx, qy, qz, reach, best,
+        mp, lbox, lds_boxes, s_list, s_wbox, s_ctl, s_tick, lane, wave, sm, qx, qy, qz, reach, best,
         [&](int nm, int jb0, int jb1) {
             if constexpr (EXACT) nn_visit_exact<2>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
             else nn_visit_fast<2>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
@@ -313,7 +328,7 @@ __device__ __forceinline__ bool coop_item_pass(const NnProblem& pb, const TiledM
     if (prof) {
         dbg[0] = __builtin_amdgcn_s_memtime();
         dbg[1] = n_staged | ((unsigned long long)pn[1] << 16) | ((unsigned long long)pn[2] << 32) | ((unsigned long long)pn[0] << 48);
-        dbg[4] = pc[0]; dbg[5] = pc[1]; dbg[6] = pc[2]; dbg[7] = pc[3];  // staging, distance passes, tile-box wait, tile tests (+ the passes inside)
+        dbg[4] = pc[0]; dbg[5] = pc[1] | (pc[4] << 32); dbg[6] = pc[2]; dbg[7] = pc[3];  // staging, distance passes | list fill + barrier, tile-box wait, tile tests (+ the passes inside)
     }
 
     // ---- merge the four partial results per query through LDS ----
@@ -423,6 +438,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
     __shared__ int s_list[kMaxList];                  // super-tiles some query reaches (written by wave 0, streamed by all)
     __shared__ float s_wbox[6];                       // the wave box (wave 0's reduction)
     __shared__ int s_ctl[2];                          // [0] entries in s_list
+    __shared__ int s_tick[kMaxList];                  // per listed super-tile: the next candidate tile to hand out (coop_sweep)
     __shared__ unsigned int s_mg[kCoopParts][6][64];  // per wave: its partial result for the 128 queries
     __shared__ unsigned int s_flag[4];                // [0..1] tie seen by finishing wave 0/1, [2] staged points
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
@@ -471,11 +487,11 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
 
     CoopResult res;
     unsigned long long dbg[8] = {};
-    if (coop_item_pass<false>(pb, mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, sm, s_mg, s_flag, lane, wave, qx, qy, qz, qi, js, sd, thr2,
+    if (coop_item_pass<false>(pb, mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, s_tick, sm, s_mg, s_flag, lane, wave, qx, qy, qz, qi, js, sd, thr2,
                               res, prof, dbg)) {
         // exact distance ties in this item: once more with the per-pair (d2, original index) key
         unsigned long long dbg2[8];
-        (void)coop_item_pass<true>(pb, mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, sm, s_mg, s_flag, lane, wave, qx, qy, qz, qi, js, sd,
+        (void)coop_item_pass<true>(pb, mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, s_tick, sm, s_mg, s_flag, lane, wave, qx, qy, qz, qi, js, sd,
                                    thr2, res, false, dbg2);
     }
 
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
         // (two 32-bit cycle counts per slot from [2] on)
         auto pk = [](unsigned long long lo, unsigned long long hi) { return (lo & 0xffffffffull) | (hi << 32); };
         w[0] = t_wave0; w[1] = wall_clock64(); w[2] = pk(c1 - c0, c2 - c1); w[3] = pk(dbg[0] - c2, dbg[2] - dbg[0]);
-        w[4] = pk(__builtin_amdgcn_s_memtime() - dbg[2], dbg[6]); w[5] = pk(dbg[7], dbg[4]); w[6] = pk(dbg[5], 0ull); w[7] = dbg[1];
+        w[4] = pk(__builtin_amdgcn_s_memtime() - dbg[2], dbg[6]); w[5] = pk(dbg[7], dbg[4]); w[6] = pk(dbg[5] & 0xffffffffull, dbg[5] >> 32); w[7] = dbg[1];
     }
     if (threadIdx.x == 0 && s_flag[2])  // executed work in units of 64 (query, point) pairs; slotted: no same-address burst
         atomicAdd(pb.staged + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, (unsigned long long)s_flag[2] * 2ull);

@@ -496,6 +496,7 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
     __shared__ int s_list[kMaxList];
     __shared__ float s_wbox[6];
     __shared__ int s_ctl[4];
+    __shared__ int s_tick[kMaxList];
     __shared__ unsigned long long s_mk[kCoopParts - 1][K][64];
     __shared__ int s_mpos[kCoopParts - 1][K][64];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -583,10 +584,10 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
     if (qi >= N) { q2x[0] = q2y[0] = q2z[0] = 1.0e18f; reach2[0] = -1.0f; kb2[0] = -1.0f; }
     unsigned long long n_staged = 0ull;
     if (!skip_sweep) {   // (workgroup-uniform: the barriers inside are met by all four waves)
-        unsigned long long pc[4] = {};
+        unsigned long long pc[5] = {};
         unsigned int pn[3] = {};
         float(*sm)[64] = s_m[wave];
-        n_staged = coop_sweep<true>(mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, lane, wave, sm, q2x, q2y, q2z, reach2, kb2, [&](int nm, int jb0, int jb1) {
+        n_staged = coop_sweep<true>(mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, s_tick, lane, wave, sm, q2x, q2y, q2z, reach2, kb2, [&](int nm, int jb0, int jb1) {
             for (int m = 0; m < nm; m += 4) {
                 const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
                 const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
