@@ -28,7 +28,7 @@ def test_loop_closure_montecarlo_shipped_settings_is_a_device_batch(pkg, O, synt
         d = rng.normal(0, 1, 4) * np.array([0.3, 0.3, 0.3, np.deg2rad(2.0)])
         guesses.append(synth.pose_from_xyzypr(d[0], d[1], d[2], d[3], 0, 0))
     icp = pkg.ICP(device=0)
-    icp.align_multi_init(g, l, guesses[:2], p)                   # warm-up
+    icp.align_multi_init(g, l, guesses, p)                       # warm-up (all ten: the per-guess plane buffers are allocated once)
     t0 = time.perf_counter()
     res, best = icp.align_multi_init(g, l, guesses, p)
     dt = time.perf_counter() - t0
