@@ -16,7 +16,6 @@
 #include <cmath>
 #include <algorithm>
 #include <atomic>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -638,10 +637,7 @@ int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, 
     if (n && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null cloud pointer");
     if (n > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "cloud too large for 32-bit indices");
     HIPCHK(hipSetDevice(device_));
-    const auto t_b0 = std::chrono::steady_clock::now();
     if ((rc = upload_soa(sc.raw, stream_, x, y, z, n, &sc.x, &sc.y, &sc.z))) return rc;
-    if (g_knobs.debug_stats) (void)hipStreamSynchronize(stream_);
-    const auto t_b1 = std::chrono::steady_clock::now();
     sc.n = n;
     sc.cached = true;
     // build the sorted form through the map-role path of this workspace, then hand the buffers over
@@ -655,11 +651,6 @@ int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, 
     rc = n ? prepare_tiles() : MOLA_ICP_OK;
     // (the workspace's own map is put back BEFORE any return: map_sc_ aliases the caller's cloud through a no-op deleter)
     const hipError_t es = rc ? hipSuccess : hipStreamSynchronize(stream_);
-    if (g_knobs.debug_stats) {
-        const auto t_b2 = std::chrono::steady_clock::now();
-        const double up = std::chrono::duration<double, std::milli>(t_b1 - t_b0).count(), pr = std::chrono::duration<double, std::milli>(t_b2 - t_b1).count();
-        if (up + pr > 2.0) std::fprintf(stderr, "[mola_icp debug] build_cached(%zu points): upload %.2f ms, sort + boxes %.2f ms\n", n, up, pr);
-    }
     map_sc_ = keep_sc;
     gx_ = kx; gy_ = ky; gz_ = kz; M_ = kM;
     if (es != hipSuccess) return fail(es == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("build_cached: ") + hipGetErrorString(es));
