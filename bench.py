@@ -426,7 +426,14 @@ def _self_launch(args):
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
     alive = set(range(args.gpus))
+    t_start = time.perf_counter()
+    limit_s = float(os.environ.get("MOLA_BENCH_LAUNCH_TIMEOUT_S", "1500"))   # a rank that never returns must not hold the node for ever
     while alive:
+        if time.perf_counter() - t_start > limit_s:
+            print(f"[bench] ranks {sorted(alive)} still running after {limit_s:.0f} s: stopping them", file=sys.stderr, flush=True)
+            for o in sorted(alive):
+                procs[o].kill()
+            return 124
         for r in sorted(alive):
             code = procs[r].poll()
             if code is None:
