@@ -87,6 +87,13 @@ typedef struct mola_icp_matcher_entry {
     uint32_t run_from_iteration;         /* runFromIteration                         */
     uint32_t run_up_to_iteration;        /* runUpToIteration (0 = no limit)          */
 } mola_icp_matcher_entry;
+/* entries 1.. of `quality:` (icpreg:40-46 is a sequence too): Results::quality = sum w_i q_i / sum w_i over all entries ([EXT-recalled]
+ * mp2p_icp weighs its quality evaluators; `weight` defaults to 1).  One more matcher pass per entry. */
+typedef struct mola_icp_quality_entry {
+    int32_t  quality_class;              /* MOLA_ICP_QUALITY_*                       */
+    double   quality_threshold;          /* thresholdDistance [m]                    */
+    double   weight;                     /* weight (default 1)                       */
+} mola_icp_quality_entry;
 typedef struct mola_icp_solver_entry {
     int32_t  solver_class;               /* MOLA_ICP_SOLVER_*                        */
     uint32_t solver_max_iterations;      /* params.maxIterations (Gauss-Newton)      */
@@ -127,6 +134,9 @@ typedef struct mola_icp_params {
     uint32_t n_extra_solvers;
     mola_icp_matcher_entry extra_matchers[MOLA_ICP_MAX_EXTRA_STAGES];
     mola_icp_solver_entry  extra_solvers[MOLA_ICP_MAX_EXTRA_STAGES];
+    double   quality_weight;             /* quality[0].weight (0 is read as 1: a zeroed / pre-ABI-3 struct means one evaluator) */
+    uint32_t n_extra_quality;
+    mola_icp_quality_entry extra_quality[MOLA_ICP_MAX_EXTRA_STAGES];
 } mola_icp_params;
 
 /* ---- result == the fields of mp2p_icp::Results that the reference consumes

@@ -35,6 +35,10 @@ class CSolverEntry(C.Structure):
                 ("run_up_to_iteration", C.c_uint32)]
 
 
+class CQualityEntry(C.Structure):
+    _fields_ = [("quality_class", C.c_int32), ("quality_threshold", C.c_double), ("weight", C.c_double)]
+
+
 class CParams(C.Structure):
     _fields_ = [
         ("max_iterations", C.c_uint32),
@@ -64,6 +68,9 @@ class CParams(C.Structure):
         ("n_extra_solvers", C.c_uint32),
         ("extra_matchers", CMatcherEntry * MAX_EXTRA_STAGES),
         ("extra_solvers", CSolverEntry * MAX_EXTRA_STAGES),
+        ("quality_weight", C.c_double),
+        ("n_extra_quality", C.c_uint32),
+        ("extra_quality", CQualityEntry * MAX_EXTRA_STAGES),
     ]
 
 

@@ -242,7 +242,7 @@ int align_host_clouds(mola_icp_handle* h, const float* fx, const float* fy, cons
 bool batch_eligible(const mola_icp_params& p, size_t N, size_t M)
 {
     if (N == 0 || M == 0) return false;
-    if (p.n_extra_matchers != 0 || p.n_extra_solvers != 0) return false;   // staged pipelines: stand-alone aligns (stream per pair)
+    if (p.n_extra_matchers != 0 || p.n_extra_solvers != 0 || p.n_extra_quality != 0) return false;   // staged pipelines: stand-alone aligns (stream per pair)
     if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) return true;
     if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD) return false;
     if (p.nn_kernel == MOLA_ICP_NN_TILED) return true;

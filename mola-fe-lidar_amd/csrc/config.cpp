@@ -34,6 +34,7 @@ void params_default(mola_icp_params& p)
     p.run_up_to_iteration = 0;
     p.quality_class = MOLA_ICP_QUALITY_PAIRED_RATIO;
     p.quality_threshold = 0.10;
+    p.quality_weight = 1.0;
     p.fixed_iterations = 0;
     p.nn_kernel = MOLA_ICP_NN_AUTO;
     p.skip_quality = 0;
@@ -182,14 +183,26 @@ void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p)
         }
     }
     {
-        const YamlNode& q = entry_of_seq(cfg.at("quality"), "quality", 0, 1);
-        const std::string cls = q.at("class").as_string();
-        if (cls != "mp2p_icp::QualityEvaluator_PairedRatio")
-            throw std::runtime_error("quality class=`" + cls + "` is a non-registered class. Known: "
-                                     "`mp2p_icp::QualityEvaluator_PairedRatio`.");
-        p.quality_class = MOLA_ICP_QUALITY_PAIRED_RATIO;
-        if (auto* qp = q.find("params"))
-            if (auto* n = qp->find("thresholdDistance")) p.quality_threshold = n->as_double();
+        const YamlNode& seq = cfg.at("quality");
+        auto parse_quality = [](const YamlNode& q, int32_t& cls_out, double& thr, double& weight) {
+            const std::string cls = q.at("class").as_string();
+            if (cls != "mp2p_icp::QualityEvaluator_PairedRatio")
+                throw std::runtime_error("quality class=`" + cls + "` is a non-registered class. Known: "
+                                         "`mp2p_icp::QualityEvaluator_PairedRatio`.");
+            cls_out = MOLA_ICP_QUALITY_PAIRED_RATIO;
+            if (auto* qp = q.find("params"))
+                if (auto* n = qp->find("thresholdDistance")) thr = n->as_double();
+            if (auto* n = q.find("weight")) weight = n->as_double();
+        };
+        p.quality_weight = 1.0;
+        parse_quality(entry_of_seq(seq, "quality", 0, 1 + MOLA_ICP_MAX_EXTRA_STAGES), p.quality_class, p.quality_threshold, p.quality_weight);
+        p.n_extra_quality = (uint32_t)seq.seq.size() - 1;
+        for (uint32_t i = 0; i < p.n_extra_quality; ++i) {
+            mola_icp_quality_entry& e = p.extra_quality[i];
+            e = mola_icp_quality_entry{};
+            e.quality_threshold = 0.10; e.weight = 1.0;
+            parse_quality(entry_of_seq(seq, "quality", i + 1, 1 + MOLA_ICP_MAX_EXTRA_STAGES), e.quality_class, e.quality_threshold, e.weight);
+        }
     }
 }
 

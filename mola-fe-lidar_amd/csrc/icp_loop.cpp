@@ -76,6 +76,15 @@ int validate_params(const mola_icp_params& p)
 {
     if (p.n_extra_matchers > MOLA_ICP_MAX_EXTRA_STAGES || p.n_extra_solvers > MOLA_ICP_MAX_EXTRA_STAGES)
         return fail(MOLA_ICP_E_BADARG, "n_extra_matchers / n_extra_solvers exceed MOLA_ICP_MAX_EXTRA_STAGES");
+    if (p.n_extra_quality > MOLA_ICP_MAX_EXTRA_STAGES) return fail(MOLA_ICP_E_BADARG, "n_extra_quality exceeds MOLA_ICP_MAX_EXTRA_STAGES");
+    for (uint32_t e = 0; e < p.n_extra_quality; ++e) {
+        const mola_icp_quality_entry& q = p.extra_quality[e];
+        if (q.quality_class != MOLA_ICP_QUALITY_PAIRED_RATIO) return fail(MOLA_ICP_E_BADARG, "unknown quality_class");
+        if (!(q.quality_threshold > 0) || !std::isfinite(q.quality_threshold))
+            return fail(MOLA_ICP_E_BADARG, "quality thresholdDistance must be a positive finite distance");
+        if (!(q.weight >= 0) || !std::isfinite(q.weight)) return fail(MOLA_ICP_E_BADARG, "quality weight must be finite and >= 0");
+    }
+    if (p.n_extra_quality && !(p.quality_weight >= 0)) return fail(MOLA_ICP_E_BADARG, "quality weight must be finite and >= 0");
     if (p.n_extra_matchers == 0 && p.n_extra_solvers == 0) return validate_single(p);
     // several entries: no two matchers may be active in one iteration (mixed pairings in one solve are not run), and every
     // (matcher, solver) combination an iteration can meet must be a pipeline this build runs
@@ -245,12 +254,22 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mol
     if (p.skip_quality) quality = -1.0;
     else if (st.n_local_total() > 0 && st.n_map_total() > 0) {
         TraceRange tr_q("mola_icp.quality");
-        if ((rc = st.match(T, p.quality_threshold, p, nullptr))) return rc;
-        double qacc[kNAcc];
-        if ((rc = st.accumulate(p, T, 0, nullptr, nullptr, true, qacc))) return rc;
-        if ((rc = st.allreduce(qacc))) return rc;
         const double denom = (double)(st.n_local_total() < st.n_map_total() ? st.n_local_total() : st.n_map_total());
-        quality = qacc[16] / denom;
+        // one PairedRatio pass per `quality:` entry, combined by weight (a single entry: that entry's ratio, whatever its weight)
+        double wsum = 0, qsum = 0;
+        for (uint32_t e = 0; e <= p_all.n_extra_quality && e <= MOLA_ICP_MAX_EXTRA_STAGES; ++e) {
+            const double thr = e ? p_all.extra_quality[e - 1].quality_threshold : p_all.quality_threshold;
+            double w = e ? p_all.extra_quality[e - 1].weight : p_all.quality_weight;
+            if (e == 0 && w == 0) w = 1.0;
+            if ((rc = st.match(T, thr, p, nullptr))) return rc;
+            double qacc[kNAcc];
+            if ((rc = st.accumulate(p, T, 0, nullptr, nullptr, true, qacc))) return rc;
+            if ((rc = st.allreduce(qacc))) return rc;
+            if (p_all.n_extra_quality == 0) { qsum = qacc[16] / denom; wsum = 1.0; break; }
+            qsum += w * (qacc[16] / denom);
+            wsum += w;
+        }
+        quality = wsum > 0 ? qsum / wsum : 0.0;
     }
     const double t2 = now_ms();
 
@@ -278,8 +297,8 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
 {
     int rc = validate_params(p);
     if (rc) return rc;
-    if (p.n_extra_matchers != 0 || p.n_extra_solvers != 0)
-        return fail(MOLA_ICP_E_UNSUPPORTED, "the batched loop runs single-entry `matchers:` / `solvers:` pipelines (staged pipelines: align the pairs one by one)");
+    if (p.n_extra_matchers != 0 || p.n_extra_solvers != 0 || p.n_extra_quality != 0)
+        return fail(MOLA_ICP_E_UNSUPPORTED, "the batched loop runs single-entry `matchers:` / `solvers:` / `quality:` pipelines (staged pipelines: align the pairs one by one)");
     const bool planes = p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE;
     const int K = st.size();
     if (K <= 0) return MOLA_ICP_OK;

@@ -133,3 +133,35 @@ def test_p2p_then_point2plane_on_the_gpu(pkg, O, synth):
     for x in rb:
         assert x.nIterations == r.nIterations and np.array_equal(x.optimal_tf, r.optimal_tf)
     icp.close()
+
+
+def test_several_quality_evaluators_are_weighed(pkg, O, golden):
+    """`quality:` is a sequence too (icpreg:40-46): Results::quality = sum w_i q_i / sum w_i -- one PairedRatio pass per entry"""
+    g, l = golden["A_map"], golden["A_local"]
+    txt = (STAGED % dict(last_p2p=2, first_second=3, **P2P2)).replace(
+        "      thresholdDistance: 0.10\n",
+        "      thresholdDistance: 0.10\n    weight: 1.0\n  - class: mp2p_icp::QualityEvaluator_PairedRatio\n    params:\n      thresholdDistance: 0.30\n    weight: 3.0\n")
+    p = pkg.Parameters.load_from(txt)
+    assert p.n_extra_quality == 1 and p.quality_weight == 1.0
+    assert p.c.extra_quality[0].quality_threshold == pytest.approx(0.30) and p.c.extra_quality[0].weight == 3.0
+    st = OracleStages(O, g, l)
+    gates = []
+
+    def match(T, thr):
+        gates.append(thr)
+        return st.match(T, thr)
+
+    r = pkg.run_loop(match, st.accumulate, np.eye(4), p, l.shape[1], g.shape[1])
+    assert gates[-2:] == [pytest.approx(0.10), pytest.approx(0.30)]        # the two quality passes, in order
+    kd = O.KdTree(g)
+    denom = min(l.shape[1], g.shape[1])
+    q = [O.match(g, l, r.optimal_tf, thr, kd)[2] / denom for thr in (0.10, 0.30)]
+    assert r.quality == pytest.approx((1.0 * q[0] + 3.0 * q[1]) / 4.0, abs=1e-12)
+    # a single entry keeps its own ratio whatever its weight
+    one = pkg.Parameters.load_from((STAGED % dict(last_p2p=2, first_second=3, **P2P2)).replace("      thresholdDistance: 0.10\n", "      thresholdDistance: 0.10\n    weight: 7.0\n"))
+    r1 = pkg.run_loop(st.match, st.accumulate, np.eye(4), one, l.shape[1], g.shape[1])
+    assert one.n_extra_quality == 0 and r1.quality == pytest.approx(q[0], abs=1e-12)
+    # an unknown class in a later entry fails at load time, naming it
+    with pytest.raises(pkg.IcpError) as ex:
+        pkg.Parameters.load_from(txt.replace("mp2p_icp::QualityEvaluator_PairedRatio\n    params:\n      thresholdDistance: 0.30", "mp2p_icp::QualityEvaluator_Voxels\n    params:\n      thresholdDistance: 0.30"))
+    assert ex.value.status == pkg._lib.E_CONFIG and "QualityEvaluator_Voxels" in str(ex.value)
