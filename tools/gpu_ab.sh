@@ -9,7 +9,7 @@ python bench.py $Q "$@" > gpurun_out/$tag/default2.json 2> gpurun_out/$tag/defau
 python - <<PY
 import json
 for n in ("default", "knob", "default2"):
-    j = json.load(open("gpurun_out/$tag/%s.json" % n))
+    j = json.loads(open("gpurun_out/$tag/%s.json" % n).read().strip().splitlines()[-1])  # (RCCL prints a banner first)
     s = j.get("shipped_point2plane_gn", {})
     print(n, "it/s %.0f  ms/step %.4f  matcher ms %.4f  shipped it/s %.0f" % (j["value"], j["ms_per_step"], j["roofline"]["kernel_ms"], s.get("value", 0)))
 PY
