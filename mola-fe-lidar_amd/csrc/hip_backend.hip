@@ -213,7 +213,12 @@ static int upload_soa(DevBuf& buf, hipStream_t st, const float* x, const float* 
     int rc = buf.reserve(sizeof(float) * 3 * (np ? np : 64));
     if (rc) return rc;
     float* base = buf.as<float>();
-    if (n) {
+    if (n && y == x + n && z == y + n) {
+        // one [3][n] block on the host (what the Python binding and a row-major 3 x n matrix hand over): one copy instead of
+        // three (each pageable copy is a staged, synchronous call of its own); the rows land np floats apart
+        if (n == np) HIPCHK(hipMemcpyAsync(base, x, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
+        else HIPCHK(hipMemcpy2DAsync(base, sizeof(float) * np, x, sizeof(float) * n, sizeof(float) * n, 3, hipMemcpyHostToDevice, st));
+    } else if (n) {
         HIPCHK(hipMemcpyAsync(base, x, sizeof(float) * n, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(base + np, y, sizeof(float) * n, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(base + 2 * np, z, sizeof(float) * n, hipMemcpyHostToDevice, st));
@@ -316,7 +321,7 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
 }
 
 int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
-                       const float bbox[6], DevBuf& scratch, float* sxyz, int* perm);
+                       const float* bbox_dev, DevBuf& scratch, float* sxyz, int* perm);
 int select_in_box(hipStream_t stream, const float* x, const float* y, const float* z, size_t n, const float lo[3], const float hi[3],
                   DevBuf& scratch, int* sel, size_t* n_kept_host);
 int gather_by_index(hipStream_t stream, const float* x, const float* y, const float* z, const int* sel, size_t n, float* ox, float* oy,
@@ -349,7 +354,7 @@ int HipWorkspace::set_local_shard(const float* x, const float* y, const float* z
         const size_t padded = (n_total + kQPW - 1) / kQPW * kQPW;
         if ((rc = sorted.reserve(sizeof(float) * 3 * padded))) return rc;
         if ((rc = perm.reserve(sizeof(int) * padded))) { sorted.release(); return rc; }   // (an OOM path: leak nothing)
-        if ((rc = morton_sort_points(stream_, fx, fy, fz, n_total, padded, bbox, sort_scratch_, sorted.as<float>(), perm.as<int>()))) {
+        if ((rc = morton_sort_points(stream_, fx, fy, fz, n_total, padded, bbox_dev(), sort_scratch_, sorted.as<float>(), perm.as<int>()))) {
             sorted.release(); perm.release();
             return rc;
         }
@@ -476,7 +481,7 @@ int HipWorkspace::prepare_map()
     float* bbox = part + 6 * nb;
     hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(256), 0, stream_, gx_, gy_, gz_, M, part);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, stream_, part, nb, bbox);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, stream_, part, nb, bbox);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(meta_host_, bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -509,25 +514,46 @@ int HipWorkspace::prepare_map()
 }
 
 int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
-                       const float bbox[6], DevBuf& scratch, float* sxyz, int* perm);
+                       const float* bbox_dev, DevBuf& scratch, float* sxyz, int* perm);
 
-int HipWorkspace::bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6])
+// Bounding box of a device cloud into the device block bbox_dev() and, by an asynchronous copy, into slot `slot` of the pinned block:
+// nothing waits here.  The sort that follows reads the device block; the host looks at its copy (finite coordinates?) at the next
+// wait it makes anyway (check_bboxes(): behind the first accumulation of an align, or behind a cache build's synchronisation).
+int HipWorkspace::bbox_async(const float* x, const float* y, const float* z, size_t n, int slot)
 {
     int rc;
     const int nb = 256;
     if ((rc = map_meta_.reserve(sizeof(float) * (6 * nb + 8)))) return rc;
     float* part = map_meta_.as<float>();
-    float* bbox = part + 6 * nb;
     hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(256), 0, stream_, x, y, z, (int)n, part);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, stream_, part, nb, bbox);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, stream_, part, nb, bbox_dev());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(meta_host_, bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
-    for (int k = 0; k < 6; ++k) {
-        if (!std::isfinite(meta_host_[k])) return fail(MOLA_ICP_E_BADARG, "a cloud has non-finite coordinates");
-        out[k] = meta_host_[k];
+    HIPCHK(hipMemcpyAsync(meta_host_ + 8 * slot, bbox_dev(), sizeof(float) * 6, hipMemcpyDeviceToHost, stream_));
+    bbox_pending_ |= 1u << slot;
+    return MOLA_ICP_OK;
+}
+
+// after a wait that covers everything enqueued on stream_ so far
+int HipWorkspace::check_bboxes()
+{
+    const unsigned int pending = bbox_pending_;
+    bbox_pending_ = 0;
+    for (int slot = 0; slot < 2; ++slot) {
+        if (!(pending & (1u << slot))) continue;
+        for (int k = 0; k < 6; ++k)
+            if (!std::isfinite(meta_host_[8 * slot + k])) return fail(MOLA_ICP_E_BADARG, "a cloud has non-finite coordinates");
     }
+    return MOLA_ICP_OK;
+}
+
+int HipWorkspace::bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6])
+{
+    int rc = bbox_async(x, y, z, n, 0);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(stream_));
+    if ((rc = check_bboxes())) return rc;
+    for (int k = 0; k < 6; ++k) out[k] = meta_host_[k];
     return MOLA_ICP_OK;
 }
 
@@ -536,8 +562,7 @@ int HipWorkspace::prepare_tiles()
 {
     if (map_sc_->ready) return MOLA_ICP_OK;
     int rc;
-    float bbox[6];
-    if ((rc = bbox_of(gx_, gy_, gz_, M_, bbox))) return rc;
+    if ((rc = bbox_async(gx_, gy_, gz_, M_, 0))) return rc;
     const size_t super_pts = (size_t)kTileG * kSuper;
     map_sc_->n_super = (int)((M_ + super_pts - 1) / super_pts);
     map_sc_->n_super = (map_sc_->n_super + 63) / 64 * 64;  // whole top boxes (the padding tiles get empty boxes)
@@ -549,17 +574,17 @@ int HipWorkspace::prepare_tiles()
     if ((rc = map_sc_->tbox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_tiles_p))) return rc;
     if ((rc = map_sc_->sbox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_super))) return rc;
     if ((rc = map_sc_->ubox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_top))) return rc;
-    if ((rc = morton_sort_points(stream_, gx_, gy_, gz_, M_, map_sc_->padded, bbox, sort_scratch_, map_sc_->sorted.as<float>(),
+    if ((rc = morton_sort_points(stream_, gx_, gy_, gz_, M_, map_sc_->padded, bbox_dev(), sort_scratch_, map_sc_->sorted.as<float>(),
                                  map_sc_->perm.as<int>())))
         return rc;
     const float* sx = map_sc_->sorted.as<float>();
-    hipLaunchKernelGGL(k_tile_boxes, dim3((unsigned)((map_sc_->n_tiles_p + 255) / 256)), dim3(256), 0, stream_, sx, sx + map_sc_->padded,
+    hipLaunchKernelGGL(k_tile_boxes, dim3((unsigned)((map_sc_->n_tiles_p + 7) / 8)), dim3(256), 0, stream_, sx, sx + map_sc_->padded,
                        sx + 2 * map_sc_->padded, (int)M_, map_sc_->n_tiles_p, map_sc_->tbox.as<float>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((map_sc_->n_super + 255) / 256)), dim3(256), 0, stream_, map_sc_->tbox.as<float>(),
+    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((map_sc_->n_super + 3) / 4)), dim3(256), 0, stream_, map_sc_->tbox.as<float>(),
                        map_sc_->n_tiles_p, map_sc_->n_super, map_sc_->sbox.as<float>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((map_sc_->n_top + 255) / 256)), dim3(256), 0, stream_, map_sc_->sbox.as<float>(),
+    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((map_sc_->n_top + 3) / 4)), dim3(256), 0, stream_, map_sc_->sbox.as<float>(),
                        map_sc_->n_super, map_sc_->n_top, map_sc_->ubox.as<float>());
     HIPCHK(hipGetLastError());
     map_sc_->ready = true;
@@ -571,12 +596,11 @@ int HipWorkspace::prepare_queries()
 {
     if (loc_sc_->ready) return MOLA_ICP_OK;
     int rc;
-    float bbox[6];
-    if ((rc = bbox_of(lx_, ly_, lz_, N_, bbox))) return rc;
+    if ((rc = bbox_async(lx_, ly_, lz_, N_, 1))) return rc;
     loc_sc_->padded = (N_ + kQPW - 1) / kQPW * kQPW;
     if ((rc = loc_sc_->sorted.reserve(sizeof(float) * 3 * loc_sc_->padded))) return rc;
     if ((rc = loc_sc_->perm.reserve(sizeof(int) * loc_sc_->padded))) return rc;
-    if ((rc = morton_sort_points(stream_, lx_, ly_, lz_, N_, loc_sc_->padded, bbox, sort_scratch_, loc_sc_->sorted.as<float>(),
+    if ((rc = morton_sort_points(stream_, lx_, ly_, lz_, N_, loc_sc_->padded, bbox_dev(), sort_scratch_, loc_sc_->sorted.as<float>(),
                                  loc_sc_->perm.as<int>())))
         return rc;
     loc_sc_->ready = true;
@@ -654,6 +678,8 @@ int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, 
     map_sc_ = keep_sc;
     gx_ = kx; gy_ = ky; gz_ = kz; M_ = kM;
     if (es != hipSuccess) return fail(es == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("build_cached: ") + hipGetErrorString(es));
+    if (!rc) rc = check_bboxes();   // (the cloud's bounding box arrived with that synchronisation)
+    else bbox_pending_ = 0;
     return rc;
 }
 
@@ -1147,6 +1173,7 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
     if (g_knobs.no_direct_readback) {
         HIPCHK(hipMemcpyAsync(plane_acc_host_, dacc, sizeof(double) * (kNAccPlane + 1), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
+        if (bbox_pending_) { const int rcb = check_bboxes(); if (rcb) return rcb; }
     } else {
         if (!direct) {  // (after the collective, or an empty shard's zeros)
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, stream_, dacc, kNAccPlane + 1, plane_acc_host_, kNAccPlane + 2, seq);
@@ -1499,6 +1526,7 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
         }
         HIPCHK(hipMemcpyAsync(hc, counter, sizeof(unsigned int), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
+        if (bbox_pending_) { const int rcb = check_bboxes(); if (rcb) return rcb; }
         *n_pairs = *hc;
     }
     return MOLA_ICP_OK;
@@ -1525,13 +1553,17 @@ int HipWorkspace::check_slab(const Mat4& T, double threshold)
 int HipWorkspace::spin_for(volatile unsigned long long* flag, unsigned long long seq)
 {
     for (unsigned long long spins = 0; spins < 400000000ull; ++spins) {  // ~ seconds
-        if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return MOLA_ICP_OK; }
+        if (*flag == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            // (the block was published behind everything enqueued before it: a bounding box copied for the host has landed too)
+            return bbox_pending_ ? check_bboxes() : MOLA_ICP_OK;
+        }
         __builtin_ia32_pause();
     }
     HIPCHK(hipStreamSynchronize(stream_));
     if (*flag != seq) return fail(MOLA_ICP_E_HIP, "the device did not publish its result block");
     std::atomic_thread_fence(std::memory_order_acquire);
-    return MOLA_ICP_OK;
+    return bbox_pending_ ? check_bboxes() : MOLA_ICP_OK;
 }
 
 int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int stage, const double cl[3],
@@ -1553,6 +1585,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         if (rc2) return rc2;
         HIPCHK(hipMemcpyAsync(acc_host_, acc_dev_.p, sizeof(double) * kNAcc, hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
+        if (bbox_pending_) { const int rcb = check_bboxes(); if (rcb) return rcb; }
         std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);
         return MOLA_ICP_OK;
     }
@@ -1641,6 +1674,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         if (g_knobs.no_direct_readback) {
             HIPCHK(hipMemcpyAsync(acc_host_, acc_dev_.p, sizeof(double) * kNAcc, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
+            if (bbox_pending_) { const int rcb = check_bboxes(); if (rcb) return rcb; }
             std::memcpy(acc, acc_host_, sizeof(double) * kNAcc);
             return MOLA_ICP_OK;
         }
@@ -1688,6 +1722,7 @@ int HipWorkspace::copy_pairing(int32_t* idx_out, float* d2_out)
         if (d2_out) HIPCHK(hipMemcpyAsync(d2_out, d2_.p, sizeof(float) * N_, hipMemcpyDeviceToHost, stream_));
     }
     HIPCHK(hipStreamSynchronize(stream_));
+    if (bbox_pending_) { const int rcb = check_bboxes(); if (rcb) return rcb; }
     return MOLA_ICP_OK;
 }
 
@@ -2185,6 +2220,7 @@ int HipWorkspace::sync()
     if (!inited_) return MOLA_ICP_OK;
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipStreamSynchronize(stream_));
+    if (bbox_pending_) { const int rcb = check_bboxes(); if (rcb) return rcb; }
     return MOLA_ICP_OK;
 }
 

@@ -151,7 +151,11 @@ class HipWorkspace final : public Stages {
     int prepare_map();    // derived map image for the MFMA matcher
     int prepare_tiles();    // Morton-sorted map + tile boxes for the tiled matcher
     int prepare_queries();  // Morton-sorted local cloud
-    int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);
+    int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);   // (waits)
+    int bbox_async(const float* x, const float* y, const float* z, size_t n, int slot);   // device block + pinned slot, no wait
+    int check_bboxes();                                                                     // after the next wait on stream_
+    float* bbox_dev() { return map_meta_.as<float>() + 6 * 256; }
+    unsigned int bbox_pending_ = 0;
     int launch_tiled(const struct PoseF& P, float thr2, bool use_seed, unsigned int* counter);
     int fill_nn_problem(const struct PoseF& P, float thr2, bool use_seed, NnProblem& pb);
     int launch_coop(const struct PoseF& P, float thr2, bool use_seed);

@@ -200,39 +200,50 @@ __global__ __launch_bounds__(256) void k_remap_indices(const int* __restrict__ i
     out[i] = j >= 0 ? orig[j] : -1;
 }
 
-// boxes of the map tiles (one thread per tile) and super-tiles (one thread per super-tile); SoA [6][n]
+// boxes of the map tiles and of the two levels above them; SoA [6][n].  One 32-lane group per tile (a point per lane, coalesced;
+// a thread per tile walking its 32 points took 13 us for a 120k-point map), one wave per super-tile (a tile box per lane; a thread
+// per super-tile took 19 + 9 us for the two upper levels: 384 dependent loads each).  min / max: the boxes do not depend on the order.
 __global__ __launch_bounds__(256) void k_tile_boxes(const float* __restrict__ sx, const float* __restrict__ sy,
                                                     const float* __restrict__ sz, int M, int n_tiles_p,
                                                     float* __restrict__ tbox)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_tiles_p) return;
+    static_assert(kTileG == 32, "one 32-lane group per tile");
+    const int t = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (t >= n_tiles_p) return;   // (whole 32-lane groups leave together)
+    const int j = t * kTileG + l;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    const int j0 = t * kTileG, j1 = min(j0 + kTileG, M);
-    for (int j = j0; j < j1; ++j) {
-        mn[0] = fminf(mn[0], sx[j]); mx[0] = fmaxf(mx[0], sx[j]);
-        mn[1] = fminf(mn[1], sy[j]); mx[1] = fmaxf(mx[1], sy[j]);
-        mn[2] = fminf(mn[2], sz[j]); mx[2] = fmaxf(mx[2], sz[j]);
-    }
+    if (j < M) { mn[0] = mx[0] = sx[j]; mn[1] = mx[1] = sy[j]; mn[2] = mx[2] = sz[j]; }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { tbox[k * n_tiles_p + t] = mn[k]; tbox[(3 + k) * n_tiles_p + t] = mx[k]; }
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 32));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 32));
+        }
+    }
+    if (l < 3) tbox[l * n_tiles_p + t] = l == 0 ? mn[0] : l == 1 ? mn[1] : mn[2];
+    else if (l < 6) tbox[l * n_tiles_p + t] = l == 3 ? mx[0] : l == 4 ? mx[1] : mx[2];
 }
 
 __global__ __launch_bounds__(256) void k_super_boxes(const float* __restrict__ tbox, int n_tiles_p, int n_super,
                                                      float* __restrict__ sbox)
 {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_super) return;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int t = s * kSuper; t < (s + 1) * kSuper; ++t) {
+    static_assert(kSuper == 64, "one wave per super-tile, a tile box per lane");
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (s >= n_super) return;   // (whole waves leave together)
+    const int t = s * kSuper + l;
+    float v[6];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            mn[k] = fminf(mn[k], tbox[k * n_tiles_p + t]);
-            mx[k] = fmaxf(mx[k], tbox[(3 + k) * n_tiles_p + t]);
+    for (int k = 0; k < 6; ++k) v[k] = tbox[k * n_tiles_p + t];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(v[k], off);
+            v[k] = k < 3 ? fminf(v[k], o) : fmaxf(v[k], o);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { sbox[k * n_super + s] = mn[k]; sbox[(3 + k) * n_super + s] = mx[k]; }
+    if (l < 6) sbox[l * n_super + s] = l == 0 ? v[0] : l == 1 ? v[1] : l == 2 ? v[2] : l == 3 ? v[3] : l == 4 ? v[4] : v[5];
 }
 
 // ---- map preparation for the MFMA matcher (once per map) -------------------------------
@@ -243,8 +254,10 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const float* __restrict__ 
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
         const float v[3] = {gx[i], gy[i], gz[i]};
+        // (fminf / fmaxf drop a NaN: a coordinate that is not a finite number poisons the maximum instead -- +inf survives the
+        // whole reduction and fails the host's finiteness check of the box)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fabsf(v[k]) <= 3.4028234e38f ? fmaxf(mx[k], v[k]) : INFINITY; }
     }
     __shared__ float sm[4][6];
 #pragma unroll
@@ -263,13 +276,29 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(64) void k_bbox_final(const float* __restrict__ part, int nblocks, float* __restrict__ out)
+// (256 threads, a partial row each, then a fixed-shape min / max tree: six lanes walking all rows one after the other took 22 us)
+__global__ __launch_bounds__(256) void k_bbox_final(const float* __restrict__ part, int nblocks, float* __restrict__ out)
 {
+    float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = k < 3 ? fminf(v[k], part[b * 6 + k]) : fmaxf(v[k], part[b * 6 + k]);
+    }
+    __shared__ float sm[4][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(v[k], off);
+            v[k] = k < 3 ? fminf(v[k], o) : fmaxf(v[k], o);
+        }
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
     if (threadIdx.x < 6) {
-        float v = part[threadIdx.x];
-        for (int b = 1; b < nblocks; ++b)
-            v = threadIdx.x < 3 ? fminf(v, part[b * 6 + threadIdx.x]) : fmaxf(v, part[b * 6 + threadIdx.x]);
-        out[threadIdx.x] = v;
+        float r = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) r = threadIdx.x < 3 ? fminf(r, sm[w][threadIdx.x]) : fmaxf(r, sm[w][threadIdx.x]);
+        out[threadIdx.x] = r;
     }
 }
 

@@ -50,12 +50,18 @@ __device__ __forceinline__ unsigned int hilbert30(unsigned int x, unsigned int y
     return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
 }
 
+// (the bounding box is read from device memory, where the reduction in front of this kernel left it: no host round trip between them)
 __global__ __launch_bounds__(256) void k_curve_keys(const float* __restrict__ gx, const float* __restrict__ gy,
-                                                    const float* __restrict__ gz, int M, float x0, float y0, float z0,
-                                                    float scale, unsigned int* __restrict__ keys, int* __restrict__ vals)
+                                                    const float* __restrict__ gz, int M, const float* __restrict__ bbox,
+                                                    unsigned int* __restrict__ keys, int* __restrict__ vals)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
+    const float x0 = bbox[0], y0 = bbox[1], z0 = bbox[2];
+    float ext = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, bbox[3 + k] - bbox[k]);
+    const float scale = ext > 0 ? 1023.999f / ext : 0.f;  // isotropic cells
     const unsigned int ix = (unsigned int)fminf(fmaxf((gx[i] - x0) * scale, 0.f), 1023.f);
     const unsigned int iy = (unsigned int)fminf(fmaxf((gy[i] - y0) * scale, 0.f), 1023.f);
     const unsigned int iz = (unsigned int)fminf(fmaxf((gz[i] - z0) * scale, 0.f), 1023.f);
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const float* __restrict__
 
 // sorted copies: sxyz = 3 * M_padded floats (SoA), perm[M] = original index of sorted position
 int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
-                    const float bbox[6], DevBuf& scratch, float* sxyz, int* perm)
+                    const float* bbox /*device: min xyz, max xyz*/, DevBuf& scratch, float* sxyz, int* perm)
 {
     if (M == 0) return MOLA_ICP_OK;
     const int Mi = (int)M;
@@ -98,12 +104,8 @@ int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, con
     unsigned int* k_out = reinterpret_cast<unsigned int*>(base + a);
     int* v_in = reinterpret_cast<int*>(base + 2 * a);
     void* tmp = base + 3 * a;
-    float ext = 0.f;
-    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, bbox[3 + k] - bbox[k]);
-    const float scale = ext > 0 ? 1023.999f / ext : 0.f;  // isotropic cells
     const unsigned nb = (unsigned)((M + 255) / 256);
-    hipLaunchKernelGGL(k_curve_keys, dim3(nb), dim3(256), 0, stream, gx, gy, gz, Mi, bbox[0], bbox[1], bbox[2], scale, k_in,
-                       v_in);
+    hipLaunchKernelGGL(k_curve_keys, dim3(nb), dim3(256), 0, stream, gx, gy, gz, Mi, bbox, k_in, v_in);
     HIPCHK(hipGetLastError());
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k_in, k_out, v_in, perm, Mi, 0, 30, stream));
     hipLaunchKernelGGL(k_gather_sorted, dim3((unsigned)((M_padded + 255) / 256)), dim3(256), 0, stream, gx, gy, gz, perm,

@@ -281,6 +281,39 @@ def test_edge_cases(pkg, icp, golden):
     assert icp.align(g, l, np.eye(4), p2p_params(pkg, max_iterations=2)).nIterations == 2
 
 
+def test_non_finite_coordinates_are_refused(pkg, golden):
+    """The bounding box of a new cloud is no longer waited for (its sort reads it on the device); the host checks its copy at the
+    next wait it makes anyway: a NaN / inf coordinate must still fail the call it came with, through every way a cloud gets in."""
+    import os
+    g, l = golden["A_map"], golden["A_local"]
+    shipped = pkg.Parameters.load_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "params", "icp-settings-regular.yaml"))
+    # the tiled matcher needs >= 8192 points a side: tile the golden clouds
+    reps = 8192 // min(g.shape[1], l.shape[1]) + 1
+    big_g = np.ascontiguousarray(np.concatenate([g + np.float32(0.001 * k) for k in range(reps)], axis=1))
+    big_l = np.ascontiguousarray(np.concatenate([l + np.float32(0.001 * k) for k in range(reps)], axis=1))
+    for params in (p2p_params(pkg), shipped):
+        for which in ("map", "local"):
+            for bad_value in (np.nan, np.inf):
+                icp = pkg.ICP(device=0)
+                a, b = big_g.copy(), big_l.copy()
+                (a if which == "map" else b)[1, 77] = bad_value
+                with pytest.raises(pkg.IcpError) as e:
+                    icp.align(a, b, np.eye(4), params)
+                assert e.value.status == pkg._lib.E_BADARG and "non-finite" in str(e.value), (which, bad_value)
+                # ... and the handle is usable afterwards
+                r = icp.align(big_g, big_l, np.eye(4), params)
+                assert r.nIterations >= 1
+    icp = pkg.ICP(device=0)
+    a = big_g.copy()
+    a[2, 5] = np.nan
+    with pytest.raises(pkg.IcpError) as e:
+        icp.cloud_put(1, a)
+    assert e.value.status == pkg._lib.E_BADARG
+    icp.cloud_put(1, big_g)
+    icp.cloud_put(2, big_l)
+    assert icp.align_cached(1, 2, np.eye(4), shipped).nIterations >= 1
+
+
 def test_align_is_reentrant_per_handle(pkg, O, icp, golden, synth, small_scene):
     """>=4 threads on ONE handle with DIFFERENT per-call params, as the reference's pool does
     (src/LidarOdometry.cpp:94-96, 287-290, 869)."""
