@@ -388,6 +388,8 @@ def main():
         # (params/icp-settings-loop-closure.yaml = Point2Plane + Gauss-Newton): the lockstep device batch since round 3
         out["config3_batch_shipped"] = config3_batch(pkg, synth, icp, args.batch_pairs, False, cpu_flags, shipped=True)
         out["loop_closure_montecarlo"] = montecarlo_leg(pkg, synth, icp)
+    if extras and args.e2e:
+        out["odometry_stream"] = odometry_stream_leg(pkg, synth)
 
     if use_dist:
         if allreduce_used == "rccl":
@@ -647,6 +649,40 @@ def align_e2e(pkg, synth, icp, g1m, l1m, seed, with_cpu, cpu_flags):
             e["cpu"] = c
         out[name] = e
     return out
+
+
+def odometry_stream_leg(pkg, synth, n_scans=24):
+    """rows f1 + f4 (src/LidarOdometry.cpp:190-514): a drive down the scene at 10 m/s, one 64-ring scan (~115k points) every 0.1 s,
+    through the front-end mirror (`LidarOdometry.on_new_observation` = `mola_lo_process_scan`) with params/kitti-default.yaml:
+    per scan, the new cloud is uploaded, sorted and boxed ONCE (it is `to` now and `from` for the next scan: the cloud cache),
+    aligned against the previous scan with the constant-velocity guess, the keyframe / twist bookkeeping runs on the host."""
+    lp = pkg.LidarOdometryParams.load_from_file(os.path.join(ROOT, "params", "kitti-default.yaml"), ROOT)
+    scans = []
+    for k in range(n_scans):
+        pose = synth.pose_from_xyzypr(-14.0 + 1.0 * k, 0.3 * np.sin(0.3 * k), 0.0, 0.005 * k, 0, 0)
+        scans.append((100.0 + 0.1 * k, synth.lidar_scan(pose, seed=50 + k)))
+    icp = pkg.ICP(device=0)
+    lo = pkg.LidarOdometry(lp, icp=icp)
+    ms, its, ran, kfs = [], [], 0, []
+    for rep in range(2):   # (the first pass warms allocations and clocks; the second is reported)
+        lo.reset()
+        ms, its, ran, kfs = [], [], 0, []
+        for k, (t, pc) in enumerate(scans):
+            t0 = time.perf_counter()
+            st = lo.on_new_observation(t + 1000.0 * rep, pc)
+            ms.append((time.perf_counter() - t0) * 1e3)
+            if st.icp is not None:
+                ran += 1
+                its.append(int(st.icp.nIterations))
+            if st.keyframe_created:
+                kfs.append(k)
+    lo.close()
+    steady = ms[2:]   # (scan 0 has no partner, scan 1 no velocity yet)
+    med = float(np.median(steady))
+    return {"workload": f"{n_scans} scans of ~{int(np.mean([pc.shape[1] for _, pc in scans]))} points, 0.1 s and 1 m apart, params/kitti-default.yaml, host buffers in, pose out",
+            "ms_per_scan_median": med, "ms_per_scan_min": float(np.min(steady)), "ms_per_scan_max": float(np.max(steady)),
+            "scans_per_s": 1e3 / med, "realtime_factor_at_10_hz": 100.0 / med, "icp_ran": ran, "iterations_per_scan_median": float(np.median(its)) if its else 0.0,
+            "ms_per_scan": [round(float(v), 3) for v in ms], "keyframes": kfs}
 
 
 def montecarlo_leg(pkg, synth, icp, n_guesses=10, n=100_000):
