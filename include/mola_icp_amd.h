@@ -236,7 +236,10 @@ int mola_icp_comm_destroy(mola_icp_handle* h);
 /* ---- the hot path ------------------------------------------------------ */
 /* Replaces mp2p_icp::ICP::align() as called at src/LidarOdometry.cpp:869-871.
  * Host pointers; copies both clouds to HBM, runs every iteration on the GPU,
- * never retains caller pointers.  Thread-safe per handle. */
+ * never retains caller pointers.  Thread-safe per handle.
+ * A cloud with a coordinate that is not a finite number (NaN, +-inf) is refused with MOLA_ICP_E_BADARG
+ * ("non-finite coordinates") by the call that brought it in -- every align entry point, mola_icp_cloud_put --
+ * decided on the device from the cloud's bounding box; the handle stays usable. */
 int mola_icp_align(mola_icp_handle* h,
                    const float* from_x, const float* from_y, const float* from_z, size_t M,
                    const float* to_x, const float* to_y, const float* to_z, size_t N,
