@@ -962,6 +962,15 @@ int mola_icp_cloud_drop(mola_icp_handle* h, uint64_t id)
     });
 }
 
+int mola_icp_device_pool_trim(int device, size_t keep_bytes, size_t* parked_bytes_out)
+{
+    return guarded([&]() -> int {
+        device_pool_trim(keep_bytes);
+        if (parked_bytes_out) *parked_bytes_out = device_pool_bytes(device);
+        return MOLA_ICP_OK;
+    });
+}
+
 int mola_icp_cloud_count(mola_icp_handle* h, size_t* count_out, size_t* device_bytes_out)
 {
     return guarded([&]() -> int {

@@ -19,7 +19,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -93,18 +96,107 @@ static const char* const kSlabMsg =
 static Knobs g_knobs = read_knobs();
 void reload_env_knobs() { g_knobs = read_knobs(); }
 
+// ---- parked device blocks (DevBuf::pooled) ------------------------------------------------------------------
+// An odometry stream drops one cached cloud per scan: six hipFree calls, ~90 us of a 0.75-ms scan (HIP API trace), each of
+// them a device-wide synchronisation that also stalls every other handle's stream.  Parked blocks are handed out again to
+// requests they fit without much waste; beyond MOLA_ICP_POOL_MB (default 1024) per device a released block is freed at once.
+// The lists are never destroyed (the HIP runtime may be gone before static destructors run; the process's teardown
+// returns the memory).
+namespace {
+constexpr int kPoolDevices = 16;
+struct BlockPool {
+    std::mutex m;
+    std::multimap<size_t, void*> free_[kPoolDevices];
+    size_t bytes[kPoolDevices] = {};
+    size_t limit = 1024ull << 20;
+    BlockPool()
+    {
+        if (const char* e = std::getenv("MOLA_ICP_POOL_MB")) limit = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    }
+};
+BlockPool& block_pool()
+{
+    static BlockPool* pool = new BlockPool;   // (deliberately leaked: see above)
+    return *pool;
+}
+}  // namespace
+
+void device_pool_trim(size_t keep_bytes)
+{
+    BlockPool& bp = block_pool();
+    std::lock_guard<std::mutex> lk(bp.m);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < kPoolDevices; ++d) {
+        if (bp.free_[d].empty()) continue;
+        (void)hipSetDevice(d);
+        while (bp.bytes[d] > keep_bytes && !bp.free_[d].empty()) {   // the largest blocks first
+            auto it = std::prev(bp.free_[d].end());
+            (void)hipFree(it->second);
+            bp.bytes[d] -= it->first;
+            bp.free_[d].erase(it);
+        }
+    }
+    (void)hipSetDevice(cur);
+}
+
+size_t device_pool_bytes(int device)
+{
+    BlockPool& bp = block_pool();
+    std::lock_guard<std::mutex> lk(bp.m);
+    return device >= 0 && device < kPoolDevices ? bp.bytes[device] : 0;
+}
+
 int DevBuf::reserve(size_t bytes)
 {
     if (bytes <= cap && p) return MOLA_ICP_OK;
     release();
-    const size_t want = bytes < 256 ? 256 : bytes;
-    HIPCHK(hipMalloc(&p, want));
+    size_t want = bytes < 256 ? 256 : bytes;
+    if (pooled) {
+        want = (want + 4095) / 4096 * 4096;
+        int d = 0;
+        HIPCHK(hipGetDevice(&d));
+        dev = d;
+        if (d >= 0 && d < kPoolDevices) {
+            BlockPool& bp = block_pool();
+            std::lock_guard<std::mutex> lk(bp.m);
+            auto it = bp.free_[d].lower_bound(want);
+            if (it != bp.free_[d].end() && it->first <= want + want / 2 + 65536) {   // (a fit without much waste)
+                p = it->second;
+                cap = it->first;
+                bp.bytes[d] -= cap;
+                bp.free_[d].erase(it);
+                return MOLA_ICP_OK;
+            }
+        }
+    }
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory) {   // parked blocks are free memory as far as the caller is concerned
+        (void)hipGetLastError();
+        device_pool_trim(0);
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        p = nullptr;
+        return fail(e == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
     cap = want;
     return MOLA_ICP_OK;
 }
 
 void DevBuf::release()
 {
+    if (p && pooled && dev >= 0 && dev < kPoolDevices) {
+        BlockPool& bp = block_pool();
+        std::lock_guard<std::mutex> lk(bp.m);
+        if (bp.bytes[dev] + cap <= bp.limit) {
+            bp.free_[dev].emplace(cap, p);
+            bp.bytes[dev] += cap;
+            p = nullptr;
+            cap = 0;
+            return;
+        }
+    }
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;

@@ -32,10 +32,17 @@ void reload_env_knobs();  // re-reads the MOLA_ICP_* diagnostic variables (tests
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    // pooled: release() parks the block in a per-device free list instead of hipFree (which synchronises the whole device and
+    // takes ~15 us a call), reserve() looks there first.  Only for buffers that are released when no work on them is in flight
+    // on ANY stream -- the clouds (SortedCloud): every entry point that uses one returns after its work has completed.
+    bool pooled = false;
+    int dev = -1;               // (pooled blocks: the device they live on)
     int reserve(size_t bytes);  // grows (never shrinks); contents are NOT preserved
     void release();
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
+void device_pool_trim(size_t keep_bytes);   // hipFree parked blocks down to keep_bytes per device (0: all)
+size_t device_pool_bytes(int device);
 
 // A cloud in Hilbert order with its three box levels (the tiled kernels' view of a map; its sorted coordinates and
 // permutation also serve the query role).  Owned by a workspace, or shared through the handle's cloud cache.
@@ -47,6 +54,7 @@ struct SortedCloud {
     size_t padded = 0;
     int n_tiles_p = 0, n_super = 0, n_top = 0;
     bool ready = false, cached = false;
+    SortedCloud() { raw.pooled = sorted.pooled = perm.pooled = tbox.pooled = sbox.pooled = ubox.pooled = true; }
     ~SortedCloud() { raw.release(); sorted.release(); perm.release(); tbox.release(); sbox.release(); ubox.release(); }
 };
 

@@ -310,6 +310,13 @@ class ICP:
         L.check(L.lib().mola_icp_cloud_count(self._h, C.byref(n), C.byref(b)))
         return n.value, b.value
 
+    @staticmethod
+    def device_pool_trim(device: int = 0, keep_bytes: int = 0) -> int:
+        """free parked device blocks of dropped clouds down to `keep_bytes` per device; returns what stays parked on `device`"""
+        b = C.c_size_t()
+        L.check(L.lib().mola_icp_device_pool_trim(int(device), int(keep_bytes), C.byref(b)))
+        return b.value
+
     def align_cached(self, from_id: int, to_id: int, init_guess_to_wrt_from, params: Parameters) -> Results:
         T = _pose16(init_guess_to_wrt_from)
         r = L.CResult()

@@ -281,6 +281,31 @@ def test_edge_cases(pkg, icp, golden):
     assert icp.align(g, l, np.eye(4), p2p_params(pkg, max_iterations=2)).nIterations == 2
 
 
+def test_dropped_clouds_park_their_device_blocks(pkg, synth, small_scene):
+    """A stream of put / align / drop (an odometry drive drops one cloud per scan): the dropped clouds' device blocks are parked and
+    handed to the next cloud -- results are those of fresh allocations, the parked amount stays bounded, and the trim call frees it."""
+    pkg.ICP.device_pool_trim(0, 0)
+    icp = pkg.ICP(device=0)
+    p = p2p_params(pkg, max_iterations=10, matcher_threshold=0.6)
+    ref = pkg.ICP(device=0)
+    clouds = [synth.make_pair(9000 + 37 * k, 9000 + 37 * k, seed=500 + k, scene=small_scene)[1] for k in range(8)]
+    parked = []
+    icp.cloud_put(0, clouds[0])
+    for k in range(1, 8):
+        icp.cloud_put(k, clouds[k])
+        r = icp.align_cached(k - 1, k, np.eye(4), p)
+        s = ref.align(clouds[k - 1], clouds[k], np.eye(4), p)
+        assert r.nIterations == s.nIterations and np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality, k
+        icp.cloud_drop(k - 1)
+        parked.append(pkg.ICP.device_pool_trim(0, 1 << 40))    # (a limit nothing reaches: just reads the parked amount)
+    # (a dropped cloud lives until the workspace that used it last lets go of it: one align later)
+    assert parked[-1] > 0                         # dropped clouds' blocks are parked ...
+    assert max(parked) <= 2 * parked[1] + (1 << 20)   # ... and later clouds take them instead of piling up new ones (one cloud's worth, padded, stays)
+    assert pkg.ICP.device_pool_trim(0, 0) == 0
+    icp.cloud_put(99, clouds[0])                  # (after a trim: plain allocations again)
+    assert icp.align_cached(99, 7, np.eye(4), p).nIterations >= 1
+
+
 def test_non_finite_coordinates_are_refused(pkg, golden):
     """The bounding box of a new cloud is no longer waited for (its sort reads it on the device); the host checks its copy at the
     next wait it makes anyway: a NaN / inf coordinate must still fail the call it came with, through every way a cloud gets in."""
