@@ -634,7 +634,12 @@ int HipWorkspace::check_bboxes()
     for (int slot = 0; slot < 2; ++slot) {
         if (!(pending & (1u << slot))) continue;
         for (int k = 0; k < 6; ++k)
-            if (!std::isfinite(meta_host_[8 * slot + k])) return fail(MOLA_ICP_E_BADARG, "a cloud has non-finite coordinates");
+            if (!std::isfinite(meta_host_[8 * slot + k])) {
+                // (not "prepared": another align on the same resident clouds must run into the same refusal)
+                if (slot == 0 && !map_sc_->cached) map_sc_->ready = false;
+                if (slot == 1 && !loc_sc_->cached) loc_sc_->ready = false;
+                return fail(MOLA_ICP_E_BADARG, "a cloud has non-finite coordinates");
+            }
     }
     return MOLA_ICP_OK;
 }

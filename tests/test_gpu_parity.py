@@ -325,6 +325,11 @@ def test_non_finite_coordinates_are_refused(pkg, golden):
                 with pytest.raises(pkg.IcpError) as e:
                     icp.align(a, b, np.eye(4), params)
                 assert e.value.status == pkg._lib.E_BADARG and "non-finite" in str(e.value), (which, bad_value)
+                try:                                 # ... and nothing is left on the device that a resident align could run on
+                    rr = icp.align_resident(np.eye(4), params)
+                    assert rr.nIterations == 0 and rr.n_pairs == 0
+                except pkg.IcpError:
+                    pass
                 # ... and the handle is usable afterwards
                 r = icp.align(big_g, big_l, np.eye(4), params)
                 assert r.nIterations >= 1
