@@ -771,10 +771,12 @@ int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, 
     sc.ready = false;
     rc = n ? prepare_tiles() : MOLA_ICP_OK;
     // (the workspace's own map is put back BEFORE any return: map_sc_ aliases the caller's cloud through a no-op deleter)
-    const hipError_t es = rc ? hipSuccess : hipStreamSynchronize(stream_);
+    // (also on a failure half-way: the caller destroys the cloud, and its parked blocks may be handed to another handle at once --
+    // nothing of this build may still be running on them)
+    const hipError_t es = hipStreamSynchronize(stream_);
     map_sc_ = keep_sc;
     gx_ = kx; gy_ = ky; gz_ = kz; M_ = kM;
-    if (es != hipSuccess) return fail(es == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("build_cached: ") + hipGetErrorString(es));
+    if (es != hipSuccess && !rc) return fail(es == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("build_cached: ") + hipGetErrorString(es));
     if (!rc) rc = check_bboxes();   // (the cloud's bounding box arrived with that synchronisation)
     else bbox_pending_ = 0;
     return rc;
