@@ -64,6 +64,7 @@ struct Knobs {
     int knn_coop = -1;         // MOLA_ICP_KNN_COOP (-1 = by cloud size, 0 = k_knn_planes, 1 = k_knn_coop: one workgroup per item)
     bool planes_valu = false;  // MOLA_ICP_PLANES_VALU: the plane form accumulated by k_accumulate_planes (VALU) instead of the fp64-MFMA kernel
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
+    bool no_bootstrap = false;   // MOLA_ICP_NO_BOOTSTRAP: the first plane-matcher launch of an align on odometry-size clouds sweeps without seeds
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
@@ -80,6 +81,7 @@ static Knobs read_knobs()
     k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
     k.no_fused_rows = std::getenv("MOLA_ICP_NO_FUSED_ROWS") != nullptr;
+    k.no_bootstrap = std::getenv("MOLA_ICP_NO_BOOTSTRAP") != nullptr;
     k.planes_valu = std::getenv("MOLA_ICP_PLANES_VALU") != nullptr;
     k.knn_coop = std::getenv("MOLA_ICP_KNN_COOP") ? (geti("MOLA_ICP_KNN_COOP") != 0 ? 1 : 0) : -1;
     if (const char* e = std::getenv("MOLA_ICP_SPLIT_SHARE")) { const double v = std::atof(e); if (v > 0.01 && v < 100.0) k.split_share = v; }
@@ -1009,6 +1011,31 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if ((rc = knn_pos_.reserve(sizeof(int) * loc_sc_->padded * 9))) return rc;  // lists of knn + 1 entries
     if ((rc = knn_lb_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
     if ((rc = plane_cache_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
+    // The first launch of an align has no lists to start from: its sweep begins at the whole gate, and on an odometry-size scan it is
+    // the longest kernel of the align by far (269 us of the 660 us of kernels of a scan in the odometry stream).  The caller's
+    // guess is a motion model's (src/LidarOdometry.cpp:264-276): the queries sit near their neighbours already.  So: one
+    // nearest-neighbour pass first (k_nn_coop, ~35 us at 120k), and every query starts from the knn + 1 map points AROUND its
+    // nearest neighbour on the Hilbert curve (k_bootstrap_seeds) -- candidates like any seed (exact: the sweep that follows is
+    // complete under the bound they give), no certificates, no cached planes.  Only the cooperative kernel's range (odometry
+    // sizes) and only the first launch: as a general replacement for stale lists the same idea lost everywhere (DESIGN.md,
+    // 'measured and dropped').
+    bool bootstrapped = false;
+    {
+        const bool have_seed = knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed;
+        const size_t items64 = (N_ + 63) / 64;
+        const bool coop_range = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : items64 <= (size_t)num_cus_ * 8;
+        if (!have_seed && coop_range && !g_knobs.no_bootstrap && !g_knobs.no_knn_seed && M_ >= 64) {
+            mola_icp_params pn = p;
+            pn.nn_kernel = MOLA_ICP_NN_AUTO;
+            if ((rc = match(T, p.matcher_threshold, pn, nullptr))) return rc;
+            if (pairing_sorted_) {
+                hipLaunchKernelGGL(k_bootstrap_seeds, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, ts_pos_.as<int>(), (int)N_, (int)M_,
+                                   (int)p.knn + 1, knn_pos_.as<int>());
+                HIPCHK(hipGetLastError());
+                bootstrapped = true;
+            }
+        }
+    }
     PoseF P;
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) P.R[3 * r + c] = (float)T(r, c);
@@ -1080,10 +1107,10 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if (grid > (n_items + 3) / 4) grid = (n_items + 3) / 4;
     if (grid_ver > (n_items + 3) / 4) grid_ver = (n_items + 3) / 4;
     if (grid4 > (n_items + 3) / 4) grid4 = (n_items + 3) / 4;
-    const int knn_seed = (knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed) ? 1 : 0;
+    const int knn_seed = (bootstrapped || (knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed)) ? 1 : 0;
     // the cached plane of an unchanged neighbour list carries the planar / non-planar decision of the launch that
     // solved it: reusable only under the same planeEigenThreshold (the seeds themselves do not depend on it)
-    const int plane_cache_ok = (knn_seed && planes_eig_thr_ == p.plane_eigen_threshold) ? 1 : 0;
+    const int plane_cache_ok = (knn_seed && !bootstrapped && planes_eig_thr_ == p.plane_eigen_threshold) ? 1 : 0;
     // the counting flavour pays off when few items will need the insertion flavour afterwards: judged by the
     // number of items whose lists changed in the previous iteration (read back with its accumulators)
     // ... and only inside a converging sequence of poses: the first launch of another align on the same clouds starts far from
@@ -1098,7 +1125,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     }
     const bool converging = step <= 4.0 * knn_last_step_ + 1e-9;
     knn_last_step_ = knn_seed ? step : 1e30;   // (after an unseeded launch any step counts as "converging")
-    const bool verify = knn_seed && knn_changed_items_ >= 0.0 && knn_changed_items_ < 0.3 * (double)n_items && converging &&
+    const bool verify = knn_seed && !bootstrapped && knn_changed_items_ >= 0.0 && knn_changed_items_ < 0.3 * (double)n_items && converging &&
                         !g_knobs.no_knn_verify;
     knn_changed_items_ = -1.0;  // consumed: only an accumulate_planes() after this launch renews it
     if ((rc = redo_list_.reserve(sizeof(int) * (size_t)n_items))) return rc;
@@ -1130,7 +1157,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     for (int k = 0; k < 9; ++k) cert.Pprev.R[k] = knn_last_P_[k];
     for (int k = 0; k < 3; ++k) cert.Pprev.t[k] = knn_last_P_[9 + k];
     cert.lb = knn_lb_.as<float>();
-    cert.on = (knn_seed && !g_knobs.no_certify) ? 1 : 0;
+    cert.on = (knn_seed && !bootstrapped && !g_knobs.no_certify) ? 1 : 0;
     cert.stats = profiling_ ? stats_.as<unsigned long long>() : nullptr;
     // the lists' own gate (KnnCert): 1.1 x the matcher's; seeds kept under one gate are not reused under another
     const float thr2x = g_knobs.no_certify ? thr2 : thr2 * 1.21f;

@@ -656,6 +656,19 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
     }
 }
 
+// Seeds for a launch that has no lists yet (HipWorkspace::match_planes): the K map points around each query's nearest neighbour
+// on the Hilbert curve -- K distinct sorted positions [s, s + K) with the neighbour in the middle, -1 where the query has none.
+__global__ __launch_bounds__(256) void k_bootstrap_seeds(const int* __restrict__ nn_pos /*sorted-map position of the NN per sorted query*/,
+                                                         int N, int M, int K, int* __restrict__ knn_pos /*N x K*/)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int pos = nn_pos[i];
+    int s = pos - K / 2;
+    s = s < 0 ? 0 : (s > M - K ? M - K : s);
+    for (int j = 0; j < K; ++j) knn_pos[(size_t)i * K + j] = pos >= 0 ? s + j : -1;
+}
+
 // the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
 // x = [R row-major (9), t (3)]  with  phi = [n (x) l, n],  d = n.c :   A = sum phi phi^T (78 unique),
 // b = sum phi d (12), c0 = sum d^2, count.  ONE pass -> the whole Gauss-Newton inner loop runs on the host.
