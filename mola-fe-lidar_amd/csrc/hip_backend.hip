@@ -64,7 +64,7 @@ struct Knobs {
     int knn_coop = -1;         // MOLA_ICP_KNN_COOP (-1 = by cloud size, 0 = k_knn_planes, 1 = k_knn_coop: one workgroup per item)
     bool planes_valu = false;  // MOLA_ICP_PLANES_VALU: the plane form accumulated by k_accumulate_planes (VALU) instead of the fp64-MFMA kernel
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
-    bool no_bootstrap = false;   // MOLA_ICP_NO_BOOTSTRAP: the first plane-matcher launch of an align on odometry-size clouds sweeps without seeds
+    bool no_bootstrap = false;   // MOLA_ICP_NO_BOOTSTRAP: the first plane-matcher launch of an align sweeps without seeds
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
@@ -1016,15 +1016,13 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     // guess is a motion model's (src/LidarOdometry.cpp:264-276): the queries sit near their neighbours already.  So: one
     // nearest-neighbour pass first (k_nn_coop, ~35 us at 120k), and every query starts from the knn + 1 map points AROUND its
     // nearest neighbour on the Hilbert curve (k_bootstrap_seeds) -- candidates like any seed (exact: the sweep that follows is
-    // complete under the bound they give), no certificates, no cached planes.  Only the cooperative kernel's range (odometry
-    // sizes) and only the first launch: as a general replacement for stale lists the same idea lost everywhere (DESIGN.md,
-    // 'measured and dropped').
+    // complete under the bound they give), no certificates, no cached planes.  Only the first launch: as a general replacement
+    // for stale lists the same idea lost everywhere ('measured and dropped').  At 1M x 1M the seeded launch that follows
+    // is the dense-build flavour: shipped pipeline 4 770-4 810 -> 4 910 it/s over 20 iterations.
     bool bootstrapped = false;
     {
         const bool have_seed = knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed;
-        const size_t items64 = (N_ + 63) / 64;
-        const bool coop_range = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : items64 <= (size_t)num_cus_ * 8;
-        if (!have_seed && coop_range && !g_knobs.no_bootstrap && !g_knobs.no_knn_seed && M_ >= 64) {
+        if (!have_seed && !g_knobs.no_bootstrap && !g_knobs.no_knn_seed && M_ >= 64) {
             mola_icp_params pn = p;
             pn.nn_kernel = MOLA_ICP_NN_AUTO;
             if ((rc = match(T, p.matcher_threshold, pn, nullptr))) return rc;
