@@ -1025,7 +1025,10 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         if (!have_seed && !g_knobs.no_bootstrap && !g_knobs.no_knn_seed && M_ >= 64) {
             mola_icp_params pn = p;
             pn.nn_kernel = MOLA_ICP_NN_AUTO;
-            if ((rc = match(T, p.matcher_threshold, pn, nullptr))) return rc;
+            // (under HALF the plane matcher's gate: a query whose nearest neighbour is farther than that starts without seeds --
+            // the pass costs with its gate, 79 us at 0.7 m on a 120k scan, and seeds that far away bound little; measured 1 / 0.5 /
+            // 0.25 of the gate: config 0's first iteration 193-197 / 180 / 201 us, odometry stream 0.65-0.71 / 0.63-0.67 / 0.64-0.67 ms)
+            if ((rc = match(T, 0.5 * p.matcher_threshold, pn, nullptr))) return rc;
             if (pairing_sorted_) {
                 hipLaunchKernelGGL(k_bootstrap_seeds, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, ts_pos_.as<int>(), (int)N_, (int)M_,
                                    (int)p.knn + 1, knn_pos_.as<int>());
@@ -1564,7 +1567,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         if (rc) return rc;
         last_kernel_ = MOLA_ICP_NN_TILED;
         pairing_sorted_ = true;
-        counters_clean_ = false;
+        if (!coop) counters_clean_ = false;   // (the cooperative kernel has no queue and no redo list: it leaves the counters as they are)
         if (profiling_) {
             HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
             ev_used_ += 2;
