@@ -262,7 +262,9 @@ int HipWorkspace::init()
     HIPCHK(hipEventCreateWithFlags(&ev_order_b_, hipEventDisableTiming));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * (kNAcc + 8), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(acc_host_, 0, sizeof(double) * (kNAcc + 8));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocDefault));
+    // (the sort's first kernel writes a cloud's bounding box straight into this block: mapped, coherent)
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&meta_host_), sizeof(float) * 16, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(meta_host_, 0, sizeof(float) * 16);
     int rc;
     if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8) + sizeof(unsigned int) * 2 * kQueues * kQueueStride))) return rc;
     if ((rc = stats_.reserve(sizeof(unsigned long long) * kStatSlots * kStatStride))) return rc;
@@ -414,8 +416,11 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
     return MOLA_ICP_OK;
 }
 
-int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
-                       const float* bbox_dev, DevBuf& scratch, float* sxyz, int* perm);
+int hilbert_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
+                        const float* box_rows, int n_box_rows, float* box_dev, float* box_host, DevBuf& scratch, float* sxyz, int* perm,
+                        float* sbox, int n_super, float* ubox, int n_top);
+int boxes_of_sorted(hipStream_t stream, const float* sxyz, size_t M, size_t M_padded, int n_tiles_p, int n_super, int n_top, float* tbox,
+                    float* sbox, float* ubox, const float* cloud_box);
 int select_in_box(hipStream_t stream, const float* x, const float* y, const float* z, size_t n, const float lo[3], const float hi[3],
                   DevBuf& scratch, int* sel, size_t* n_kept_host);
 int gather_by_index(hipStream_t stream, const float* x, const float* y, const float* z, const int* sel, size_t n, float* ox, float* oy,
@@ -448,7 +453,9 @@ int HipWorkspace::set_local_shard(const float* x, const float* y, const float* z
         const size_t padded = (n_total + kQPW - 1) / kQPW * kQPW;
         if ((rc = sorted.reserve(sizeof(float) * 3 * padded))) return rc;
         if ((rc = perm.reserve(sizeof(int) * padded))) { sorted.release(); return rc; }   // (an OOM path: leak nothing)
-        if ((rc = morton_sort_points(stream_, fx, fy, fz, n_total, padded, bbox_dev(), sort_scratch_, sorted.as<float>(), perm.as<int>()))) {
+        // (bbox_of left the finished box in the device block: one row)
+        if ((rc = hilbert_sort_points(stream_, fx, fy, fz, n_total, padded, bbox_dev(), 1, nullptr, nullptr, sort_scratch_, sorted.as<float>(),
+                                      perm.as<int>(), nullptr, 0, nullptr, 0))) {
             sorted.release(); perm.release();
             return rc;
         }
@@ -607,24 +614,33 @@ int HipWorkspace::prepare_map()
     return MOLA_ICP_OK;
 }
 
-int morton_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
-                       const float* bbox_dev, DevBuf& scratch, float* sxyz, int* perm);
-
 // Bounding box of a device cloud into the device block bbox_dev() and, by an asynchronous copy, into slot `slot` of the pinned block:
-// nothing waits here.  The sort that follows reads the device block; the host looks at its copy (finite coordinates?) at the next
-// wait it makes anyway (check_bboxes(): behind the first accumulation of an align, or behind a cache build's synchronisation).
-int HipWorkspace::bbox_async(const float* x, const float* y, const float* z, size_t n, int slot)
+// nothing waits here.  The host looks at its copy (finite coordinates?) at the next wait it makes anyway (check_bboxes(): behind
+// the first accumulation of an align, or behind a cache build's synchronisation).  `owner`: the prepared-cloud object that must
+// not count as prepared if the box turns out not to be finite (may be null).
+int HipWorkspace::bbox_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner)
 {
     int rc;
-    const int nb = 256;
-    if ((rc = map_meta_.reserve(sizeof(float) * (6 * nb + 8)))) return rc;
-    float* part = map_meta_.as<float>();
-    hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(256), 0, stream_, x, y, z, (int)n, part);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, stream_, part, nb, bbox_dev());
+    if ((rc = bbox_rows_async(x, y, z, n, slot, owner))) return rc;
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, stream_, map_meta_.as<float>(), bbox_n_rows_, bbox_dev());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(meta_host_ + 8 * slot, bbox_dev(), sizeof(float) * 6, hipMemcpyDeviceToHost, stream_));
+    return MOLA_ICP_OK;
+}
+
+// The prepare chain's form: only the per-block rows (map_meta_: [kBboxRows][6]); the sort's first kernel finishes the box itself
+// and writes it to bbox_dev() and to the pinned slot (map_sort.hip, HilbertKeys) -- no launch and no copy in between.
+int HipWorkspace::bbox_rows_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner)
+{
+    int rc;
+    if ((rc = map_meta_.reserve(sizeof(float) * (6 * kBboxRows + 8)))) return rc;
+    // (1024 points per workgroup and trip, the four loads of a thread issued together: a 120k-point scan is one trip of 118 workgroups)
+    bbox_n_rows_ = (int)std::min<size_t>((size_t)kBboxRows, (n + 1023) / 1024);
+    if (bbox_n_rows_ < 1) bbox_n_rows_ = 1;
+    hipLaunchKernelGGL(k_bbox_rows, dim3(bbox_n_rows_), dim3(256), 0, stream_, x, y, z, (int)n, map_meta_.as<float>());
+    HIPCHK(hipGetLastError());
     bbox_pending_ |= 1u << slot;
+    bbox_owner_[slot] = owner;
     return MOLA_ICP_OK;
 }
 
@@ -633,22 +649,26 @@ int HipWorkspace::check_bboxes()
 {
     const unsigned int pending = bbox_pending_;
     bbox_pending_ = 0;
+    int rc = MOLA_ICP_OK;
     for (int slot = 0; slot < 2; ++slot) {
+        const std::shared_ptr<SortedCloud> owner = bbox_owner_[slot].lock();   // (gone: nothing to mark)
+        bbox_owner_[slot].reset();
         if (!(pending & (1u << slot))) continue;
         for (int k = 0; k < 6; ++k)
             if (!std::isfinite(meta_host_[8 * slot + k])) {
-                // (not "prepared": another align on the same resident clouds must run into the same refusal)
-                if (slot == 0 && !map_sc_->cached) map_sc_->ready = false;
-                if (slot == 1 && !loc_sc_->cached) loc_sc_->ready = false;
-                return fail(MOLA_ICP_E_BADARG, "a cloud has non-finite coordinates");
+                // (not "prepared": another align on the same resident clouds must run into the same refusal -- the cloud the box
+                // belongs to, whichever role it was prepared in)
+                if (owner) owner->ready = false;
+                if (!rc) rc = fail(MOLA_ICP_E_BADARG, "a cloud has non-finite coordinates");
+                break;
             }
     }
-    return MOLA_ICP_OK;
+    return rc;
 }
 
 int HipWorkspace::bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6])
 {
-    int rc = bbox_async(x, y, z, n, 0);
+    int rc = bbox_async(x, y, z, n, 0, std::shared_ptr<SortedCloud>());
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(stream_));
     if ((rc = check_bboxes())) return rc;
@@ -656,53 +676,48 @@ int HipWorkspace::bbox_of(const float* x, const float* y, const float* z, size_t
     return MOLA_ICP_OK;
 }
 
-// Once per map: Morton order, tile boxes, super-tile boxes.
+// Once per map: Hilbert order, tile boxes, super-tile boxes, top boxes -- five launches enqueued back to back (map_sort.hip).
 int HipWorkspace::prepare_tiles()
 {
     if (map_sc_->ready) return MOLA_ICP_OK;
     int rc;
-    if ((rc = bbox_async(gx_, gy_, gz_, M_, 0))) return rc;
+    SortedCloud& sc = *map_sc_;
+    if ((rc = bbox_rows_async(gx_, gy_, gz_, M_, 0, map_sc_))) return rc;
     const size_t super_pts = (size_t)kTileG * kSuper;
-    map_sc_->n_super = (int)((M_ + super_pts - 1) / super_pts);
-    map_sc_->n_super = (map_sc_->n_super + 63) / 64 * 64;  // whole top boxes (the padding tiles get empty boxes)
-    map_sc_->n_top = map_sc_->n_super / 64;
-    map_sc_->n_tiles_p = map_sc_->n_super * kSuper;
-    map_sc_->padded = (size_t)map_sc_->n_tiles_p * kTileG;
-    if ((rc = map_sc_->sorted.reserve(sizeof(float) * 3 * map_sc_->padded))) return rc;
-    if ((rc = map_sc_->perm.reserve(sizeof(int) * map_sc_->padded))) return rc;
-    if ((rc = map_sc_->tbox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_tiles_p))) return rc;
-    if ((rc = map_sc_->sbox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_super))) return rc;
-    if ((rc = map_sc_->ubox.reserve(sizeof(float) * 6 * (size_t)map_sc_->n_top))) return rc;
-    if ((rc = morton_sort_points(stream_, gx_, gy_, gz_, M_, map_sc_->padded, bbox_dev(), sort_scratch_, map_sc_->sorted.as<float>(),
-                                 map_sc_->perm.as<int>())))
+    sc.n_super = (int)((M_ + super_pts - 1) / super_pts);
+    sc.n_super = (sc.n_super + 63) / 64 * 64;  // whole top boxes (the padding tiles get empty boxes)
+    sc.n_top = sc.n_super / 64;
+    sc.n_tiles_p = sc.n_super * kSuper;
+    sc.padded = (size_t)sc.n_tiles_p * kTileG;
+    if ((rc = sc.sorted.reserve(sizeof(float) * 3 * sc.padded))) return rc;
+    if ((rc = sc.perm.reserve(sizeof(int) * sc.padded))) return rc;
+    if ((rc = sc.tbox.reserve(sizeof(float) * 6 * (size_t)sc.n_tiles_p))) return rc;
+    if ((rc = sc.sbox.reserve(sizeof(float) * 6 * (size_t)sc.n_super))) return rc;
+    if ((rc = sc.ubox.reserve(sizeof(float) * 6 * (size_t)sc.n_top))) return rc;
+    if ((rc = hilbert_sort_points(stream_, gx_, gy_, gz_, M_, sc.padded, map_meta_.as<float>(), bbox_n_rows_, bbox_dev(), meta_host_, sort_scratch_,
+                                  sc.sorted.as<float>(), sc.perm.as<int>(), sc.sbox.as<float>(), sc.n_super, sc.ubox.as<float>(), sc.n_top)))
         return rc;
-    const float* sx = map_sc_->sorted.as<float>();
-    hipLaunchKernelGGL(k_tile_boxes, dim3((unsigned)((map_sc_->n_tiles_p + 7) / 8)), dim3(256), 0, stream_, sx, sx + map_sc_->padded,
-                       sx + 2 * map_sc_->padded, (int)M_, map_sc_->n_tiles_p, map_sc_->tbox.as<float>());
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((map_sc_->n_super + 3) / 4)), dim3(256), 0, stream_, map_sc_->tbox.as<float>(),
-                       map_sc_->n_tiles_p, map_sc_->n_super, map_sc_->sbox.as<float>());
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_super_boxes, dim3((unsigned)((map_sc_->n_top + 3) / 4)), dim3(256), 0, stream_, map_sc_->sbox.as<float>(),
-                       map_sc_->n_super, map_sc_->n_top, map_sc_->ubox.as<float>());
-    HIPCHK(hipGetLastError());
-    map_sc_->ready = true;
+    if ((rc = boxes_of_sorted(stream_, sc.sorted.as<float>(), M_, sc.padded, sc.n_tiles_p, sc.n_super, sc.n_top, sc.tbox.as<float>(),
+                              sc.sbox.as<float>(), sc.ubox.as<float>(), bbox_dev())))
+        return rc;
+    sc.ready = true;
     return MOLA_ICP_OK;
 }
 
-// Once per local cloud: Morton order of the queries (a rigid motion keeps them compact).
+// Once per local cloud: Hilbert order of the queries (a rigid motion keeps them compact) -- four launches.
 int HipWorkspace::prepare_queries()
 {
     if (loc_sc_->ready) return MOLA_ICP_OK;
     int rc;
-    if ((rc = bbox_async(lx_, ly_, lz_, N_, 1))) return rc;
-    loc_sc_->padded = (N_ + kQPW - 1) / kQPW * kQPW;
-    if ((rc = loc_sc_->sorted.reserve(sizeof(float) * 3 * loc_sc_->padded))) return rc;
-    if ((rc = loc_sc_->perm.reserve(sizeof(int) * loc_sc_->padded))) return rc;
-    if ((rc = morton_sort_points(stream_, lx_, ly_, lz_, N_, loc_sc_->padded, bbox_dev(), sort_scratch_, loc_sc_->sorted.as<float>(),
-                                 loc_sc_->perm.as<int>())))
+    SortedCloud& sc = *loc_sc_;
+    if ((rc = bbox_rows_async(lx_, ly_, lz_, N_, 1, loc_sc_))) return rc;
+    sc.padded = (N_ + kQPW - 1) / kQPW * kQPW;
+    if ((rc = sc.sorted.reserve(sizeof(float) * 3 * sc.padded))) return rc;
+    if ((rc = sc.perm.reserve(sizeof(int) * sc.padded))) return rc;
+    if ((rc = hilbert_sort_points(stream_, lx_, ly_, lz_, N_, sc.padded, map_meta_.as<float>(), bbox_n_rows_, bbox_dev(), meta_host_ + 8, sort_scratch_,
+                                  sc.sorted.as<float>(), sc.perm.as<int>(), nullptr, 0, nullptr, 0)))
         return rc;
-    loc_sc_->ready = true;
+    sc.ready = true;
     return MOLA_ICP_OK;
 }
 
@@ -779,8 +794,11 @@ int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, 
     map_sc_ = keep_sc;
     gx_ = kx; gy_ = ky; gz_ = kz; M_ = kM;
     if (es != hipSuccess && !rc) return fail(es == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("build_cached: ") + hipGetErrorString(es));
-    if (!rc) rc = check_bboxes();   // (the cloud's bounding box arrived with that synchronisation)
-    else bbox_pending_ = 0;
+    // (the cloud's bounding box arrived with that synchronisation; a box that is not finite clears `ready` on THIS cloud -- the
+    // owner recorded with the box -- not on whichever cloud sits in the workspace's map role)
+    if (!rc) rc = check_bboxes();
+    else { bbox_pending_ = 0; bbox_owner_[0].reset(); bbox_owner_[1].reset(); }
+    if (rc) sc.ready = false;
     return rc;
 }
 

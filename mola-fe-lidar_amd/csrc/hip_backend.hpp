@@ -160,10 +160,14 @@ class HipWorkspace final : public Stages {
     int prepare_tiles();    // Morton-sorted map + tile boxes for the tiled matcher
     int prepare_queries();  // Morton-sorted local cloud
     int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);   // (waits)
-    int bbox_async(const float* x, const float* y, const float* z, size_t n, int slot);   // device block + pinned slot, no wait
+    static constexpr int kBboxRows = 256;   // workgroups of k_bbox_partial = partial rows in map_meta_
+    int bbox_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner);   // device block + pinned slot, no wait
+    int bbox_rows_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner);   // the partial rows only (the sort finishes the box)
     int check_bboxes();                                                                     // after the next wait on stream_
-    float* bbox_dev() { return map_meta_.as<float>() + 6 * 256; }
+    float* bbox_dev() { return map_meta_.as<float>() + 6 * kBboxRows; }
     unsigned int bbox_pending_ = 0;
+    int bbox_n_rows_ = 0;   // rows k_bbox_rows wrote last
+    std::weak_ptr<SortedCloud> bbox_owner_[2];   // the prepared-cloud object each pending box belongs to (marked "not prepared" if the box is not finite)
     int launch_tiled(const struct PoseF& P, float thr2, bool use_seed, unsigned int* counter);
     int fill_nn_problem(const struct PoseF& P, float thr2, bool use_seed, NnProblem& pb);
     int launch_coop(const struct PoseF& P, float thr2, bool use_seed);

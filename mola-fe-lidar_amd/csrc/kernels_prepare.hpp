@@ -276,6 +276,47 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const float* __restrict__ 
     }
 }
 
+// The prepare chain's form of the same rows: 1024 points per workgroup and trip, a thread's four loads issued together (the cloud
+// has just been uploaded: every load is a trip to HBM, and k_bbox_partial's grid-stride loop made them one after another -- 8.8 us
+// for a 120k-point scan).  Same semantics per value (a non-finite coordinate poisons the maximum).  Rows [gridDim.x][6].
+__global__ __launch_bounds__(256) void k_bbox_rows(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                   const float* __restrict__ gz, int M, float* __restrict__ part)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i0 = (int)blockIdx.x * 1024 + (int)threadIdx.x; i0 < M; i0 += (int)gridDim.x * 1024) {
+        float v[4][3];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            ok[u] = i < M;
+            v[u][0] = v[u][1] = v[u][2] = 0.f;
+            if (ok[u]) { v[u][0] = gx[i]; v[u][1] = gy[i]; v[u][2] = gz[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[u][k]); mx[k] = fabsf(v[u][k]) <= 3.4028234e38f ? fmaxf(mx[k], v[u][k]) : INFINITY; }
+            }
+    }
+    __shared__ float sm[4][6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], off));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off));
+        }
+        if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][k] = mn[k]; sm[threadIdx.x >> 6][3 + k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
 // (256 threads, a partial row each, then a fixed-shape min / max tree: six lanes walking all rows one after the other took 22 us)
 __global__ __launch_bounds__(256) void k_bbox_final(const float* __restrict__ part, int nblocks, float* __restrict__ out)
 {

@@ -12,7 +12,7 @@ rows = [r for r in csv.DictReader(open("$OUT/kernel_trace.csv"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void mola_icp_amd::", "").replace("mola_icp_amd::", "")[:56]
 # the last scan: from the last k_bbox_partial on
-start = max(i for i, r in enumerate(rows) if "k_bbox_partial" in r["Kernel_Name"])
+start = max(i for i, r in enumerate(rows) if "k_bbox_rows" in r["Kernel_Name"] or "k_bbox_partial" in r["Kernel_Name"])
 scan = rows[start:]
 t0 = int(scan[0]["Start_Timestamp"]); prev = None; busy = 0.0
 print("the last scan of the drive (upload excluded: the first kernel is the new cloud's bounding box)")
