@@ -65,6 +65,7 @@ struct Knobs {
     bool planes_valu = false;  // MOLA_ICP_PLANES_VALU: the plane form accumulated by k_accumulate_planes (VALU) instead of the fp64-MFMA kernel
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
     bool no_bootstrap = false;   // MOLA_ICP_NO_BOOTSTRAP: the first plane-matcher launch of an align sweeps without seeds
+    bool bootstrap_nn = false;   // MOLA_ICP_BOOTSTRAP_NN: ... is seeded around each query's nearest neighbour (an NN pass first) instead of around its Hilbert key's place
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
@@ -82,6 +83,7 @@ static Knobs read_knobs()
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
     k.no_fused_rows = std::getenv("MOLA_ICP_NO_FUSED_ROWS") != nullptr;
     k.no_bootstrap = std::getenv("MOLA_ICP_NO_BOOTSTRAP") != nullptr;
+    k.bootstrap_nn = std::getenv("MOLA_ICP_BOOTSTRAP_NN") != nullptr;
     k.planes_valu = std::getenv("MOLA_ICP_PLANES_VALU") != nullptr;
     k.knn_coop = std::getenv("MOLA_ICP_KNN_COOP") ? (geti("MOLA_ICP_KNN_COOP") != 0 ? 1 : 0) : -1;
     if (const char* e = std::getenv("MOLA_ICP_SPLIT_SHARE")) { const double v = std::atof(e); if (v > 0.01 && v < 100.0) k.split_share = v; }
@@ -418,7 +420,7 @@ int HipWorkspace::set_local_device(const float* x, const float* y, const float* 
 
 int hilbert_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
                         const float* box_rows, int n_box_rows, float* box_dev, float* box_host, DevBuf& scratch, float* sxyz, int* perm,
-                        float* sbox, int n_super, float* ubox, int n_top);
+                        float* sbox, int n_super, float* ubox, int n_top, unsigned int* keys_sorted);
 int boxes_of_sorted(hipStream_t stream, const float* sxyz, size_t M, size_t M_padded, int n_tiles_p, int n_super, int n_top, float* tbox,
                     float* sbox, float* ubox, const float* cloud_box);
 int select_in_box(hipStream_t stream, const float* x, const float* y, const float* z, size_t n, const float lo[3], const float hi[3],
@@ -455,7 +457,7 @@ int HipWorkspace::set_local_shard(const float* x, const float* y, const float* z
         if ((rc = perm.reserve(sizeof(int) * padded))) { sorted.release(); return rc; }   // (an OOM path: leak nothing)
         // (bbox_of left the finished box in the device block: one row)
         if ((rc = hilbert_sort_points(stream_, fx, fy, fz, n_total, padded, bbox_dev(), 1, nullptr, nullptr, sort_scratch_, sorted.as<float>(),
-                                      perm.as<int>(), nullptr, 0, nullptr, 0))) {
+                                      perm.as<int>(), nullptr, 0, nullptr, 0, nullptr))) {
             sorted.release(); perm.release();
             return rc;
         }
@@ -694,11 +696,14 @@ int HipWorkspace::prepare_tiles()
     if ((rc = sc.tbox.reserve(sizeof(float) * 6 * (size_t)sc.n_tiles_p))) return rc;
     if ((rc = sc.sbox.reserve(sizeof(float) * 6 * (size_t)sc.n_super))) return rc;
     if ((rc = sc.ubox.reserve(sizeof(float) * 6 * (size_t)sc.n_top))) return rc;
-    if ((rc = hilbert_sort_points(stream_, gx_, gy_, gz_, M_, sc.padded, map_meta_.as<float>(), bbox_n_rows_, bbox_dev(), meta_host_, sort_scratch_,
-                                  sc.sorted.as<float>(), sc.perm.as<int>(), sc.sbox.as<float>(), sc.n_super, sc.ubox.as<float>(), sc.n_top)))
+    if ((rc = sc.keys.reserve(sizeof(unsigned int) * (M_ ? M_ : 1)))) return rc;
+    if ((rc = sc.box.reserve(sizeof(float) * 8))) return rc;
+    if ((rc = hilbert_sort_points(stream_, gx_, gy_, gz_, M_, sc.padded, map_meta_.as<float>(), bbox_n_rows_, sc.box.as<float>(), meta_host_, sort_scratch_,
+                                  sc.sorted.as<float>(), sc.perm.as<int>(), sc.sbox.as<float>(), sc.n_super, sc.ubox.as<float>(), sc.n_top,
+                                  sc.keys.as<unsigned int>())))
         return rc;
     if ((rc = boxes_of_sorted(stream_, sc.sorted.as<float>(), M_, sc.padded, sc.n_tiles_p, sc.n_super, sc.n_top, sc.tbox.as<float>(),
-                              sc.sbox.as<float>(), sc.ubox.as<float>(), bbox_dev())))
+                              sc.sbox.as<float>(), sc.ubox.as<float>(), sc.box.as<float>())))
         return rc;
     sc.ready = true;
     return MOLA_ICP_OK;
@@ -715,7 +720,7 @@ int HipWorkspace::prepare_queries()
     if ((rc = sc.sorted.reserve(sizeof(float) * 3 * sc.padded))) return rc;
     if ((rc = sc.perm.reserve(sizeof(int) * sc.padded))) return rc;
     if ((rc = hilbert_sort_points(stream_, lx_, ly_, lz_, N_, sc.padded, map_meta_.as<float>(), bbox_n_rows_, bbox_dev(), meta_host_ + 8, sort_scratch_,
-                                  sc.sorted.as<float>(), sc.perm.as<int>(), nullptr, 0, nullptr, 0)))
+                                  sc.sorted.as<float>(), sc.perm.as<int>(), nullptr, 0, nullptr, 0, nullptr)))
         return rc;
     sc.ready = true;
     return MOLA_ICP_OK;
@@ -1026,7 +1031,9 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if ((rc = prepare_tiles())) return rc;
     if ((rc = prepare_queries())) return rc;
     if ((rc = planes_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
-    if ((rc = knn_pos_.reserve(sizeof(int) * loc_sc_->padded * 9))) return rc;  // lists of knn + 1 entries
+    // the stored lists (knn + 1 entries per query: positions, coordinates, original indices; kernels_planes.hpp: KnnSeeds)
+    if ((rc = knn_pos_.reserve(knn_seeds_bytes(loc_sc_->padded, (int)p.knn + 1)))) return rc;
+    const KnnSeeds seeds = knn_seeds_at(knn_pos_.p, loc_sc_->padded, (int)p.knn + 1);
     if ((rc = knn_lb_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
     if ((rc = plane_cache_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
     // The first launch of an align has no lists to start from: its sweep begins at the whole gate, and on an odometry-size scan it is
@@ -1041,15 +1048,42 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     {
         const bool have_seed = knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed;
         if (!have_seed && !g_knobs.no_bootstrap && !g_knobs.no_knn_seed && M_ >= 64) {
-            mola_icp_params pn = p;
-            pn.nn_kernel = MOLA_ICP_NN_AUTO;
-            // (under HALF the plane matcher's gate: a query whose nearest neighbour is farther than that starts without seeds --
-            // the pass costs with its gate, 79 us at 0.7 m on a 120k scan, and seeds that far away bound little; measured 1 / 0.5 /
-            // 0.25 of the gate: config 0's first iteration 193-197 / 180 / 201 us, odometry stream 0.65-0.71 / 0.63-0.67 / 0.64-0.67 ms)
-            if ((rc = match(T, 0.5 * p.matcher_threshold, pn, nullptr))) return rc;
-            if (pairing_sorted_) {
-                hipLaunchKernelGGL(k_bootstrap_seeds, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, ts_pos_.as<int>(), (int)N_, (int)M_,
-                                   (int)p.knn + 1, knn_pos_.as<int>());
+            const bool by_key = !g_knobs.bootstrap_nn && map_sc_->keys.p != nullptr && map_sc_->box.p != nullptr;
+            if (!by_key) {
+                mola_icp_params pn = p;
+                pn.nn_kernel = MOLA_ICP_NN_AUTO;
+                // (under HALF the plane matcher's gate: a query whose nearest neighbour is farther than that starts without seeds --
+                // the pass costs with its gate, 79 us at 0.7 m on a 120k scan, and seeds that far away bound little; measured 1 / 0.5 /
+                // 0.25 of the gate: config 0's first iteration 193-197 / 180 / 201 us, odometry stream 0.65-0.71 / 0.63-0.67 / 0.64-0.67 ms)
+                if ((rc = match(T, 0.5 * p.matcher_threshold, pn, nullptr))) return rc;
+            }
+            if (by_key || pairing_sorted_) {
+                PoseF Pb;
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) Pb.R[3 * r + c] = (float)T(r, c);
+                    Pb.t[r] = (float)T(r, 3);
+                }
+                const float* slq = loc_sc_->sorted.as<float>();
+#define MOLA_LAUNCH_BOOTSTRAP(KK)                                                                                                     \
+    do {                                                                                                                              \
+        if (by_key)                                                                                                                   \
+            hipLaunchKernelGGL((k_bootstrap_seeds<KK, true>), dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, (const int*)nullptr, \
+                               map_sc_->keys.as<unsigned int>(), map_sc_->box.as<float>(), slq, slq + loc_sc_->padded,              \
+                               slq + 2 * loc_sc_->padded, (int)N_, Pb, tiled_map(), (int)M_, seeds);                                \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_bootstrap_seeds<KK, false>), dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, ts_pos_.as<int>(), \
+                               (const unsigned int*)nullptr, (const float*)nullptr, slq, slq + loc_sc_->padded,                      \
+                               slq + 2 * loc_sc_->padded, (int)N_, Pb, tiled_map(), (int)M_, seeds);                                \
+    } while (0)
+                switch (p.knn) {
+                    case 3: MOLA_LAUNCH_BOOTSTRAP(4); break;
+                    case 4: MOLA_LAUNCH_BOOTSTRAP(5); break;
+                    case 5: MOLA_LAUNCH_BOOTSTRAP(6); break;
+                    case 6: MOLA_LAUNCH_BOOTSTRAP(7); break;
+                    case 7: MOLA_LAUNCH_BOOTSTRAP(8); break;
+                    default: MOLA_LAUNCH_BOOTSTRAP(9); break;
+                }
+#undef MOLA_LAUNCH_BOOTSTRAP
                 HIPCHK(hipGetLastError());
                 bootstrapped = true;
             }
@@ -1076,7 +1110,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if (profiling_) HIPCHK(hipEventRecord(ev_[ev_used_], stream_));
     const float* sl = loc_sc_->sorted.as<float>();
     const TiledMap mp = tiled_map();
-    unsigned long long* staged = profiling_ ? stats_.as<unsigned long long>() : nullptr;  // evaluated pairs, slotted (statistics only)
+    unsigned long long* staged = (profiling_ || g_knobs.debug_stats == 3) ? stats_.as<unsigned long long>() : nullptr;  // evaluated pairs, slotted (statistics only)
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
@@ -1177,7 +1211,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     for (int k = 0; k < 3; ++k) cert.Pprev.t[k] = knn_last_P_[9 + k];
     cert.lb = knn_lb_.as<float>();
     cert.on = (knn_seed && !bootstrapped && !g_knobs.no_certify) ? 1 : 0;
-    cert.stats = profiling_ ? stats_.as<unsigned long long>() : nullptr;
+    cert.stats = (profiling_ || g_knobs.debug_stats == 3) ? stats_.as<unsigned long long>() : nullptr;
     // the lists' own gate (KnnCert): 1.1 x the matcher's; seeds kept under one gate are not reused under another
     const float thr2x = g_knobs.no_certify ? thr2 : thr2 * 1.21f;
     for (int k = 0; k < 9; ++k) knn_last_P_[k] = P.R[k];
@@ -1188,7 +1222,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 #define MOLA_LAUNCH_KNN_D(KK, VER, QLL, DENSE, QUEUE, LIST)                                                               \
     hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL, DENSE>), dim3(VER ? grid_ver : (DENSE ? grid4 : grid)), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
                        sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold,   \
-                       planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), knn_pos_.as<int>(), knn_seed, plane_cache_ok, QUEUE, \
+                       planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), seeds, knn_seed, plane_cache_ok, QUEUE, \
                        counter + 2, LIST, ((QUEUE) == tq ? tq + kQueues * kQueueStride : tq) + 1, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>(), g_knobs.early_pop ? 1 : 0, cert)
 #define MOLA_LAUNCH_KNN_QL(KK, QLL)                                                                                  \
     do {                                                                                                             \
@@ -1215,7 +1249,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const bool knn_coop = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8;
 #define MOLA_LAUNCH_KNN_COOP(KK)                                                                                       \
     hipLaunchKernelGGL((k_knn_coop<KK, 1>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, kb, thr2, thr2x,    \
-                       p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, cert.stats)
+                       p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, cert.stats, (unsigned long long*)nullptr)
     if (knn_coop) {
         KnnBatch<1> kb;
         KnnProblem& kp = kb.p[0];
@@ -1224,10 +1258,47 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         kp.mp = mp;
         kp.P = P;
         kp.Pprev = cert.Pprev;
-        kp.out = planes_.as<PlanePair>(); kp.cache = plane_cache_.as<PlanePair>(); kp.knn_pos = knn_pos_.as<int>();
+        kp.out = planes_.as<PlanePair>(); kp.cache = plane_cache_.as<PlanePair>(); kp.seeds = seeds;
         kp.lb = cert.lb;
         kp.use_seed = knn_seed; kp.use_cache = plane_cache_ok; kp.cert_on = cert.on;
         kp.changed_items = tq + kQueues * kQueueStride + 1;
+        if (g_knobs.debug_stats == 4 && p.knn == 6) {   // diagnostics: where the waves of every item spend their cycles
+            DevBuf dg;
+            if ((rc = dg.reserve(sizeof(unsigned long long) * kKnnDiagWords * 4 * (size_t)n_items64))) return rc;
+            HIPCHK(hipMemsetAsync(dg.p, 0, sizeof(unsigned long long) * kKnnDiagWords * 4 * (size_t)n_items64, stream_));
+            hipLaunchKernelGGL((k_knn_coop<7, 1, true>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, kb, thr2, thr2x, p.matcher_threshold,
+                               p.plane_eigen_threshold, staged, lds_boxes, cert.stats, dg.as<unsigned long long>());
+            HIPCHK(hipGetLastError());
+            std::vector<unsigned long long> h((size_t)kKnnDiagWords * 4 * (size_t)n_items64);
+            HIPCHK(hipMemcpyAsync(h.data(), dg.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            dg.release();
+            static const char* const names[12] = {"prologue (seeds, sort, certificate)", "wait at the first barrier", "sweep (all of it)", "  list fill + its barrier",
+                                                  "  tile-box wait", "  tile tests + passes", "    staging (wait for points)", "    distance passes + insertions",
+                                                  "merge (+ barrier)", "epilogue (planes, stores)", "", "whole item"};
+            auto pct = [](std::vector<unsigned long long>& v, double q) { if (v.empty()) return 0ull; std::sort(v.begin(), v.end()); return v[(size_t)(q * (double)(v.size() - 1))]; };
+            std::fprintf(stderr, "[mola_icp debug] k_knn_coop<7> item phases, shader cycles (median / p90 / max): leader wave | other waves; N=%zu seed=%d cert=%d step=%.5f\n", N_, knn_seed, cert.on, step);
+            for (int w = 0; w < 12; ++w) {
+                if (w == 10) continue;
+                std::vector<unsigned long long> a, b;
+                for (int it = 0; it < n_items64; ++it)
+                    for (int wv = 0; wv < 4; ++wv) (wv == 0 ? a : b).push_back(h[((size_t)it * 4 + wv) * kKnnDiagWords + w]);
+                std::fprintf(stderr, "[mola_icp debug]   %-38s %7llu / %7llu / %7llu | %7llu / %7llu / %7llu\n", names[w], pct(a, 0.5), pct(a, 0.9), pct(a, 1.0), pct(b, 0.5),
+                             pct(b, 0.9), pct(b, 1.0));
+            }
+            std::vector<unsigned long long> staged_v, tests_v, open_v, supers_v;
+            unsigned long long n_changed = 0, n_skip = 0;
+            for (int it = 0; it < n_items64; ++it) {
+                unsigned long long st = 0, tt = 0;
+                for (int wv = 0; wv < 4; ++wv) { const unsigned long long c = h[((size_t)it * 4 + wv) * kKnnDiagWords + 10]; st += c & 0xfffffull; tt += (c >> 32) & 0xfffffull; }
+                const unsigned long long c0 = h[((size_t)it * 4) * kKnnDiagWords + 10];
+                staged_v.push_back(st); tests_v.push_back(tt); open_v.push_back((c0 >> 52) & 0xffull); supers_v.push_back((c0 >> 20) & 0xfffull);
+                n_changed += (c0 >> 60) & 1ull; n_skip += (c0 >> 61) & 1ull;
+            }
+            std::fprintf(stderr, "[mola_icp debug]   per item (median / p90 / max): staged points %llu / %llu / %llu, tile tests %llu / %llu / %llu, super-tiles entered %llu / %llu / %llu, lanes not certified %llu / %llu / %llu; items with a plane solve %llu, items that skipped the sweep %llu of %d\n",
+                         pct(staged_v, 0.5), pct(staged_v, 0.9), pct(staged_v, 1.0), pct(tests_v, 0.5), pct(tests_v, 0.9), pct(tests_v, 1.0), pct(supers_v, 0.5), pct(supers_v, 0.9),
+                         pct(supers_v, 1.0), pct(open_v, 0.5), pct(open_v, 0.9), pct(open_v, 1.0), n_changed, n_skip, n_items64);
+        } else
         switch (p.knn) {
             case 3: MOLA_LAUNCH_KNN_COOP(4); break;
             case 4: MOLA_LAUNCH_KNN_COOP(5); break;
@@ -1263,6 +1334,16 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         knn_plan_interval_ = knn_order_valid_ ? (knn_plan_interval_ < 16 ? knn_plan_interval_ * 2 : 16) : 1;
         knn_order_valid_ = true;
         knn_launches_since_order_ = 0;
+    }
+    if (g_knobs.debug_stats == 3) {   // diagnostics: what the certificates did in THIS launch (a synchronisation per launch)
+        HIPCHK(hipMemcpyAsync(stats_host_, stats_.p, sizeof(unsigned long long) * kStatSlots * kStatStride, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        unsigned long long certified = 0, skipped = 0, staged64 = 0;
+        for (int k = 0; k < kStatSlots; ++k) { staged64 += stats_host_[(size_t)k * kStatStride]; certified += stats_host_[(size_t)k * kStatStride + 1]; skipped += stats_host_[(size_t)k * kStatStride + 2]; }
+        HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, stream_));
+        std::fprintf(stderr, "[mola_icp debug] plane matcher launch: N=%zu items=%d %s seed=%d cert=%d bootstrapped=%d step=%.5f m | certified queries %llu (%.1f %%), items that skipped the sweep %llu (%.1f %%), pairs/query %.1f\n",
+                     N_, n_items64, knn_coop ? "coop" : (verify ? "persistent+count" : "persistent"), knn_seed, cert.on, (int)bootstrapped, step, certified,
+                     100.0 * (double)certified / (double)N_, skipped, 100.0 * (double)skipped / (double)n_items64, 64.0 * (double)staged64 / (double)N_);
     }
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;
@@ -1348,7 +1429,7 @@ int HipWorkspace::copy_planes(uint8_t* valid, double* centroid, double* normal, 
     if ((rc = tmp_pairs.reserve(sizeof(PlanePair) * N_))) return rc;
     if ((rc = tmp_knn.reserve(sizeof(int) * N_ * 8))) { tmp_pairs.release(); return rc; }
     hipLaunchKernelGGL(k_unpermute_planes, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, loc_sc_->perm.as<int>(),
-                       planes_.as<PlanePair>(), map_sc_->perm.as<int>(), knn_pos_.as<int>(), planes_knn_, (int)N_,
+                       planes_.as<PlanePair>(), knn_seeds_at(knn_pos_.p, loc_sc_->padded, planes_knn_ + 1), planes_knn_, (int)N_,
                        tmp_pairs.as<PlanePair>(), tmp_knn.as<int>());
     std::vector<PlanePair> hp(N_);
     std::vector<int> hk(N_ * (size_t)planes_knn_);
@@ -1656,6 +1737,24 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
         pairing_sorted_ = false;
         if (n_pairs) *n_pairs = 0;
         return MOLA_ICP_OK;
+    }
+    // No pairing of these clouds to start from, but the plane matcher's lists (the quality pass behind a point-to-plane loop whose
+    // first launch was seeded by key, without an NN pass): the first entry of every list -- the nearest map point at the loop's last
+    // pose -- seeds the tiled matcher.
+    if (!seed_valid_ && knn_seed_valid_ && planes_knn_ >= 3 && !g_knobs.no_warm_start && !planes_empty_ && loc_sc_->ready && map_sc_->ready &&
+        (p.nn_kernel == MOLA_ICP_NN_TILED || (p.nn_kernel == MOLA_ICP_NN_AUTO && N_ >= 8192 && M_ >= 8192))) {
+        if ((rc = ts_pos_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
+        if ((rc = ts_idx_.reserve(sizeof(int) * loc_sc_->padded))) return rc;
+        if ((rc = ts_d2_.reserve(sizeof(float) * loc_sc_->padded))) return rc;
+        if ((rc = ts_gs_.reserve(sizeof(float) * 3 * loc_sc_->padded))) return rc;
+        float* gs = ts_gs_.as<float>();
+        hipLaunchKernelGGL(k_nn_seeds_from_lists, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_,
+                           knn_seeds_at(knn_pos_.p, loc_sc_->padded, planes_knn_ + 1), (int)N_, ts_pos_.as<int>(), ts_idx_.as<int>(), gs,
+                           gs + loc_sc_->padded, gs + 2 * loc_sc_->padded);
+        HIPCHK(hipGetLastError());
+        seed_valid_ = true;
+        pairing_sorted_ = true;
+        pairing_valid_ = false;   // (seeds, not a pairing)
     }
     if ((rc = launch_nn(T, thr2, p.nn_kernel))) return rc;
     pairing_valid_ = true;
@@ -2190,7 +2289,7 @@ int HipBatch::init_planes(int knn)
         const size_t np = pr.loc->padded;
         if ((rc = b.planes.reserve(sizeof(PlanePair) * np))) return rc;
         if ((rc = b.plane_cache.reserve(sizeof(PlanePair) * np))) return rc;
-        if ((rc = b.knn_pos.reserve(sizeof(int) * np * 9))) return rc;   // lists of knn + 1 entries
+        if ((rc = b.knn_pos.reserve(knn_seeds_bytes(np, knn + 1)))) return rc;   // lists of knn + 1 entries (KnnSeeds)
         if ((rc = b.knn_lb.reserve(sizeof(float) * np))) return rc;
         if ((rc = b.plane_partials.reserve(sizeof(double) * kNAccPlane * 512))) return rc;
     }
@@ -2247,7 +2346,8 @@ int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_
             }
             for (int q = 0; q < 9; ++q) kp.Pprev.R[q] = bf.knn_last_P[q];
             for (int q = 0; q < 3; ++q) kp.Pprev.t[q] = bf.knn_last_P[9 + q];
-            kp.out = bf.planes.as<PlanePair>(); kp.cache = bf.plane_cache.as<PlanePair>(); kp.knn_pos = bf.knn_pos.as<int>();
+            kp.out = bf.planes.as<PlanePair>(); kp.cache = bf.plane_cache.as<PlanePair>();
+            kp.seeds = knn_seeds_at(bf.knn_pos.p, pr.loc->padded, (int)p.knn + 1);
             kp.lb = bf.knn_lb.as<float>();
             const int seed = (bf.knn_seed_valid && bf.planes_knn == (int)p.knn && !g_knobs.no_knn_seed) ? 1 : 0;
             kp.use_seed = seed;
@@ -2271,7 +2371,7 @@ int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_
         unsigned long long* staged = ws_.profiling_ ? sc_.stats.as<unsigned long long>() : nullptr;
 #define MOLA_LAUNCH_KNN_COOP_B(KK)                                                                                          \
     hipLaunchKernelGGL((k_knn_coop<KK, kKnnMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, kb, thr2, thr2x, \
-                       p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, (unsigned long long*)nullptr)
+                       p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, (unsigned long long*)nullptr, (unsigned long long*)nullptr)
         switch (p.knn) {
             case 3: MOLA_LAUNCH_KNN_COOP_B(4); break;
             case 4: MOLA_LAUNCH_KNN_COOP_B(5); break;

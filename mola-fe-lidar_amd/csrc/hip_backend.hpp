@@ -51,11 +51,13 @@ struct SortedCloud {
     const float *x = nullptr, *y = nullptr, *z = nullptr;
     size_t n = 0;
     DevBuf sorted, perm, tbox, sbox, ubox;
+    DevBuf keys;                                    // a map's Hilbert keys in sorted order (n entries) ...
+    DevBuf box;                                     // ... and the box they were quantised in (min xyz, max xyz): a query's place in the map
     size_t padded = 0;
     int n_tiles_p = 0, n_super = 0, n_top = 0;
     bool ready = false, cached = false;
-    SortedCloud() { raw.pooled = sorted.pooled = perm.pooled = tbox.pooled = sbox.pooled = ubox.pooled = true; }
-    ~SortedCloud() { raw.release(); sorted.release(); perm.release(); tbox.release(); sbox.release(); ubox.release(); }
+    SortedCloud() { raw.pooled = sorted.pooled = perm.pooled = tbox.pooled = sbox.pooled = ubox.pooled = keys.pooled = box.pooled = true; }
+    ~SortedCloud() { raw.release(); sorted.release(); perm.release(); tbox.release(); sbox.release(); ubox.release(); keys.release(); box.release(); }
 };
 
 class HipBatch;

@@ -36,6 +36,52 @@ __device__ __forceinline__ float down_f32(double x)
     return f;
 }
 
+__device__ __forceinline__ unsigned int spread10(unsigned int v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// Skilling's axes -> transposed Hilbert index (J. Skilling, "Programming the Hilbert curve", 2004), 3-D, 10 bits
+__device__ __forceinline__ unsigned int hilbert30(unsigned int x, unsigned int y, unsigned int z)
+{
+    unsigned int X[3] = {x, y, z};
+    const unsigned int Mtop = 1u << 9;
+    for (unsigned int Q = Mtop; Q > 1; Q >>= 1) {
+        const unsigned int Pm = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= Pm;
+            else { const unsigned int t = (X[0] ^ X[i]) & Pm; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    unsigned int t = 0;
+    for (unsigned int Q = Mtop; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+}
+
+// the key of a point in a cloud's frame: box = min xyz, max xyz of the cloud the keys belong to (isotropic 10-bit cells; a point
+// outside the box lands in the nearest cell)
+__device__ __forceinline__ unsigned int hilbert_key_in_box(const float (&box)[6], float x, float y, float z)
+{
+    float ext = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, box[3 + k] - box[k]);
+    const float scale = ext > 0 ? 1023.999f / ext : 0.f;  // isotropic cells
+    const unsigned int ix = (unsigned int)fminf(fmaxf((x - box[0]) * scale, 0.f), 1023.f);
+    const unsigned int iy = (unsigned int)fminf(fmaxf((y - box[1]) * scale, 0.f), 1023.f);
+    const unsigned int iz = (unsigned int)fminf(fmaxf((z - box[2]) * scale, 0.f), 1023.f);
+    return hilbert30(ix, iy, iz);
+}
+
 constexpr float kPadCoord = 1.0e18f;  // padding map points: d2 ~ 3e36, finite, never the minimum
 
 // Sum of NV per-thread doubles over a 256-thread block, in a fixed order: eight values at a time are laid out in LDS

@@ -67,22 +67,43 @@ __device__ __forceinline__ void eig_sym3_dev(const double Cin[3][3], double ev[3
         for (int k = 0; k < 3; k++) V[r][k] = Vs[r][k];
 }
 
+// The stored neighbour lists of a cloud pair -- the next launch's seeds.  Entry-major (entry j of sorted query i at [j * stride + i]:
+// a wave's 64 queries read an entry with one coalesced load), and each neighbour's COORDINATES and original index sit beside its
+// sorted-map position: a launch's prologue is one round trip of coalesced loads.  (Rounds 2-3 kept positions only, query-major:
+// 7 strided loads, then 28 gathered words per query for the coordinates and indices, a dependent second trip -- and the
+// cooperative kernel does it in all four waves of an item.  A kernel made of just that prologue and the epilogue took 20-24 us at
+// 120k queries: most of what a late launch of the Gauss-Newton loop costs.)
+struct KnnSeeds {
+    int* pos;            // sorted-map position of the neighbour; -1: none
+    float *x, *y, *z;    // its coordinates, as stored in the map
+    unsigned int* oidx;  // its original index (the tie-break half of the list's keys)
+    size_t stride;       // queries per entry row (>= N)
+};
+__host__ __device__ inline size_t knn_seeds_bytes(size_t stride, int entries) { return 5u * sizeof(int) * stride * (size_t)entries; }
+__host__ __device__ inline KnnSeeds knn_seeds_at(void* base, size_t stride, int entries)
+{
+    int* b = static_cast<int*>(base);
+    const size_t a = stride * (size_t)entries;
+    return KnnSeeds{b, reinterpret_cast<float*>(b + a), reinterpret_cast<float*>(b + 2 * a), reinterpret_cast<float*>(b + 3 * a),
+                    reinterpret_cast<unsigned int*>(b + 4 * a), stride};
+}
+
 // Epilogue of one query of the point-to-plane matcher: kp / kd = its sorted neighbour list of KL = K + 1 entries (sorted-map
 // positions, squared distances; -1 / gate^2 in the unused tail), (qx, qy, qz) the moved query.  The plane is that of the
 // first K; the extra entry is only a seed -- it is what makes the list's last distance a lower bound on every point
-// OUTSIDE the K nearest (certified lists, k_knn_planes).  Writes knn_pos (next launch's seeds, KL per query), the plane of
-// the list into `cache` when it had to be solved, the pairing into `out`.  Returns whether SOME lane of the wave had to
+// OUTSIDE the K nearest (certified lists, k_knn_planes).  Writes the seeds (next launch's: KL entries per query, only where they
+// differ from what is stored), the plane of the list into `cache` when it had to be solved, the pairing into `out`.  Returns whether SOME lane of the wave had to
 // solve a plane (= the item's lists changed).
 template <int KL>
-__device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&kp)[KL], const float (&kd)[KL], float qx, float qy, float qz,
+__device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&kp)[KL], const float (&kd)[KL], const unsigned int (&ko)[KL] /*original indices*/,
+                                               float qx, float qy, float qz,
                                                int i, int N, float thr2, double threshold, double plane_eig_thr,
-                                               PlanePair* __restrict__ out, PlanePair* __restrict__ cache, int* __restrict__ knn_pos,
+                                               PlanePair* __restrict__ out, PlanePair* __restrict__ cache, const KnnSeeds& seeds,
                                                int use_seed, int use_cache)
 {
     constexpr int K = KL - 1;
     bool item_changed = false;
     {
-            
             const bool in = i < N;
             const size_t ic = in ? (size_t)i : (size_t)(N - 1);
             int m = 0;
@@ -91,28 +112,45 @@ __device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&k
             // (the list may go on beyond the gate, up to the extended gate of k_knn_planes: seeds, never part of a plane)
             bool same = use_seed != 0 && use_cache != 0;
             if (same) same = cache[ic].n_neigh == m;
+            bool differs = use_seed == 0;   // some stored entry (the extra one included) is not this launch's
+            if (use_seed) {
 #pragma unroll
-            for (int j = 0; j < KL; ++j) {
-                if (use_seed && j < K) same &= knn_pos[ic * KL + j] == kp[j];
-                if (in) knn_pos[ic * KL + j] = kp[j];
+                for (int j = 0; j < KL; ++j) {
+                    const int old = seeds.pos[(size_t)j * seeds.stride + ic];
+                    if (j < K) same &= old == kp[j];
+                    differs |= old != kp[j];
+                }
             }
             PlanePair pl;  // the plane of the list: valid = "is a plane" (before the query-distance test)
             pl.valid = 0; pl.n_neigh = m;
 #pragma unroll
             for (int a = 0; a < 3; ++a) { pl.c[a] = 0; pl.n[a] = 0; }
             const bool solve = in && !same;
-            if (__any(solve)) {
-                item_changed = true;
+            const bool fetch = in && (differs || !same);   // the list's points are needed: to be stored as seeds, or for the plane
+            if (__any(fetch)) {
+                item_changed = __any(solve);
+                float fx[KL], fy[KL], fz[KL];
+#pragma unroll
+                for (int j = 0; j < KL; ++j) {
+                    fx[j] = fy[j] = fz[j] = 0.f;
+                    if (fetch && kp[j] >= 0) { fx[j] = mp.sx[kp[j]]; fy[j] = mp.sy[kp[j]]; fz[j] = mp.sz[kp[j]]; }
+                }
+                if (in && differs) {
+#pragma unroll
+                    for (int j = 0; j < KL; ++j) {
+                        const size_t at = (size_t)j * seeds.stride + ic;
+                        seeds.pos[at] = kp[j];
+                        seeds.x[at] = fx[j]; seeds.y[at] = fy[j]; seeds.z[at] = fz[j];
+                        seeds.oidx[at] = ko[j];
+                    }
+                }
                 if (solve && m >= 3) {
-                    double px[K], py[K], pz[K];
+                    // (the points stay fp32 in registers and are widened where they are used: exact, and 36 registers fewer
+                    //  than three arrays of doubles)
                     double mean[3] = {0, 0, 0};
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        px[j] = py[j] = pz[j] = 0;
-                        if (j < m) {
-                            px[j] = mp.sx[kp[j]]; py[j] = mp.sy[kp[j]]; pz[j] = mp.sz[kp[j]];
-                            mean[0] += px[j]; mean[1] += py[j]; mean[2] += pz[j];
-                        }
+                        if (j < m) { mean[0] += (double)fx[j]; mean[1] += (double)fy[j]; mean[2] += (double)fz[j]; }
                     }
                     const double dm = (double)m;
                     mean[0] /= dm; mean[1] /= dm; mean[2] /= dm;
@@ -120,7 +158,7 @@ __device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&k
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
                         if (j < m) {
-                            const double dd[3] = {px[j] - mean[0], py[j] - mean[1], pz[j] - mean[2]};
+                            const double dd[3] = {(double)fx[j] - mean[0], (double)fy[j] - mean[1], (double)fz[j] - mean[2]};
 #pragma unroll
                             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -194,11 +232,11 @@ constexpr float kCertUp = 1.0f + 2.0e-6f, kCertDown = 1.0f - 2.0e-6f;  // ~ (1 +
 // more from the fourth wave per SIMD than they lose to the spills (C3: 521 / 561 / 303 / 194 us -> 458 / 489 / 257 / 143); the
 // unseeded launch, where every lane is inserting, does not (554 -> 610 us) and keeps the spill-free build at three.
 template <int K /*list length: knn + 1*/, bool VERIFY, int QL, bool DENSE = false>
-__global__ __launch_bounds__(256, (K <= 7 ? (DENSE ? 4 : 3) : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+__global__ __launch_bounds__(256, (K <= 7 ? ((DENSE || VERIFY) ? 4 : 3) : 2)) void k_knn_planes(const float* __restrict__ slx, const float* __restrict__ sly,
                                                     const float* __restrict__ slz, int N, TiledMap mp, PoseF P,
                                                     float thr2, float thr2x /*the lists' own gate^2 >= thr2 (see below)*/, double threshold, double plane_eig_thr,
                                                     PlanePair* __restrict__ out, PlanePair* __restrict__ cache /*the plane of each query's list*/,
-                                                    int* __restrict__ knn_pos /*N x K: in = last launch's neighbours (use_seed), out = this launch's*/,
+                                                    KnnSeeds seeds /*in = last launch's neighbours (use_seed), out = this launch's*/,
                                                     int use_seed, int use_cache /*cached planes were decided with this launch's planeEigenThreshold*/,
                                                     unsigned int* __restrict__ queue,
                                                     unsigned int* __restrict__ redo_count, int* __restrict__ redo_list,
@@ -281,14 +319,13 @@ __global__ __launch_bounds__(256, (K <= 7 ? (DENSE ? 4 : 3) : 2)) void k_knn_pla
             for (int k = 0; k < QL; ++k) {
                 const int ic = qi[k] < N ? qi[k] : N - 1;
                 int js[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) js[j] = knn_pos[(size_t)ic * K + j];
                 float gx[K], gy[K], gz[K];
                 unsigned int go[K];
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int jc = js[j] >= 0 ? js[j] : 0;
-                    gx[j] = mp.sx[jc]; gy[j] = mp.sy[jc]; gz[j] = mp.sz[jc]; go[j] = (unsigned int)mp.perm[jc];
+                for (int j = 0; j < K; ++j) {   // (one trip, coalesced: the seeds carry their coordinates and indices)
+                    const size_t at = (size_t)j * seeds.stride + (size_t)ic;
+                    js[j] = seeds.pos[at];
+                    gx[j] = seeds.x[at]; gy[j] = seeds.y[at]; gz[j] = seeds.z[at]; go[j] = seeds.oidx[at];
                 }
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
@@ -429,9 +466,10 @@ __global__ __launch_bounds__(256, (K <= 7 ? (DENSE ? 4 : 3) : 2)) void k_knn_pla
 #pragma unroll
         for (int k = 0; k < QL; ++k) {
             float kd[K];
+            unsigned int ko[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) kd[j] = kd_of(k, j);
-            item_changed |= plane_epilogue<K>(mp, kp[k], kd, qx[k], qy[k], qz[k], qi[k], N, thr2, threshold, plane_eig_thr, out, cache, knn_pos,
+            for (int j = 0; j < K; ++j) { kd[j] = kd_of(k, j); ko[j] = (unsigned int)(kk[k][j] & 0xffffffffull); }
+            item_changed |= plane_epilogue<K>(mp, kp[k], kd, ko, qx[k], qy[k], qz[k], qi[k], N, thr2, threshold, plane_eig_thr, out, cache, seeds,
                                               use_seed, use_cache);
         }
         }  // (epilogue)
@@ -478,7 +516,7 @@ struct KnnProblem {
     PoseF Pprev;                    // the pose of the launch that wrote lb / the seeds (KnnCert)
     PlanePair* out;                 // the plane pairing, sorted query order
     PlanePair* cache;               // the plane of each query's stored list
-    int* knn_pos;                   // N x K: in = last launch's neighbours (use_seed), out = this launch's
+    KnnSeeds seeds;                 // in = last launch's neighbours (use_seed), out = this launch's
     float* lb;                      // per query: lower bound on the distance to every point outside its list (KnnCert)
     int use_seed, use_cache, cert_on;
     unsigned int* changed_items;    // 8 slots, kQueueStride words apart: items whose lists changed
@@ -487,41 +525,47 @@ constexpr int kKnnMaxBatch = 12;    // problems per launch (kernel arguments are
 template <int KMAX> struct KnnBatch { KnnProblem p[KMAX]; };
 static_assert(sizeof(KnnBatch<kKnnMaxBatch>) <= 3900, "KnnBatch must fit the kernel-argument segment");
 
-template <int K /*list length: knn + 1*/, int KMAX /*problems per launch: blockIdx.y*/>
-__global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch, float thr2, float thr2x, double threshold, double plane_eig_thr,
-                                                     unsigned long long* __restrict__ staged_total /*slotted, may be null*/, int lds_boxes,
-                                                     unsigned long long* __restrict__ cert_stats /*diagnostics, may be null*/)
+// LDS of one cooperative item (k_knn_coop, k_knn_coop_groups)
+template <int K>
+struct KnnCoopLds {
+    __attribute__((aligned(16))) float s_m[4][4][64];
+    int s_list[kMaxList];
+    float s_wbox[6];
+    int s_ctl[4];
+    int s_tick[kMaxList];
+    unsigned long long s_mk[kCoopParts - 1][K][64];
+    int s_mpos[kCoopParts - 1][K][64];
+};
+
+// One cooperative item: the four waves of the workgroup hold the same 64 queries (lane -> qi; >= N: none), deal the candidate
+// tiles among themselves (coop_sweep), merge their lists through LDS; wave 0 runs the plane epilogue.  Called by ALL four waves
+// (barriers inside); nothing of S may be touched by the caller before its next barrier.  CERT: derive the certificates (KnnCert).
+constexpr int kKnnDiagWords = 12;   // MOLA_ICP_DEBUG_STATS=4: shader-clock phases of every wave of every item (see knn_coop_item)
+template <int K, bool CERT, bool DIAG = false>
+__device__ __forceinline__ void knn_coop_item(KnnCoopLds<K>& S, const KnnProblem& pb, const TiledMap& mp, const lds_f32* lbox, int lds_boxes, int qi,
+                                              float thr2, float thr2x, double threshold, double plane_eig_thr,
+                                              unsigned long long* __restrict__ staged_total, unsigned long long* __restrict__ cert_stats,
+                                              int lane, int wave, unsigned long long* __restrict__ diag = nullptr /*DIAG: this wave's record*/)
 {
-    __shared__ __attribute__((aligned(16))) float s_m[4][4][64];
-    __shared__ int s_list[kMaxList];
-    __shared__ float s_wbox[6];
-    __shared__ int s_ctl[4];
-    __shared__ int s_tick[kMaxList];
-    __shared__ unsigned long long s_mk[kCoopParts - 1][K][64];
-    __shared__ int s_mpos[kCoopParts - 1][K][64];
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const KnnProblem& pb = batch.p[KMAX == 1 ? 0 : blockIdx.y];
+    unsigned long long dt[6] = {};
+    if (DIAG) dt[0] = __builtin_amdgcn_s_memtime();
+    // (the body is written out with plain locals, as the kernel had it before it became a function: the same lists held in a struct
+    //  cost this kernel 40 vector registers -- 123 -> 164 -- and with them its fourth workgroup per CU)
     const int N = pb.N;
-    const int item = xcd_item((int)blockIdx.x, (N + 63) / 64);
-    if (item * 64 >= N) return;  // (the grid is rounded up to whole XCD ranges / sized for the batch's largest problem; uniform: before any barrier)
-    const TiledMap mp = pb.mp;
     const PoseF P = pb.P;
     const float* __restrict__ slx = pb.slx;
     const float* __restrict__ sly = pb.sly;
     const float* __restrict__ slz = pb.slz;
     PlanePair* __restrict__ out = pb.out;
     PlanePair* __restrict__ cache = pb.cache;
-    int* __restrict__ knn_pos = pb.knn_pos;
+    const KnnSeeds seeds = pb.seeds;
     const int use_seed = pb.use_seed, use_cache = pb.use_cache;
     unsigned int* __restrict__ changed_items = pb.changed_items;
     KnnCert cert;
     cert.Pprev = pb.Pprev;
     cert.lb = pb.lb;
-    cert.on = pb.cert_on;
+    cert.on = CERT ? pb.cert_on : 0;
     cert.stats = cert_stats;
-    const lds_f32* lbox = (const lds_f32*)s_dyn;
-    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
 
     unsigned long long kk[K];
     int kp[K];
@@ -537,7 +581,6 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
             kk[j - 1] = sw ? tk : kk[j - 1]; kp[j - 1] = sw ? tp : kp[j - 1];
         }
     };
-    const int qi = item * 64 + lane;
     const int ic = qi < N ? qi : N - 1;
     const float lx = slx[ic], ly = sly[ic], lz = slz[ic];
     float qx, qy, qz;
@@ -546,14 +589,13 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
     for (int j = 0; j < K; ++j) { kk[j] = (unsigned long long)__float_as_uint(thr2x) << 32; kp[j] = -1; }
     if (use_seed) {
         int js[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) js[j] = knn_pos[(size_t)ic * K + j];
         float gx[K], gy[K], gz[K];
         unsigned int go[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const int jc = js[j] >= 0 ? js[j] : 0;
-            gx[j] = mp.sx[jc]; gy[j] = mp.sy[jc]; gz[j] = mp.sz[jc]; go[j] = (unsigned int)mp.perm[jc];
+        for (int j = 0; j < K; ++j) {   // (one trip, coalesced: the seeds carry their coordinates and indices)
+            const size_t at = (size_t)j * seeds.stride + (size_t)ic;
+            js[j] = seeds.pos[at];
+            gx[j] = seeds.x[at]; gy[j] = seeds.y[at]; gz[j] = seeds.z[at]; go[j] = seeds.oidx[at];
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -565,7 +607,7 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
     // (bounds, seeds, planes: wave 0, in the epilogue) before every wave has read its part: the barrier below
     bool certd = false;
     float lb_new = 0.f;
-    if (cert.on && use_seed) {
+    if (CERT && cert.on && use_seed) {
         float ox, oy, oz;
         xform(cert.Pprev, lx, ly, lz, ox, oy, oz);
         const float delta = sqrtf(dist2(qx, qy, qz, ox, oy, oz)) * kCertUp + 1e-18f;
@@ -576,18 +618,20 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
     }
     const unsigned long long cert_mask = __ballot(certd);
     const bool skip_sweep = !__any(qi < N && !certd);
+    if (DIAG) dt[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (DIAG) dt[2] = __builtin_amdgcn_s_memtime();
     float q2x[2] = {qx, 1.0e18f}, q2y[2] = {qy, 1.0e18f}, q2z[2] = {qz, 1.0e18f};
     float reach2[2] = {reach_of(kd_of(K - 1), qx, qy, qz), -1.0f};
     float kb2[2] = {kd_of(K - 1), -1.0f};
     if (certd) { reach2[0] = -1.0f; kb2[0] = -1.0f; }
     if (qi >= N) { q2x[0] = q2y[0] = q2z[0] = 1.0e18f; reach2[0] = -1.0f; kb2[0] = -1.0f; }
     unsigned long long n_staged = 0ull;
+    unsigned long long pc[5] = {};
+    unsigned int pn[3] = {};
     if (!skip_sweep) {   // (workgroup-uniform: the barriers inside are met by all four waves)
-        unsigned long long pc[5] = {};
-        unsigned int pn[3] = {};
-        float(*sm)[64] = s_m[wave];
-        n_staged = coop_sweep<true>(mp, lbox, lds_boxes != 0, s_list, s_wbox, s_ctl, s_tick, lane, wave, sm, q2x, q2y, q2z, reach2, kb2, [&](int nm, int jb0, int jb1) {
+        float(*sm)[64] = S.s_m[wave];
+        n_staged = coop_sweep<true>(mp, lbox, lds_boxes != 0, S.s_list, S.s_wbox, S.s_ctl, S.s_tick, lane, wave, sm, q2x, q2y, q2z, reach2, kb2, [&](int nm, int jb0, int jb1) {
             for (int m = 0; m < nm; m += 4) {
                 const float4 X = *reinterpret_cast<const float4*>(&sm[0][m]);
                 const float4 Y = *reinterpret_cast<const float4*>(&sm[1][m]);
@@ -617,19 +661,20 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
                     if (qi < N && !certd) kb2[0] = kd_of(K - 1);   // live bound (see k_knn_planes)
                 }
             }
-        }, false, pc, pn);
+        }, DIAG, pc, pn);
+        if (DIAG) dt[3] = __builtin_amdgcn_s_memtime();
         // merge: the other three waves' lists through LDS into wave 0's
         if (wave > 0) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) { s_mk[wave - 1][j][lane] = kk[j]; s_mpos[wave - 1][j][lane] = kp[j]; }
+            for (int j = 0; j < K; ++j) { S.s_mk[wave - 1][j][lane] = kk[j]; S.s_mpos[wave - 1][j][lane] = kp[j]; }
         }
         __syncthreads();
         if (wave == 0) {
             for (int w = 0; w < kCoopParts - 1; ++w) {
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
-                    const unsigned long long ck = s_mk[w][j][lane];
-                    const int cp = s_mpos[w][j][lane];
+                    const unsigned long long ck = S.s_mk[w][j][lane];
+                    const int cp = S.s_mpos[w][j][lane];
                     bool take = cp >= 0 && ck < kk[K - 1];
 #pragma unroll
                     for (int i = 0; i < K; ++i) take &= kp[i] != cp;
@@ -642,31 +687,159 @@ __global__ __launch_bounds__(256, 3) void k_knn_coop(const KnnBatch<KMAX> batch,
     }
     if (lane == 0 && n_staged && staged_total)   // (each wave its own tiles: units of 64 pairs, one query per lane)
         atomicAdd(staged_total + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride, n_staged);
-    if (wave != 0) return;   // (no barrier below)
+    if (DIAG) { dt[4] = __builtin_amdgcn_s_memtime(); if (skip_sweep) dt[3] = dt[2]; }
+    auto diag_record = [&](bool changed) {   // [prologue, wait, sweep, list fill + barrier, tile-box wait, tile tests + passes, staging, distance passes, merge, epilogue, counts, total]
+        if (DIAG && diag && lane == 0) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            const unsigned long long n_open = (unsigned long long)__popcll(__ballot(true));   // (placeholder lane count: whole wave)
+            (void)n_open;
+            diag[0] = dt[1] - dt[0]; diag[1] = dt[2] - dt[1]; diag[2] = dt[3] - dt[2]; diag[3] = pc[4]; diag[4] = pc[2]; diag[5] = pc[3];
+            diag[6] = pc[0]; diag[7] = pc[1]; diag[8] = dt[4] - dt[3]; diag[9] = t_end - dt[4];
+            diag[10] = (n_staged & 0xfffffull) | ((unsigned long long)(pn[1] & 0xfffu) << 20) | ((unsigned long long)(pn[2] & 0xfffffu) << 32) |
+                       ((unsigned long long)__popcll(~cert_mask) << 52) | ((unsigned long long)(changed ? 1 : 0) << 60) | ((unsigned long long)(skip_sweep ? 1 : 0) << 61);
+            diag[11] = t_end - dt[0];
+        }
+    };
+    if (wave != 0) { diag_record(false); return; }   // (no barrier below)
     if (qi < N) cert.lb[qi] = certd ? lb_new : sqrtf(kd_of(K - 1)) * kCertDown;
     float kd[K];
+    unsigned int ko[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) kd[j] = kd_of(j);
-    const bool changed = plane_epilogue<K>(mp, kp, kd, qx, qy, qz, qi, N, thr2, threshold, plane_eig_thr, out, cache, knn_pos, use_seed, use_cache);
+    for (int j = 0; j < K; ++j) { kd[j] = kd_of(j); ko[j] = (unsigned int)(kk[j] & 0xffffffffull); }
+    const bool changed = plane_epilogue<K>(mp, kp, kd, ko, qx, qy, qz, qi, N, thr2, threshold, plane_eig_thr, out, cache, seeds, use_seed, use_cache);
     if (lane == 0 && changed && changed_items) atomicAdd(changed_items + (size_t)(blockIdx.x & (kQueues - 1)) * kQueueStride, 1u);   // (batched launches do not count)
     if (cert.stats && lane == 0 && cert_mask) {
         unsigned long long* st = cert.stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride;
         atomicAdd(st + 1, (unsigned long long)__popcll(cert_mask));
         if (skip_sweep) atomicAdd(st + 2, 1ull);
     }
+    diag_record(changed);
 }
 
-// Seeds for a launch that has no lists yet (HipWorkspace::match_planes): the K map points around each query's nearest neighbour
-// on the Hilbert curve -- K distinct sorted positions [s, s + K) with the neighbour in the middle, -1 where the query has none.
-__global__ __launch_bounds__(256) void k_bootstrap_seeds(const int* __restrict__ nn_pos /*sorted-map position of the NN per sorted query*/,
-                                                         int N, int M, int K, int* __restrict__ knn_pos /*N x K*/)
+template <int K /*list length: knn + 1*/, int KMAX /*problems per launch: blockIdx.y*/, bool DIAG = false>
+__global__ __launch_bounds__(256, (K <= 7 ? 4 : 3)) void k_knn_coop(const KnnBatch<KMAX> batch, float thr2, float thr2x, double threshold, double plane_eig_thr,
+                                                     unsigned long long* __restrict__ staged_total /*slotted, may be null*/, int lds_boxes,
+                                                     unsigned long long* __restrict__ cert_stats /*diagnostics, may be null*/,
+                                                     unsigned long long* __restrict__ diag = nullptr /*DIAG: [item][wave][kKnnDiagWords]*/)
+{
+    __shared__ KnnCoopLds<K> S;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const KnnProblem& pb = batch.p[KMAX == 1 ? 0 : blockIdx.y];
+    const int N = pb.N;
+    const int item = xcd_item((int)blockIdx.x, (N + 63) / 64);
+    if (item * 64 >= N) return;  // (the grid is rounded up to whole XCD ranges / sized for the batch's largest problem; uniform: before any barrier)
+    const TiledMap mp = pb.mp;
+    const lds_f32* lbox = (const lds_f32*)s_dyn;
+    if (lds_boxes) load_boxes_to_lds(mp, (lds_f32*)s_dyn);
+    knn_coop_item<K, true, DIAG>(S, pb, mp, lbox, lds_boxes, item * 64 + lane, thr2, thr2x, threshold, plane_eig_thr, staged_total, cert_stats, lane, wave,
+                                 DIAG && diag ? diag + ((size_t)item * 4 + wave) * kKnnDiagWords : nullptr);
+}
+
+// Seeds for a launch that has no lists yet (HipWorkspace::match_planes).  An NN pass has given every query its nearest map point;
+// that point names a PLACE in the map -- its tile and the two tiles next to it on the Hilbert curve, 96 points that lie around the
+// query if anything does -- and the KL nearest of those 96 are the seeds: exact candidates like any seed (the sweep that follows is
+// complete under the bound they give), -1 where the query has no neighbour.  (Round 3 took the KL points AROUND the neighbour on the
+// curve, whichever they were: the first launch of an odometry scan then evaluated 2 000 pairs per query where the second, seeded by
+// real lists, evaluates 350.)
+// Not the KL nearest of the 96 exactly -- the best of each of G = 8 (12 for lists of nine) interleaved groups of candidates, sorted,
+// the first KL kept: one compare and two selects per candidate where a sorted insertion, with 64 lanes inserting at different
+// times, walked its bubble for nearly every point (31 us at 120k queries against 8).  The bound the sweep starts from is the
+// largest of them: a little above the true KL-th distance, far below the curve neighbours'.
+// BY_KEY: no NN pass at all -- the place is where the query's own Hilbert key (in the map's frame) falls among the map's sorted keys:
+// the map points of its cell, or the cells next to it on the curve.  Close in space most of the time, not always (the curve has
+// seams); a poor place only costs a wider sweep.
+template <int KL, bool BY_KEY>
+__global__ __launch_bounds__(256) void k_bootstrap_seeds(const int* __restrict__ nn_pos /*sorted-map position of the NN per sorted query (!BY_KEY)*/,
+                                                         const unsigned int* __restrict__ map_keys /*the map's keys, ascending (BY_KEY)*/,
+                                                         const float* __restrict__ map_box /*the box they were quantised in (BY_KEY)*/,
+                                                         const float* __restrict__ slx, const float* __restrict__ sly,
+                                                         const float* __restrict__ slz, int N, PoseF P, TiledMap mp, int M, KnnSeeds seeds)
+{
+    constexpr int G = KL <= 8 ? 8 : 12;
+    static_assert(KL <= G && (3 * kTileG) % G == 0, "groups");
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float qx, qy, qz;
+    xform(P, slx[i], sly[i], slz[i], qx, qy, qz);
+    int pos;
+    if constexpr (BY_KEY) {
+        float box[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) box[k] = map_box[k];
+        const unsigned int key = hilbert_key_in_box(box, qx, qy, qz);
+        int step = 1;
+        while (step < M) step <<= 1;   // (uniform)
+        pos = 0;   // number of map keys below the query's
+        for (step >>= 1; step > 0; step >>= 1) {
+            const int q = pos + step;
+            if (q <= M && map_keys[q - 1] < key) pos = q;
+        }
+        pos = pos < M ? pos : M - 1;
+    } else {
+        pos = nn_pos[i];
+    }
+    if (pos < 0) {
+#pragma unroll
+        for (int j = 0; j < KL; ++j) seeds.pos[(size_t)j * seeds.stride + (size_t)i] = -1;
+        return;
+    }
+    const int n_tiles = (M + kTileG - 1) / kTileG;
+    int t0 = (pos / kTileG) - 1;
+    t0 = t0 > n_tiles - 3 ? n_tiles - 3 : t0;
+    t0 = t0 < 0 ? 0 : t0;
+    unsigned long long kk[G];   // per group: the smallest (d2 bits << 32 | sorted position)
+#pragma unroll
+    for (int j = 0; j < G; ++j) kk[j] = ~0ull;
+    for (int c = 0; c < 3 * kTileG; c += G) {
+        const int p0 = t0 * kTileG + c;
+        if (p0 >= M) break;   // (the sorted arrays are padded to whole tiles: the loads below stay inside them)
+#pragma unroll
+        for (int h = 0; h < G; h += 4) {
+            const float4 X = *reinterpret_cast<const float4*>(mp.sx + p0 + h);
+            const float4 Y = *reinterpret_cast<const float4*>(mp.sy + p0 + h);
+            const float4 Z = *reinterpret_cast<const float4*>(mp.sz + p0 + h);
+            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned long long key = ((unsigned long long)__float_as_uint(dist2(qx, qy, qz, xs[u], ys[u], zs[u])) << 32) | (unsigned int)(p0 + h + u);
+                if (p0 + h + u >= M) key = ~0ull;   // (a padding point)
+                kk[h + u] = key < kk[h + u] ? key : kk[h + u];
+            }
+        }
+    }
+    // ascending (a bubble network over G values), the first KL are the seeds
+#pragma unroll
+    for (int a = 0; a < G - 1; ++a)
+#pragma unroll
+        for (int j = G - 1; j > a; --j) {
+            const bool sw = kk[j] < kk[j - 1];
+            const unsigned long long x = kk[j - 1], y = kk[j];
+            kk[j - 1] = sw ? y : x;
+            kk[j] = sw ? x : y;
+        }
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+        const size_t at = (size_t)j * seeds.stride + (size_t)i;
+        if (kk[j] == ~0ull) { seeds.pos[at] = -1; continue; }
+        const int ps = (int)(unsigned int)(kk[j] & 0xffffffffull);
+        seeds.pos[at] = ps;
+        seeds.x[at] = mp.sx[ps]; seeds.y[at] = mp.sy[ps]; seeds.z[at] = mp.sz[ps];
+        seeds.oidx[at] = (unsigned int)mp.perm[ps];
+    }
+}
+
+// The nearest-neighbour matcher's seeds from the plane matcher's lists (the quality pass behind a point-to-plane loop: its queries
+// start from the first entry of their lists -- the nearest map point at the loop's last pose -- instead of from nothing)
+__global__ __launch_bounds__(256) void k_nn_seeds_from_lists(KnnSeeds seeds, int N, int* __restrict__ pos_s, int* __restrict__ idx_s,
+                                                             float* __restrict__ gsx, float* __restrict__ gsy, float* __restrict__ gsz)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const int pos = nn_pos[i];
-    int s = pos - K / 2;
-    s = s < 0 ? 0 : (s > M - K ? M - K : s);
-    for (int j = 0; j < K; ++j) knn_pos[(size_t)i * K + j] = pos >= 0 ? s + j : -1;
+    const int ps = seeds.pos[i];   // (entry 0)
+    pos_s[i] = ps;
+    idx_s[i] = ps >= 0 ? (int)seeds.oidx[i] : -1;
+    gsx[i] = ps >= 0 ? seeds.x[i] : 0.f; gsy[i] = ps >= 0 ? seeds.y[i] : 0.f; gsz[i] = ps >= 0 ? seeds.z[i] : 0.f;
 }
 
 // the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
@@ -894,17 +1067,16 @@ __global__ __launch_bounds__(1024) void k_reduce_rows_batch(const PlaneAccBatch 
 
 // plane pairing in sorted query order -> original order (tests / callers that want the pairing)
 __global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict__ qperm, const PlanePair* __restrict__ in,
-                                                          const int* __restrict__ perm, const int* __restrict__ knn_pos,
-                                                          int K, int N, PlanePair* __restrict__ out, int* __restrict__ knn_idx)
+                                                          KnnSeeds seeds, int K, int N, PlanePair* __restrict__ out, int* __restrict__ knn_idx)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const int o = qperm[i];
     out[o] = in[i];
-    if (knn_idx && knn_pos)
+    if (knn_idx && seeds.pos)
         for (int j = 0; j < K; ++j) {
-            const int ps = knn_pos[(size_t)i * (K + 1) + j];  // (stored lists hold one entry more than knn, and may go on beyond the gate)
-            knn_idx[(size_t)o * K + j] = (j < in[i].n_neigh && ps >= 0) ? perm[ps] : -1;
+            const size_t at = (size_t)j * seeds.stride + (size_t)i;   // (stored lists hold one entry more than knn, and may go on beyond the gate)
+            knn_idx[(size_t)o * K + j] = (j < in[i].n_neigh && seeds.pos[at] >= 0) ? (int)seeds.oidx[at] : -1;
         }
 }
 

@@ -27,6 +27,7 @@
 #include <utility>
 
 #include "hip_backend.hpp"
+#include "kernels_common.hpp"
 #include "sort_net.hpp"
 
 namespace mola_icp_amd {
@@ -44,38 +45,6 @@ constexpr int kSortThreads = kSortRun / sortnet::kE;
 constexpr int kSortLog = 11;
 constexpr int kSortFanLog = 3, kSortFan = 1 << kSortFanLog;   // runs merged per level: 131072 items with two levels, 1M with three
 static_assert((1 << kSortLog) == kSortRun && kSortRun % 256 == 0, "run length (a merge workgroup of 256 never straddles runs)");
-
-__device__ __forceinline__ unsigned int spread10(unsigned int v)
-{
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-
-// Skilling's axes -> transposed Hilbert index (J. Skilling, "Programming the Hilbert curve", 2004), 3-D, 10 bits
-__device__ __forceinline__ unsigned int hilbert30(unsigned int x, unsigned int y, unsigned int z)
-{
-    unsigned int X[3] = {x, y, z};
-    const unsigned int Mtop = 1u << 9;
-    for (unsigned int Q = Mtop; Q > 1; Q >>= 1) {
-        const unsigned int Pm = Q - 1;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (X[i] & Q) X[0] ^= Pm;
-            else { const unsigned int t = (X[0] ^ X[i]) & Pm; X[0] ^= t; X[i] ^= t; }
-        }
-    }
-    X[1] ^= X[0];
-    X[2] ^= X[1];
-    unsigned int t = 0;
-    for (unsigned int Q = Mtop; Q > 1; Q >>= 1)
-        if (X[2] & Q) t ^= Q - 1;
-    X[0] ^= t; X[1] ^= t; X[2] ^= t;
-    return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
-}
 
 // ---- Hilbert keys of a cloud ---------------------------------------------------------------------------------------------
 // The bounding box arrives as rows [n_rows][6] (min xyz, max xyz): k_bbox_partial's per-block rows, or one finished row.  Every
@@ -113,14 +82,7 @@ __global__ __launch_bounds__(256) void k_hilbert_keys(const float* __restrict__ 
     }
     const int i = (int)blockIdx.x * 256 + tid;
     if (i >= n) return;
-    float ext = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, box[3 + k] - box[k]);
-    const float scale = ext > 0 ? 1023.999f / ext : 0.f;  // isotropic cells
-    const unsigned int ix = (unsigned int)fminf(fmaxf((x[i] - box[0]) * scale, 0.f), 1023.f);
-    const unsigned int iy = (unsigned int)fminf(fmaxf((y[i] - box[1]) * scale, 0.f), 1023.f);
-    const unsigned int iz = (unsigned int)fminf(fmaxf((z[i] - box[2]) * scale, 0.f), 1023.f);
-    keys[i] = hilbert30(ix, iy, iz);
+    keys[i] = hilbert_key_in_box(box, x[i], y[i], z[i]);
 }
 
 // keys from an array -- optionally through an indirection (the second pass of a two-pass sort reads them in the first pass's order)
@@ -220,6 +182,7 @@ __global__ __launch_bounds__(256) void k_rank_merge(const unsigned int* __restri
     idx_out[dest] = idx;
     if (GATHER) {
         sx[dest] = gx[idx]; sy[dest] = gy[idx]; sz[dest] = gz[idx];
+        if (keys_out) keys_out[dest] = keys_in[p];   // (a map keeps its sorted keys: a query's place in it is a binary search away)
     } else {
         keys_out[dest] = keys_in[p];
     }
@@ -248,7 +211,7 @@ static SortScratch sort_scratch_at(char* base, size_t n)
 // it gathers) and, with gather arguments, the points.  Keys must be <= 0xfffffffe.
 static int sort_by_key(hipStream_t stream, const ArrayKeys& kg, size_t n, const SortScratch& s, unsigned int* order_out, size_t n_padded,
                        const float* gx, const float* gy, const float* gz, float* sx, float* sy, float* sz, float* sbox, int n_super,
-                       float* ubox, int n_top)
+                       float* ubox, int n_top, unsigned int* keys_sorted_out = nullptr /*with the gather: the keys in sorted order (n entries)*/)
 {
     const int ni = (int)n;
     const unsigned n_runs = (unsigned)((n + kSortRun - 1) / kSortRun);
@@ -261,7 +224,7 @@ static int sort_by_key(hipStream_t stream, const ArrayKeys& kg, size_t n, const 
         const long long n_pad_in = (long long)((n + L - 1) / L * L);
         if (last && gx) {
             hipLaunchKernelGGL((k_rank_merge<true>), dim3((unsigned)((n_padded + 255) / 256)), dim3(256), 0, stream, kin, iin, ni, n_pad_in,
-                               (int)n_padded, logL, (unsigned int*)nullptr, order_out, gx, gy, gz, sx, sy, sz, sbox, n_super, ubox, n_top);
+                               (int)n_padded, logL, keys_sorted_out, order_out, gx, gy, gz, sx, sy, sz, sbox, n_super, ubox, n_top);
         } else {
             // (not the last level: the output is the next level's input -- padded to whole runs of L * fan-in)
             const unsigned long long Ln = L * kSortFan;
@@ -283,7 +246,7 @@ static int sort_by_key(hipStream_t stream, const ArrayKeys& kg, size_t n, const 
 // (either may be null).  sbox / ubox (may be null): [6][n_super] / [6][n_top], reset for k_boxes.
 int hilbert_sort_points(hipStream_t stream, const float* gx, const float* gy, const float* gz, size_t M, size_t M_padded,
                         const float* box_rows, int n_box_rows, float* box_dev, float* box_host, DevBuf& scratch, float* sxyz, int* perm,
-                        float* sbox, int n_super, float* ubox, int n_top)
+                        float* sbox, int n_super, float* ubox, int n_top, unsigned int* keys_sorted /*M entries, may be null*/)
 {
     if (M == 0) return MOLA_ICP_OK;
     if (M_padded > (size_t)0x7fffff00) return fail(MOLA_ICP_E_BADARG, "cloud too large for the 32-bit sort");
@@ -296,7 +259,7 @@ int hilbert_sort_points(hipStream_t stream, const float* gx, const float* gy, co
                        box_host, keys);
     HIPCHK(hipGetLastError());
     return sort_by_key(stream, ArrayKeys{keys, nullptr}, M, s, reinterpret_cast<unsigned int*>(perm), M_padded, gx, gy, gz, sxyz,
-                       sxyz + M_padded, sxyz + 2 * M_padded, sbox, n_super, ubox, n_top);
+                       sxyz + M_padded, sxyz + 2 * M_padded, sbox, n_super, ubox, n_top, keys_sorted);
 }
 
 // ---- the three box levels of a sorted map, one launch -------------------------------------------------------------------
