@@ -394,6 +394,10 @@ int mola_icp_accumulate_planes(mola_icp_handle* h, double acc_out[MOLA_ICP_NACC_
 int mola_icp_solve_gauss_newton_planes(const double acc[MOLA_ICP_NACC_PLANES], const double T0[16],
                                        uint32_t max_iterations, double T_out[16], double* final_cost,
                                        uint32_t* iterations_done);
+/* Mixed pairings in one solve (`matchers:` is a sequence, params/icp-settings-regular.yaml:28-39; all entries initialised together,
+ * src/LidarOdometry.cpp:83-84): adds the share of a point-to-point pairing -- its MOLA_ICP_NACC unit-weight sums, accumulated at
+ * pose T -- to the quadratic form above (a point-to-point residual is three plane residuals with the normals e_x, e_y, e_z). */
+int mola_icp_mixed_form(const double acc_p2p[MOLA_ICP_NACC], const double T[16], double form_inout[MOLA_ICP_NACC_PLANES]);
 /* Horn closed form on an accumulator block (row a9).  cl/cg may be NULL
  * (weighted means of acc).  Returns MOLA_ICP_E_BADARG if W<=0. */
 int mola_icp_solve_horn(const double acc[MOLA_ICP_NACC], const double* cl, const double* cg, double T_out[16]);

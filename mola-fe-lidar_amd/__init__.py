@@ -9,11 +9,11 @@ from . import _lib
 from ._lib import (IcpError, NN_AUTO, NN_MFMA, NN_TILED, NN_VALU, TERM_MAX_ITERATIONS, TERM_NO_PAIRINGS, TERM_SOLVER_ERROR,
                    TERM_STALLED, TERM_UNDEFINED)
 from .icp import (DevicePool, ICP, Parameters, pool_assignment, Results, pose_from_xyzypr, pose_to_xyzypr, run_loop, run_loop_batch, se3_log,
-                  solve_gauss_newton_planes, solve_horn, stall_deltas)
+                  solve_gauss_newton_planes, solve_horn, stall_deltas, mixed_form)
 
 from .lidar_odometry import (CheckResult, LidarOdometry, LidarOdometryParams, Step, check_nonadjacent, montecarlo_guesses,
                              select_checks)
 
 __all__ = ["LidarOdometry", "LidarOdometryParams", "Step", "CheckResult", "check_nonadjacent", "montecarlo_guesses", "select_checks", "ICP", "DevicePool", "pool_assignment", "Parameters", "Results", "IcpError", "pose_from_xyzypr", "pose_to_xyzypr", "se3_log",
-           "stall_deltas", "solve_horn", "solve_gauss_newton_planes", "run_loop", "run_loop_batch", "NN_AUTO", "NN_VALU", "NN_MFMA", "NN_TILED", "TERM_UNDEFINED",
+           "stall_deltas", "solve_horn", "solve_gauss_newton_planes", "mixed_form", "run_loop", "run_loop_batch", "NN_AUTO", "NN_VALU", "NN_MFMA", "NN_TILED", "TERM_UNDEFINED",
            "TERM_NO_PAIRINGS", "TERM_SOLVER_ERROR", "TERM_MAX_ITERATIONS", "TERM_STALLED"]

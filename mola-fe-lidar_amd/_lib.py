@@ -230,6 +230,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_uint64)]),
     "mola_icp_accumulate_planes": (C.c_int, [_H, _DP]),
     "mola_icp_solve_gauss_newton_planes": (C.c_int, [_DP, _DP, C.c_uint32, _DP, _DP, C.POINTER(C.c_uint32)]),
+    "mola_icp_mixed_form": (C.c_int, [_DP, _DP, _DP]),
     "mola_icp_solve_horn": (C.c_int, [_DP, _DP, _DP, _DP]),
     "mola_icp_stall_deltas": (C.c_int, [_DP, _DP, _DP, _DP]),
     "mola_icp_se3_log": (C.c_int, [_DP, _DP]),

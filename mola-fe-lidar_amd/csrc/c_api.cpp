@@ -1198,6 +1198,13 @@ int mola_icp_accumulate_planes(mola_icp_handle* h, double acc_out[MOLA_ICP_NACC_
     });
 }
 
+int mola_icp_mixed_form(const double acc_p2p[MOLA_ICP_NACC], const double T[16], double form_inout[MOLA_ICP_NACC_PLANES])
+{
+    if (!acc_p2p || !T || !form_inout) return fail(MOLA_ICP_E_BADARG, "null argument");
+    mixed_form(acc_p2p, mat_from(T), form_inout);
+    return MOLA_ICP_OK;
+}
+
 int mola_icp_solve_gauss_newton_planes(const double acc[MOLA_ICP_NACC_PLANES], const double T0[16],
                                        uint32_t max_iterations, double T_out[16], double* final_cost,
                                        uint32_t* iterations_done)

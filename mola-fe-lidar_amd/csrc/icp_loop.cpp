@@ -50,27 +50,37 @@ mola_icp_params with_entries(const mola_icp_params& p, int k, int j)
 int validate_single(const mola_icp_params& p);
 }  // namespace
 
-// The `matchers:` / `solvers:` entries in force at iteration `it` as a single-entry parameter set (see mola_icp_matcher_entry).
-// Returns false when no matcher's range holds the iteration (no pairings).  An iteration no solver's range holds keeps the
-// LAST solver listed ([EXT] mp2p_icp tries its solvers in order; a pipeline without any solver for an iteration cannot solve).
-bool stage_params(const mola_icp_params& p, uint32_t it, mola_icp_params& eff)
+// The `matchers:` / `solvers:` entries in force at iteration `it` as single-entry parameter sets (see mola_icp_matcher_entry).
+// Returns the number of matchers whose range holds the iteration: 0 = none (no pairings); 1 = `eff`; 2 = `eff` and `eff2`, the
+// first two active entries in the order listed -- validate_params admits that only for one Matcher_Points_DistanceThreshold plus
+// one Matcher_Point2Plane, whose pairings feed ONE Gauss-Newton solve (mixed_form below).  *solver_in_range = false when no
+// solver's range holds the iteration: nothing can solve it, the align ends with SolverError ([EXT] mp2p_icp tries its solvers in
+// order and reports SolverError when none succeeds); `eff` then carries the last solver listed.
+int stage_params(const mola_icp_params& p, uint32_t it, mola_icp_params& eff, mola_icp_params* eff2, bool* solver_in_range)
 {
-    int k_act = -1;
+    int k_act[2] = {-1, -1}, n_act = 0;
     for (int k = 0; k <= (int)p.n_extra_matchers && k <= MOLA_ICP_MAX_EXTRA_STAGES; ++k) {
         const uint32_t from = k ? p.extra_matchers[k - 1].run_from_iteration : p.run_from_iteration;
         const uint32_t upto = k ? p.extra_matchers[k - 1].run_up_to_iteration : p.run_up_to_iteration;
-        if (in_range(it, from, upto)) { k_act = k; break; }
+        if (in_range(it, from, upto)) { if (n_act < 2) k_act[n_act] = k; ++n_act; }
     }
-    if (k_act < 0) return false;
-    int j_act = (int)p.n_extra_solvers;
+    if (solver_in_range) *solver_in_range = true;
+    if (n_act == 0) return 0;
+    int j_act = -1;
     for (int j = 0; j <= (int)p.n_extra_solvers && j <= MOLA_ICP_MAX_EXTRA_STAGES; ++j) {
         const uint32_t from = j ? p.extra_solvers[j - 1].run_from_iteration : p.solver_run_from_iteration;
         const uint32_t upto = j ? p.extra_solvers[j - 1].run_up_to_iteration : p.solver_run_up_to_iteration;
         if (in_range(it, from, upto)) { j_act = j; break; }
     }
-    eff = with_entries(p, k_act, j_act);
-    return true;
+    if (j_act < 0) {
+        if (solver_in_range) *solver_in_range = false;
+        j_act = (int)p.n_extra_solvers;
+    }
+    eff = with_entries(p, k_act[0], j_act);
+    if (n_act >= 2 && eff2) *eff2 = with_entries(p, k_act[1], j_act);
+    return n_act;
 }
+bool stage_params(const mola_icp_params& p, uint32_t it, mola_icp_params& eff) { return stage_params(p, it, eff, nullptr, nullptr) > 0; }
 
 int validate_params(const mola_icp_params& p)
 {
@@ -86,27 +96,43 @@ int validate_params(const mola_icp_params& p)
     }
     if (p.n_extra_quality && !(p.quality_weight >= 0)) return fail(MOLA_ICP_E_BADARG, "quality weight must be finite and >= 0");
     if (p.n_extra_matchers == 0 && p.n_extra_solvers == 0) return validate_single(p);
-    // several entries: no two matchers may be active in one iteration (mixed pairings in one solve are not run), and every
-    // (matcher, solver) combination an iteration can meet must be a pipeline this build runs
-    const uint32_t n_it = p.max_iterations < 4096 ? p.max_iterations : 4096;   // (ranges beyond are checked when met)
-    for (uint32_t it = 0; it < n_it; ++it) {
-        int active = 0;
-        for (int k = 0; k <= (int)p.n_extra_matchers; ++k) {
-            const uint32_t from = k ? p.extra_matchers[k - 1].run_from_iteration : p.run_from_iteration;
-            const uint32_t upto = k ? p.extra_matchers[k - 1].run_up_to_iteration : p.run_up_to_iteration;
-            active += in_range(it, from, upto) ? 1 : 0;
-        }
-        if (active > 1)
-            return fail(MOLA_ICP_E_UNSUPPORTED, "matchers: " + std::to_string(active) + " entries are active in iteration " + std::to_string(it) +
-                                                    " (overlapping runFromIteration / runUpToIteration ranges): pairings of several matchers in "
-                                                    "one solve are not run by this build -- give the entries disjoint iteration ranges");
-        mola_icp_params eff;
-        if (stage_params(p, it, eff)) {
-            const int rc = validate_single(eff);
-            if (rc) return rc;
-        }
+    // Several entries.  Which entries are active changes only where a range begins or ends: every distinct combination an align
+    // can meet is met at iteration 0 or at one of those boundaries (no walk over the iterations, no cut-off).
+    std::vector<uint32_t> probes{0u};
+    auto add_range = [&](uint32_t from, uint32_t upto) {
+        probes.push_back(from);
+        if (upto != 0 && upto != 0xffffffffu) probes.push_back(upto + 1);
+    };
+    add_range(p.run_from_iteration, p.run_up_to_iteration);
+    add_range(p.solver_run_from_iteration, p.solver_run_up_to_iteration);
+    for (uint32_t k = 0; k < p.n_extra_matchers; ++k) add_range(p.extra_matchers[k].run_from_iteration, p.extra_matchers[k].run_up_to_iteration);
+    for (uint32_t j = 0; j < p.n_extra_solvers; ++j) add_range(p.extra_solvers[j].run_from_iteration, p.extra_solvers[j].run_up_to_iteration);
+    bool any = false;
+    for (uint32_t it : probes) {
+        if (it >= p.max_iterations) continue;
+        any = true;
+        mola_icp_params eff, eff2;
+        bool solver_ok = true;
+        const int n_act = stage_params(p, it, eff, &eff2, &solver_ok);
+        if (n_act == 0) continue;
+        int rc = validate_single(eff);
+        if (rc) return rc;
+        if (n_act == 1) continue;
+        if ((rc = validate_single(eff2))) return rc;
+        const bool one_of_each = n_act == 2 && eff.matcher_class != eff2.matcher_class;
+        if (!one_of_each)
+            return fail(MOLA_ICP_E_UNSUPPORTED, "matchers: " + std::to_string(n_act) + " entries are active in iteration " + std::to_string(it) +
+                                                    ": this build merges the pairings of ONE mp2p_icp::Matcher_Points_DistanceThreshold and ONE "
+                                                    "mp2p_icp::Matcher_Point2Plane in a solve -- give other combinations disjoint runFromIteration / "
+                                                    "runUpToIteration ranges");
+        if (eff.solver_class != MOLA_ICP_SOLVER_GAUSS_NEWTON)
+            return fail(MOLA_ICP_E_UNSUPPORTED, "point-to-point and point-to-plane pairings in one iteration (" + std::to_string(it) +
+                                                    ") need mp2p_icp::Solver_GaussNewton (Solver_Horn only consumes point-to-point pairings)");
+        if (p.use_scale_outlier_detector || p.use_robust_kernel)
+            return fail(MOLA_ICP_E_UNSUPPORTED, "pairingsWeightParameters (scale outlier detector / robust kernel) are not available when two "
+                                                    "matchers feed one solve");
     }
-    if (n_it == 0) return validate_single(with_entries(p, 0, 0));
+    if (!any) return validate_single(with_entries(p, 0, 0));
     return MOLA_ICP_OK;
 }
 
@@ -179,6 +205,50 @@ static int solve_on_pairing(Stages& st, const mola_icp_params& p, const Mat4& Tc
     return MOLA_ICP_OK;
 }
 
+// Mixed pairings in one solve (the reference's `matchers:` is "a sequence of one or more", params/icp-settings-regular.yaml:28-39,
+// all initialised together at src/LidarOdometry.cpp:83-84; [EXT] mp2p_icp hands the pairings of every active matcher to the solver).
+// The Gauss-Newton cost of the iteration is  sum_planes (n.(R l + t - c))^2 + sum_points |R l + t - g|^2 -- and a point-to-point
+// pairing is three plane terms with the normals e_x, e_y, e_z and d = g_x, g_y, g_z: its share of the quadratic form
+// x^T A x - 2 b^T x + c0 (x = [R row-major, t]) follows from the 24 sums the point-to-point accumulation already delivers --
+//   A[3k+i][3k+j] += sum l_i l_j,  A[3k+i][9+k] += sum l_i,  A[9+k][9+k] += W,  b[3k+i] += sum l_i g_k,  b[9+k] += sum g_k  (k = x, y, z)
+// -- no kernel of its own.  sum |g|^2 is not among the sums; c0 is set so that the form's value at the matcher's pose equals the
+// accumulated sum of squared distances (acc[17]; it only enters the reported cost / rmse, never the step).  Unit weights.
+void mixed_form(const double acc[kNAcc], const Mat4& T, double pacc[kNAccPlaneHost])
+{
+    auto at = [](int a, int b) { if (a > b) { const int t = a; a = b; b = t; } return a * 12 - a * (a - 1) / 2 + (b - a); };   // upper triangle, row-major
+    const double W = acc[0];
+    const double* sl = acc + 1;
+    const double* sg = acc + 4;
+    const double* slg = acc + 7;                         // sum l_i g_k at [3 i + k]
+    const double sll[3][3] = {{acc[18], acc[19], acc[20]}, {acc[19], acc[21], acc[22]}, {acc[20], acc[22], acc[23]}};
+    double A[12][12] = {}, b[12] = {};
+    for (int k = 0; k < 3; ++k) {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) A[3 * k + i][3 * k + j] = sll[i][j];
+            A[3 * k + i][9 + k] = A[9 + k][3 * k + i] = sl[i];
+            b[3 * k + i] = slg[3 * i + k];
+        }
+        A[9 + k][9 + k] = W;
+        b[9 + k] = sg[k];
+    }
+    double x[12];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) x[3 * r + c] = T(r, c);
+        x[9 + r] = T(r, 3);
+    }
+    double q = 0;   // x^T A x - 2 b^T x at the matcher's pose
+    for (int i = 0; i < 12; ++i) {
+        double v = 0;
+        for (int j = 0; j < 12; ++j) v += A[i][j] * x[j];
+        q += x[i] * (v - 2 * b[i]);
+    }
+    for (int i = 0; i < 12; ++i)
+        for (int j = i; j < 12; ++j) pacc[at(i, j)] += A[i][j];
+    for (int i = 0; i < 12; ++i) pacc[78 + i] += b[i];
+    pacc[90] += acc[17] - q;
+    pacc[91] += acc[16];
+}
+
 int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mola_icp_result* out)
 {
     int rc = validate_params(p_all);
@@ -200,9 +270,12 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mol
     TraceRange tr_loop("mola_icp.iterations");
     for (; it < p.max_iterations; ++it) {
         bool run_matcher;
+        int n_active = 1;
+        bool solver_in_range = true;
+        mola_icp_params p2 = p;   // (two matchers active: the second one's single-entry set)
         if (staged) {
-            run_matcher = stage_params(p_all, it, p);
-            if (run_matcher && (rc = validate_params(p))) return rc;   // (an iteration beyond the range validate_params walked)
+            n_active = stage_params(p_all, it, p, &p2, &solver_in_range);
+            run_matcher = n_active > 0;
         } else {
             run_matcher = it >= p.run_from_iteration && (p.run_up_to_iteration == 0 || it <= p.run_up_to_iteration);
         }
@@ -210,11 +283,31 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mol
             term = MOLA_ICP_TERM_NO_PAIRINGS;
             break;
         }
-        last_planes = p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE;
+        if (!solver_in_range) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }   // no `solvers:` entry covers this iteration
+        last_planes = p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE || n_active == 2;
         Mat4 Tn = T;
         double pairs_global = 0;
         bool solver_error = false;
-        if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) {
+        if (n_active == 2) {
+            // one Matcher_Points_DistanceThreshold + one Matcher_Point2Plane (validate_params): both pair ALL local points at this
+            // pose ([EXT] no "already matched" exclusion between matchers), one Gauss-Newton solve over the sum of their costs
+            const mola_icp_params& pp = p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE ? p : p2;
+            const mola_icp_params& pq = p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE ? p2 : p;
+            double pacc[kNAccPlaneHost];
+            if ((rc = st.match_planes(T, pp))) return rc;
+            if ((rc = st.accumulate_planes(pacc))) return rc;
+            if ((rc = st.match(T, pq.matcher_threshold, pq, nullptr))) return rc;
+            if ((rc = st.accumulate(pq, T, 0, nullptr, nullptr, true, acc))) return rc;
+            if ((rc = st.allreduce(acc))) return rc;
+            mixed_form(acc, T, pacc);
+            pairs_global = pacc[91];
+            if (!(pairs_global > 0)) { term = MOLA_ICP_TERM_NO_PAIRINGS; break; }
+            double cost = 0;
+            if (!solve_gauss_newton_planes(pacc, T, pp.solver_max_iterations, Tn, &cost)) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }
+            plane_pairs = pairs_global;
+            plane_rmse = std::sqrt((cost > 0 ? cost : 0.0) / pairs_global);
+            std::memcpy(last_pacc, pacc, sizeof last_pacc);
+        } else if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) {
             // row f3: plane pairings -> ONE accumulation pass (the quadratic form of the cost) -> host Gauss-Newton
             double pacc[kNAccPlaneHost];
             if ((rc = st.match_planes(T, p))) return rc;

@@ -81,9 +81,15 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
 // ms_iterations, ms_quality of *out (other fields untouched).
 int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p, mola_icp_result* out);
 
+// adds the share of a point-to-point pairing (its 24 unit-weight sums, accumulated at pose T) to the 92-term quadratic form of the
+// Gauss-Newton cost (mixed pairings in one solve: icp_loop.cpp)
+void mixed_form(const double acc[kNAcc], const Mat4& T, double pacc[kNAccPlaneHost]);
+
 int validate_params(const mola_icp_params& p);
 // the single-entry parameter set in force at iteration `it` of a staged pipeline (include/mola_icp_amd.h: mola_icp_matcher_entry);
 // false: no matcher's range holds the iteration
 bool stage_params(const mola_icp_params& p, uint32_t it, mola_icp_params& eff);
+// ... and the general form: the number of active matchers (0, 1, 2: eff, eff2), whether a solver's range holds the iteration
+int stage_params(const mola_icp_params& p, uint32_t it, mola_icp_params& eff, mola_icp_params* eff2, bool* solver_in_range);
 
 }  // namespace mola_icp_amd

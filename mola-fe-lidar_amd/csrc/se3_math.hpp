@@ -125,8 +125,22 @@ inline void stall_deltas(const Mat4& T, const Mat4& Tprev, double& d_xyz, double
     d_rot = std::sqrt(lg[3] * lg[3] + lg[4] * lg[4] + lg[5] * lg[5]);
 }
 
-// Cyclic Jacobi on a symmetric 4x4; returns the unit eigenvector of the largest eigenvalue.
-inline void max_eigvec_sym4(double A[4][4], double q[4])
+// Degenerate geometry (the soft-failure branch the caller relies on is src/LidarOdometry.cpp:873-877).
+// A solve is refused -- the iteration ends the align with SolverError, the pose stays the last one solved (the guess, if none) --
+// when its system does not determine the pose, judged RELATIVELY (the CPU checker restates the same rule):
+//   * Horn: fewer than 3 pairings; or the largest eigenvalue of N(S) is not separated from the second by more than kSingularRel of
+//     the largest magnitude -- a line (S of rank 1: the rotation about it is free) -- or S itself is zero to rounding (all queries
+//     in one point);
+//   * Gauss-Newton / covariance: a pivot of the 6 x 6 normal matrix not above kSingularRel of its largest entry -- one plane (rank
+//     3), one line of normals, ...  (rounds 1-3 compared pivots with 1e-300: a rank-deficient system has pivots of 1e-16 of the
+//     scale, passed, and produced a step of 1e+16).
+// Rounding leaves ~1e-16 of the scale in a pivot that should be zero and the two sides build their systems in different orders,
+// so the decision is taken five orders of magnitude away from both.
+constexpr double kSingularRel = 1e-11;
+
+// Cyclic Jacobi on a symmetric 4x4; returns the unit eigenvector of the largest eigenvalue and (gap_rel, may be null) how far the
+// largest eigenvalue is from the second, relative to the largest eigenvalue magnitude.
+inline void max_eigvec_sym4(double A[4][4], double q[4], double* gap_rel = nullptr)
 {
     double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
     for (int sweep = 0; sweep < 50; ++sweep) {
@@ -163,6 +177,14 @@ inline void max_eigvec_sym4(double A[4][4], double q[4])
     int b = 0;
     for (int i = 1; i < 4; ++i)
         if (A[i][i] > A[b][b]) b = i;
+    if (gap_rel) {
+        double second = -1e300, mag = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (i != b && A[i][i] > second) second = A[i][i];
+            if (std::fabs(A[i][i]) > mag) mag = std::fabs(A[i][i]);
+        }
+        *gap_rel = mag > 0 ? (A[b][b] - second) / mag : 0.0;
+    }
     double n = 0;
     for (int k = 0; k < 4; ++k) n += V[k][b] * V[k][b];
     n = std::sqrt(n);
@@ -176,6 +198,7 @@ inline bool solve_horn(const double acc[kNAcc], const double* cl_in, const doubl
 {
     const double W = acc[0];
     if (!(W > 0) || !std::isfinite(W)) return false;
+    if (!(acc[16] >= 3.0)) return false;   // fewer than three pairings do not fix a rotation
     double cl[3], cg[3];
     for (int k = 0; k < 3; ++k) {
         cl[k] = cl_in ? cl_in[k] : acc[1 + k] / W;
@@ -190,8 +213,18 @@ inline bool solve_horn(const double acc[kNAcc], const double* cl_in, const doubl
         {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
         {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
         {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
-    double q[4];
-    max_eigvec_sym4(N, q);
+    // (S is a difference of sums: when every query is the same point it is rounding noise around zero -- judged against the size
+    //  of the sums it was formed from)
+    double raw = 0, n_mag = 0;
+    for (int k = 0; k < 9; ++k) raw = std::fmax(raw, std::fabs(acc[7 + k]));
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) raw = std::fmax(raw, std::fabs(W * cl[r] * cg[c]));
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) n_mag = std::fmax(n_mag, std::fabs(N[i][j]));
+    if (!(n_mag > kSingularRel * raw)) return false;
+    double q[4], gap = 0;
+    max_eigvec_sym4(N, q, &gap);
+    if (!(gap > kSingularRel)) return false;   // the rotation is not determined (kSingularRel, above)
     for (int k = 0; k < 4; ++k)
         if (!std::isfinite(q[k])) return false;
     double w = q[0], x = q[1], y = q[2], z = q[3];
@@ -243,12 +276,15 @@ inline bool pose_covariance(const double acc[kNAcc], const Mat4& T, double cov[3
             H[3 + i][3 + j] = (i == j ? trP : 0.0) - P[i][j];
         }
     for (int i = 0; i < 6; ++i) H[i][6 + i] = 1.0;
-    // Gauss-Jordan with partial pivoting
+    // Gauss-Jordan with partial pivoting (a pivot not above kSingularRel of the matrix' largest entry: singular)
+    double h_scale = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) h_scale = std::fmax(h_scale, std::fabs(H[i][j]));
     for (int c = 0; c < 6; ++c) {
         int piv = c;
         for (int r = c + 1; r < 6; ++r)
             if (std::fabs(H[r][c]) > std::fabs(H[piv][c])) piv = r;
-        if (std::fabs(H[piv][c]) < 1e-300) return false;
+        if (!(std::fabs(H[piv][c]) > kSingularRel * h_scale)) return false;
         if (piv != c)
             for (int k = 0; k < 12; ++k) { const double tmp = H[c][k]; H[c][k] = H[piv][k]; H[piv][k] = tmp; }
         const double inv = 1.0 / H[c][c];
@@ -364,12 +400,16 @@ inline bool solve_gauss_newton_planes(const double acc[kNAccPlaneForm], const Ma
             for (int i = 0; i < 12; ++i) g += J[i][a] * res[i];
             H[a][6] = -g;
         }
-        // solve H d = -g (Gaussian elimination, partial pivoting)
+        // solve H d = -g (Gaussian elimination, partial pivoting; a pivot not above kSingularRel of the normal matrix' largest
+        // entry: the pairings do not determine the pose -- one plane, one direction of normals -- SolverError)
+        double h_scale = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int k = 0; k < 6; ++k) h_scale = std::fmax(h_scale, std::fabs(H[a][k]));
         for (int c = 0; c < 6; ++c) {
             int piv = c;
             for (int r = c + 1; r < 6; ++r)
                 if (std::fabs(H[r][c]) > std::fabs(H[piv][c])) piv = r;
-            if (std::fabs(H[piv][c]) < 1e-300) return false;
+            if (!(std::fabs(H[piv][c]) > kSingularRel * h_scale)) return false;
             if (piv != c)
                 for (int k = 0; k < 7; ++k) { const double t = H[c][k]; H[c][k] = H[piv][k]; H[piv][k] = t; }
             for (int r = c + 1; r < 6; ++r) {
@@ -447,11 +487,14 @@ inline bool pose_covariance_planes(const double acc[kNAccPlaneForm], const Mat4&
         }
         H[a][6 + a] = 1.0;
     }
-    for (int c = 0; c < 6; ++c) {  // Gauss-Jordan with partial pivoting
+    double h_scale = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) h_scale = std::fmax(h_scale, std::fabs(H[i][j]));
+    for (int c = 0; c < 6; ++c) {  // Gauss-Jordan with partial pivoting (singular: as above)
         int piv = c;
         for (int r = c + 1; r < 6; ++r)
             if (std::fabs(H[r][c]) > std::fabs(H[piv][c])) piv = r;
-        if (std::fabs(H[piv][c]) < 1e-300) return false;
+        if (!(std::fabs(H[piv][c]) > kSingularRel * h_scale)) return false;
         if (piv != c)
             for (int k = 0; k < 12; ++k) { const double t = H[c][k]; H[c][k] = H[piv][k]; H[piv][k] = t; }
         const double inv = 1.0 / H[c][c];

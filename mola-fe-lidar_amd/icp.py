@@ -85,6 +85,15 @@ def solve_gauss_newton_planes(acc, T0, max_iterations=20):
     return T.reshape(4, 4), cost.value, its.value
 
 
+def mixed_form(acc_p2p, T, form) -> np.ndarray:
+    """the 92-term quadratic form `form` plus the share of a point-to-point pairing (its 24 sums at pose T)"""
+    acc_p2p = np.ascontiguousarray(acc_p2p, dtype=np.float64)
+    out = np.array(form, dtype=np.float64)
+    assert acc_p2p.shape == (L.NACC,) and out.shape == (92,)
+    L.check(L.lib().mola_icp_mixed_form(_dp(acc_p2p), _dp(_pose16(T)), _dp(out)))
+    return out
+
+
 def solve_horn(acc, cl=None, cg=None) -> np.ndarray:
     acc = np.ascontiguousarray(acc, dtype=np.float64)
     assert acc.shape == (L.NACC,)

@@ -580,10 +580,18 @@ static void jacobi_sym4(double A[4][4], double V[4][4], double ev[4])
     for (int i = 0; i < 4; i++) ev[i] = A[i][i];
 }
 
+/* Degenerate geometry, judged relatively (the same rule as the product's csrc/se3_math.hpp, kSingularRel): Horn refuses
+ * fewer than 3 pairings, an S that is zero to rounding (all queries in one point) and a largest eigenvalue of N(S) that is
+ * not separated from the second (a line: S of rank 1); the 6 x 6 solves refuse a pivot not above ORC_SINGULAR_REL of the matrix' largest entry (one
+ * plane: rank 3).  The align then ends with SolverError at the last pose solved (src/LidarOdometry.cpp:873-877 is the
+ * caller's soft-failure branch). */
+#define ORC_SINGULAR_REL 1e-11
+
 int orc_horn(const double acc[ORC_NACC], const double* cl_in, const double* cg_in, double T[16])
 {
     const double W = acc[0];
     if (!(W > 0)) return -1;
+    if (!(acc[16] >= 3.0)) return -3;
     double cl[3], cg[3];
     for (int k = 0; k < 3; k++) {
         cl[k] = cl_in ? cl_in[k] : acc[1 + k] / W;
@@ -599,10 +607,28 @@ int orc_horn(const double acc[ORC_NACC], const double* cl_in, const double* cg_i
                        {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
                        {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
                        {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
+    {   /* S is a difference of sums: all queries in one point leave rounding noise around zero -- judged against the sums */
+        double raw = 0, n_mag = 0;
+        for (int k = 0; k < 9; k++) if (fabs(acc[7 + k]) > raw) raw = fabs(acc[7 + k]);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) if (fabs(W * cl[r] * cg[c]) > raw) raw = fabs(W * cl[r] * cg[c]);
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) if (fabs(Nm[i][j]) > n_mag) n_mag = fabs(Nm[i][j]);
+        if (!(n_mag > ORC_SINGULAR_REL * raw)) return -5;
+    }
     double V[4][4], ev[4];
     jacobi_sym4(Nm, V, ev);
     int best = 0;
     for (int i = 1; i < 4; i++) if (ev[i] > ev[best]) best = i;
+    {
+        double second = -1e300, mag = 0;
+        for (int i = 0; i < 4; i++) {
+            if (i != best && ev[i] > second) second = ev[i];
+            if (fabs(ev[i]) > mag) mag = fabs(ev[i]);
+        }
+        const double gap = mag > 0 ? (ev[best] - second) / mag : 0.0;
+        if (!(gap > ORC_SINGULAR_REL)) return -4;
+    }
     double qw = V[0][best], qx = V[1][best], qy = V[2][best], qz = V[3][best];
     const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
     if (!(qn > 0)) return -2;
@@ -845,10 +871,12 @@ static void solve6(double H[6][6], const double g[6], double x[6], int* ok)
     double A[6][7];
     for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) A[i][j] = H[i][j]; A[i][6] = g[i]; }
     *ok = 1;
+    double scale = 0;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) if (fabs(H[i][j]) > scale) scale = fabs(H[i][j]);
     for (int c = 0; c < 6; c++) {
         int piv = c;
         for (int r = c + 1; r < 6; r++) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
-        if (fabs(A[piv][c]) < 1e-300) { *ok = 0; return; }
+        if (!(fabs(A[piv][c]) > ORC_SINGULAR_REL * scale)) { *ok = 0; return; }
         if (piv != c) for (int k = 0; k < 7; k++) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
         for (int r = c + 1; r < 6; r++) {
             const double f = A[r][c] / A[c][c];
@@ -884,10 +912,15 @@ static void se3_exp(const double d[6], double T[16])
     T[12] = T[13] = T[14] = 0; T[15] = 1;
 }
 
-/* Gauss-Newton on the point-to-plane pairings, left perturbation T <- exp(delta) T.  Returns 0 ok. */
-int orc_solve_gauss_newton(const float* lx, const float* ly, const float* lz, size_t N, const uint8_t* valid,
-                           const double* centroid, const double* normal, const double Tcur[16], uint32_t max_iters,
-                           double Tnew[16], double* final_cost, uint32_t* iters_done)
+/* Gauss-Newton on the point-to-plane pairings -- and, when pp_idx is given, on point-to-point pairings as well (mixed pairings in
+ * one solve: the reference's `matchers:` is a sequence, params/icp-settings-regular.yaml:28-39, src/LidarOdometry.cpp:83-84; [EXT]
+ * mp2p_icp hands every active matcher's pairings to the solver; unit weights): cost = sum (n.(p - c))^2 + sum |p - g|^2, p = T l.
+ * A point-to-point residual is three plane residuals with the normals e_x, e_y, e_z.  Left perturbation T <- exp(delta) T.
+ * Returns 0 ok. */
+int orc_solve_gauss_newton_mixed(const float* lx, const float* ly, const float* lz, size_t N, const uint8_t* valid,
+                                 const double* centroid, const double* normal, const int32_t* pp_idx, const float* gx, const float* gy,
+                                 const float* gz, const double Tcur[16], uint32_t max_iters, double Tnew[16], double* final_cost,
+                                 uint32_t* iters_done)
 {
     double T[16];
     memcpy(T, Tcur, sizeof T);
@@ -918,6 +951,22 @@ int orc_solve_gauss_newton(const float* lx, const float* ly, const float* lz, si
             cost += r0 * r0;
             n++;
         }
+        for (size_t i = 0; pp_idx && i < N; i++) {
+            if (pp_idx[i] < 0) continue;
+            const double l[3] = {lx[i], ly[i], lz[i]};
+            const double gq[3] = {gx[pp_idx[i]], gy[pp_idx[i]], gz[pp_idx[i]]};
+            double p[3];
+            for (int r = 0; r < 3; r++) p[r] = T[4 * r] * l[0] + T[4 * r + 1] * l[1] + T[4 * r + 2] * l[2] + T[4 * r + 3];
+            for (int k = 0; k < 3; k++) {
+                double nn[3] = {0, 0, 0};
+                nn[k] = 1.0;
+                const double r0 = p[k] - gq[k];
+                const double J[6] = {nn[0], nn[1], nn[2], p[1] * nn[2] - p[2] * nn[1], p[2] * nn[0] - p[0] * nn[2], p[0] * nn[1] - p[1] * nn[0]};
+                for (int a = 0; a < 6; a++) { g[a] += J[a] * r0; for (int b = 0; b < 6; b++) H[a][b] += J[a] * J[b]; }
+                cost += r0 * r0;
+            }
+            n++;
+        }
         if (n < 3) return -1;
         double mg[6], d[6];
         int ok;
@@ -936,6 +985,69 @@ int orc_solve_gauss_newton(const float* lx, const float* ly, const float* lz, si
     memcpy(Tnew, T, sizeof T);
     if (final_cost) *final_cost = cost;
     if (iters_done) *iters_done = it;
+    return 0;
+}
+
+int orc_solve_gauss_newton(const float* lx, const float* ly, const float* lz, size_t N, const uint8_t* valid,
+                           const double* centroid, const double* normal, const double Tcur[16], uint32_t max_iters,
+                           double Tnew[16], double* final_cost, uint32_t* iters_done)
+{
+    return orc_solve_gauss_newton_mixed(lx, ly, lz, N, valid, centroid, normal, NULL, NULL, NULL, NULL, Tcur, max_iters, Tnew, final_cost,
+                                        iters_done);
+}
+
+/* align with BOTH matchers active in every iteration (Matcher_Points_DistanceThreshold at p->matcher_threshold +
+ * Matcher_Point2Plane at plane_threshold) feeding one Gauss-Newton solve; same loop / stall test / quality as orc_align */
+int orc_align_mixed(const float* gx, const float* gy, const float* gz, size_t M, const float* lx, const float* ly,
+                    const float* lz, size_t N, const double Tinit[16], const orc_params* p, double plane_threshold,
+                    double plane_eigen_threshold, int knn, uint32_t solver_max_iters, orc_result* res)
+{
+    memset(res, 0, sizeof *res);
+    double T[16], Tprev[16];
+    memcpy(T, Tinit, sizeof T);
+    memcpy(Tprev, Tinit, sizeof T);
+    uint8_t* valid = (uint8_t*)calloc(N ? N : 1, 1);
+    double* cen = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    double* nor = (double*)malloc(sizeof(double) * 3 * (N ? N : 1));
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (N ? N : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (N ? N : 1));
+    orc_kdtree* tree = NULL;
+    if (p->use_kdtree) tree = orc_kdtree_build(gx, gy, gz, M);
+    res->termination = ORC_TERM_UNDEFINED;
+    uint32_t it = 0;
+    const double t0 = now_s();
+    for (; it < p->max_iterations; it++) {
+        size_t kept_pl = 0, kept_pp = 0;
+        if (N && M) {
+            kept_pl = orc_match_point2plane(gx, gy, gz, M, tree, lx, ly, lz, N, T, plane_threshold, plane_eigen_threshold, knn, valid, cen,
+                                            nor, NULL);
+            kept_pp = orc_match(gx, gy, gz, M, tree, lx, ly, lz, N, T, p->matcher_threshold, idx, d2);
+        }
+        if (!(kept_pl + kept_pp)) { res->termination = ORC_TERM_NO_PAIRINGS; break; }
+        double Tn[16], cost;
+        if (orc_solve_gauss_newton_mixed(lx, ly, lz, N, valid, cen, nor, idx, gx, gy, gz, T, solver_max_iters, Tn, &cost, NULL)) {
+            res->termination = ORC_TERM_SOLVER_ERROR;
+            break;
+        }
+        res->n_pairs = kept_pl + kept_pp;
+        res->rmse = sqrt(cost / (double)(kept_pl + kept_pp));
+        memcpy(T, Tn, sizeof T);
+        double dxyz, drot;
+        orc_stall_deltas(T, Tprev, &dxyz, &drot);
+        if (!p->fixed_iterations && fabs(dxyz) < p->min_abs_step_trans && fabs(drot) < p->min_abs_step_rot) {
+            res->termination = ORC_TERM_STALLED;
+            it++;
+            break;
+        }
+        memcpy(Tprev, T, sizeof T);
+    }
+    if (res->termination == ORC_TERM_UNDEFINED) res->termination = ORC_TERM_MAX_ITERATIONS;
+    res->n_iterations = it;
+    res->iter_s = now_s() - t0;
+    memcpy(res->T, T, sizeof T);
+    res->quality = orc_quality_paired_ratio(gx, gy, gz, M, tree, lx, ly, lz, N, T, p->quality_threshold, idx, d2);
+    orc_kdtree_free(tree);
+    free(idx); free(d2); free(valid); free(cen); free(nor);
     return 0;
 }
 

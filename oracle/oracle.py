@@ -339,6 +339,26 @@ def solve_gauss_newton(local, valid, centroid, normal, Tcur, max_iters=20):
     return Tn.reshape(4, 4), cost.value, its.value
 
 
+def align_mixed(map_pc, local, T_init, p: OParams, plane_threshold=0.7, plane_eigen_threshold=0.07, knn=6, solver_max_iters=20):
+    """both matchers active in every iteration (point-to-point at p.matcher_threshold, point-to-plane at plane_threshold), one
+    Gauss-Newton solve over the sum of their costs"""
+    L = _bind_p2pl()
+    if not getattr(L, "_mixed_bound", False):
+        L.orc_align_mixed.restype = C.c_int
+        L.orc_align_mixed.argtypes = [_FP, _FP, _FP, C.c_size_t, _FP, _FP, _FP, C.c_size_t, _DP, C.POINTER(OParams), C.c_double,
+                                      C.c_double, C.c_int, C.c_uint32, C.POINTER(OResult)]
+        L._mixed_bound = True
+    gx, gy, gz, M = _rows(map_pc)
+    lx, ly, lz, N = _rows(local)
+    T = np.ascontiguousarray(T_init, dtype=np.float64).reshape(16)
+    res = OResult()
+    rc = L.orc_align_mixed(_f(gx), _f(gy), _f(gz), M, _f(lx), _f(ly), _f(lz), N, _d(T), C.byref(p), float(plane_threshold),
+                           float(plane_eigen_threshold), int(knn), int(solver_max_iters), C.byref(res))
+    assert rc == 0
+    return dict(T=np.array(res.T).reshape(4, 4), quality=res.quality, n_iterations=res.n_iterations,
+                termination=res.termination, n_pairs=res.n_pairs, rmse=res.rmse, iter_s=res.iter_s)
+
+
 def align_p2pl(map_pc, local, T_init, p: OParams, plane_eigen_threshold=0.07, knn=6, solver_max_iters=20):
     L = _bind_p2pl()
     gx, gy, gz, M = _rows(map_pc)

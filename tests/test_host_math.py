@@ -49,19 +49,41 @@ def test_horn_known_answers(pkg, golden, name):
     assert np.abs(T - golden[f"B_{name}_T"]).max() < 2e-5
 
 
-def test_horn_degenerate(pkg):
+def _acc_of(l, g):
+    acc = np.zeros(24)
+    acc[0] = acc[16] = l.shape[1]
+    acc[1:4], acc[4:7], acc[7:16] = l.sum(1), g.sum(1), (l @ g.T).reshape(9)
+    return acc
+
+
+def test_horn_degenerate(pkg, O):
+    """csrc/se3_math.hpp, kSingularRel: a solve whose pairings do not determine the pose is REFUSED (the loop ends with
+    SolverError) -- no pairings, fewer than three, a line (the rotation about it is free), all queries in one point -- and the
+    checker refuses the same inputs; a plane of pairings is fine for Horn"""
     with pytest.raises(pkg.IcpError):
         pkg.solve_horn(np.zeros(24))
-    # colinear cloud: Horn still returns a proper rotation (the free axis is arbitrary)
     t = np.linspace(-1, 1, 50)
-    l = np.stack([t, 0 * t, 0 * t])
-    g = l + np.array([[0.1], [0.0], [0.0]])
-    acc = np.zeros(24)
-    acc[0] = acc[16] = 50
-    acc[1:4], acc[4:7], acc[7:16] = l.sum(1), g.sum(1), (l @ g.T).reshape(9)
-    T = pkg.solve_horn(acc)
-    assert np.linalg.det(T[:3, :3]) == pytest.approx(1.0, abs=1e-12)
-    np.testing.assert_allclose(T[:3, :3] @ l + T[:3, 3:4], g, atol=1e-9)
+    line = np.stack([t, 0.3 * t, -0.2 * t])
+    shift = np.array([[0.1], [0.0], [0.05]])
+    rng = np.random.default_rng(0)
+    cases = {
+        "two pairings": rng.normal(size=(3, 2)),
+        "a line": line,
+        "one point fifty times": np.repeat(rng.normal(size=(3, 1)), 50, axis=1),
+    }
+    for name, l in cases.items():
+        acc = _acc_of(l, l + shift)
+        with pytest.raises(pkg.IcpError):
+            pkg.solve_horn(acc)
+        with pytest.raises(ValueError):
+            O.horn(acc)
+    # coplanar pairings determine the pose
+    plane = np.stack([rng.uniform(-1, 1, 40), rng.uniform(-1, 1, 40), np.zeros(40)])
+    Tgt = pkg.pose_from_xyzypr([0.1, -0.2, 0.05, 0.02, -0.01, 0.03])
+    g = Tgt[:3, :3] @ plane + Tgt[:3, 3:4]
+    T = pkg.solve_horn(_acc_of(plane, g))
+    np.testing.assert_allclose(T, Tgt, atol=1e-12)
+    np.testing.assert_allclose(O.horn(_acc_of(plane, g)), Tgt, atol=1e-12)
 
 
 def test_stall_deltas(pkg, O):

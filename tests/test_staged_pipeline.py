@@ -66,11 +66,22 @@ def test_sequences_parse_into_entries(pkg):
 
 
 def test_overlapping_matchers_and_impossible_stage_pairs_are_refused(pkg):
-    # two matchers active in the same iteration = mixed pairings in one solve: not run, said so
+    # a point-to-point and a point-to-plane matcher active in the same iteration feed ONE solve -- which must be Gauss-Newton
+    # (Horn only consumes point-to-point pairings): here iterations 3..5 meet Solver_Horn
     p = pkg.Parameters.load_from(STAGED % dict(last_p2p=5, first_second=3, **P2PL))
     with pytest.raises(pkg.IcpError) as ex:
         pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), p, 10, 10)
+    assert ex.value.status == pkg._lib.E_UNSUPPORTED and "Solver_GaussNewton" in str(ex.value)
+    # two matchers of the SAME class active together: not merged, said so
+    p = pkg.Parameters.load_from(STAGED % dict(last_p2p=5, first_second=3, **P2P2))
+    with pytest.raises(pkg.IcpError) as ex:
+        pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), p, 10, 10)
     assert ex.value.status == pkg._lib.E_UNSUPPORTED and "active in iteration 3" in str(ex.value)
+    # ... also far beyond the first iterations (the ranges are intersected, not walked: rounds 1-3 looked at 4096 iterations)
+    txt = (STAGED % dict(last_p2p=90000, first_second=70000, **P2P2)).replace("maxIterations: 60", "maxIterations: 100000")
+    with pytest.raises(pkg.IcpError) as ex:
+        pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), pkg.Parameters.load_from(txt), 10, 10)
+    assert ex.value.status == pkg._lib.E_UNSUPPORTED and "active in iteration 70000" in str(ex.value)
     # Point2Plane pairings meeting Solver_Horn in some iteration: the same rule as for single entries, found per stage
     txt = (STAGED % dict(last_p2p=2, first_second=3, **P2PL)).replace("runUpToIteration: 2\n  - class: mp2p_icp::Solver_GaussNewton",
                                                                        "runUpToIteration: 9\n  - class: mp2p_icp::Solver_GaussNewton")
@@ -84,6 +95,103 @@ def test_overlapping_matchers_and_impossible_stage_pairs_are_refused(pkg):
     with pytest.raises(pkg.IcpError) as ex:
         pkg.run_loop_batch([(lambda T, thr: 0, lambda *a: np.zeros(24), 1, 1)], [np.eye(4)], ok)
     assert ex.value.status == pkg._lib.E_UNSUPPORTED and "single-entry" in str(ex.value)
+
+
+def test_an_iteration_no_solver_covers_ends_in_solver_error(pkg, O, golden):
+    """`solvers:` with a gap: iterations 0..2 have Solver_Horn, the next entry starts at 5 -- iteration 3 has pairings and nothing to
+    solve them with: SolverError there ([EXT] mp2p_icp reports it when no solver succeeds; rounds 1-3 silently used the last entry)"""
+    g, l = golden["A_map"], golden["A_local"]
+    txt = (STAGED % dict(last_p2p=60, first_second=61, **P2P2)).replace("runUpToIteration: 60\n  - class: mp2p_icp::Solver_GaussNewton\n    params:",
+                                                                         "runUpToIteration: 2\n  - class: mp2p_icp::Solver_GaussNewton\n    params:\n      runFromIteration: 5")
+    p = pkg.Parameters.load_from(txt)
+    assert p.solver_run_up_to_iteration == 2 and p.c.extra_solvers[0].run_from_iteration == 5
+    st = OracleStages(O, g, l)
+    r = pkg.run_loop(st.match, st.accumulate, np.eye(4), p, l.shape[1], g.shape[1])
+    assert r.terminationReason == pkg.TERM_SOLVER_ERROR and r.nIterations == 3
+    a = O.align(g, l, np.eye(4), O.params(max_iterations=3, matcher_threshold=1.0, min_abs_step_trans=5e-5, min_abs_step_rot=1e-5, fixed_iterations=True))
+    np.testing.assert_allclose(r.optimal_tf, a["T"], atol=1e-10)     # the pose of the last iteration that was solved
+
+
+MIXED = """
+icp_class: mp2p_icp::ICP
+params:
+  maxIterations: 100
+  minAbsStep_trans: 5e-5
+  minAbsStep_rot: 1e-5
+solvers:
+  - class: mp2p_icp::Solver_GaussNewton
+    params:
+      maxIterations: 20
+matchers:
+  - class: mp2p_icp::Matcher_Points_DistanceThreshold
+    params:
+      threshold: 0.35
+  - class: mp2p_icp::Matcher_Point2Plane
+    params:
+      distanceThreshold: 0.70
+      planeEigenThreshold: 0.07
+      knn: 6
+quality:
+  - class: mp2p_icp::QualityEvaluator_PairedRatio
+    params:
+      thresholdDistance: 0.10
+"""
+
+
+def test_mixed_form_is_the_point_to_point_cost(pkg):
+    """host math: the share of point-to-point pairings in the 92-term quadratic form (csrc/icp_loop.cpp: mixed_form), against a
+    numpy restatement term by term -- x^T A x - 2 b^T x + c0 must be sum |R l + t - g|^2 at ANY pose, and a Gauss-Newton solve on it
+    must land on the Horn / Kabsch minimiser"""
+    rng = np.random.default_rng(1)
+    l = rng.uniform(-20, 20, (3, 500))
+    Tgt = pkg.pose_from_xyzypr([0.3, -0.2, 0.1, 0.03, -0.02, 0.01])
+    g = Tgt[:3, :3] @ l + Tgt[:3, 3:4] + rng.normal(0, 0.02, (3, 500))
+    T0 = pkg.pose_from_xyzypr([0.1, 0.0, 0.0, 0.01, 0, 0])
+    acc = np.zeros(24)
+    acc[0] = acc[16] = 500
+    acc[1:4], acc[4:7], acc[7:16] = l.sum(1), g.sum(1), (l @ g.T).reshape(9)
+    acc[17] = float((((T0[:3, :3] @ l + T0[:3, 3:4]) - g) ** 2).sum())
+    ll = l @ l.T
+    acc[18:24] = [ll[0, 0], ll[0, 1], ll[0, 2], ll[1, 1], ll[1, 2], ll[2, 2]]
+    form = pkg.mixed_form(acc, T0, np.zeros(92))
+    A = np.zeros((12, 12))
+    A[np.triu_indices(12)] = form[:78]
+    A = A + np.triu(A, 1).T
+    b, c0, n = form[78:90], form[90], form[91]
+    assert n == 500
+    for T in (T0, Tgt, np.eye(4)):
+        x = np.r_[T[:3, :3].reshape(9), T[:3, 3]]
+        want = float((((T[:3, :3] @ l + T[:3, 3:4]) - g) ** 2).sum())
+        assert x @ A @ x - 2 * b @ x + c0 == pytest.approx(want, rel=1e-9)
+    T, cost, its = pkg.solve_gauss_newton_planes(form, T0, 20)
+    np.testing.assert_allclose(T, pkg.solve_horn(acc), atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_two_matchers_in_one_solve_on_the_gpu(pkg, O, synth):
+    """VERDICT r3 "next" 4: Matcher_Points_DistanceThreshold + Matcher_Point2Plane, both unrestricted, one Solver_GaussNewton -- the
+    reference's `matchers:` schema (params/icp-settings-regular.yaml:28-39) -- loads, aligns, and equals the checker's mixed
+    Gauss-Newton (iterations, termination, pose < 1e-7, pairs, quality)"""
+    scene = synth.Scene(scene_seed=3, half=12.0, wall_y=5.0, wall_h=4.0, n_boxes=8)
+    Tgt = synth.pose_from_xyzypr(0.20, -0.10, 0.03, np.deg2rad(1.0), np.deg2rad(-0.3), np.deg2rad(0.2))
+    g, l, _ = synth.make_pair(30000, 26000, seed=12, T_gt=Tgt, scene=scene)
+    p = pkg.Parameters.load_from(MIXED)
+    assert p.n_extra_matchers == 1 and p.run_up_to_iteration == 0 and p.c.extra_matchers[0].run_up_to_iteration == 0
+    icp = pkg.ICP(device=0)
+    r = icp.align(g, l, np.eye(4), p)
+    op = O.params(max_iterations=100, matcher_threshold=0.35, quality_threshold=0.10, min_abs_step_trans=5e-5, min_abs_step_rot=1e-5)
+    ref = O.align_mixed(g, l, np.eye(4), op, 0.70, 0.07, 6, 20)
+    assert r.nIterations == ref["n_iterations"] and r.terminationReason == ref["termination"], (r.nIterations, ref["n_iterations"])
+    rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+    assert rot < 1e-7 and trans < 1e-7, (rot, trans)
+    assert r.n_pairs == ref["n_pairs"] and r.quality == pytest.approx(ref["quality"], abs=1e-12)
+    assert r.rmse == pytest.approx(ref["rmse"], rel=1e-4)
+    gt_rot, gt_trans = O.pose_error(r.optimal_tf, Tgt)
+    assert gt_rot < 2e-3 and gt_trans < 2e-2
+    # through the cloud cache and the batch entry (stand-alone path for multi-matcher pipelines): the same result
+    rb = icp.align_batch([(g, l)], [np.eye(4)], p)[0]
+    assert rb.nIterations == r.nIterations and np.array_equal(rb.optimal_tf, r.optimal_tf)
+    icp.close()
 
 
 def test_loop_switches_matchers_by_iteration(pkg, O, golden):
