@@ -408,8 +408,20 @@ def _self_launch(args):
     anything in this process has touched the GPU -- a process that has initialised HIP is never re-executed.  Rank 0's
     stdout is this process's stdout (the ONE JSON line); the other ranks' stdout goes to stderr.  Any rank failing -> the
     others are stopped (by their exact PIDs) and the exit code is non-zero."""
-    import socket
     import subprocess
+    # (the rendezvous port is picked by bind-and-close: another process can take it before rank 0 binds it.  A launch whose ranks
+    #  ALL fail within the first seconds -- the signature of a lost rendezvous -- is repeated once on a new port.)
+    for attempt in range(2):
+        t_try = time.perf_counter()
+        rc, n_failed = _launch_ranks(args, subprocess)
+        if rc == 0 or attempt == 1 or n_failed < args.gpus or time.perf_counter() - t_try > 45.0:
+            return rc
+        print("[bench] every rank failed at once: launching again on another port", file=sys.stderr, flush=True)
+    return rc
+
+
+def _launch_ranks(args, subprocess):
+    import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -427,6 +439,7 @@ def _self_launch(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
+    n_failed = 0
     alive = set(range(args.gpus))
     t_start = time.perf_counter()
     limit_s = float(os.environ.get("MOLA_BENCH_LAUNCH_TIMEOUT_S", "1500"))   # a rank that never returns must not hold the node for ever
@@ -435,19 +448,20 @@ def _self_launch(args):
             print(f"[bench] ranks {sorted(alive)} still running after {limit_s:.0f} s: stopping them", file=sys.stderr, flush=True)
             for o in sorted(alive):
                 procs[o].kill()
-            return 124
+            return 124, 0
         for r in sorted(alive):
             code = procs[r].poll()
             if code is None:
                 continue
             alive.discard(r)
+            n_failed += 1 if code != 0 else 0
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
                 print(f"[bench] rank {r} exited with code {code}: stopping the other ranks", file=sys.stderr, flush=True)
                 for o in sorted(alive):
                     procs[o].terminate()
         time.sleep(0.05)
-    return rc
+    return rc, n_failed
 
 
 def kernel_sources_sha1():

@@ -303,8 +303,9 @@ int mola_icp_cloud_drop(mola_icp_handle* h, uint64_t id);        /* MOLA_ICP_E_B
 int mola_icp_cloud_count(mola_icp_handle* h, size_t* count_out, size_t* device_bytes_out);
 /* The device blocks of dropped / replaced clouds are parked per device (up to MOLA_ICP_POOL_MB, default 1024) and handed to
  * the next cloud instead of being freed: hipFree synchronises the whole device, and an odometry stream drops a cloud per scan.
- * mola_icp_device_pool_trim() frees parked blocks until at most keep_bytes per device remain (0: all of them);
- * *parked_bytes_out (may be null) = what is still parked on `device` afterwards.  Process-wide, thread-safe. */
+ * mola_icp_device_pool_trim() frees the blocks parked on `device` (-1: on every device) until at most keep_bytes remain there
+ * (0: all of them); *parked_bytes_out (may be null) = what is still parked on `device` afterwards (0 for -1).  Only that
+ * device is touched: hipFree synchronises the device it frees on.  Process-wide, thread-safe. */
 int mola_icp_device_pool_trim(int device, size_t keep_bytes, size_t* parked_bytes_out);
 /* mola_icp_align() between two cached clouds (`from` = map, `to` = local) */
 int mola_icp_align_cached(mola_icp_handle* h, uint64_t from_id, uint64_t to_id, const double init_T[16],

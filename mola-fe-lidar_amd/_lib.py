@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmola_icp_amd.so")
+# (MOLA_ICP_LIB_PATH: a sanitizer build of the host code -- tools/sanitize.sh; never needed in production)
+LIB_PATH = os.environ.get("MOLA_ICP_LIB_PATH") or os.path.join(_HERE, "lib", "libmola_icp_amd.so")
 
 NACC = 24
 ABI_VERSION = 3   # MOLA_ICP_ABI_VERSION of include/mola_icp_amd.h

@@ -115,6 +115,7 @@ struct mola_icp_pool {
 namespace {
 
 constexpr int kBatchChunk = 12;  // pairs advanced together by mola_icp_align_batch (= problems per batched launch)
+constexpr size_t kBatchPlanesMaxQueries = 256 * 8 * 64;   // = the stand-alone path's range of k_knn_coop (hip_backend.hip: match_planes)
 
 double now_ms()
 {
@@ -243,7 +244,9 @@ bool batch_eligible(const mola_icp_params& p, size_t N, size_t M)
 {
     if (N == 0 || M == 0) return false;
     if (p.n_extra_matchers != 0 || p.n_extra_solvers != 0 || p.n_extra_quality != 0) return false;   // staged pipelines: stand-alone aligns (stream per pair)
-    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) return true;
+    // (the batched plane matcher is the cooperative kernel, one workgroup per 64 queries: it serves the sizes the stand-alone path
+    //  gives to it -- up to ~131k queries; larger pairs go one by one through the persistent kernel, a stream per pair)
+    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) return N <= (size_t)kBatchPlanesMaxQueries;
     if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD) return false;
     if (p.nn_kernel == MOLA_ICP_NN_TILED) return true;
     return p.nn_kernel == MOLA_ICP_NN_AUTO && N >= 8192 && M >= 8192;
@@ -965,8 +968,9 @@ int mola_icp_cloud_drop(mola_icp_handle* h, uint64_t id)
 int mola_icp_device_pool_trim(int device, size_t keep_bytes, size_t* parked_bytes_out)
 {
     return guarded([&]() -> int {
-        device_pool_trim(keep_bytes);
-        if (parked_bytes_out) *parked_bytes_out = device_pool_bytes(device);
+        if (device < -1 || device >= 16) return fail(MOLA_ICP_E_BADARG, "device index out of range (-1 = every device)");
+        device_pool_trim(keep_bytes, device);   // (only that device's parked blocks: hipFree synchronises the device it frees on)
+        if (parked_bytes_out) *parked_bytes_out = device >= 0 ? device_pool_bytes(device) : 0;
         return MOLA_ICP_OK;
     });
 }

@@ -125,13 +125,14 @@ BlockPool& block_pool()
 }
 }  // namespace
 
-void device_pool_trim(size_t keep_bytes)
+void device_pool_trim(size_t keep_bytes, int device)
 {
     BlockPool& bp = block_pool();
     std::lock_guard<std::mutex> lk(bp.m);
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (int d = 0; d < kPoolDevices; ++d) {
+        if (device >= 0 && d != device) continue;
         if (bp.free_[d].empty()) continue;
         (void)hipSetDevice(d);
         while (bp.bytes[d] > keep_bytes && !bp.free_[d].empty()) {   // the largest blocks first
@@ -177,7 +178,7 @@ int DevBuf::reserve(size_t bytes)
     hipError_t e = hipMalloc(&p, want);
     if (e == hipErrorOutOfMemory) {   // parked blocks are free memory as far as the caller is concerned
         (void)hipGetLastError();
-        device_pool_trim(0);
+        device_pool_trim(0, -1);
         e = hipMalloc(&p, want);
     }
     if (e != hipSuccess) {

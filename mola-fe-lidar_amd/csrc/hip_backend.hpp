@@ -41,7 +41,7 @@ struct DevBuf {
     void release();
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
-void device_pool_trim(size_t keep_bytes);   // hipFree parked blocks down to keep_bytes per device (0: all)
+void device_pool_trim(size_t keep_bytes, int device = -1);   // hipFree parked blocks of one device (-1: every device) down to keep_bytes (0: all)
 size_t device_pool_bytes(int device);
 
 // A cloud in Hilbert order with its three box levels (the tiled kernels' view of a map; its sorted coordinates and
