@@ -61,8 +61,14 @@ def main():
     ap.add_argument("--cpu-baseline-iters", type=int, default=5, help="0 disables every CPU leg")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed code path (process group + RCCL communicator) even with one rank")
-    ap.add_argument("--allreduce", choices=["rccl", "hook"], default="rccl",
-                    help="rccl: native RCCL on the device block; hook: torch.distributed from the host hook")
+    ap.add_argument("--allreduce", choices=["local", "rccl", "hook"], default="local",
+                    help="local: the node-local shared-memory mailbox on the host, where the sums are consumed (one node: what "
+                         "this bench is); rccl: native RCCL on the device block (the multi-node path, and the fallback); "
+                         "hook: torch.distributed from the host hook")
+    ap.add_argument("--guess-dt", type=float, default=1.0, help="sharded runs: how far (m) the pose may end from the guess -- sizes each rank's map slab")
+    ap.add_argument("--guess-drot-deg", type=float, default=3.0, help="sharded runs: how far (deg) the pose may rotate from the guess")
+    ap.add_argument("--c5-map", type=int, default=10_000_000, help="map points of the configs[4] leg (0 = skip)")
+    ap.add_argument("--c5-steps", type=int, default=20)
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing aid for 1-GPU boxes: ranks share the visible GPUs (rank %% device_count), the process "
                          "group is gloo and the accumulator all-reduce goes through the host hook -- exercises the "
@@ -71,6 +77,7 @@ def main():
                     help="iterations of the shipped Point2Plane+GaussNewton pipeline measured beside the default path")
     ap.add_argument("--dense-iters", type=int, default=3, help="iterations of the dense MFMA kernel measured beside the default path (0 = skip)")
     ap.add_argument("--e2e", type=int, default=1, help="0 skips the align_e2e legs (configs[0], [1], [2] from host buffers)")
+    ap.add_argument("--paced-passes", type=int, default=3, help="passes of the 24-scan drive timed with the scans delivered at 10 Hz of wall time")
     ap.add_argument("--batch-pairs", type=int, default=64, help="pairs of the configs[3] leg (0 = skip)")
     args = ap.parse_args()
 
@@ -97,7 +104,8 @@ def main():
         args.share_gpu = True
     if args.share_gpu:
         local_rank = local_rank % max(1, torch.cuda.device_count())
-        args.allreduce = "hook"
+        if args.allreduce == "rccl":   # (RCCL cannot put two ranks on one device)
+            args.allreduce = "local"
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -122,46 +130,69 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if args.share_gpu else dev   # where the bench's own small collectives live
     tg = torch.from_numpy(g).to(dev)
+    tl = torch.from_numpy(np.ascontiguousarray(l)).to(dev)
     icp = pkg.ICP(device=local_rank)
-    slab = None
-    if world == 1:
-        tl = torch.from_numpy(np.ascontiguousarray(l)).to(dev)
-        icp.set_map(tg)
-        icp.set_local(tl)
-    else:
-        # Spatially compact shards: this rank's slice of the scan's Hilbert order, cut on the device (a random 1/W
-        # subsample would be W times sparser than the map: every 128-query group would sweep W times more map tiles) --
-        # and only the part of the map that shard can reach: its box grown by the gate + the pose correction of this
-        # pair (0.54 m, 2.1 deg at up to 60 m from the origin), not W copies of the whole map.
-        tl = torch.from_numpy(np.ascontiguousarray(l)).to(dev)
-        n_shard = icp.set_local_shard(tl, rank, world)
-        lo, hi = 0, n_shard                 # (queries_per_gpu below)
-        slab_margin = GATE_M + 5.0      # gate + 0.54 m + 2.1 deg at up to 85 m from the origin (3.1 m) + slack
-        blo, bhi = icp.shard_reach_box(np.eye(4), slab_margin)
-        kept = icp.set_map_slab(tg, blo, bhi)
-        slab = {"map_points_kept": kept, "map_points_total": M, "margin_m": slab_margin}
-        del tl
+    guess_dt, guess_drot = args.guess_dt, np.deg2rad(args.guess_drot_deg)
+
+    def place_clouds(icp_, tg_, tl_, margin_scale=1.0):
+        """one GPU: both clouds whole.  Sharded: this rank's slice of the scan's Hilbert order, cut on the device (a random 1/W
+        subsample would be W times sparser than the map: every 128-query group would sweep W times more map tiles) -- and only the
+        part of the map that shard can reach from any pose within (guess_dt, guess_drot) of the guess: sharded.slab_margin_for_guess,
+        from the gate, the stated uncertainty of the guess and how far from the origin THIS shard lies -- not W copies of the map."""
+        if world == 1:
+            icp_.set_map(tg_)
+            icp_.set_local(tl_)
+            return int(tl_.shape[1]), None
+        n_shard = icp_.set_local_shard(tl_, rank, world)
+        blo0, bhi0 = icp_.shard_reach_box(np.eye(4), 0.0)
+        margin = margin_scale * sharded.slab_margin_for_guess(blo0, bhi0, GATE_M, guess_dt, guess_drot)
+        blo, bhi = icp_.shard_reach_box(np.eye(4), margin)
+        kept = icp_.set_map_slab(tg_, blo, bhi)
+        return n_shard, {"map_points_kept": kept, "map_points_total": int(tg_.shape[1]), "margin_m": margin,
+                         "margin_rule": f"gate {GATE_M} m + {guess_dt} m + 2 sin({args.guess_drot_deg} deg / 2) x the shard's farthest corner from the origin"}
+
+    n_shard, slab = place_clouds(icp, tg, tl)
+    lo, hi = 0, n_shard                 # (queries_per_gpu below)
     icp.set_global_sizes(N, M)
     allreduce_used = None
-    rccl_nranks = None
+    comm_nranks = None
+    local_comm = None
+
+    def agree(ok):   # every rank must take the same path
+        if not use_dist:
+            return ok
+        flag = torch.tensor([0 if ok else 1], device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag.item()) == 0
+
     if use_dist:
         allreduce_used = args.allreduce
-        if args.allreduce == "rccl":
+        if allreduce_used == "local":
+            try:
+                local_comm = icp.comm_init_local()
+                comm_nranks = icp.comm_nranks()   # the ranks that joined the mailbox
+                ok = comm_nranks == world
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] node-local communicator failed on rank {rank} ({e}); trying RCCL", file=sys.stderr, flush=True)
+                ok = False
+            if not agree(ok):
+                icp.comm_destroy()
+                local_comm, comm_nranks = None, None
+                allreduce_used = "hook" if args.share_gpu else "rccl"
+        if allreduce_used == "rccl":
             try:
                 icp.comm_init()
-                rccl_nranks = icp.comm_nranks()   # what RCCL itself reports (ncclCommCount)
+                comm_nranks = icp.comm_nranks()   # what RCCL itself reports (ncclCommCount)
+                ok = True
             except Exception as e:  # keep the run alive: torch.distributed carries the 24 doubles instead
                 print(f"[bench] native RCCL communicator failed on rank {rank} ({e}); using the torch.distributed hook",
                       file=sys.stderr, flush=True)
-                allreduce_used = "hook"
-        # every rank must take the same path
-        flag = torch.tensor([1 if allreduce_used == "hook" else 0], device=cdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) == 1:
-            if allreduce_used == "rccl":
-                icp.comm_destroy()
-            allreduce_used = "hook"
-            rccl_nranks = None
+                ok = False
+            if not agree(ok):
+                if ok:
+                    icp.comm_destroy()
+                allreduce_used, comm_nranks = "hook", None
+        if allreduce_used == "hook":
             icp.set_allreduce(sharded.make_allreduce(device=dev))
 
     p = pkg.Parameters()
@@ -188,9 +219,8 @@ def main():
             except pkg.IcpError as e:
                 if "map slab" not in str(e) or attempt == 3:
                     raise
-                slab_margin *= 2.0
-                blo, bhi = icp.shard_reach_box(np.eye(4), slab_margin)
-                slab = {"map_points_kept": icp.set_map_slab(tg, blo, bhi), "map_points_total": M, "margin_m": slab_margin, "recut": attempt + 1}
+                _, slab = place_clouds(icp, tg, tl, margin_scale=2.0 ** (attempt + 1))   # (the guess was worse than stated)
+                slab["recut"] = attempt + 1
     # Device warm-up (untimed, the same count on every rank): the GPU has idled through seconds of host-side cloud
     # generation and its clocks take a few hundred milliseconds of work to settle -- behind 3 warm-up steps alone the
     # matcher launch read 106.5 us, behind 300 of them 100.1 us.  Then the W warm-up steps the caller asked for.
@@ -282,11 +312,14 @@ def main():
                                f"iterations, point-to-point NN (gate {GATE_M} m) + Horn, seed {args.seed}",
                    "n_local": N, "n_map": M, "gate_m": GATE_M, "queries_per_gpu": hi - lo,
                    "parallelism": (f"query-shard x{world}, {allreduce_used} all-reduce" if use_dist else "single GPU"),
-                   "ranks_share_gpus": bool(args.share_gpu and world > 1), "rccl_nranks": rccl_nranks,
+                   "ranks_share_gpus": bool(args.share_gpu and world > 1), "comm_nranks": comm_nranks,
                    "nn_kernel": roof["kernel"], "map_slab_rank0": slab},
         "roofline": roof,
         "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(res.optimal_tf, T_gt))),
     }
+    if args.c5_map > 0:
+        out["c5_sharded"] = c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev, cdev, use_dist, allreduce_used,
+                                   local_comm, place_clouds, barrier)
     extras = rank == 0 and world == 1
 
     if extras and args.nn_kernel in ("auto", "tiled") and args.dense_iters > 0:
@@ -309,32 +342,50 @@ def main():
         # the reference's shipped pipeline (Point2Plane knn 6 + Gauss-Newton, icp-settings-regular.yaml) on the same clouds
         ps = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-regular.yaml"))
         ps.fixed_iterations, ps.skip_quality, ps.max_iterations = 1, 1, args.shipped_iters
-        icp.align_resident(T0, ps)  # warm-up
+        icp.align_resident(T0, ps)  # warm-up (allocations, clocks)
+        # ... whose neighbour lists, seeds and plane cache would make the timed repeat a different, cheaper run than a registration
+        # of a NEW pair: dropped (the sorted clouds stay resident, as the metric says); the warm repeat is reported beside it
+        icp.forget_warm_start()
         t0 = time.perf_counter()
         rs = icp.align_resident(T0, ps)
         torch.cuda.synchronize()
         ts = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        icp.align_resident(T0, ps)
+        torch.cuda.synchronize()
+        ts_warm = time.perf_counter() - t0
+        icp.forget_warm_start()
         icp.set_profiling(True)
         rs = icp.align_resident(T0, ps)
         icp.set_profiling(False)
-        k_ms = rs.ms_nn_kernel / max(1, rs.n_nn_launches)
-        # the plane matcher against the HBM roofline: DESIGN section 4's bytes per launch -- both sorted clouds once, and per
-        # query the plane pairing written (56 B) + its cached twin (56 B), the K + 1 seed positions read and written back
+        # the plane matcher against the HBM roofline, PER ITERATION: an iteration's matcher work is one to three launches
+        # (the search, then verification / counting launches of microseconds) -- an average over launches, as round 3
+        # printed, weights those as if they were searches.  Bytes: DESIGN section 4 -- both sorted clouds once, and per query
+        # the plane pairing written (56 B) + its cached twin (56 B), the K + 1 list positions read and written back
         # (4 (K + 1) B) and the certified bound (4 B): 12 N + 12 M + (112 + 4 (K + 1) + 4) N
+        it_ms = rs.ms_nn_kernel / max(1, int(rs.nIterations))
         bytes_alg = 12.0 * N + 12.0 * M + (112.0 + 4.0 * (int(ps.knn) + 1) + 4.0) * N
-        pairs_exec = rs.nn_pairs_evaluated / max(1, rs.n_nn_launches)
-        roof_s = {"bound": "hbm", "achieved": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                  "kernel": "k_knn_planes", "kernel_ms": k_ms, "bytes_per_launch": bytes_alg,
-                  "note": f"average over the {rs.n_nn_launches} matcher launches of the {args.shipped_iters}-iteration run (unseeded, seeded-insertion, "
-                          "certified / counting launches: profiles/r03 breaks them out)",
-                  "pairs_evaluated_per_query": pairs_exec / max(1, N),
-                  "executed_tflops": 8.0 * pairs_exec / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0}
+        pairs_it = rs.nn_pairs_evaluated / max(1, int(rs.nIterations))
+        roof_s = {"bound": "hbm", "achieved": bytes_alg / (it_ms * 1e-3) / 1e9 if it_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                  "kernel": "k_knn_planes", "matcher_ms_per_iteration": it_ms, "bytes_per_iteration": bytes_alg,
+                  "launches": int(rs.n_nn_launches), "iterations": int(rs.nIterations),
+                  "note": f"matcher time of the {int(rs.nIterations)}-iteration run (HIP events around its {rs.n_nn_launches} launches: key bootstrap, "
+                          "list-seeded searches, certified / counting launches) divided by the ITERATIONS, first align on the pair "
+                          "(no lists from an earlier align); the kernel is compute-bound in its distance sweep, not HBM-bound: "
+                          "`executed_tflops` is the rate that explains its time",
+                  "pairs_evaluated_per_query_per_iteration": pairs_it / max(1, N),
+                  "executed_tflops": 8.0 * pairs_it / (it_ms * 1e-3) / 1e12 if it_ms > 0 else 0.0}
         roof_s["frac"] = roof_s["achieved"] / PEAK_HBM_GBS
-        roof_s.update(_recorded_counters("k_knn_planes", N, M))
+        rec = _recorded_counters("k_knn_planes", N, M)
+        if isinstance(rec.get("pmc"), dict):   # (a per-LAUNCH fraction of the recorded pass: not comparable with `frac` above)
+            rec["pmc"] = {k: v for k, v in rec["pmc"].items() if k != "frac_of_hbm_peak"}
+        roof_s.update(rec)
         out["shipped_point2plane_gn"] = {"value": args.shipped_iters / ts, "unit": "iterations/s",
+                                         "state": "resident sorted clouds, no lists / seeds / plane cache from earlier aligns (mola_icp_forget_warm_start)",
+                                         "value_repeat_on_warm_lists": args.shipped_iters / ts_warm,
                                          "iterations": args.shipped_iters, "knn": int(ps.knn),
                                          "gate_m": float(ps.matcher_threshold),
-                                         "kernel_ms": k_ms, "pairs": int(rs.n_pairs), "roofline": roof_s,
+                                         "matcher_ms_per_iteration": it_ms, "pairs": int(rs.n_pairs), "roofline": roof_s,
                                          "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(rs.optimal_tf, T_gt)))}
 
     if extras and args.shipped_iters > 0:
@@ -342,12 +393,19 @@ def main():
         # how long a registration takes -- the shipped pipeline with its stall test, resident clouds, from the identity to termination
         pt = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-regular.yaml"))
         pt.skip_quality = 1
-        icp.align_resident(T0, pt)
+        icp.align_resident(T0, pt)   # warm-up; its lists / seeds / plane cache are dropped: a registration meets a pair once
+        icp.forget_warm_start()
         t0 = time.perf_counter()
         rt = icp.align_resident(T0, pt)
         torch.cuda.synchronize()
+        t_first = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        icp.align_resident(T0, pt)
+        torch.cuda.synchronize()
+        t_rep = (time.perf_counter() - t0) * 1e3
         out["time_to_pose"] = {"pipeline": "icp-settings-regular.yaml (Point2Plane knn 6 + Gauss-Newton, stall test 5e-5 m / 1e-5 rad), resident 1M x 1M clouds, from the identity",
-                               "ms": (time.perf_counter() - t0) * 1e3, "iterations": int(rt.nIterations), "termination": rt.termination_name,
+                               "ms": t_first, "state": "sorted clouds resident, nothing kept from earlier aligns (mola_icp_forget_warm_start)",
+                               "ms_repeat_on_warm_lists": t_rep, "iterations": int(rt.nIterations), "termination": rt.termination_name,
                                "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(rt.optimal_tf, T_gt)))}
         # ... and what the headline hides: the same 40-step align from a GPU that has idled (clocks down), one shot
         time.sleep(1.5)
@@ -390,9 +448,14 @@ def main():
         out["loop_closure_montecarlo"] = montecarlo_leg(pkg, synth, icp)
     if extras and args.e2e:
         out["odometry_stream"] = odometry_stream_leg(pkg, synth)
+        # what a robot sees: the same drive with the scans arriving at the sensor's 10 Hz, not back to back (the GPU idles
+        # ~99 ms between scans and its clocks fall), and on the cloud sizes the reference's filters actually hand to align()
+        out["odometry_stream_10hz"] = odometry_stream_leg(pkg, synth, period_s=0.1, passes=args.paced_passes)
+        out["odometry_stream_small"] = odometry_stream_leg(pkg, synth, n_rings=16, n_az=1250)
+        out["odometry_stream_small_10hz"] = odometry_stream_leg(pkg, synth, period_s=0.1, n_rings=16, n_az=1250, passes=args.paced_passes)
 
     if use_dist:
-        if allreduce_used == "rccl":
+        if allreduce_used in ("rccl", "local"):
             icp.comm_destroy()
         dist.destroy_process_group()
     if rank == 0:
@@ -400,6 +463,65 @@ def main():
         ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in C stdio: the JSON must be the LAST line
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev, cdev, use_dist, allreduce_used, local_comm, place_clouds, barrier):
+    """BASELINE.json configs[4]: a 10M-point global map vs the 1M-point scan, query-sharded with a map slab per rank and the
+    per-iteration all-reduce of the accumulators -- the config the sharded path is FOR (at 1M x 1M a rank's shard is a ~15 us kernel
+    behind a fixed ~100 us of launches and host turns; ten times the map puts the time back into the matcher).  Same scan, same
+    ground truth, same collective as the headline; its own handle.  At N = 1: the whole job on one GPU -- the base of the curve."""
+    N, M5 = args.n_local, args.c5_map
+    g5, l5, T_gt = synth.make_pair(N, M5, seed=args.seed)
+    tg5 = torch.from_numpy(g5).to(dev)
+    tl5 = torch.from_numpy(np.ascontiguousarray(l5)).to(dev)
+    del g5
+    icp5 = pkg.ICP(device=local_rank)
+    n_shard, slab = place_clouds(icp5, tg5, tl5)
+    icp5.set_global_sizes(N, M5)
+    if use_dist:
+        if allreduce_used == "local":
+            icp5.comm_init_local(comm=local_comm)
+        elif allreduce_used == "rccl":
+            icp5.comm_init()
+        else:
+            icp5.set_allreduce(sharded.make_allreduce(device=dev))
+    p = pkg.Parameters()
+    p.matcher_threshold, p.fixed_iterations, p.skip_quality, p.max_iterations = GATE_M, 1, 1, args.c5_steps
+    T0 = np.eye(4)
+    for attempt in range(4):   # rehearsal = warm-up (allocations, the slab check over the whole trajectory: see the headline)
+        try:
+            icp5.align_resident(T0, p)
+            break
+        except pkg.IcpError as e:
+            if world == 1 or "map slab" not in str(e) or attempt == 3:
+                raise
+            _, slab = place_clouds(icp5, tg5, tl5, margin_scale=2.0 ** (attempt + 1))
+            slab["recut"] = attempt + 1
+    icp5.align_resident(T0, p)
+    barrier()
+    t0 = time.perf_counter()
+    r = icp5.align_resident(T0, p)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    icp5.set_profiling(True)
+    rp = icp5.align_resident(T0, p)
+    icp5.set_profiling(False)
+    k_ms = rp.ms_nn_kernel / max(1, rp.n_nn_launches)
+    leg = {"workload": f"configs[4]: {N} scan points vs a {M5}-point global map, {args.c5_steps} fixed iterations, point-to-point (gate {GATE_M} m) + Horn, "
+                       "query-sharded, one map slab per rank, one all-reduce of 24 doubles per iteration",
+           "value": args.c5_steps / dt, "unit": "iterations/s", "ms_per_step": dt / args.c5_steps * 1e3, "n_gpus": world, "scaling": "strong",
+           "n_local": N, "n_map": M5, "queries_per_gpu": n_shard, "map_slab_rank0": slab,
+           "matcher_ms_per_launch_rank0": k_ms, "pairs_evaluated_per_query_rank0": rp.nn_pairs_evaluated / max(1, rp.n_nn_launches) / max(1, n_shard),
+           "all_reduce": allreduce_used if use_dist else None,
+           "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(r.optimal_tf, T_gt)))}
+    if use_dist and allreduce_used in ("local", "rccl"):
+        icp5.comm_destroy()   # (detaches the shared mailbox; destroys this handle's own RCCL communicator)
+    icp5.close()
+    return leg
 
 
 def _self_launch(args):
@@ -665,7 +787,7 @@ def align_e2e(pkg, synth, icp, g1m, l1m, seed, with_cpu, cpu_flags):
     return out
 
 
-def odometry_stream_leg(pkg, synth, n_scans=24):
+def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, n_rings=64, n_az=1875, passes=1):
     """rows f1 + f4 (src/LidarOdometry.cpp:190-514): a drive down the scene at 10 m/s, one 64-ring scan (~115k points) every 0.1 s,
     through the front-end mirror (`LidarOdometry.on_new_observation` = `mola_lo_process_scan`) with params/kitti-default.yaml:
     per scan, the new cloud is uploaded, sorted and boxed ONCE (it is `to` now and `from` for the next scan: the cloud cache),
@@ -674,14 +796,19 @@ def odometry_stream_leg(pkg, synth, n_scans=24):
     scans = []
     for k in range(n_scans):
         pose = synth.pose_from_xyzypr(-14.0 + 1.0 * k, 0.3 * np.sin(0.3 * k), 0.0, 0.005 * k, 0, 0)
-        scans.append((100.0 + 0.1 * k, synth.lidar_scan(pose, seed=50 + k)))
+        scans.append((100.0 + 0.1 * k, synth.lidar_scan(pose, n_rings=n_rings, n_az=n_az, seed=50 + k)))
     icp = pkg.ICP(device=0)
     lo = pkg.LidarOdometry(lp, icp=icp)
-    ms, its, ran, kfs = [], [], 0, []
-    for rep in range(2):   # (the first pass warms allocations and clocks; the second is reported)
+    ms, its, ran, kfs, steady = [], [], 0, [], []
+    for rep in range(1 + passes):   # (the first pass warms allocations and clocks; the others are reported)
         lo.reset()
         ms, its, ran, kfs = [], [], 0, []
+        paced = period_s is not None and rep >= 1   # (the warming pass runs back to back)
+        t_next = time.perf_counter()
         for k, (t, pc) in enumerate(scans):
+            if paced:   # the scan arrives when the sensor delivers it: the GPU and the host thread have idled since the last one
+                t_next += period_s
+                time.sleep(max(0.0, t_next - time.perf_counter()))
             t0 = time.perf_counter()
             st = lo.on_new_observation(t + 1000.0 * rep, pc)
             ms.append((time.perf_counter() - t0) * 1e3)
@@ -690,11 +817,16 @@ def odometry_stream_leg(pkg, synth, n_scans=24):
                 its.append(int(st.icp.nIterations))
             if st.keyframe_created:
                 kfs.append(k)
+        if rep >= 1:
+            steady += ms[2:]   # (scan 0 has no partner, scan 1 no velocity yet)
     lo.close()
-    steady = ms[2:]   # (scan 0 has no partner, scan 1 no velocity yet)
     med = float(np.median(steady))
-    return {"workload": f"{n_scans} scans of ~{int(np.mean([pc.shape[1] for _, pc in scans]))} points, 0.1 s and 1 m apart, params/kitti-default.yaml, host buffers in, pose out",
-            "ms_per_scan_median": med, "ms_per_scan_min": float(np.min(steady)), "ms_per_scan_max": float(np.max(steady)),
+    arrival = (f"delivered every {period_s * 1e3:.0f} ms of wall time (the sensor's rate: GPU clocks and host caches as a robot meets them)"
+               if period_s is not None else "delivered back to back (GPU clocks stay up)")
+    return {"workload": f"{passes} x {n_scans} scans of ~{int(np.mean([pc.shape[1] for _, pc in scans]))} points ({n_rings} rings x {n_az} azimuths), 0.1 s and 1 m apart, "
+                        f"{arrival}, params/kitti-default.yaml, host buffers in, pose out",
+            "ms_per_scan_median": med, "ms_per_scan_p99": float(np.percentile(steady, 99)),
+            "ms_per_scan_min": float(np.min(steady)), "ms_per_scan_max": float(np.max(steady)),
             "scans_per_s": 1e3 / med, "realtime_factor_at_10_hz": 100.0 / med, "icp_ran": ran, "iterations_per_scan_median": float(np.median(its)) if its else 0.0,
             "ms_per_scan": [round(float(v), 3) for v in ms], "keyframes": kfs}
 

@@ -233,6 +233,27 @@ int mola_icp_comm_init(mola_icp_handle* h, const uint8_t id[128], int nranks, in
 int mola_icp_comm_nranks(mola_icp_handle* h, int* nranks_out);
 int mola_icp_comm_destroy(mola_icp_handle* h);
 
+/* The node-local communicator: the all-reduce of ONE node's ranks through a POSIX shared-memory mailbox (csrc/local_comm.cpp).
+ * The reduced block is consumed by each rank's host thread (the fp64 solve), and a single-GPU iteration already ends with the
+ * device writing the block to pinned host memory: the ranks exchange the 24 (92) doubles there, between cores -- no launch, no
+ * device-side wait, ~1 us instead of the ~25 us of a 192-byte RCCL all-reduce; every rank adds the rows in rank order, so all
+ * ranks hold the same bits.  What `bench.py --gpus N` uses on one node; RCCL above stays for ranks on different nodes.
+ *  - create: COLLECTIVE over the ranks of the node; `name` = a POSIX shm name unique to this job (rank 0 picks it and ships it
+ *    like the RCCL id); returns once all `nranks` ranks have joined (then the name is unlinked: nothing is left in /dev/shm),
+ *    MOLA_ICP_E_COMM after `timeout_s` (<= 0: 30 s) -- the same time-out bounds every wait of an all-reduce;
+ *  - allreduce: sums buf[0, n) (n <= 120, host memory) over the ranks in place; the ranks must make the same calls in the same
+ *    order (a rank found ahead, or with another n, is MOLA_ICP_E_COMM on every rank, not a hang);
+ *  - abort: this rank cannot go on (an error outside the collective): the others' next all-reduce fails at once;
+ *  - attach_local: the handle's resident-cloud aligns reduce through `c` (NULL detaches); `c` stays the caller's to destroy,
+ *    after mola_icp_comm_destroy(h) or mola_icp_destroy(h).  mola_icp_comm_nranks() then reports the ranks that joined `c`. */
+typedef struct mola_icp_local_comm mola_icp_local_comm;
+int mola_icp_local_comm_create(const char* name, int nranks, int rank, double timeout_s, mola_icp_local_comm** out);
+int mola_icp_local_comm_allreduce(mola_icp_local_comm* c, double* buf, int n);
+int mola_icp_local_comm_nranks(mola_icp_local_comm* c, int* nranks_out);
+int mola_icp_local_comm_abort(mola_icp_local_comm* c);
+int mola_icp_local_comm_destroy(mola_icp_local_comm* c);
+int mola_icp_comm_attach_local(mola_icp_handle* h, mola_icp_local_comm* c);
+
 /* ---- the hot path ------------------------------------------------------ */
 /* Replaces mp2p_icp::ICP::align() as called at src/LidarOdometry.cpp:869-871.
  * Host pointers; copies both clouds to HBM, runs every iteration on the GPU,
@@ -332,6 +353,12 @@ int mola_icp_voxel_downsample(mola_icp_handle* h, const float* x, const float* y
  * odometry sizes and the counter read-back a stream synchronisation per align; n_nn_launches is always filled.
  * (The reference's counterpart is its mrpt::system::CTimeLogger profiler, src/LidarOdometry.cpp:296-297, 858.) */
 int mola_icp_set_profiling(mola_icp_handle* h, int on);
+/* Drop what earlier matches / aligns left behind for the resident clouds in place -- neighbour lists, pairing seeds, the
+ * plane cache, the per-item cost orders -- and keep the prepared (sorted) clouds: the next align costs what the FIRST
+ * align on this pair cost.  For measurements (bench.py times a registration on state a repeat of the same align would
+ * otherwise have warmed) and for callers that re-register the same pair from an unrelated guess.  (No reference
+ * counterpart: mp2p_icp::ICP::align() keeps nothing between calls, src/LidarOdometry.cpp:869-871.) */
+int mola_icp_forget_warm_start(mola_icp_handle* h);
 int mola_icp_set_map_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M);
 int mola_icp_set_map_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t M);
 int mola_icp_set_local_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t N);

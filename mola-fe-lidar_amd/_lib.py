@@ -173,6 +173,7 @@ _H = C.c_void_p
 SIGNATURES = {
     "mola_icp_abi_version": (C.c_int, []),
     "mola_icp_set_profiling": (C.c_int, [_H, C.c_int]),
+    "mola_icp_forget_warm_start": (C.c_int, [_H]),
     "mola_icp_set_local_shard_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "mola_icp_set_local_shard_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "mola_icp_local_shard_indices": (C.c_int, [_H, C.POINTER(C.c_int32)]),
@@ -196,6 +197,12 @@ SIGNATURES = {
     "mola_icp_comm_init": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "mola_icp_comm_nranks": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "mola_icp_comm_destroy": (C.c_int, [_H]),
+    "mola_icp_local_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)]),
+    "mola_icp_local_comm_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
+    "mola_icp_local_comm_nranks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "mola_icp_local_comm_abort": (C.c_int, [C.c_void_p]),
+    "mola_icp_local_comm_destroy": (C.c_int, [C.c_void_p]),
+    "mola_icp_comm_attach_local": (C.c_int, [_H, C.c_void_p]),
     "mola_icp_align": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, _FP, _FP, _FP, C.c_size_t, _DP,
                                  C.POINTER(CParams), C.POINTER(CResult)]),
     "mola_icp_align_batch": (C.c_int, [_H, C.c_size_t, C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),

@@ -54,6 +54,7 @@ struct mola_icp_handle {
         if (spare_clouds.size() < 64) spare_clouds.push_back(std::move(c));
     }
     mola_icp_allreduce_fn ar_fn = nullptr;
+    mola_icp_local_comm* local_comm = nullptr;        // mola_icp_comm_attach_local (not owned)
     void* ar_user = nullptr;
     void* comm = nullptr;  // RCCL communicator of the query-sharded path
     std::mutex cache_mtx;  // guards the cloud cache (row f4)
@@ -463,6 +464,14 @@ int mola_icp_set_profiling(mola_icp_handle* h, int on)
     return MOLA_ICP_OK;
 }
 
+int mola_icp_forget_warm_start(mola_icp_handle* h)
+{
+    if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+    std::lock_guard<std::mutex> lk(h->mtx);
+    if (h->resident) h->resident->forget_warm_start();
+    return MOLA_ICP_OK;
+}
+
 int mola_icp_set_allreduce(mola_icp_handle* h, mola_icp_allreduce_fn fn, void* user)
 {
     if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
@@ -504,11 +513,26 @@ int mola_icp_comm_init(mola_icp_handle* h, const uint8_t id[128], int nranks, in
     });
 }
 
+int mola_icp_comm_attach_local(mola_icp_handle* h, mola_icp_local_comm* c)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        if (h->comm) return fail(MOLA_ICP_E_BADARG, "the handle has an RCCL communicator: destroy it first");
+        h->resident->sync();
+        h->local_comm = c;
+        if (c) h->resident->set_allreduce(&local_comm_hook, c);
+        else h->resident->set_allreduce(nullptr, nullptr);
+        return MOLA_ICP_OK;
+    });
+}
+
 int mola_icp_comm_nranks(mola_icp_handle* h, int* nranks_out)
 {
     return guarded([&]() -> int {
         if (!h || !nranks_out) return fail(MOLA_ICP_E_BADARG, "null argument");
         std::lock_guard<std::mutex> lk(h->mtx);
+        if (!h->comm && h->local_comm) return mola_icp_local_comm_nranks(h->local_comm, nranks_out);
         if (!h->comm) return fail(MOLA_ICP_E_BADARG, "no communicator: call mola_icp_comm_init first");
         return rccl_comm_count(h->comm, nranks_out);
     });
@@ -521,6 +545,10 @@ int mola_icp_comm_destroy(mola_icp_handle* h)
         std::lock_guard<std::mutex> lk(h->mtx);
         h->resident->sync();
         h->resident->set_comm(nullptr);
+        if (h->local_comm) {  // (not owned: the caller destroys it with mola_icp_local_comm_destroy)
+            h->local_comm = nullptr;
+            h->resident->set_allreduce(nullptr, nullptr);
+        }
         const int rc = h->comm ? rccl_comm_destroy(h->comm) : MOLA_ICP_OK;
         h->comm = nullptr;
         return rc;

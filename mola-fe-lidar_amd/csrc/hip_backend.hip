@@ -836,6 +836,18 @@ void HipWorkspace::use_cached_local(const std::shared_ptr<SortedCloud>& sc)
     knn_seed_valid_ = false;
 }
 
+void HipWorkspace::forget_warm_start()
+{
+    planes_valid_ = false;
+    cost_valid_ = false;
+    order_valid_ = false;
+    knn_cost_valid_ = false;
+    knn_order_valid_ = false;
+    knn_seed_valid_ = false;
+    pairing_valid_ = false;
+    seed_valid_ = false;
+}
+
 int HipWorkspace::order_begin()
 {
     HIPCHK(hipEventRecord(ev_order_a_, stream_));

@@ -26,6 +26,8 @@ int rccl_comm_init(void** comm, int nranks, const RcclUniqueId& id, int rank);
 int rccl_allreduce_sum_f64(void* comm, double* dev_buf, size_t n, hipStream_t stream);
 int rccl_comm_count(void* comm, int* nranks);   // what RCCL itself reports for the communicator
 int rccl_comm_destroy(void* comm);
+// the node-local shared-memory all-reduce (local_comm.cpp) in the shape of the all-reduce hook; user = the LocalComm
+int local_comm_hook(double* buf, int n, int device_ptr, void* user);
 
 void reload_env_knobs();  // re-reads the MOLA_ICP_* diagnostic variables (tests); they are otherwise read once per process
 
@@ -150,6 +152,9 @@ class HipWorkspace final : public Stages {
     // per-launch HIP events + executed-pair counters (ms_nn_kernel, nn_pairs_evaluated of the results).  Off by default:
     // the two event packets cost ~8 us per iteration at odometry sizes, the counter read-back a stream synchronisation.
     void set_profiling(bool on) { profiling_ = on; }
+    // drop what earlier matches left for the clouds in place (neighbour lists, pairing seeds, plane cache, per-item cost
+    // orders); the prepared (sorted) clouds stay.  The next align pays what the first align on these clouds paid.
+    void forget_warm_start();
     void reset_stats();
     int collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used, uint64_t* pairs = nullptr);
 

@@ -37,6 +37,17 @@ def spatial_order(points: np.ndarray, bits: int = 10) -> np.ndarray:
     return np.argsort(key, kind="stable")
 
 
+def slab_margin_for_guess(box_lo, box_hi, gate: float, max_dt: float, max_drot: float) -> float:
+    """How far beyond its own box (at the guess) a query shard can reach into the map while the pose stays within
+    (max_dt metres, max_drot radians) of the guess: a point p moves by at most max_dt + 2 sin(max_drot / 2) |p| under such a
+    correction (rotation about the frame origin), and pairs within `gate` of where it lands.  `box_lo/hi` = the shard's box at the
+    guess with zero margin (`ICP.shard_reach_box(guess, 0)`); the farthest corner bounds |p|.  The margin a rank passes to
+    `shard_reach_box(guess, margin)` before cutting its map slab -- per rank: a shard near the origin needs less than one 80 m out."""
+    lo, hi = np.asarray(box_lo, np.float64), np.asarray(box_hi, np.float64)
+    far = float(np.linalg.norm(np.maximum(np.abs(lo), np.abs(hi))))
+    return float(gate + max_dt + 2.0 * np.sin(0.5 * max_drot) * far)
+
+
 def make_allreduce(group=None, device=None):
     """Returns fn(acc: np.ndarray[float64]) that sums `acc` in place over the process group.
     gloo: reduces the host buffer directly.  nccl (= RCCL): stages through a device tensor."""
@@ -61,6 +72,60 @@ def make_allreduce(group=None, device=None):
         dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=group)
         acc[:] = stage.cpu().numpy()
     return fn
+
+
+class LocalComm:
+    """The node-local communicator (`mola_icp_local_comm_*`, csrc/local_comm.cpp): the all-reduce of one node's ranks through
+    a shared-memory mailbox on the host -- where the reduced block is consumed.  `create` is collective; `name` must be unique
+    to the job (`LocalComm.from_group` lets rank 0 pick one and ships it over torch.distributed)."""
+
+    def __init__(self, name: str, nranks: int, rank: int, timeout_s: float = 30.0):
+        import ctypes as C
+        from . import _lib as L
+        self._L = L
+        self._c = C.c_void_p()
+        L.check(L.lib().mola_icp_local_comm_create(name.encode(), int(nranks), int(rank), float(timeout_s), C.byref(self._c)))
+        self.rank, self.world = rank, nranks
+
+    @classmethod
+    def from_group(cls, group=None, timeout_s: float = 30.0):
+        import os
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        names = [f"mola_icp_{os.getpid()}_{int.from_bytes(os.urandom(6), 'little'):x}" if rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(names, src=src, group=group)
+        return cls(names[0], world, rank, timeout_s)
+
+    @property
+    def handle(self):
+        return self._c
+
+    def allreduce(self, acc: np.ndarray) -> None:
+        """sum a contiguous float64 array (<= 120 values) in place over the ranks; every rank gets the same bits"""
+        import ctypes as C
+        assert acc.dtype == np.float64 and acc.flags["C_CONTIGUOUS"]
+        self._L.check(self._L.lib().mola_icp_local_comm_allreduce(self._c, acc.ctypes.data_as(C.POINTER(C.c_double)), int(acc.size)))
+
+    def nranks(self) -> int:
+        import ctypes as C
+        n = C.c_int(0)
+        self._L.check(self._L.lib().mola_icp_local_comm_nranks(self._c, C.byref(n)))
+        return int(n.value)
+
+    def abort(self) -> None:
+        self._L.check(self._L.lib().mola_icp_local_comm_abort(self._c))
+
+    def close(self) -> None:
+        if self._c:
+            self._L.lib().mola_icp_local_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class ShardedICP:

@@ -11,7 +11,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "4", "--warmup", "1", "--device-warmup-aligns", "1", "--n-local", "60000", "--n-map", "70000",
-         "--cpu-baseline-iters", "0", "--shipped-iters", "0", "--dense-iters", "0", "--e2e", "0", "--batch-pairs", "0"]
+         "--cpu-baseline-iters", "0", "--shipped-iters", "0", "--dense-iters", "0", "--e2e", "0", "--batch-pairs", "0",
+         "--c5-map", "150000", "--c5-steps", "3"]
 
 
 def _run(extra, timeout=600):
@@ -41,28 +42,35 @@ def test_self_launch_reports_a_failing_rank(pkg):
 
 @pytest.mark.gpu
 def test_two_self_launched_ranks_share_the_gpu():
-    r = _run(["--gpus", "2"])    # fewer devices than ranks: the ranks share the GPU (gloo + the host hook), said in the line
+    r = _run(["--gpus", "2"])    # fewer devices than ranks: the ranks share the GPU, said in the line; the node-local all-reduce
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0
-    assert j["config"]["ranks_share_gpus"] is True and "query-shard x2" in j["config"]["parallelism"]
+    assert j["config"]["ranks_share_gpus"] is True and "query-shard x2, local all-reduce" in j["config"]["parallelism"]
+    assert j["config"]["comm_nranks"] == 2        # both ranks joined the mailbox
     assert j["config"]["queries_per_gpu"] in (30000,)
+    assert j["config"]["map_slab_rank0"]["margin_m"] > 2.0 and "recut" not in j["config"]["map_slab_rank0"]
+    c5 = j["c5_sharded"]                          # configs[4]'s shape beside the headline, slab per rank
+    assert c5["n_map"] == 150000 and c5["value"] > 0 and c5["map_slab_rank0"]["map_points_kept"] < 150000
     r1 = _run(["--gpus", "1"])
     j1 = _json_line(r1.stdout)
-    # same job: the two-rank pose is the one-rank pose (fp64 sums in another order)
-    assert abs(j["pose_err_vs_gt"]["rot_rad"] - j1["pose_err_vs_gt"]["rot_rad"]) < 1e-9
-    assert abs(j["pose_err_vs_gt"]["trans_m"] - j1["pose_err_vs_gt"]["trans_m"]) < 1e-9
+    # same job: the two-rank pose is the one-rank pose (fp64 sums in another order) -- "to 1e-12" on the new collective
+    assert abs(j["pose_err_vs_gt"]["rot_rad"] - j1["pose_err_vs_gt"]["rot_rad"]) < 1e-12
+    assert abs(j["pose_err_vs_gt"]["trans_m"] - j1["pose_err_vs_gt"]["trans_m"]) < 1e-12
+    c51 = j1["c5_sharded"]
+    assert abs(c5["pose_err_vs_gt"]["rot_rad"] - c51["pose_err_vs_gt"]["rot_rad"]) < 1e-12
+    assert abs(c5["pose_err_vs_gt"]["trans_m"] - c51["pose_err_vs_gt"]["trans_m"]) < 1e-12
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("allreduce", ["rccl", "hook"])
-def test_one_rank_distributed_path_rccl_on_and_off(allreduce):
+@pytest.mark.parametrize("allreduce", ["local", "rccl", "hook"])
+def test_one_rank_distributed_path_over_every_collective(allreduce):
     r = _run(["--gpus", "1", "--force-dist", "--allreduce", allreduce])
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 1
     assert allreduce in j["config"]["parallelism"]
-    if allreduce == "rccl":
-        assert j["config"]["rccl_nranks"] == 1     # what ncclCommCount reports
+    if allreduce in ("rccl", "local"):
+        assert j["config"]["comm_nranks"] == 1     # what ncclCommCount / the mailbox's join count reports
     else:
-        assert j["config"]["rccl_nranks"] is None
+        assert j["config"]["comm_nranks"] is None

@@ -174,3 +174,30 @@ def test_shipped_align_does_not_depend_on_certified_lists(pkg, synth, monkeypatc
         assert a.nn_pairs_evaluated < 0.75 * b.nn_pairs_evaluated, (a.nn_pairs_evaluated, b.nn_pairs_evaluated)
     finally:
         _env(pkg, monkeypatch)
+
+
+def test_forget_warm_start_gives_the_first_aligns_run_again(pkg, synth):
+    """mola_icp_forget_warm_start: the repeat of an align on warmed lists takes fewer matcher launches' worth of pairs; after
+    forgetting, the run is the first one again -- same pose bit for bit (it always is), and the first run's evaluated-pair count"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g, l, _ = synth.make_pair(120_000, 100_000, seed=21)
+    icp = pkg.ICP(device=0)
+    icp.set_profiling(True)
+    icp.set_map(g)
+    icp.set_local(l)
+    p = pkg.Parameters.load_from_file(os.path.join(root, "params", "icp-settings-regular.yaml"))
+    p.max_iterations, p.fixed_iterations, p.skip_quality = 8, 1, 1
+    first = icp.align_resident(np.eye(4), p)
+    warm = icp.align_resident(np.eye(4), p)
+    icp.forget_warm_start()
+    again = icp.align_resident(np.eye(4), p)
+    icp.close()
+    assert np.array_equal(first.optimal_tf, warm.optimal_tf) and np.array_equal(first.optimal_tf, again.optimal_tf)
+    assert first.n_pairs == warm.n_pairs == again.n_pairs
+    # (the count itself wobbles by a tile or two between identical runs: the waves of a cooperative item race to tighten the
+    # shared bound, which changes what they skip -- never what they find)
+    wobble = abs(again.nn_pairs_evaluated - first.nn_pairs_evaluated)
+    assert wobble < 1e-3 * first.nn_pairs_evaluated, (first.nn_pairs_evaluated, again.nn_pairs_evaluated)
+    assert again.n_nn_launches == first.n_nn_launches
+    assert abs(warm.nn_pairs_evaluated - first.nn_pairs_evaluated) > 10 * max(wobble, 4096), (first.nn_pairs_evaluated, warm.nn_pairs_evaluated)
