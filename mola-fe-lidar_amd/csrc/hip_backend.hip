@@ -66,6 +66,7 @@ struct Knobs {
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
     bool no_bootstrap = false;   // MOLA_ICP_NO_BOOTSTRAP: the first plane-matcher launch of an align sweeps without seeds
     bool bootstrap_nn = false;   // MOLA_ICP_BOOTSTRAP_NN: ... is seeded around each query's nearest neighbour (an NN pass first) instead of around its Hilbert key's place
+    bool no_quality_lists = false;  // MOLA_ICP_NO_QUALITY_LISTS: the PairedRatio pass behind a point-to-plane loop is always a matcher pass
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
@@ -82,6 +83,7 @@ static Knobs read_knobs()
     k.no_split = std::getenv("MOLA_ICP_NO_SPLIT") != nullptr;
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
     k.no_fused_rows = std::getenv("MOLA_ICP_NO_FUSED_ROWS") != nullptr;
+    k.no_quality_lists = std::getenv("MOLA_ICP_NO_QUALITY_LISTS") != nullptr;
     k.no_bootstrap = std::getenv("MOLA_ICP_NO_BOOTSTRAP") != nullptr;
     k.bootstrap_nn = std::getenv("MOLA_ICP_BOOTSTRAP_NN") != nullptr;
     k.planes_valu = std::getenv("MOLA_ICP_PLANES_VALU") != nullptr;
@@ -1952,6 +1954,49 @@ int HipWorkspace::allreduce(double acc[kNAcc])
     const int rc = ar_fn_(acc, kNAcc, 0, ar_user_);
     if (rc) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(rc));
     if (std::isnan(acc[16])) { slab_violation_ = false; return fail(MOLA_ICP_E_BADARG, kSlabMsg); }
+    return MOLA_ICP_OK;
+}
+
+// The PairedRatio count from the plane matcher's certified lists (k_quality_from_lists): available right behind a point-to-plane loop
+// on the clouds in place; any query the lists cannot decide sends the caller back to the matcher pass (same count either way).
+int HipWorkspace::quality_pairs(const Mat4& T, double threshold, const mola_icp_params& p, double acc[kNAcc], bool* done)
+{
+    *done = false;
+    if (!inited_ || !knn_seed_valid_ || planes_knn_ < 1 || planes_empty_ || g_knobs.no_certify || g_knobs.no_knn_seed || g_knobs.no_quality_lists ||
+        !loc_sc_ || !loc_sc_->ready || N_ == 0 || g_knobs.no_direct_readback)
+        return MOLA_ICP_OK;
+    (void)p;
+    int rc;
+    HIPCHK(hipSetDevice(device_));
+    if (!item_part_host_) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&item_part_host_), sizeof(double) * 32 * kItemRedBlocks, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(item_part_host_, 0, sizeof(double) * 32 * kItemRedBlocks);
+    }
+    PoseF P, Pprev;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) P.R[3 * r + c] = (float)T(r, c);
+        P.t[r] = (float)T(r, 3);
+    }
+    for (int k = 0; k < 9; ++k) Pprev.R[k] = knn_last_P_[k];
+    for (int k = 0; k < 3; ++k) Pprev.t[k] = knn_last_P_[9 + k];
+    const float thr2 = (float)(threshold * threshold);
+    const int G = (int)std::min<size_t>((N_ + 1023) / 1024, (size_t)kItemRedBlocks);
+    const unsigned long long seq = ++readback_seq_;
+    const float* sl = loc_sc_->sorted.as<float>();
+    hipLaunchKernelGGL(k_quality_from_lists, dim3(G), dim3(1024), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded, (int)N_, P, Pprev, thr2,
+                       knn_seeds_at(knn_pos_.p, loc_sc_->padded, planes_knn_ + 1), planes_knn_ + 1, knn_lb_.as<float>(), item_part_host_, seq);
+    HIPCHK(hipGetLastError());
+    double pairs = 0.0, open = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double* row = item_part_host_ + 32 * (size_t)g;
+        if ((rc = spin_for(reinterpret_cast<volatile unsigned long long*>(const_cast<double*>(row)) + kNAcc + 6, seq))) return rc;
+        pairs += row[16];
+        open += row[0];
+    }
+    if (open > 0.0) return MOLA_ICP_OK;   // undecided queries: the matcher pass answers (exactly the same count)
+    for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
+    acc[16] = pairs;
+    *done = true;
     return MOLA_ICP_OK;
 }
 

@@ -130,6 +130,7 @@ class HipWorkspace final : public Stages {
     int accumulate(const mola_icp_params& p, const Mat4& Tcur, int stage, const double cl[3], const double cg[3],
                    bool reset_outliers, double acc[kNAcc]) override;
     int allreduce(double acc[kNAcc]) override;
+    int quality_pairs(const Mat4& T, double threshold, const mola_icp_params& p, double acc[kNAcc], bool* done) override;
     uint64_t n_local_total() const override { return n_local_total_ ? n_local_total_ : N_; }
     uint64_t n_map_total() const override { return n_map_total_ ? n_map_total_ : M_; }
 

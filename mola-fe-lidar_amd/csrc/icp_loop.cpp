@@ -354,9 +354,13 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mol
             const double thr = e ? p_all.extra_quality[e - 1].quality_threshold : p_all.quality_threshold;
             double w = e ? p_all.extra_quality[e - 1].weight : p_all.quality_weight;
             if (e == 0 && w == 0) w = 1.0;
-            if ((rc = st.match(T, thr, p, nullptr))) return rc;
             double qacc[kNAcc];
-            if ((rc = st.accumulate(p, T, 0, nullptr, nullptr, true, qacc))) return rc;
+            bool counted = false;
+            if ((rc = st.quality_pairs(T, thr, p, qacc, &counted))) return rc;
+            if (!counted) {
+                if ((rc = st.match(T, thr, p, nullptr))) return rc;
+                if ((rc = st.accumulate(p, T, 0, nullptr, nullptr, true, qacc))) return rc;
+            }
             if ((rc = st.allreduce(qacc))) return rc;
             if (p_all.n_extra_quality == 0) { qsum = qacc[16] / denom; wsum = 1.0; break; }
             qsum += w * (qacc[16] / denom);

@@ -45,6 +45,14 @@ struct Stages {
     }
     // sum acc across ranks in place (no-op for a single rank)
     virtual int allreduce(double acc[kNAcc]) { (void)acc; return MOLA_ICP_OK; }
+    // row a11: this rank's pair count of a PairedRatio pass at pose T (acc[16]; the other entries zero), if the stages can give it
+    // WITHOUT a matcher pass -- *done = false (the default): the loop runs match() + accumulate() as always
+    virtual int quality_pairs(const Mat4& T, double threshold, const mola_icp_params& p, double acc[kNAcc], bool* done)
+    {
+        (void)T; (void)threshold; (void)p; (void)acc;
+        *done = false;
+        return MOLA_ICP_OK;
+    }
     virtual uint64_t n_local_total() const = 0;
     virtual uint64_t n_map_total() const = 0;
 };

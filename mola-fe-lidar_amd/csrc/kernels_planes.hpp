@@ -842,6 +842,56 @@ __global__ __launch_bounds__(256) void k_nn_seeds_from_lists(KnnSeeds seeds, int
     gsx[i] = ps >= 0 ? seeds.x[i] : 0.f; gsy[i] = ps >= 0 ? seeds.y[i] : 0.f; gsz[i] = ps >= 0 ? seeds.z[i] : 0.f;
 }
 
+// The PairedRatio pass behind a point-to-plane loop, from the lists alone (src/LidarOdometry.cpp:869-871 hands back `quality` with
+// every align; params/icp-settings-regular.yaml:33-36: thresholdDistance 0.10 m).  The quality is a COUNT -- queries whose nearest map
+// point lies within the threshold at the final pose -- and the lists answer that without a search: (i) an entry of the query's stored
+// list closer than the threshold (contract arithmetic on the stored coordinates: the same bits the matcher would compute) => paired,
+// whatever else is out there; (ii) no such entry, and every point OUTSIDE the list provably beyond the threshold -- at least lb away at
+// the pose that wrote the list, the query has moved by delta since (KnnCert's bound and margins) => not paired; (iii) neither: counted
+// as `open`, and the caller runs the nearest-neighbour pass after all (a query whose whole list sits within 2 delta of the threshold:
+// practically never).  Entry 0 was the nearest at the list's pose: nearly every paired query stops there.
+// One launch of <= kItemRedBlocks workgroups; block g publishes [pairs, open] + the sequence flag in row g of the pinned block
+// (the layout of k_reduce_items' rows: value [16] = pairs as the accumulator block carries them, [0] = open).
+__global__ __launch_bounds__(1024) void k_quality_from_lists(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                             const float* __restrict__ slz, int N, PoseF P, PoseF Pprev, float thr2,
+                                                             KnnSeeds seeds, int KL, const float* __restrict__ lb,
+                                                             double* __restrict__ host_out, unsigned long long seq)
+{
+    __shared__ unsigned int s_pairs[16], s_open[16];
+    unsigned int pairs = 0u, open = 0u;
+    for (int i = (int)blockIdx.x * 1024 + (int)threadIdx.x; i < N; i += (int)gridDim.x * 1024) {
+        const float lx = slx[i], ly = sly[i], lz = slz[i];
+        float qx, qy, qz;
+        xform(P, lx, ly, lz, qx, qy, qz);
+        bool paired = false;
+        for (int e = 0; e < KL && !paired; ++e) {
+            const size_t at = (size_t)e * seeds.stride + (size_t)i;
+            if (seeds.pos[at] >= 0) paired = dist2(qx, qy, qz, seeds.x[at], seeds.y[at], seeds.z[at]) < thr2;
+        }
+        if (paired) { ++pairs; continue; }
+        float ox, oy, oz;
+        xform(Pprev, lx, ly, lz, ox, oy, oz);
+        const float delta = sqrtf(dist2(qx, qy, qz, ox, oy, oz)) * kCertUp + 1e-18f;
+        const float m = (lb[i] - delta) * kCertDown;
+        if (!(m > 0.f && m * m * kCertDown > thr2)) ++open;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pairs += __shfl_down(pairs, o); open += __shfl_down(open, o); }
+    if (lane == 0) { s_pairs[wave] = pairs; s_open[wave] = open; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tp = 0u, to = 0u;
+        for (int w = 0; w < 16; ++w) { tp += s_pairs[w]; to += s_open[w]; }
+        double* row = host_out + 32 * (size_t)blockIdx.x;
+        row[16] = (double)tp;
+        row[0] = (double)to;
+        __threadfence_system();
+        reinterpret_cast<volatile unsigned long long*>(row)[kNAcc + 6] = seq;
+        __threadfence_system();
+    }
+}
+
 // the point-to-plane cost  sum (n.(R l + t - c))^2  is the quadratic form  x^T A x - 2 b^T x + c0  in
 // x = [R row-major (9), t (3)]  with  phi = [n (x) l, n],  d = n.c :   A = sum phi phi^T (78 unique),
 // b = sum phi d (12), c0 = sum d^2, count.  ONE pass -> the whole Gauss-Newton inner loop runs on the host.

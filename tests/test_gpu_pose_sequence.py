@@ -11,7 +11,7 @@ from tests.helpers import p2p_params
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
-KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_QPL", "MOLA_ICP_NO_CERTIFY", "MOLA_ICP_KNN_COOP")
+KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_QPL", "MOLA_ICP_NO_CERTIFY", "MOLA_ICP_KNN_COOP", "MOLA_ICP_NO_QUALITY_LISTS")
 
 
 def _env(pkg, monkeypatch, **kv):
@@ -201,3 +201,37 @@ def test_forget_warm_start_gives_the_first_aligns_run_again(pkg, synth):
     assert wobble < 1e-3 * first.nn_pairs_evaluated, (first.nn_pairs_evaluated, again.nn_pairs_evaluated)
     assert again.n_nn_launches == first.n_nn_launches
     assert abs(warm.nn_pairs_evaluated - first.nn_pairs_evaluated) > 10 * max(wobble, 4096), (first.nn_pairs_evaluated, warm.nn_pairs_evaluated)
+
+
+@pytest.mark.parametrize("thr", [0.10, 0.02, 0.5, 0.9])
+def test_quality_from_the_lists_is_the_matcher_passes_count(pkg, O, synth, monkeypatch, thr):
+    """row a11 behind a point-to-plane loop: PairedRatio counted from the certified lists (k_quality_from_lists) = the count of the
+    nearest-neighbour pass it replaces (MOLA_ICP_NO_QUALITY_LISTS=1), bit for bit -- thresholds below, at and beyond the lists' own
+    gate (0.77 m: beyond it the lists cannot decide and the pass runs), on a pair with partial overlap (unpaired queries), and equal
+    to the checker's quality"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g, l, _ = synth.make_pair(60_000, 50_000, seed=31)
+    l = np.ascontiguousarray(l[:, l[0] > np.percentile(l[0], 30)])   # (a scan that covers part of the map only ...)
+    g = np.ascontiguousarray(g[:, g[0] < np.percentile(g[0], 80)])   # (... and a map that lacks part of the scan)
+    p = pkg.Parameters.load_from_file(os.path.join(root, "params", "icp-settings-regular.yaml"))
+    p.max_iterations = 12
+    p.quality_threshold = thr
+    res = {}
+    try:
+        for mode in ("lists", "pass"):
+            _env(pkg, monkeypatch, **({"MOLA_ICP_NO_QUALITY_LISTS": "1"} if mode == "pass" else {}))
+            icp = pkg.ICP(device=0)
+            icp.set_map(g)
+            icp.set_local(l)
+            res[mode] = icp.align_resident(np.eye(4), p)
+            icp.close()
+    finally:
+        _env(pkg, monkeypatch)
+    a, b = res["lists"], res["pass"]
+    assert np.array_equal(a.optimal_tf, b.optimal_tf) and a.nIterations == b.nIterations
+    assert a.quality == b.quality and 0.0 < a.quality < 0.999
+    op = O.params_from_product(p)
+    rc = O.align_p2pl(g, l, np.eye(4), op, p.plane_eigen_threshold, int(p.knn), int(p.solver_max_iterations))
+    assert int(rc["n_iterations"]) == a.nIterations
+    assert a.quality == pytest.approx(rc["quality"], abs=1e-12)
