@@ -67,6 +67,8 @@ def main():
                          "hook: torch.distributed from the host hook")
     ap.add_argument("--guess-dt", type=float, default=1.0, help="sharded runs: how far (m) the pose may end from the guess -- sizes each rank's map slab")
     ap.add_argument("--guess-drot-deg", type=float, default=3.0, help="sharded runs: how far (deg) the pose may rotate from the guess")
+    ap.add_argument("--balance-rounds", type=int, default=2,
+                    help="sharded runs: rounds of cost-balanced re-cutting of the query shards before anything is timed (0 = equal counts)")
     ap.add_argument("--c5-map", type=int, default=10_000_000, help="map points of the configs[4] leg (0 = skip)")
     ap.add_argument("--c5-steps", type=int, default=20)
     ap.add_argument("--share-gpu", action="store_true",
@@ -134,16 +136,20 @@ def main():
     icp = pkg.ICP(device=local_rank)
     guess_dt, guess_drot = args.guess_dt, np.deg2rad(args.guess_drot_deg)
 
-    def place_clouds(icp_, tg_, tl_, margin_scale=1.0):
+    def place_clouds(icp_, tg_, tl_, margin_scale=1.0, cuts=None):
         """one GPU: both clouds whole.  Sharded: this rank's slice of the scan's Hilbert order, cut on the device (a random 1/W
         subsample would be W times sparser than the map: every 128-query group would sweep W times more map tiles) -- and only the
         part of the map that shard can reach from any pose within (guess_dt, guess_drot) of the guess: sharded.slab_margin_for_guess,
-        from the gate, the stated uncertainty of the guess and how far from the origin THIS shard lies -- not W copies of the map."""
+        from the gate, the stated uncertainty of the guess and how far from the origin THIS shard lies -- not W copies of the map.
+        `cuts` = explicit boundaries (cost-balanced: balance_shards below); None = equal counts."""
         if world == 1:
             icp_.set_map(tg_)
             icp_.set_local(tl_)
             return int(tl_.shape[1]), None
-        n_shard = icp_.set_local_shard(tl_, rank, world)
+        if cuts is None:
+            n_shard = icp_.set_local_shard(tl_, rank, world)
+        else:
+            n_shard = icp_.set_local_shard_range(tl_, cuts[rank], cuts[rank + 1])
         blo0, bhi0 = icp_.shard_reach_box(np.eye(4), 0.0)
         margin = margin_scale * sharded.slab_margin_for_guess(blo0, bhi0, GATE_M, guess_dt, guess_drot)
         blo, bhi = icp_.shard_reach_box(np.eye(4), margin)
@@ -151,7 +157,52 @@ def main():
         return n_shard, {"map_points_kept": kept, "map_points_total": int(tg_.shape[1]), "margin_m": margin,
                          "margin_rule": f"gate {GATE_M} m + {guess_dt} m + 2 sin({args.guess_drot_deg} deg / 2) x the shard's farthest corner from the origin"}
 
-    n_shard, slab = place_clouds(icp, tg, tl)
+    def balance_shards(icp_, tg_, tl_, n_total, pp, rounds):
+        """Cuts of equal COST (sharded.balanced_cuts): where the guess is far off, the matcher's cost per query varies several-fold
+        along the scan -- a rotation error displaces distant queries by metres, their search balls hold a hundred tiles -- and a
+        step is as long as its slowest rank (profiles/r04/sharded/shard_step_c5*.jsonl: equal counts leave one rank of eight at
+        2.2x the mean).  Every round: each rank times a short align on the shards in force, the W times are summed into one vector
+        (torch.distributed; not timed), all ranks cut again at the same places.  Returns (n_shard, slab, record)."""
+        cuts = [sharded.shard_bounds(n_total, r, world)[0] for r in range(world)] + [n_total]
+        n_shard, slab = place_clouds(icp_, tg_, tl_)
+        rec = []
+        q = pp.copy()
+        q.max_iterations, q.fixed_iterations, q.skip_quality = 4, 1, 1
+        best = None   # (cuts, slowest rank's step): the cuts in force at the end are the best ones MEASURED, not the last ones tried
+        for rnd in range(rounds + 1 if world > 1 else 0):
+            try:
+                icp_.align_resident(np.eye(4), q)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                icp_.align_resident(np.eye(4), q)
+                torch.cuda.synchronize()
+                mine = (time.perf_counter() - t0) / 4
+            except pkg.IcpError:
+                mine = float("nan")   # (a slab too small for this probe: keep the cuts in force, the rehearsal below re-cuts the slabs)
+            v = torch.zeros(world, dtype=torch.float64, device=cdev)
+            v[rank] = mine
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            cost = v.cpu().numpy()
+            if not np.all(np.isfinite(cost)):
+                break
+            rec.append({"cuts": list(cuts), "step_ms": [float(c) * 1e3 for c in cost]})
+            if best is None or float(cost.max()) < best[1]:
+                best = (list(cuts), float(cost.max()))
+            if rnd == rounds:
+                break
+            cuts = sharded.balanced_cuts(cuts, cost)
+            n_shard, slab = place_clouds(icp_, tg_, tl_, cuts=cuts)
+        if best is not None and best[0] != list(cuts):
+            cuts = best[0]
+            n_shard, slab = place_clouds(icp_, tg_, tl_, cuts=cuts)
+        return n_shard, slab, {"rounds": rec, "cuts": list(cuts)}, cuts
+
+    probe_p = pkg.Parameters()
+    probe_p.matcher_threshold = GATE_M
+    if world > 1 and args.balance_rounds > 0:
+        n_shard, slab, balance, cuts = balance_shards(icp, tg, tl, N, probe_p, args.balance_rounds)
+    else:
+        (n_shard, slab), balance, cuts = place_clouds(icp, tg, tl), None, None
     lo, hi = 0, n_shard                 # (queries_per_gpu below)
     icp.set_global_sizes(N, M)
     allreduce_used = None
@@ -223,7 +274,7 @@ def main():
             except pkg.IcpError as e:
                 if "map slab" not in str(e) or attempt == 3:
                     raise
-                _, slab = place_clouds(icp, tg, tl, margin_scale=2.0 ** (attempt + 1))   # (the guess was worse than stated)
+                _, slab = place_clouds(icp, tg, tl, margin_scale=2.0 ** (attempt + 1), cuts=cuts)   # (the guess was worse than stated)
                 slab["recut"] = attempt + 1
     # Device warm-up (untimed, the same count on every rank): the GPU has idled through seconds of host-side cloud
     # generation and its clocks take a few hundred milliseconds of work to settle -- behind 3 warm-up steps alone the
@@ -320,13 +371,13 @@ def main():
                    "n_local": N, "n_map": M, "gate_m": GATE_M, "queries_per_gpu": hi - lo,
                    "parallelism": (f"query-shard x{world}, {allreduce_used} all-reduce" if use_dist else "single GPU"),
                    "ranks_share_gpus": bool(args.share_gpu and world > 1), "comm_nranks": comm_nranks,
-                   "nn_kernel": roof["kernel"], "map_slab_rank0": slab},
+                   "nn_kernel": roof["kernel"], "map_slab_rank0": slab, "shard_balance": balance},
         "roofline": roof,
         "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(res.optimal_tf, T_gt))),
     }
     if args.c5_map > 0:
         out["c5_sharded"] = c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev, cdev, use_dist, allreduce_used,
-                                   local_comm, place_clouds, barrier)
+                                   local_comm, place_clouds, balance_shards, barrier)
     extras = rank == 0 and world == 1
 
     if extras and args.nn_kernel in ("auto", "tiled") and args.dense_iters > 0:
@@ -458,8 +509,8 @@ def main():
         # what a robot sees: the same drive with the scans arriving at the sensor's 10 Hz, not back to back (the GPU idles
         # ~99 ms between scans and its clocks fall), and on the cloud sizes the reference's filters actually hand to align()
         out["odometry_stream_10hz"] = odometry_stream_leg(pkg, synth, period_s=0.1, passes=args.paced_passes)
-        out["odometry_stream_small"] = odometry_stream_leg(pkg, synth, n_rings=16, n_az=1250)
-        out["odometry_stream_small_10hz"] = odometry_stream_leg(pkg, synth, period_s=0.1, n_rings=16, n_az=1250, passes=args.paced_passes)
+        out["odometry_stream_small"] = odometry_stream_leg(pkg, synth, decimate=10)
+        out["odometry_stream_small_10hz"] = odometry_stream_leg(pkg, synth, period_s=0.1, decimate=10, passes=args.paced_passes)
 
     if use_dist:
         if allreduce_used in ("rccl", "local"):
@@ -472,7 +523,8 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev, cdev, use_dist, allreduce_used, local_comm, place_clouds, barrier):
+def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev, cdev, use_dist, allreduce_used, local_comm, place_clouds,
+           balance_shards, barrier):
     """BASELINE.json configs[4]: a 10M-point global map vs the 1M-point scan, query-sharded with a map slab per rank and the
     per-iteration all-reduce of the accumulators -- the config the sharded path is FOR (at 1M x 1M a rank's shard is a ~15 us kernel
     behind a fixed ~100 us of launches and host turns; ten times the map puts the time back into the matcher).  Same scan, same
@@ -483,7 +535,12 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
     tl5 = torch.from_numpy(np.ascontiguousarray(l5)).to(dev)
     del g5
     icp5 = pkg.ICP(device=local_rank)
-    n_shard, slab = place_clouds(icp5, tg5, tl5)
+    p = pkg.Parameters()
+    p.matcher_threshold, p.fixed_iterations, p.skip_quality, p.max_iterations = GATE_M, 1, 1, args.c5_steps
+    if world > 1 and args.balance_rounds > 0:
+        n_shard, slab, balance, cuts = balance_shards(icp5, tg5, tl5, N, p, args.balance_rounds)
+    else:
+        (n_shard, slab), balance, cuts = place_clouds(icp5, tg5, tl5), None, None
     icp5.set_global_sizes(N, M5)
     if use_dist:
         if allreduce_used == "local":
@@ -492,8 +549,6 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
             icp5.comm_init()
         else:
             icp5.set_allreduce(sharded.make_allreduce(device=dev))
-    p = pkg.Parameters()
-    p.matcher_threshold, p.fixed_iterations, p.skip_quality, p.max_iterations = GATE_M, 1, 1, args.c5_steps
     T0 = np.eye(4)
     for attempt in range(4):   # rehearsal = warm-up (allocations, the slab check over the whole trajectory: see the headline)
         try:
@@ -502,7 +557,7 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
         except pkg.IcpError as e:
             if world == 1 or "map slab" not in str(e) or attempt == 3:
                 raise
-            _, slab = place_clouds(icp5, tg5, tl5, margin_scale=2.0 ** (attempt + 1))
+            _, slab = place_clouds(icp5, tg5, tl5, margin_scale=2.0 ** (attempt + 1), cuts=cuts)
             slab["recut"] = attempt + 1
     icp5.align_resident(T0, p)
     barrier()
@@ -521,7 +576,7 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
     leg = {"workload": f"configs[4]: {N} scan points vs a {M5}-point global map, {args.c5_steps} fixed iterations, point-to-point (gate {GATE_M} m) + Horn, "
                        "query-sharded, one map slab per rank, one all-reduce of 24 doubles per iteration",
            "value": args.c5_steps / dt, "unit": "iterations/s", "ms_per_step": dt / args.c5_steps * 1e3, "n_gpus": world, "scaling": "strong",
-           "n_local": N, "n_map": M5, "queries_per_gpu": n_shard, "map_slab_rank0": slab,
+           "n_local": N, "n_map": M5, "queries_per_gpu_rank0": n_shard, "map_slab_rank0": slab, "shard_balance": balance,
            "matcher_ms_per_launch_rank0": k_ms, "pairs_evaluated_per_query_rank0": rp.nn_pairs_evaluated / max(1, rp.n_nn_launches) / max(1, n_shard),
            "all_reduce": allreduce_used if use_dist else None,
            "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(r.optimal_tf, T_gt)))}
@@ -794,7 +849,7 @@ def align_e2e(pkg, synth, icp, g1m, l1m, seed, with_cpu, cpu_flags):
     return out
 
 
-def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, n_rings=64, n_az=1875, passes=1):
+def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passes=1):
     """rows f1 + f4 (src/LidarOdometry.cpp:190-514): a drive down the scene at 10 m/s, one 64-ring scan (~115k points) every 0.1 s,
     through the front-end mirror (`LidarOdometry.on_new_observation` = `mola_lo_process_scan`) with params/kitti-default.yaml:
     per scan, the new cloud is uploaded, sorted and boxed ONCE (it is `to` now and `from` for the next scan: the cloud cache),
@@ -803,7 +858,10 @@ def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, n_rings=64, n_az=
     scans = []
     for k in range(n_scans):
         pose = synth.pose_from_xyzypr(-14.0 + 1.0 * k, 0.3 * np.sin(0.3 * k), 0.0, 0.005 * k, 0, 0)
-        scans.append((100.0 + 0.1 * k, synth.lidar_scan(pose, n_rings=n_rings, n_az=n_az, seed=50 + k)))
+        pc = synth.lidar_scan(pose, seed=50 + k)
+        # decimate = 10: what the reference's own pipeline hands to align() -- `full_pointcloud_decimation: 10`
+        # (params/kitti-default.yaml:27; src/LidarOdometry.cpp:215-224): every tenth point of the scan, ~12k of ~120k
+        scans.append((100.0 + 0.1 * k, np.ascontiguousarray(pc[:, ::decimate])))
     icp = pkg.ICP(device=0)
     lo = pkg.LidarOdometry(lp, icp=icp)
     ms, its, ran, kfs, steady = [], [], 0, [], []
@@ -830,7 +888,7 @@ def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, n_rings=64, n_az=
     med = float(np.median(steady))
     arrival = (f"delivered every {period_s * 1e3:.0f} ms of wall time (the sensor's rate: GPU clocks and host caches as a robot meets them)"
                if period_s is not None else "delivered back to back (GPU clocks stay up)")
-    return {"workload": f"{passes} x {n_scans} scans of ~{int(np.mean([pc.shape[1] for _, pc in scans]))} points ({n_rings} rings x {n_az} azimuths), 0.1 s and 1 m apart, "
+    return {"workload": f"{passes} x {n_scans} scans of ~{int(np.mean([pc.shape[1] for _, pc in scans]))} points ({'every ' + str(decimate) + 'th point of the ' if decimate > 1 else 'the full '}64-ring scan), 0.1 s and 1 m apart, "
                         f"{arrival}, params/kitti-default.yaml, host buffers in, pose out",
             "ms_per_scan_median": med, "ms_per_scan_p99": float(np.percentile(steady, 99)),
             "ms_per_scan_min": float(np.min(steady)), "ms_per_scan_max": float(np.max(steady)),

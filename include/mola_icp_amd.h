@@ -372,6 +372,14 @@ int mola_icp_set_local_shard_host(mola_icp_handle* h, const float* x, const floa
                                   int rank, int nranks, size_t* n_shard_out);
 int mola_icp_set_local_shard_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t n_total,
                                     int rank, int nranks, size_t* n_shard_out);
+/* ... or any slice [lo, hi) of that order (0 <= lo <= hi <= n_total): cuts of equal COST instead of equal count.  Where the guess is
+ * far off (a rotation error moves distant queries by metres) the matcher's cost per query varies several-fold across the scan and
+ * a launch is as long as its slowest rank: the ranks time one iteration on equal-count shards, exchange the W times (one
+ * all-reduce of a W-vector) and cut again where the cumulated cost is k / W of the total (sharded.balanced_cuts). */
+int mola_icp_set_local_shard_range_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t n_total,
+                                        size_t lo, size_t hi, size_t* n_shard_out);
+int mola_icp_set_local_shard_range_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t n_total,
+                                          size_t lo, size_t hi, size_t* n_shard_out);
 int mola_icp_local_shard_indices(mola_icp_handle* h, int32_t* idx_out);
 /* The part of the map this rank's shard can reach: [lo, hi] = the shard's bounding box moved by T and grown by `margin`
  * (mola_icp_shard_reach_box), then only the map points inside it are kept, prepared and searched

@@ -176,6 +176,8 @@ SIGNATURES = {
     "mola_icp_forget_warm_start": (C.c_int, [_H]),
     "mola_icp_set_local_shard_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "mola_icp_set_local_shard_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "mola_icp_set_local_shard_range_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mola_icp_set_local_shard_range_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mola_icp_local_shard_indices": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "mola_icp_shard_reach_box": (C.c_int, [_H, _DP, C.c_double, _DP, _DP]),
     "mola_icp_set_map_slab_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, _DP, _DP, C.POINTER(C.c_size_t)]),

@@ -1117,6 +1117,30 @@ int mola_icp_set_local_shard_device(mola_icp_handle* h, const float* dx, const f
     });
 }
 
+int mola_icp_set_local_shard_range_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t n_total, size_t lo,
+                                        size_t hi, size_t* n_shard_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        const int rc = h->resident->set_local_shard_range(x, y, z, n_total, lo, hi, false);
+        if (!rc && n_shard_out) *n_shard_out = h->resident->N();
+        return rc;
+    });
+}
+
+int mola_icp_set_local_shard_range_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t n_total, size_t lo,
+                                          size_t hi, size_t* n_shard_out)
+{
+    return guarded([&]() -> int {
+        if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+        std::lock_guard<std::mutex> lk(h->mtx);
+        const int rc = h->resident->set_local_shard_range(dx, dy, dz, n_total, lo, hi, true);
+        if (!rc && n_shard_out) *n_shard_out = h->resident->N();
+        return rc;
+    });
+}
+
 int mola_icp_local_shard_indices(mola_icp_handle* h, int32_t* idx_out)
 {
     return guarded([&]() -> int {

@@ -437,14 +437,22 @@ int gather_by_index(hipStream_t stream, const float* x, const float* y, const fl
 // bounding box, so every rank cuts the same order; the full copy is transient.
 int HipWorkspace::set_local_shard(const float* x, const float* y, const float* z, size_t n_total, int rank, int nranks, bool on_device)
 {
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MOLA_ICP_E_BADARG, "bad rank / nranks");
+    const size_t base = n_total / (size_t)nranks, rem = n_total % (size_t)nranks;
+    const size_t lo = (size_t)rank * base + std::min((size_t)rank, rem), n = base + ((size_t)rank < rem ? 1 : 0);
+    return set_local_shard_range(x, y, z, n_total, lo, lo + n, on_device);
+}
+
+// ... and any slice [lo, hi) of that order (cost-balanced cuts: sharded.balanced_cuts)
+int HipWorkspace::set_local_shard_range(const float* x, const float* y, const float* z, size_t n_total, size_t lo, size_t hi, bool on_device)
+{
     int rc = init();
     if (rc) return rc;
-    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MOLA_ICP_E_BADARG, "bad rank / nranks");
+    if (lo > hi || hi > n_total) return fail(MOLA_ICP_E_BADARG, "shard range outside the scan");
     if (n_total && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null local-cloud pointer");
     if (n_total > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "local cloud too large for 32-bit indices");
     HIPCHK(hipSetDevice(device_));
-    const size_t base = n_total / (size_t)nranks, rem = n_total % (size_t)nranks;
-    const size_t lo = (size_t)rank * base + std::min((size_t)rank, rem), n = base + ((size_t)rank < rem ? 1 : 0);
+    const size_t n = hi - lo;
     const float *fx = x, *fy = y, *fz = z;
     if (!on_device) {
         if ((rc = upload_soa(stage_in_, stream_, x, y, z, n_total, &fx, &fy, &fz))) return rc;

@@ -118,6 +118,7 @@ class HipWorkspace final : public Stages {
     // row e (query sharding): this rank's spatially compact shard of a scan every rank sees in full -- the scan is put in
     // Hilbert order on the device (a transient copy) and the slice [lo, hi) of that order is kept as the local cloud
     int set_local_shard(const float* x, const float* y, const float* z, size_t n_total, int rank, int nranks, bool on_device);
+    int set_local_shard_range(const float* x, const float* y, const float* z, size_t n_total, size_t lo, size_t hi, bool on_device);
     int copy_shard_indices(int32_t* idx_out);  // original scan indices of the shard's points, in the shard's order
     // ... and the part of the map that shard can reach: the points inside [lo, hi] (original indices are kept: pairings
     // still name ORIGINAL map points).  match() refuses a pose that moves the shard's reach out of the box.

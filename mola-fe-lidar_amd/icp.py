@@ -394,6 +394,23 @@ class ICP:
         self._shard_n = int(n.value)
         return self._shard_n
 
+    def set_local_shard_range(self, pc_full, lo: int, hi: int) -> int:
+        """keeps the slice [lo, hi) of the full scan's Hilbert order as the local cloud (cost-balanced cuts:
+        `sharded.balanced_cuts`); returns the shard's size"""
+        n = C.c_size_t(0)
+        if self._is_device_tensor(pc_full):
+            import torch
+            assert pc_full.dtype == torch.float32 and pc_full.dim() == 2 and pc_full.shape[0] == 3 and pc_full.is_contiguous()
+            torch.cuda.current_stream(pc_full.device).synchronize()   # see set_map
+            L.check(L.lib().mola_icp_set_local_shard_range_device(self._h, pc_full[0].data_ptr(), pc_full[1].data_ptr(),
+                                                                  pc_full[2].data_ptr(), pc_full.shape[1], int(lo), int(hi), C.byref(n)))
+        else:
+            x, y, z, nt = _soa(pc_full)
+            L.check(L.lib().mola_icp_set_local_shard_range_host(self._h, _fp(x), _fp(y), _fp(z), nt, int(lo), int(hi), C.byref(n)))
+        self._keep_local = None
+        self._shard_n = int(n.value)
+        return self._shard_n
+
     def local_shard_indices(self) -> np.ndarray:
         """the shard's points as indices into the full scan, in the shard's own order"""
         idx = np.empty(max(1, getattr(self, "_shard_n", 0)), dtype=np.int32)

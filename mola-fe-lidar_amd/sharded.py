@@ -48,6 +48,30 @@ def slab_margin_for_guess(box_lo, box_hi, gate: float, max_dt: float, max_drot: 
     return float(gate + max_dt + 2.0 * np.sin(0.5 * max_drot) * far)
 
 
+def balanced_cuts(cuts, cost) -> list[int]:
+    """Cuts of equal COST.  `cuts` = the W + 1 boundaries of the shards in force (positions in the scan's Hilbert order, cuts[0] = 0,
+    cuts[W] = n), `cost` = what each shard's step cost (W values: seconds of a timed iteration, or the matcher's own time) -- taken
+    as uniform inside a shard.  Returns W + 1 new boundaries where the cumulated cost reaches k / W of the total.  Every rank
+    computes the same cuts from the same all-reduced cost vector.  One or two rounds settle: the cost per query varies smoothly
+    along the curve (it follows how far the guess displaces that part of the scan)."""
+    cuts = [int(c) for c in cuts]
+    w = len(cuts) - 1
+    cost = np.maximum(np.asarray(cost, np.float64), 1e-12)
+    assert w >= 1 and cost.shape == (w,) and all(cuts[k] <= cuts[k + 1] for k in range(w))
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    new = [0]
+    for k in range(1, w):
+        target = cum[-1] * k / w
+        j = int(np.searchsorted(cum, target, side="right") - 1)
+        j = min(max(j, 0), w - 1)
+        frac = (target - cum[j]) / cost[j]
+        new.append(int(round(cuts[j] + frac * (cuts[j + 1] - cuts[j]))))
+    new.append(cuts[-1])
+    for k in range(1, w + 1):   # monotone, whatever the rounding did
+        new[k] = max(new[k], new[k - 1])
+    return new
+
+
 def make_allreduce(group=None, device=None):
     """Returns fn(acc: np.ndarray[float64]) that sums `acc` in place over the process group.
     gloo: reduces the host buffer directly.  nccl (= RCCL): stages through a device tensor."""

@@ -102,3 +102,19 @@ def test_spatial_order_is_a_compact_permutation(pkg):
         lo, hi = sharded.shard_bounds(pts.shape[1], r, 8)
         assert spread(pts[:, order[lo:hi]]) < 0.65 * spread(pts[:, lo:hi])
     assert np.array_equal(order, sharded.spatial_order(pts))  # deterministic: every rank computes the same cut
+
+
+def test_balanced_cuts_and_slab_margin():
+    """sharded.balanced_cuts: equal cost per shard under the piecewise-uniform model, monotone, end points kept;
+    sharded.slab_margin_for_guess: gate + translation bound + the chord of the rotation bound at the farthest corner"""
+    sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+    cuts = sharded.balanced_cuts([0, 250, 500, 750, 1000], [1.0, 1.0, 4.0, 1.0])
+    assert cuts[0] == 0 and cuts[-1] == 1000 and cuts == sorted(cuts)
+    # cost density per point: 1/250, 1/250, 4/250, 1/250 -> every new shard carries 7/4
+    dens = np.repeat([1.0, 1.0, 4.0, 1.0], 250) / 250.0
+    shares = [dens[cuts[k]:cuts[k + 1]].sum() for k in range(4)]
+    np.testing.assert_allclose(shares, 7.0 / 4.0, atol=0.02)
+    assert sharded.balanced_cuts([0, 10, 20], [1.0, 1.0]) == [0, 10, 20]
+    assert sharded.balanced_cuts([0, 0, 20], [0.0, 1.0])[1] in range(0, 21)       # an empty shard, a zero cost: no division by zero
+    m = sharded.slab_margin_for_guess([-3, -4, 0], [1, 2, 12], gate=1.0, max_dt=0.5, max_drot=np.deg2rad(2.0))
+    assert m == pytest.approx(1.0 + 0.5 + 2 * np.sin(np.deg2rad(1.0)) * 13.0)

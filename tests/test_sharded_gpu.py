@@ -1,6 +1,7 @@
 """SURVEY.md §8 row e on the hardware that is there (one GPU): the shard is cut on the device from the scan's Hilbert
 order, a rank keeps only the part of the map its shard can reach, and two ranks -- fresh child processes, gloo, the real
 HIP stages, the all-reduce hook -- reproduce the single-process pose."""
+import importlib
 import os
 import socket
 import subprocess
@@ -119,4 +120,25 @@ def test_comm_init_argument_errors(pkg):
     assert L.lib().mola_icp_comm_init(None, ident, 1, 0) == L.E_BADARG
     assert L.lib().mola_icp_comm_unique_id(None) == L.E_BADARG
     assert L.lib().mola_icp_comm_destroy(icp._h) == 0          # nothing to destroy: fine
+    icp.close()
+
+
+@pytest.mark.gpu
+def test_shard_by_range_is_the_rank_slice_and_any_other_slice(pkg, synth):
+    """mola_icp_set_local_shard_range_*: [lo, hi) of the scan's Hilbert order -- rank r of W is the range of shard_bounds, and
+    uneven cuts partition the scan"""
+    sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+    _, l, _ = synth.make_pair(30_011, 1000, seed=3)
+    icp = pkg.ICP(device=0)
+    n = l.shape[1]
+    assert icp.set_local_shard(l, 1, 3) == sharded.shard_bounds(n, 1, 3)[1] - sharded.shard_bounds(n, 1, 3)[0]
+    by_rank = icp.local_shard_indices().copy()
+    lo, hi = sharded.shard_bounds(n, 1, 3)
+    assert icp.set_local_shard_range(l, lo, hi) == hi - lo
+    assert np.array_equal(icp.local_shard_indices(), by_rank)
+    cuts = [0, 17, 17, 20_000, n]
+    seen = np.concatenate([(icp.set_local_shard_range(l, cuts[k], cuts[k + 1]), icp.local_shard_indices()[:cuts[k + 1] - cuts[k]].copy())[1] for k in range(4)])
+    assert np.array_equal(np.sort(seen), np.arange(n))
+    with pytest.raises(pkg.IcpError):
+        icp.set_local_shard_range(l, 5, n + 1)
     icp.close()

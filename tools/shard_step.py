@@ -20,6 +20,7 @@ ap.add_argument("--config", choices=["c3", "c5"], default="c3")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--n-map", type=int, default=0)
+ap.add_argument("--balance-rounds", type=int, default=2)
 args = ap.parse_args()
 pkg = importlib.import_module("mola-fe-lidar_amd")
 synth = importlib.import_module("mola-fe-lidar_amd.synth")
@@ -62,7 +63,7 @@ else:
     tg, tl = torch.from_numpy(g).cuda(), torch.from_numpy(np.ascontiguousarray(l)).cuda()
     icp = pkg.ICP(device=0)
     base = None
-    for world in worlds:
+    def measure(world, cuts):
         rows = []
         for rank in range(world):
             if world == 1:
@@ -70,7 +71,7 @@ else:
                 icp.set_local(tl)
                 n_shard, kept, margin = l.shape[1], M, 0.0
             else:
-                n_shard = icp.set_local_shard(tl, rank, world)
+                n_shard = icp.set_local_shard_range(tl, cuts[rank], cuts[rank + 1])
                 blo0, bhi0 = icp.shard_reach_box(np.eye(4), 0.0)
                 margin = sharded.slab_margin_for_guess(blo0, bhi0, GATE, 1.0, np.deg2rad(3.0))
                 blo, bhi = icp.shard_reach_box(np.eye(4), margin)
@@ -79,8 +80,17 @@ else:
             ms, k_ms = timed(icp)
             rows.append({"rank": rank, "queries": n_shard, "map_points_kept": kept, "margin_m": margin, "ms_per_iteration": ms,
                          "matcher_ms_per_launch": k_ms})
-        worst = max(rows, key=lambda r: r["ms_per_iteration"])
-        base = base or worst["ms_per_iteration"]
-        print(json.dumps({"config": "c5", "n_map": M, "world": world, "step_ms_slowest_rank": worst["ms_per_iteration"],
-                          "projected_speedup_before_collective": base / worst["ms_per_iteration"],
-                          "step_ms_mean_rank": float(np.mean([r["ms_per_iteration"] for r in rows])), "ranks": rows}), flush=True)
+        return rows
+
+    for world in worlds:
+        n = l.shape[1]
+        cuts = [sharded.shard_bounds(n, r, world)[0] for r in range(world)] + [n]
+        for rnd in range(1 if world == 1 else 1 + args.balance_rounds):
+            rows = measure(world, cuts)
+            worst = max(rows, key=lambda r: r["ms_per_iteration"])
+            base = base or worst["ms_per_iteration"]
+            print(json.dumps({"config": "c5", "n_map": M, "world": world, "cuts": "equal counts" if rnd == 0 else f"cost-balanced, round {rnd}",
+                              "step_ms_slowest_rank": worst["ms_per_iteration"],
+                              "projected_speedup_before_collective": base / worst["ms_per_iteration"],
+                              "step_ms_mean_rank": float(np.mean([r["ms_per_iteration"] for r in rows])), "ranks": rows}), flush=True)
+            cuts = sharded.balanced_cuts(cuts, [r["ms_per_iteration"] for r in rows])
