@@ -232,6 +232,7 @@ HipWorkspace::~HipWorkspace()
     planes_.release(); knn_pos_.release(); plane_acc_.release(); plane_cache_.release();
     if (plane_acc_host_) (void)hipHostFree(plane_acc_host_);
     if (item_part_host_) (void)hipHostFree(item_part_host_);
+    if (quality_host_) (void)hipHostFree(quality_host_);
     item_part_.release();
     sort_scratch_.release();
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
@@ -1976,9 +1977,9 @@ int HipWorkspace::quality_pairs(const Mat4& T, double threshold, const mola_icp_
     (void)p;
     int rc;
     HIPCHK(hipSetDevice(device_));
-    if (!item_part_host_) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&item_part_host_), sizeof(double) * 32 * kItemRedBlocks, hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(item_part_host_, 0, sizeof(double) * 32 * kItemRedBlocks);
+    if (!quality_host_) {   // (a block of its own: a record's data word must never sit where another kernel's sequence flag is awaited)
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&quality_host_), sizeof(unsigned long long) * 2 * kQualityBlocks, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(quality_host_, 0, sizeof(unsigned long long) * 2 * kQualityBlocks);
     }
     PoseF P, Pprev;
     for (int r = 0; r < 3; ++r) {
@@ -1988,18 +1989,28 @@ int HipWorkspace::quality_pairs(const Mat4& T, double threshold, const mola_icp_
     for (int k = 0; k < 9; ++k) Pprev.R[k] = knn_last_P_[k];
     for (int k = 0; k < 3; ++k) Pprev.t[k] = knn_last_P_[9 + k];
     const float thr2 = (float)(threshold * threshold);
-    const int G = (int)std::min<size_t>((N_ + 1023) / 1024, (size_t)kItemRedBlocks);
+    const int G = (int)std::min<size_t>((N_ + 1023) / 1024, (size_t)kQualityBlocks);
     const unsigned long long seq = ++readback_seq_;
     const float* sl = loc_sc_->sorted.as<float>();
-    hipLaunchKernelGGL(k_quality_from_lists, dim3(G), dim3(1024), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded, (int)N_, P, Pprev, thr2,
-                       knn_seeds_at(knn_pos_.p, loc_sc_->padded, planes_knn_ + 1), planes_knn_ + 1, knn_lb_.as<float>(), item_part_host_, seq);
+    unsigned long long* recs = quality_host_;
+    const KnnSeeds seeds = knn_seeds_at(knn_pos_.p, loc_sc_->padded, planes_knn_ + 1);
+#define MOLA_QUALITY_CASE(KL_)                                                                                                              \
+    case KL_:                                                                                                                               \
+        hipLaunchKernelGGL(k_quality_from_lists<KL_>, dim3(G), dim3(256), 0, stream_, sl, sl + loc_sc_->padded, sl + 2 * loc_sc_->padded, (int)N_, \
+                           P, Pprev, thr2, seeds, knn_lb_.as<float>(), recs, seq);                                                          \
+        break;
+    switch (planes_knn_ + 1) {
+        MOLA_QUALITY_CASE(4) MOLA_QUALITY_CASE(5) MOLA_QUALITY_CASE(6) MOLA_QUALITY_CASE(7) MOLA_QUALITY_CASE(8) MOLA_QUALITY_CASE(9)
+        default: return MOLA_ICP_OK;   // (no such list length: the matcher pass answers)
+    }
+#undef MOLA_QUALITY_CASE
     HIPCHK(hipGetLastError());
     double pairs = 0.0, open = 0.0;
     for (int g = 0; g < G; ++g) {
-        const double* row = item_part_host_ + 32 * (size_t)g;
-        if ((rc = spin_for(reinterpret_cast<volatile unsigned long long*>(const_cast<double*>(row)) + kNAcc + 6, seq))) return rc;
-        pairs += row[16];
-        open += row[0];
+        if ((rc = spin_for(recs + 2 * (size_t)g + 1, seq))) return rc;
+        const unsigned long long v = const_cast<volatile unsigned long long*>(recs)[2 * (size_t)g];
+        pairs += (double)(unsigned int)(v & 0xffffffffull);
+        open += (double)(unsigned int)(v >> 32);
     }
     if (open > 0.0) return MOLA_ICP_OK;   // undecided queries: the matcher pass answers (exactly the same count)
     for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;

@@ -220,6 +220,7 @@ class HipWorkspace final : public Stages {
     int rows_count_ = 0;              // ... and holds this many rows
     DevBuf item_part_;                // k_reduce_items' partial rows
     double* item_part_host_ = nullptr;  // pinned: the same, 32 doubles apart, each with its sequence flag
+    unsigned long long* quality_host_ = nullptr;  // pinned: k_quality_from_lists' per-workgroup records {pairs | open << 32, sequence}
     bool pairing_sorted_ = false;     // which representation the stored pairing / warm start is in
     DevBuf knn_lb_;   // per query: lower bound on the distance to every map point outside its stored neighbour list (KnnCert)
     double knn_last_step_ = 1e30;   // size of the pose step between the last two launches of the plane matcher (flavour heuristic)

@@ -768,6 +768,8 @@ __global__ __launch_bounds__(256) void k_bootstrap_seeds(const int* __restrict__
 #pragma unroll
         for (int k = 0; k < 6; ++k) box[k] = map_box[k];
         const unsigned int key = hilbert_key_in_box(box, qx, qy, qz);
+        // (a base-8 lifting search -- seven probes per level, six levels instead of seventeen -- and batched loads of the three tiles
+        // were measured: 27.5 us against 23.1, profiles/r04/dropped_bootstrap_lifting_search.txt; the kernel is not its search)
         int step = 1;
         while (step < M) step <<= 1;   // (uniform)
         pos = 0;   // number of map keys below the query's
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(256) void k_bootstrap_seeds(const int* __restrict__
     for (int j = 0; j < G; ++j) kk[j] = ~0ull;
     for (int c = 0; c < 3 * kTileG; c += G) {
         const int p0 = t0 * kTileG + c;
-        if (p0 >= M) break;   // (the sorted arrays are padded to whole tiles: the loads below stay inside them)
+        if (p0 >= M) break;   // (the sorted arrays are padded to whole super-tiles: the loads below stay inside them)
 #pragma unroll
         for (int h = 0; h < G; h += 4) {
             const float4 X = *reinterpret_cast<const float4*>(mp.sx + p0 + h);
@@ -850,30 +852,57 @@ __global__ __launch_bounds__(256) void k_nn_seeds_from_lists(KnnSeeds seeds, int
 // the pose that wrote the list, the query has moved by delta since (KnnCert's bound and margins) => not paired; (iii) neither: counted
 // as `open`, and the caller runs the nearest-neighbour pass after all (a query whose whole list sits within 2 delta of the threshold:
 // practically never).  Entry 0 was the nearest at the list's pose: nearly every paired query stops there.
-// One launch of <= kItemRedBlocks workgroups; block g publishes [pairs, open] + the sequence flag in row g of the pinned block
-// (the layout of k_reduce_items' rows: value [16] = pairs as the accumulator block carries them, [0] = open).
-__global__ __launch_bounds__(1024) void k_quality_from_lists(const float* __restrict__ slx, const float* __restrict__ sly,
-                                                             const float* __restrict__ slz, int N, PoseF P, PoseF Pprev, float thr2,
-                                                             KnnSeeds seeds, int KL, const float* __restrict__ lb,
-                                                             double* __restrict__ host_out, unsigned long long seq)
+// One launch of <= kQualityBlocks workgroups; block g publishes {pairs | open << 32, sequence} as record g of the pinned block.
+constexpr int kQualityBlocks = 256;   // at most: one 16-byte record each in the pinned block
+template <int KL>
+__global__ __launch_bounds__(256) void k_quality_from_lists(const float* __restrict__ slx, const float* __restrict__ sly,
+                                                            const float* __restrict__ slz, int N, PoseF P, PoseF Pprev, float thr2,
+                                                            KnnSeeds seeds, const float* __restrict__ lb,
+                                                            unsigned long long* __restrict__ host_out, unsigned long long seq)
 {
-    __shared__ unsigned int s_pairs[16], s_open[16];
+    __shared__ unsigned int s_pairs[4], s_open[4];
     unsigned int pairs = 0u, open = 0u;
-    for (int i = (int)blockIdx.x * 1024 + (int)threadIdx.x; i < N; i += (int)gridDim.x * 1024) {
-        const float lx = slx[i], ly = sly[i], lz = slz[i];
-        float qx, qy, qz;
-        xform(P, lx, ly, lz, qx, qy, qz);
-        bool paired = false;
-        for (int e = 0; e < KL && !paired; ++e) {
-            const size_t at = (size_t)e * seeds.stride + (size_t)i;
-            if (seeds.pos[at] >= 0) paired = dist2(qx, qy, qz, seeds.x[at], seeds.y[at], seeds.z[at]) < thr2;
+    // four queries per thread and trip, everything the common case needs -- the query, entry 0 of its list, its bound -- loaded in
+    // ONE round trip (a first version walked query by query, entry by entry: 26 us at 120k queries for 3 MB of loads; 14 with the
+    // trips batched on 32 workgroups)
+    constexpr int U = 4;
+    const int stride = (int)gridDim.x * 256;
+    for (int i0 = (int)blockIdx.x * 256 + (int)threadIdx.x; i0 < N; i0 += U * stride) {
+        float lx[U], ly[U], lz[U], ex[U], ey[U], ez[U], bound[U];
+        int ep[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * stride;
+            const int ic = i < N ? i : N - 1;
+            lx[u] = slx[ic]; ly[u] = sly[ic]; lz[u] = slz[ic];
+            ep[u] = seeds.pos[ic]; ex[u] = seeds.x[ic]; ey[u] = seeds.y[ic]; ez[u] = seeds.z[ic];
+            bound[u] = lb[ic];
         }
-        if (paired) { ++pairs; continue; }
-        float ox, oy, oz;
-        xform(Pprev, lx, ly, lz, ox, oy, oz);
-        const float delta = sqrtf(dist2(qx, qy, qz, ox, oy, oz)) * kCertUp + 1e-18f;
-        const float m = (lb[i] - delta) * kCertDown;
-        if (!(m > 0.f && m * m * kCertDown > thr2)) ++open;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * stride;
+            if (i >= N) continue;
+            float qx, qy, qz;
+            xform(P, lx[u], ly[u], lz[u], qx, qy, qz);
+            bool paired = ep[u] >= 0 && dist2(qx, qy, qz, ex[u], ey[u], ez[u]) < thr2;
+            if (!paired) {   // the other entries, all loads at once (a lane here is the exception: most paired queries stop at entry 0)
+                int ps[KL];
+                float fx[KL], fy[KL], fz[KL];
+#pragma unroll
+                for (int e = 1; e < KL; ++e) {
+                    const size_t at = (size_t)e * seeds.stride + (size_t)i;
+                    ps[e] = seeds.pos[at]; fx[e] = seeds.x[at]; fy[e] = seeds.y[at]; fz[e] = seeds.z[at];
+                }
+#pragma unroll
+                for (int e = 1; e < KL; ++e) paired |= ps[e] >= 0 && dist2(qx, qy, qz, fx[e], fy[e], fz[e]) < thr2;
+            }
+            if (paired) { ++pairs; continue; }
+            float ox, oy, oz;
+            xform(Pprev, lx[u], ly[u], lz[u], ox, oy, oz);
+            const float delta = sqrtf(dist2(qx, qy, qz, ox, oy, oz)) * kCertUp + 1e-18f;
+            const float m = (bound[u] - delta) * kCertDown;
+            if (!(m > 0.f && m * m * kCertDown > thr2)) ++open;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -882,12 +911,11 @@ __global__ __launch_bounds__(1024) void k_quality_from_lists(const float* __rest
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int tp = 0u, to = 0u;
-        for (int w = 0; w < 16; ++w) { tp += s_pairs[w]; to += s_open[w]; }
-        double* row = host_out + 32 * (size_t)blockIdx.x;
-        row[16] = (double)tp;
-        row[0] = (double)to;
+        for (int w = 0; w < 4; ++w) { tp += s_pairs[w]; to += s_open[w]; }
+        volatile unsigned long long* rec = host_out + 2 * (size_t)blockIdx.x;   // {pairs | open << 32, sequence}
+        rec[0] = (unsigned long long)tp | ((unsigned long long)to << 32);
         __threadfence_system();
-        reinterpret_cast<volatile unsigned long long*>(row)[kNAcc + 6] = seq;
+        rec[1] = seq;
         __threadfence_system();
     }
 }
