@@ -75,8 +75,12 @@ enum {
  * mp2p_icp: a matcher outside its iteration range contributes no pairings; the solvers are tried in order):
  *   - at iteration `it` the ACTIVE matcher is the one whose [runFromIteration, runUpToIteration (0 = no limit)] holds it;
  *     none active = no pairings (terminates as NoPairings), as with a single entry;
- *   - two matchers active in the SAME iteration would feed mixed pairings to one solve: MOLA_ICP_E_UNSUPPORTED, named;
- *   - the solver of an iteration is the first `solvers:` entry whose range holds it (entries without a range: always).
+ *   - ONE Points_DistanceThreshold and ONE Point2Plane matcher may be active in the same iteration when its solver is
+ *     Solver_GaussNewton and no robust kernel / outlier weights are set: their pairings go into one solve (the point-to-point
+ *     sums enter the Gauss-Newton form as three plane terms per pairing: mola_icp_mixed_form); any other overlap is
+ *     MOLA_ICP_E_UNSUPPORTED, named;
+ *   - the solver of an iteration is the first `solvers:` entry whose range holds it (entries without a range: always); an
+ *     iteration no solver covers ends the align with MOLA_ICP_TERM_SOLVER_ERROR.
  * Typical use: point-to-point + Horn for the first iterations, then point-to-plane + Gauss-Newton. */
 #define MOLA_ICP_MAX_EXTRA_STAGES 3
 typedef struct mola_icp_matcher_entry {
@@ -177,7 +181,7 @@ int         mola_icp_abi_version(void);
 const char* mola_icp_last_error(void);            /* thread-local, never NULL */
 const char* mola_icp_status_string(int status);
 int         mola_icp_device_count(int* count);    /* gfx950 devices visible   */
-/* The MOLA_ICP_* diagnostic / tuning environment variables (DESIGN.md) are read once, when the library is loaded --
+/* The MOLA_ICP_* diagnostic / tuning environment variables (DESIGN.md, appendix) are read once, when the library is loaded --
  * never on a launch path.  Tests that toggle one on a live process call this to have them read again. */
 int         mola_icp_debug_reload_env(void);
 
@@ -236,7 +240,7 @@ int mola_icp_comm_destroy(mola_icp_handle* h);
 /* The node-local communicator: the all-reduce of ONE node's ranks through a POSIX shared-memory mailbox (csrc/local_comm.cpp).
  * The reduced block is consumed by each rank's host thread (the fp64 solve), and a single-GPU iteration already ends with the
  * device writing the block to pinned host memory: the ranks exchange the 24 (92) doubles there, between cores -- no launch, no
- * device-side wait, ~1 us instead of the ~25 us of a 192-byte RCCL all-reduce; every rank adds the rows in rank order, so all
+ * device-side wait, nothing measurable per step where a 192-byte RCCL all-reduce costs 13-19 us; every rank adds the rows in rank order, so all
  * ranks hold the same bits.  What `bench.py --gpus N` uses on one node; RCCL above stays for ranks on different nodes.
  *  - create: COLLECTIVE over the ranks of the node; `name` = a POSIX shm name unique to this job (rank 0 picks it and ships it
  *    like the RCCL id); returns once all `nranks` ranks have joined (then the name is unlinked: nothing is left in /dev/shm),

@@ -4,7 +4,7 @@
 // Why on the host.  The consumer of the reduced block is each rank's HOST thread (the Horn / Gauss-Newton solve is fp64 on the
 // CPU: icp_loop.cpp), and a single-GPU iteration already ends with the reduction kernel writing its block into pinned host memory
 // while the host spins on a sequence word (hip_backend.hip, "direct readback").  A device-side collective puts a second hop in
-// front of that: RCCL's all-reduce of 192 bytes costs ~25 us per iteration on this path, a hand-written
+// front of that: RCCL's all-reduce of 192 bytes costs 13-19 us per iteration on this path even with one rank, a hand-written
 // peer-write exchange over xGMI still needs an in-kernel wait on the slowest rank before the same host publish.  Here the hop is
 // the one the single-GPU loop already pays: every rank takes its own block off its GPU as always, stores it into its mailbox row
 // (one cache-line group) and reads the other rows -- sub-microsecond between cores of one node, no GPU work, no launch, no kernel

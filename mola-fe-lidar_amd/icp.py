@@ -509,7 +509,7 @@ class ICP:
 
     def comm_init_local(self, group=None, comm=None, timeout_s: float = 30.0):
         """Node-local communicator for the query-sharded path (`sharded.LocalComm`: a shared-memory mailbox on the host, where
-        the reduced block is consumed -- ~1 us per all-reduce instead of RCCL's ~25): collective over the group's ranks,
+        the reduced block is consumed -- nothing measurable per step where RCCL's costs 13-19 us): collective over the group's ranks,
         which must run on ONE node.  `comm` = an existing LocalComm to attach instead of creating one."""
         from .sharded import LocalComm
         self._local_comm = comm if comm is not None else LocalComm.from_group(group, timeout_s)

@@ -3,7 +3,7 @@
 would only show a launch or two later: every launch of a pose sequence must give the oracle's indices and d2 bit for bit
 -- through poses that converge, jump, change the gate between launches (as the quality pass does), meet exact ties and
 queries without any neighbour.  (Written for an experiment that kept per-query lower bounds between launches -- see
-DESIGN.md 'measured and dropped'; the sequences found a latent out-of-bounds read of the exact redo's padding lanes.)"""
+LAB_NOTEBOOK.md 'Measured and dropped'; the sequences found a latent out-of-bounds read of the exact redo's padding lanes.)"""
 import numpy as np
 import pytest
 
