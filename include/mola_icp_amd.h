@@ -324,6 +324,13 @@ int mola_icp_align_multi_init(mola_icp_handle* h,
  * tile boxes), so mola_icp_align_cached() does no upload and no sort.  put() with an existing id replaces it.
  * Thread-safe; a cloud being used by a running align stays alive until that align returns. */
 int mola_icp_cloud_put(mola_icp_handle* h, uint64_t id, const float* x, const float* y, const float* z, size_t n);
+/* mola_icp_cloud_put(to_id, ...) followed by mola_icp_align_cached(from_id, to_id, ...), as ONE call -- the odometry step: every scan is
+ * `to` now and `from` for the next one (src/LidarOdometry.cpp:278-279, 384-388).  The new cloud's prepare chain and the align's first
+ * launches go down the same stream without a host wait in between (the two separate calls leave the device idle 16-24 us there); the
+ * cloud enters the cache under to_id when the call is over.  *put_done (may be NULL) = 1 if it did -- also when the align itself
+ * failed; a cloud with non-finite coordinates is refused (MOLA_ICP_E_BADARG) and not cached.  Result = the two calls' result. */
+int mola_icp_align_cached_put(mola_icp_handle* h, uint64_t from_id, uint64_t to_id, const float* tx, const float* ty, const float* tz,
+                              size_t N, const double init_T[16], const mola_icp_params* p, mola_icp_result* out, int* put_done);
 int mola_icp_cloud_drop(mola_icp_handle* h, uint64_t id);        /* MOLA_ICP_E_BADARG if the id is unknown */
 int mola_icp_cloud_count(mola_icp_handle* h, size_t* count_out, size_t* device_bytes_out);
 /* The device blocks of dropped / replaced clouds are parked per device (up to MOLA_ICP_POOL_MB, default 1024) and handed to

@@ -226,6 +226,8 @@ SIGNATURES = {
     "mola_icp_cloud_count": (C.c_int, [_H, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "mola_icp_device_pool_trim": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mola_icp_align_cached": (C.c_int, [_H, C.c_uint64, C.c_uint64, _DP, C.POINTER(CParams), C.POINTER(CResult)]),
+    "mola_icp_align_cached_put": (C.c_int, [_H, C.c_uint64, C.c_uint64, _FP, _FP, _FP, C.c_size_t, _DP, C.POINTER(CParams), C.POINTER(CResult),
+                                            C.POINTER(C.c_int)]),
     "mola_icp_voxel_downsample": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, C.c_double, _FP, _FP, _FP, C.c_size_t,
                                             C.POINTER(C.c_size_t)]),
     "mola_icp_set_map_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t]),

@@ -223,14 +223,18 @@ int align_host_clouds(mola_icp_handle* h, const float* fx, const float* fy, cons
     const double t0 = now_ms();
     {
         TraceRange tr_up("mola_icp.upload");
-        if ((rc = ws.set_map_host(fx, fy, fz, M))) { lease.rc = rc; return rc; }
-        if ((rc = ws.set_local_host(tx, ty, tz, N))) { lease.rc = rc; return rc; }
+        // (no host wait behind the uploads: the caller's buffers outlive this frame, and the frame does not end before the stream has
+        // drained -- the align's last hand-over on success, the explicit wait below otherwise.  Two waits here cost config 0 ~20 us.)
+        if ((rc = ws.set_map_host(fx, fy, fz, M, false))) { (void)ws.sync(); lease.rc = rc; return rc; }
+        if ((rc = ws.set_local_host(tx, ty, tz, N, false))) { (void)ws.sync(); lease.rc = rc; return rc; }
     }
     ws.set_global_sizes(0, 0);
     ws.set_allreduce(nullptr, nullptr);
     const double t1 = now_ms();
     rc = align_on(ws, init_T, p, out);
     out->ms_upload = t1 - t0;
+    const int rcs = ws.sync();   // (nothing may still read the caller's buffers; cheap when the stream has drained)
+    if (!rc) rc = rcs;
     if (rc) lease.rc = rc;  // a workspace that failed is dropped, not pooled
     return rc;
 }
@@ -1047,6 +1051,52 @@ int mola_icp_align_cached(mola_icp_handle* h, uint64_t from_id, uint64_t to_id, 
         rc = align_on(ws, init_T, p, out);
         if (rc) lease.rc = rc;
         return rc;
+    });
+}
+
+int mola_icp_align_cached_put(mola_icp_handle* h, uint64_t from_id, uint64_t to_id, const float* tx, const float* ty, const float* tz,
+                              size_t N, const double init_T[16], const mola_icp_params* p, mola_icp_result* out, int* put_done)
+{
+    if (put_done) *put_done = 0;
+    return guarded([&]() -> int {
+        if (!h || !p || !out) return fail(MOLA_ICP_E_BADARG, "null argument");
+        int rc;
+        if ((rc = check_pose(init_T))) return rc;
+        if ((rc = validate_params(*p))) return rc;
+        std::shared_ptr<SortedCloud> from;
+        {
+            std::lock_guard<std::mutex> lk(h->cache_mtx);
+            auto a = h->cache.find(from_id);
+            if (a == h->cache.end()) return fail(MOLA_ICP_E_BADARG, "no cached cloud with id " + std::to_string(from_id));
+            from = a->second;
+        }
+        Lease lease(h);
+        if (lease.rc) return lease.rc;
+        HipWorkspace& ws = *lease.ws;
+        std::memset(out, 0, sizeof *out);
+        const double t0 = now_ms();
+        // the new cloud's prepare chain is only enqueued: the align's first launches follow it down the same stream, the device
+        // never idles between the two (a host wait there cost 16-24 us of an odometry step's ~500) -- and nobody else can see the
+        // cloud before it is finished: it enters the cache at the end
+        auto to = std::make_shared<SortedCloud>();
+        if ((rc = ws.build_cached(to, tx, ty, tz, N, false))) { lease.rc = rc; return rc; }
+        const double upload_ms = now_ms() - t0;
+        ws.use_cached_map(from);
+        ws.use_cached_local(to);
+        ws.set_global_sizes(0, 0);
+        ws.set_allreduce(nullptr, nullptr);
+        rc = align_on(ws, init_T, p, out);
+        out->ms_upload = upload_ms;
+        const int rc2 = ws.finish_build(*to);   // (whatever the align did: nothing of the build in flight, the box looked at)
+        if (!rc2 && to->ready) {
+            std::lock_guard<std::mutex> lk(h->cache_mtx);
+            h->cache[to_id] = to;
+            if (put_done) *put_done = 1;
+        } else {
+            ws.use_cached_local(std::make_shared<SortedCloud>());   // (no reference to a refused cloud stays in the pooled workspace)
+        }
+        if (rc || rc2) lease.rc = rc ? rc : rc2;
+        return rc ? rc : rc2;
     });
 }
 

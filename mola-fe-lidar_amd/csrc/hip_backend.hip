@@ -329,7 +329,7 @@ static int upload_soa(DevBuf& buf, hipStream_t st, const float* x, const float* 
     return MOLA_ICP_OK;
 }
 
-int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, size_t M)
+int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, size_t M, bool wait)
 {
     int rc = init();
     if (rc) return rc;
@@ -337,8 +337,9 @@ int HipWorkspace::set_map_host(const float* x, const float* y, const float* z, s
     if (M > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "map too large for 32-bit indices");
     HIPCHK(hipSetDevice(device_));
     if ((rc = upload_soa(map_own_, stream_, x, y, z, M, &gx_, &gy_, &gz_))) return rc;
-    // the host buffers may be pageable: finish the copies before returning (never retain caller pointers)
-    HIPCHK(hipStreamSynchronize(stream_));
+    // the host buffers may be pageable: finish the copies before returning (never retain caller pointers) -- unless the caller
+    // keeps them alive until it has waited for this stream itself (wait = false: mola_icp_align's own frame)
+    if (wait) HIPCHK(hipStreamSynchronize(stream_));
     M_ = M;
     slab_active_ = false;
     slab_violation_ = false;
@@ -372,7 +373,7 @@ int HipWorkspace::set_map_device(const float* x, const float* y, const float* z,
     return MOLA_ICP_OK;
 }
 
-int HipWorkspace::set_local_host(const float* x, const float* y, const float* z, size_t N)
+int HipWorkspace::set_local_host(const float* x, const float* y, const float* z, size_t N, bool wait)
 {
     int rc = init();
     if (rc) return rc;
@@ -380,7 +381,7 @@ int HipWorkspace::set_local_host(const float* x, const float* y, const float* z,
     if (N > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "local cloud too large for 32-bit indices");
     HIPCHK(hipSetDevice(device_));
     if ((rc = upload_soa(loc_own_, stream_, x, y, z, N, &lx_, &ly_, &lz_))) return rc;
-    HIPCHK(hipStreamSynchronize(stream_));
+    if (wait) HIPCHK(hipStreamSynchronize(stream_));
     N_ = N;
     loc_bbox_valid_ = false;
     shard_n_ = 0;
@@ -785,13 +786,36 @@ int HipWorkspace::voxel_downsample(const float* x, const float* y, const float* 
 // (`from`) or as the local cloud (`to`) of any later align without upload or sort: the reference keeps
 // keyframe clouds in the world model and re-reads them per nearby-KF / loop-closure ICP
 // (src/LidarOdometry.cpp:384-388, 658-666), and in odometry each scan is `to` once and `from` once (cpp:278-279).
+// Waits for the stream the way the accumulator hand-over does -- by looking -- for work that is known to be tens of microseconds
+// long (a cloud's prepare chain): hipStreamSynchronize's wake-up alone cost 8-10 us between the chain's last kernel and the align's
+// first launch.  Falls back to the blocking wait after ~0.3 ms of looking (large clouds, a busy device).
+hipError_t HipWorkspace::quick_sync()
+{
+    for (int spins = 0; spins < 4000; ++spins) {
+        const hipError_t e = hipStreamQuery(stream_);
+        if (e != hipErrorNotReady) return e;
+        for (int k = 0; k < 8; ++k) __builtin_ia32_pause();
+    }
+    return hipStreamSynchronize(stream_);
+}
+
 int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, const float* z, size_t n)
+{
+    std::shared_ptr<SortedCloud> alias(&sc, [](SortedCloud*) {});   // (the caller owns it)
+    return build_cached(alias, x, y, z, n, true);
+}
+
+// wait = false: the chain is only ENQUEUED -- the caller goes on to use the cloud on THIS workspace (same stream: ordered) and calls
+// finish_build() before anything else may touch it; the box is looked at by the first wait the host makes (spin_for / finish_build),
+// which needs `scp` to be the owning pointer (the box is recorded against it).
+int HipWorkspace::build_cached(const std::shared_ptr<SortedCloud>& scp, const float* x, const float* y, const float* z, size_t n, bool wait)
 {
     int rc = init();
     if (rc) return rc;
     if (n && (!x || !y || !z)) return fail(MOLA_ICP_E_BADARG, "null cloud pointer");
     if (n > (size_t)0x7fff0000) return fail(MOLA_ICP_E_BADARG, "cloud too large for 32-bit indices");
     HIPCHK(hipSetDevice(device_));
+    SortedCloud& sc = *scp;
     if ((rc = upload_soa(sc.raw, stream_, x, y, z, n, &sc.x, &sc.y, &sc.z))) return rc;
     sc.n = n;
     sc.cached = true;
@@ -799,22 +823,33 @@ int HipWorkspace::build_cached(SortedCloud& sc, const float* x, const float* y, 
     std::shared_ptr<SortedCloud> keep_sc = map_sc_;
     const float *kx = gx_, *ky = gy_, *kz = gz_;
     const size_t kM = M_;
-    std::shared_ptr<SortedCloud> tmp(&sc, [](SortedCloud*) {});
-    map_sc_ = tmp;
+    map_sc_ = scp;
     gx_ = sc.x; gy_ = sc.y; gz_ = sc.z; M_ = n;
     sc.ready = false;
     rc = n ? prepare_tiles() : MOLA_ICP_OK;
-    // (the workspace's own map is put back BEFORE any return: map_sc_ aliases the caller's cloud through a no-op deleter)
-    // (also on a failure half-way: the caller destroys the cloud, and its parked blocks may be handed to another handle at once --
-    // nothing of this build may still be running on them)
-    const hipError_t es = hipStreamSynchronize(stream_);
+    // (the workspace's own map is put back BEFORE any return)
+    // (on a failure half-way the caller destroys the cloud, and its parked blocks may be handed to another handle at once --
+    // nothing of this build may still be running on them: wait)
+    hipError_t es = hipSuccess;
+    if (wait || rc) es = quick_sync();
     map_sc_ = keep_sc;
     gx_ = kx; gy_ = ky; gz_ = kz; M_ = kM;
     if (es != hipSuccess && !rc) return fail(es == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("build_cached: ") + hipGetErrorString(es));
+    if (!wait && !rc) return MOLA_ICP_OK;
     // (the cloud's bounding box arrived with that synchronisation; a box that is not finite clears `ready` on THIS cloud -- the
     // owner recorded with the box -- not on whichever cloud sits in the workspace's map role)
     if (!rc) rc = check_bboxes();
     else { bbox_pending_ = 0; bbox_owner_[0].reset(); bbox_owner_[1].reset(); }
+    if (rc) sc.ready = false;
+    return rc;
+}
+
+// the end of a build_cached(..., wait = false): nothing of the chain in flight any more, the box looked at (if no wait did yet)
+int HipWorkspace::finish_build(SortedCloud& sc)
+{
+    const hipError_t es = quick_sync();
+    if (es != hipSuccess) { sc.ready = false; return fail(MOLA_ICP_E_HIP, std::string("finish_build: ") + hipGetErrorString(es)); }
+    const int rc = bbox_pending_ ? check_bboxes() : MOLA_ICP_OK;
     if (rc) sc.ready = false;
     return rc;
 }

@@ -111,9 +111,9 @@ class HipWorkspace final : public Stages {
     void set_comm(void* comm) { comm_ = comm; }
     void set_global_sizes(uint64_t nl, uint64_t nm) { n_local_total_ = nl; n_map_total_ = nm; }
 
-    int set_map_host(const float* x, const float* y, const float* z, size_t M);
+    int set_map_host(const float* x, const float* y, const float* z, size_t M, bool wait = true);
     int set_map_device(const float* x, const float* y, const float* z, size_t M);
-    int set_local_host(const float* x, const float* y, const float* z, size_t N);
+    int set_local_host(const float* x, const float* y, const float* z, size_t N, bool wait = true);
     int set_local_device(const float* x, const float* y, const float* z, size_t N);
     // row e (query sharding): this rank's spatially compact shard of a scan every rank sees in full -- the scan is put in
     // Hilbert order on the device (a transient copy) and the slice [lo, hi) of that order is kept as the local cloud
@@ -144,6 +144,9 @@ class HipWorkspace final : public Stages {
 
     // row f4: device-resident cloud cache
     int build_cached(SortedCloud& sc, const float* x, const float* y, const float* z, size_t n);  // host pointers
+    int build_cached(const std::shared_ptr<SortedCloud>& sc, const float* x, const float* y, const float* z, size_t n, bool wait);
+    int finish_build(SortedCloud& sc);
+    hipError_t quick_sync();
     void use_cached_map(const std::shared_ptr<SortedCloud>& sc);
     void use_cached_local(const std::shared_ptr<SortedCloud>& sc);
     int voxel_downsample(const float* x, const float* y, const float* z, size_t n, double voxel_size, float* out_x,

@@ -177,26 +177,33 @@ int mola_lo_process_scan(mola_lo* lo, double timestamp, const float* x, const fl
         const double last_obs_tim = lo->last_obs_tim;
         std::vector<float> px, py, pz;
         px.swap(lo->last_x); py.swap(lo->last_y); pz.swap(lo->last_z);
-        const bool had_points = lo->have_last_points && !px.empty();
         lo->last_obs_tim = timestamp;
         lo->have_last_tim = true;
         const bool use_cache = lo->icp && !lo->align_cb;
         const bool had_cached = lo->have_cached_last;
+        // (with the device cache, "there is a last cloud" means it is IN the cache: a scan whose upload was refused -- non-finite
+        // coordinates -- leaves no partner for the next one, which then starts over like a first scan)
+        const bool had_points = lo->have_last_points && !px.empty() && (!use_cache || had_cached);
         const uint64_t prev_id = lo->cached_last_id;
         uint64_t cur_id = 0;
+        // (a scan that will be aligned against the previous one is put in the cache BY that align: mola_icp_align_cached_put -- the
+        // new cloud's prepare chain and the align's first launches share a stream, no host wait in between)
+        const bool put_with_align = use_cache && n && had_points && had_cached;
         if (use_cache) {
             lo->last_x.assign(n ? 1 : 0, 0.f);  // the host copy is not needed: only "is there a last cloud"
             lo->last_y.clear(); lo->last_z.clear();
             lo->have_cached_last = false;
             if (n) {
                 cur_id = lo->cache_base | (lo->scan_no++ & 0xFFFFFFFFull);
-                const int rc = mola_icp_cloud_put(lo->icp, cur_id, x, y, z, n);
-                if (rc) {
-                    if (had_cached) (void)mola_icp_cloud_drop(lo->icp, prev_id);
-                    return rc;
+                if (!put_with_align) {
+                    const int rc = mola_icp_cloud_put(lo->icp, cur_id, x, y, z, n);
+                    if (rc) {
+                        if (had_cached) (void)mola_icp_cloud_drop(lo->icp, prev_id);
+                        return rc;
+                    }
+                    lo->have_cached_last = true;
+                    lo->cached_last_id = cur_id;
                 }
-                lo->have_cached_last = true;
-                lo->cached_last_id = cur_id;
             }
         } else {
             lo->last_x.assign(x, x + n); lo->last_y.assign(y, y + n); lo->last_z.assign(z, z + n);
@@ -238,7 +245,14 @@ int mola_lo_process_scan(mola_lo* lo, double timestamp, const float* x, const fl
             if (lo->align_cb)
                 rc = lo->align_cb(lo->align_user, px.data(), py.data(), pz.data(), px.size(), x, y, z, n, guess.m, &ip,
                                   &out->icp);
-            else  // both scans are already prepared in HBM
+            else if (put_with_align) {  // the previous scan is prepared in HBM; this one is prepared, aligned and cached in one go
+                int put_done = 0;
+                rc = mola_icp_align_cached_put(lo->icp, prev_id, cur_id, x, y, z, n, guess.m, &ip, &out->icp, &put_done);
+                if (put_done) {
+                    lo->have_cached_last = true;
+                    lo->cached_last_id = cur_id;
+                }
+            } else  // both scans are already prepared in HBM
                 rc = mola_icp_align_cached(lo->icp, prev_id, cur_id, guess.m, &ip, &out->icp);
             if (rc) return rc < 0 ? rc : fail(MOLA_ICP_E_INTERNAL, "align function failed");
             Mat4 rel;

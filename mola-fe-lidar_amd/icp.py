@@ -337,6 +337,17 @@ class ICP:
         L.check(L.lib().mola_icp_align_cached(self._h, int(from_id), int(to_id), _dp(T), C.byref(params.c), C.byref(r)))
         return Results.from_c(r)
 
+    def align_cached_put(self, from_id: int, to_id: int, to_pc, init_guess_to_wrt_from, params: Parameters) -> Results:
+        """`cloud_put(to_id, to_pc)` + `align_cached(from_id, to_id, ...)` in one call, without a host wait between the new cloud's
+        prepare chain and the align's first launches (the odometry step); the cloud is cached under `to_id` afterwards"""
+        T = _pose16(init_guess_to_wrt_from)
+        x, y, z, n = _soa(to_pc)
+        r = L.CResult()
+        done = C.c_int(0)
+        L.check(L.lib().mola_icp_align_cached_put(self._h, int(from_id), int(to_id), _fp(x), _fp(y), _fp(z), n, _dp(T), C.byref(params.c),
+                                                  C.byref(r), C.byref(done)))
+        return Results.from_c(r)
+
     def voxel_downsample(self, pc, voxel_size: float) -> np.ndarray:
         """one centroid per occupied voxel (row f4; the decimation step before the ICP) -> (3, n_voxels) float32"""
         x, y, z, n = _soa(pc)

@@ -6,6 +6,8 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
+import time
+
 import numpy as np
 
 from . import _lib as L
@@ -26,6 +28,7 @@ class Step:
     reference_kf: int
     accum_since_last_kf: np.ndarray
     icp: Results | None
+    ms_native: float = 0.0           # wall time of the mola_lo_process_scan call itself (this wrapper's marshalling excluded)
 
 
 class LidarOdometryParams:
@@ -178,9 +181,12 @@ class LidarOdometry:
     def on_new_observation(self, timestamp: float, cloud) -> Step:
         x, y, z, n = _soa(cloud)
         s = L.CLoStep()
-        L.check(L.lib().mola_lo_process_scan(self._h, float(timestamp), _fp(x), _fp(y), _fp(z), n, C.byref(s)))
+        t0 = time.perf_counter()
+        rc = L.lib().mola_lo_process_scan(self._h, float(timestamp), _fp(x), _fp(y), _fp(z), n, C.byref(s))
+        ms_native = (time.perf_counter() - t0) * 1e3
+        L.check(rc)
         fac = (s.kf_factor_from, s.kf_factor_to, np.array(s.kf_factor_pose).reshape(4, 4)) if s.kf_factor_valid else None
         return Step(s.status, bool(s.used_with_vel_params), s.dt, np.array(s.rel_pose).reshape(4, 4), np.array(s.twist),
                     s.dist_since_last_kf, s.rot_since_last_kf, bool(s.keyframe_created), fac, s.reference_kf,
                     np.array(s.accum_since_last_kf).reshape(4, 4),
-                    Results.from_c(s.icp) if s.status == L.LO_ICP_RAN else None)
+                    Results.from_c(s.icp) if s.status == L.LO_ICP_RAN else None, ms_native)

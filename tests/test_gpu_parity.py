@@ -605,3 +605,40 @@ def test_native_rccl_single_rank(pkg, icp, golden):
     b = h.align_resident(np.eye(4), pp)
     assert a.nIterations == b.nIterations and np.array_equal(a.optimal_tf, b.optimal_tf)
     h.close()
+
+
+@pytest.mark.gpu
+def test_align_cached_put_is_put_then_align(pkg, synth, small_scene):
+    """mola_icp_align_cached_put (the odometry step: the new scan is prepared, aligned and cached in one call, no host wait between
+    its prepare chain and the align's first launches) = cloud_put + align_cached, bit for bit, for both pipelines; the cloud is in
+    the cache afterwards and serves as `from`; a cloud with a NaN is refused and NOT cached, an unknown `from` is an error"""
+    icp = pkg.ICP(device=0)
+    ref = pkg.ICP(device=0)
+    shipped = pkg.Parameters.load_from_file(os.path.join(os.path.dirname(os.path.dirname(__file__)), "params", "icp-settings-regular.yaml"))
+    p2p = p2p_params(pkg, max_iterations=30, matcher_threshold=0.6)
+    clouds = [synth.make_pair(20_000 + 700 * k, 10, seed=400 + k, scene=small_scene)[1] for k in range(5)]
+    icp.cloud_put(0, clouds[0])
+    ref.cloud_put(0, clouds[0])
+    for k in range(1, 5):
+        p = shipped if k % 2 else p2p
+        r = icp.align_cached_put(k - 1, k, clouds[k], np.eye(4), p)
+        ref.cloud_put(k, clouds[k])
+        s = ref.align_cached(k - 1, k, np.eye(4), p)
+        assert r.nIterations == s.nIterations and r.terminationReason == s.terminationReason
+        assert np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality and r.n_pairs == s.n_pairs
+    assert icp.cloud_count()[0] == 5
+    bad = clouds[2].copy()
+    bad[1, 1234] = np.nan
+    with pytest.raises(pkg.IcpError, match="non-finite"):
+        icp.align_cached_put(4, 77, bad, np.eye(4), shipped)
+    assert icp.cloud_count()[0] == 5
+    with pytest.raises(pkg.IcpError):
+        icp.align_cached(4, 77, np.eye(4), shipped)
+    with pytest.raises(pkg.IcpError, match="no cached cloud"):
+        icp.align_cached_put(1234, 78, clouds[1], np.eye(4), shipped)
+    assert icp.cloud_count()[0] == 5
+    # ... and the handle is fine afterwards
+    r = icp.align_cached_put(4, 79, clouds[1], np.eye(4), shipped)
+    assert r.nIterations >= 1 and icp.cloud_count()[0] == 6
+    icp.close()
+    ref.close()

@@ -1,6 +1,6 @@
 """The prepare chain (mola-fe-lidar_amd/csrc/map_sort.hip; the role of the kd-tree build in the reference: a new global cloud
-every scan, src/LidarOdometry.cpp:215-234, 279): Hilbert keys, the hand-written stable sort (runs of 4096 through a bitonic
-network + 32-way merges by ranking), the stable compaction, the fused box levels.  CPU: the library carries no rocPRIM / hipCUB
+every scan, src/LidarOdometry.cpp:215-234, 279): Hilbert keys, the hand-written stable sort (runs of 2048 through a bitonic
+network + 8-way merges by ranking), the stable compaction, the fused box levels.  CPU: the library carries no rocPRIM / hipCUB
 code any more and the sort's logic equals std::stable_sort (tests/hosts/sort_net_test.cpp walks the device functions thread by
 thread).  GPU: the order the device produces equals a numpy restatement of the same fp32 key arithmetic + a stable argsort, at
 sizes on both sides of every run / merge-level boundary."""
