@@ -3,6 +3,7 @@
  * Test infrastructure: built by tests/test_boundary_hosts.py with `gcc -std=c11 -Wall -Wextra -Werror -pedantic`. */
 #include <math.h>
 #include <stdio.h>
+#include <unistd.h>
 #include <string.h>
 
 #include "mola_icp_amd.h"
@@ -87,6 +88,23 @@ int main(void)
         kf[2].kf_id = 9; kf[2].eucl_dist = 2.0; kf[2].topo_dist = 1;
         expect(mola_lo_select_checks(&lp, kf, 3, ids, 3, &n, &lc, &has) == MOLA_ICP_OK && n == 1 && ids[0] == 7 && has && lc == 8, "select_checks");
         expect(mola_lo_montecarlo_guesses(g6, 30.0, 2, 1u, guesses, NULL) == MOLA_ICP_OK && guesses[4] == g6[4] && guesses[0] != g6[0], "montecarlo_guesses");
+    }
+    /* the node-local communicator with one rank: create (collective of one), reduce, the error paths, destroy: host-only */
+    {
+        mola_icp_local_comm* c = NULL;
+        double v[24];
+        int n = 0, k;
+        char name[64];
+        snprintf(name, sizeof name, "mola_icp_c_walk_%ld", (long)getpid());
+        expect(mola_icp_local_comm_create(NULL, 1, 0, 1.0, &c) == MOLA_ICP_E_BADARG, "local_comm_create: NULL name -> BADARG");
+        expect(mola_icp_local_comm_create(name, 2, 2, 1.0, &c) == MOLA_ICP_E_BADARG && c == NULL, "local_comm_create: rank out of range -> BADARG");
+        expect(mola_icp_local_comm_create(name, 1, 0, 1.0, &c) == MOLA_ICP_OK && c != NULL, "local_comm_create: one rank");
+        expect(mola_icp_local_comm_nranks(c, &n) == MOLA_ICP_OK && n == 1, "local_comm_nranks == 1");
+        for (k = 0; k < 24; ++k) v[k] = 0.5 * k;
+        expect(mola_icp_local_comm_allreduce(c, v, 24) == MOLA_ICP_OK && v[7] == 3.5, "local_comm_allreduce: one rank leaves the block as it is");
+        expect(mola_icp_local_comm_allreduce(c, v, 121) == MOLA_ICP_E_BADARG, "local_comm_allreduce: payload beyond 120 -> BADARG");
+        expect(mola_icp_local_comm_allreduce(NULL, v, 24) == MOLA_ICP_E_BADARG, "local_comm_allreduce: NULL -> BADARG");
+        expect(mola_icp_local_comm_destroy(c) == MOLA_ICP_OK, "local_comm_destroy");
     }
     printf("%s (%d failure%s)\n", fails ? "FAILED" : "PASSED", fails, fails == 1 ? "" : "s");
     return fails ? 1 : 0;
