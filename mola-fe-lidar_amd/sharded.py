@@ -48,12 +48,13 @@ def slab_margin_for_guess(box_lo, box_hi, gate: float, max_dt: float, max_drot: 
     return float(gate + max_dt + 2.0 * np.sin(0.5 * max_drot) * far)
 
 
-def balanced_cuts(cuts, cost) -> list[int]:
+def balanced_cuts(cuts, cost, relax: float = 1.0) -> list[int]:
     """Cuts of equal COST.  `cuts` = the W + 1 boundaries of the shards in force (positions in the scan's Hilbert order, cuts[0] = 0,
     cuts[W] = n), `cost` = what each shard's step cost (W values: seconds of a timed iteration, or the matcher's own time) -- taken
     as uniform inside a shard.  Returns W + 1 new boundaries where the cumulated cost reaches k / W of the total.  Every rank
     computes the same cuts from the same all-reduced cost vector.  One or two rounds settle: the cost per query varies smoothly
-    along the curve (it follows how far the guess displaces that part of the scan)."""
+    along the curve (it follows how far the guess displaces that part of the scan).  `relax` < 1 moves every cut only that fraction
+    of the way (the model is crude where a shard holds a short, very expensive stretch: full steps can overshoot)."""
     cuts = [int(c) for c in cuts]
     w = len(cuts) - 1
     cost = np.maximum(np.asarray(cost, np.float64), 1e-12)
@@ -65,7 +66,8 @@ def balanced_cuts(cuts, cost) -> list[int]:
         j = int(np.searchsorted(cum, target, side="right") - 1)
         j = min(max(j, 0), w - 1)
         frac = (target - cum[j]) / cost[j]
-        new.append(int(round(cuts[j] + frac * (cuts[j + 1] - cuts[j]))))
+        target_cut = cuts[j] + frac * (cuts[j + 1] - cuts[j])
+        new.append(int(round(cuts[k] + relax * (target_cut - cuts[k]))))
     new.append(cuts[-1])
     for k in range(1, w + 1):   # monotone, whatever the rounding did
         new[k] = max(new[k], new[k - 1])
@@ -159,30 +161,60 @@ class ShardedICP:
         res = s.align(init_guess, params)   # identical Results on every rank
     """
 
-    def __init__(self, icp, group=None):
+    def __init__(self, icp, group=None, collective: str = "auto"):
+        """collective: "local" = the node-local shared-memory communicator (`LocalComm`; the ranks must share a node), "rccl" /
+        "hook" = the process group's own transport (native RCCL on the device block for the nccl backend, torch.distributed from
+        the host hook otherwise), "auto" = local when every rank reports the same host name, else the group's transport."""
         import torch.distributed as dist
         self.icp = icp
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._ar = None
+        self.collective = None
+        self._cuts = None
         if self.world > 1:
-            if dist.get_backend(group) == "nccl":
+            if collective == "auto":
+                import socket
+                names = [None] * self.world
+                dist.all_gather_object(names, socket.gethostname(), group=group)
+                collective = "local" if len(set(names)) == 1 else "group"
+            if collective == "local":
+                icp.comm_init_local(group)
+                self.collective = "local"
+            elif dist.get_backend(group) == "nccl" and collective != "hook":
                 icp.comm_init(group)  # native RCCL on the device accumulator block
+                self.collective = "rccl"
             else:
                 self._ar = make_allreduce(group)
                 icp.set_allreduce(self._ar)
+                self.collective = "hook"
 
-    def set_clouds(self, map_pc, local_pc_full, spatial: bool = True, init_guess=None, slab_margin: float | None = None):
+    def set_clouds(self, map_pc, local_pc_full, spatial: bool = True, init_guess=None, slab_margin: float | None = None,
+                   guess_uncertainty: tuple[float, float] | None = None, gate: float | None = None):
         """Every rank passes the same full clouds.  It keeps (i) a spatially compact shard of the scan: its slice of the
-        scan's Hilbert order, cut on the device (`mola_icp_set_local_shard_*`; no host argsort) and, with `slab_margin`
-        [m], (ii) only the part of the map that shard can reach from `init_guess`: its moved bounding box grown by the
-        margin (`mola_icp_set_map_slab_*`).  The margin must cover the matcher's gate plus the pose correction the align
-        may make; an align that leaves the slab fails loudly (`IcpError`, "outside its map slab") -- `align` below then
-        cuts a larger slab and runs again."""
+        scan's Hilbert order, cut on the device (`mola_icp_set_local_shard_*`; no host argsort) and, with a margin, (ii) only
+        the part of the map that shard can reach from `init_guess`: its moved bounding box grown by the margin
+        (`mola_icp_set_map_slab_*`).  The margin is `slab_margin` [m], or -- `guess_uncertainty` = (max_dt [m], max_drot [rad])
+        and `gate` [m] given -- `slab_margin_for_guess` of THIS rank's shard.  It must cover the matcher's gate plus the pose
+        correction the align may make; an align that leaves the slab fails loudly (`IcpError`, "outside its map slab") --
+        `align` below then cuts a larger slab and runs again."""
         n = local_pc_full.shape[1]
         self._full = (map_pc, local_pc_full, init_guess)
-        if spatial:
+        self._spatial = spatial
+        self._guess_uncertainty, self._gate = guess_uncertainty, gate
+        self._slab_margin = slab_margin
+        self._slab_scale = 1.0
+        self._cut_shard()
+        self._cut_slab()
+        self.icp.set_global_sizes(n, map_pc.shape[1])
+
+    def _cut_shard(self):
+        _, local_pc_full, _ = self._full
+        n = local_pc_full.shape[1]
+        if self._spatial and self._cuts is not None:
+            self.icp.set_local_shard_range(local_pc_full, self._cuts[self.rank], self._cuts[self.rank + 1])
+        elif self._spatial:
             self.icp.set_local_shard(local_pc_full, self.rank, self.world)
         else:
             lo, hi = shard_bounds(n, self.rank, self.world)
@@ -190,18 +222,71 @@ class ShardedICP:
             if hasattr(shard, "contiguous"):
                 shard = shard.contiguous()
             self.icp.set_local(shard)
-        self._slab_margin = slab_margin
-        self._cut_slab()
-        self.icp.set_global_sizes(n, map_pc.shape[1])
+
+    def balance(self, params, rounds: int = 2, probe_iterations: int = 4) -> list[int]:
+        """Cuts of equal COST instead of equal count (`balanced_cuts`): every round, each rank times `probe_iterations` fixed
+        iterations of `params` from the guess on the shards in force, the W times are all-gathered, all ranks cut again at the
+        same places; the best cuts measured stay in force.  Worth it where the guess is far off and the align takes many
+        iterations (the cost per query then varies several-fold along the scan and a step is as long as its slowest rank);
+        each round costs a re-cut of the shard and the slab (milliseconds).  Returns the cuts."""
+        import time
+        import torch
+        import torch.distributed as dist
+        from ._lib import IcpError
+        assert hasattr(self, "_full") and self._spatial and self.world > 1
+        map_pc, local_full, guess = self._full
+        n = local_full.shape[1]
+        T0 = np.eye(4) if guess is None else np.asarray(guess, np.float64).reshape(4, 4)
+        q = params.copy()
+        q.max_iterations, q.fixed_iterations, q.skip_quality = probe_iterations, 1, 1
+        cuts = self._cuts or [shard_bounds(n, r, self.world)[0] for r in range(self.world)] + [n]
+        best = None
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        for rnd in range(rounds + 1):
+            try:   # (all ranks run the same number of all-reduces: the probe is an ordinary sharded align)
+                self.icp.align_resident(T0, q)
+                t0 = time.perf_counter()
+                self.icp.align_resident(T0, q)
+                mine = (time.perf_counter() - t0) / probe_iterations
+            except IcpError:
+                mine = float("nan")
+            v = torch.zeros(self.world, dtype=torch.float64)
+            v[self.rank] = mine
+            if on_gpu:
+                v = v.cuda()
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            cost = v.cpu().numpy()
+            if not np.all(np.isfinite(cost)):
+                break
+            if best is None or float(cost.max()) < best[1]:
+                best = (list(cuts), float(cost.max()))
+            if rnd == rounds:
+                break
+            cuts = balanced_cuts(cuts, cost)
+            self._cuts = cuts
+            self._cut_shard()
+            self._cut_slab()
+        if best is not None and best[0] != list(cuts):
+            self._cuts = best[0]
+            self._cut_shard()
+            self._cut_slab()
+        return list(self._cuts or cuts)
 
     def _cut_slab(self):
         map_pc, _, init_guess = self._full
-        if self._slab_margin is None:
+        T0 = np.eye(4) if init_guess is None else np.asarray(init_guess, dtype=np.float64)
+        margin = self._slab_margin
+        if margin is None and getattr(self, "_guess_uncertainty", None) is not None and self._gate is not None:
+            lo0, hi0 = self.icp.shard_reach_box(T0, 0.0)
+            margin = slab_margin_for_guess(lo0, hi0, self._gate, self._guess_uncertainty[0], self._guess_uncertainty[1])
+        if margin is None:
             self.icp.set_map(map_pc)
             self.n_map_kept = map_pc.shape[1]
+            self.slab_margin_used = None
             return
-        T0 = np.eye(4) if init_guess is None else np.asarray(init_guess, dtype=np.float64)
-        lo, hi = self.icp.shard_reach_box(T0, self._slab_margin)
+        margin *= getattr(self, "_slab_scale", 1.0)
+        self.slab_margin_used = margin
+        lo, hi = self.icp.shard_reach_box(T0, margin)
         self.n_map_kept = self.icp.set_map_slab(map_pc, lo, hi)
 
     def set_shard(self, map_pc, local_shard, n_local_total: int):
@@ -213,7 +298,7 @@ class ShardedICP:
         """identical Results on every rank.  With a map slab: if ANY rank's pose leaves its slab, every rank doubles the
         margin, cuts again and the align is repeated (the decision is all-reduced, so the ranks stay in step)."""
         from ._lib import IcpError
-        if getattr(self, "_slab_margin", None) is None or not hasattr(self, "_full"):
+        if not hasattr(self, "_full") or getattr(self, "slab_margin_used", None) is None:
             return self.icp.align_resident(init_guess, params)
         import torch
         import torch.distributed as dist
@@ -247,6 +332,6 @@ class ShardedICP:
                 left = int(flag.item())
             if not left:
                 return res
-            self._slab_margin *= 2.0
+            self._slab_scale = getattr(self, "_slab_scale", 1.0) * 2.0
             self._cut_slab()
         raise IcpError(-1, "the align keeps leaving its map slab")

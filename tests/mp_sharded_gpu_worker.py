@@ -1,6 +1,7 @@
 """One rank of the two-rank GPU test (tests/test_sharded_gpu.py): started as a FRESH process per rank (never re-exec a
-process that has touched the GPU), gloo process group, the product's HIP stages on this rank's shard + map slab, the
-accumulator all-reduce through the host hook.  argv: rank world port outdir scenario"""
+process that has touched the GPU), gloo process group for the rendezvous, the product's HIP stages on this rank's shard + map slab,
+the accumulator all-reduce through the node-local communicator (ShardedICP's choice when every rank is on one host; scenario
+"hook": the torch.distributed hook).  argv: rank world port outdir scenario"""
 import importlib
 import os
 import sys
@@ -22,11 +23,15 @@ def main():
     try:
         g, l, Tgt = synth.make_pair(60_000, 90_000, seed=23)
         icp = pkg.ICP(device=0)
-        s = sharded.ShardedICP(icp)
-        if scenario == "p2p":
+        s = sharded.ShardedICP(icp, collective="hook" if scenario == "hook" else "auto")
+        assert s.collective == ("hook" if scenario == "hook" else "local"), s.collective
+        unc = None
+        if scenario in ("p2p", "hook", "balance"):
             p = pkg.Parameters()
             p.matcher_threshold, p.max_iterations, p.min_abs_step_trans, p.min_abs_step_rot = 1.0, 40, 5e-5, 1e-5
             margin = 4.5
+            if scenario == "balance":   # the margin from the guess' stated uncertainty, the cuts by cost
+                margin, unc = None, (1.0, np.deg2rad(3.0))
         elif scenario == "p2pl":
             p = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-regular.yaml"))
             margin = 4.5
@@ -34,12 +39,13 @@ def main():
             p = pkg.Parameters()
             p.matcher_threshold, p.max_iterations, p.min_abs_step_trans, p.min_abs_step_rot = 1.0, 40, 5e-5, 1e-5
             margin = 1.05
-        s.set_clouds(g, l, init_guess=np.eye(4), slab_margin=margin)
-        m0 = s._slab_margin
+        s.set_clouds(g, l, init_guess=np.eye(4), slab_margin=margin, guess_uncertainty=unc, gate=1.0)
+        cuts = s.balance(p, rounds=1) if scenario == "balance" else []
+        m0 = s.slab_margin_used
         r = s.align(np.eye(4), p)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), T=r.optimal_tf, nit=r.nIterations, term=r.terminationReason,
                  quality=r.quality, n_pairs=r.n_pairs, n_shard=icp._shard_n, n_map_kept=s.n_map_kept, margin0=m0,
-                 margin=s._slab_margin, shard_idx=icp.local_shard_indices())
+                 margin=s.slab_margin_used, shard_idx=icp.local_shard_indices(), cuts=np.array(cuts, dtype=np.int64))
         icp.close()
     finally:
         dist.destroy_process_group()

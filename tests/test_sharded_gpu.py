@@ -67,7 +67,7 @@ def test_device_shard_cut_and_map_slab_single_process(pkg, O, synth):
     full.close()
 
 
-@pytest.mark.parametrize("scenario", ["p2p", "p2pl", "recut"])
+@pytest.mark.parametrize("scenario", ["p2p", "p2pl", "recut", "hook", "balance"])
 def test_two_ranks_on_one_gpu_equal_single_process(pkg, synth, tmp_path, scenario):
     world = 2
     port = _free_port()
@@ -105,6 +105,10 @@ def test_two_ranks_on_one_gpu_equal_single_process(pkg, synth, tmp_path, scenari
     assert len(np.intersect1d(res[0]["shard_idx"], res[1]["shard_idx"])) == 0
     if scenario == "recut":    # the 0.54 m / 2 deg correction does not fit a 1.05 m margin: both ranks cut again, together
         assert all(float(r["margin"]) > float(r["margin0"]) for r in res)
+    if scenario == "balance":  # margin from the guess (1 m, 3 deg) and THIS shard's farthest corner; cuts by cost, the same on both ranks
+        assert all(2.0 < float(r["margin"]) < 12.0 for r in res)
+        assert np.array_equal(res[0]["cuts"], res[1]["cuts"]) and res[0]["cuts"][0] == 0 and res[0]["cuts"][-1] == l.shape[1]
+        assert int(res[0]["n_shard"]) == int(res[0]["cuts"][1])
     icp.close()
 
 

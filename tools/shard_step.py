@@ -21,6 +21,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--n-map", type=int, default=0)
 ap.add_argument("--balance-rounds", type=int, default=2)
+ap.add_argument("--relax", type=float, default=1.0)
 args = ap.parse_args()
 pkg = importlib.import_module("mola-fe-lidar_amd")
 synth = importlib.import_module("mola-fe-lidar_amd.synth")
@@ -93,4 +94,4 @@ else:
                               "step_ms_slowest_rank": worst["ms_per_iteration"],
                               "projected_speedup_before_collective": base / worst["ms_per_iteration"],
                               "step_ms_mean_rank": float(np.mean([r["ms_per_iteration"] for r in rows])), "ranks": rows}), flush=True)
-            cuts = sharded.balanced_cuts(cuts, [r["ms_per_iteration"] for r in rows])
+            cuts = sharded.balanced_cuts(cuts, [r["ms_per_iteration"] for r in rows], relax=args.relax)
