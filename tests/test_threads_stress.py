@@ -78,3 +78,40 @@ def test_eight_threads_through_the_host_side_of_the_c_abi(pkg, O, golden):
         t.join()
     assert not errors, errors
     assert len(out) == N_THREADS
+
+
+def test_local_comm_ranks_as_threads(pkg):
+    """the node-local communicator with its ranks as THREADS of one process (each its own handle and mapping of the segment):
+    the collective create, 3000 all-reduces of both block lengths in lockstep, rank-ordered sums on every rank -- the form in which
+    the sanitizer runs see both sides of the mailbox protocol (csrc/local_comm.cpp)"""
+    import importlib
+    import os
+    import threading
+    sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+    world = 4
+    name = f"mola_icp_thr_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little'):x}"
+    errs, outs = [], [None] * world
+
+    def rank_main(r):
+        try:
+            c = sharded.LocalComm(name, world, r, timeout_s=30.0)
+            acc = []
+            for k in range(3000):
+                n = 24 if k % 2 else 92
+                a = np.full(n, float(r + 1) * (k + 1))
+                c.allreduce(a)
+                if k % 500 == 0:
+                    acc.append(a.copy())
+            c.close()
+            outs[r] = acc
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs, errs
+    for r in range(world):
+        for i, k in enumerate(range(0, 3000, 500)):
+            want = sum(float(q + 1) * (k + 1) for q in range(world))
+            assert np.all(outs[r][i] == want)
