@@ -1357,6 +1357,35 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
             std::fprintf(stderr, "[mola_icp debug]   per item (median / p90 / max): staged points %llu / %llu / %llu, tile tests %llu / %llu / %llu, super-tiles entered %llu / %llu / %llu, lanes not certified %llu / %llu / %llu; items with a plane solve %llu, items that skipped the sweep %llu of %d\n",
                          pct(staged_v, 0.5), pct(staged_v, 0.9), pct(staged_v, 1.0), pct(tests_v, 0.5), pct(tests_v, 0.9), pct(tests_v, 1.0), pct(supers_v, 0.5), pct(supers_v, 0.9),
                          pct(supers_v, 1.0), pct(open_v, 0.5), pct(open_v, 0.9), pct(open_v, 1.0), n_changed, n_skip, n_items64);
+            // ... and is a heavy item a SPREAD one?  (64 consecutive sorted queries that are not compact in space: the sparse far rings
+            // of a scan, an empty stretch of the curve): the item's own bounding box, from the sorted queries
+            {
+                const size_t np_ = loc_sc_->padded;
+                std::vector<float> sq(3 * np_);
+                HIPCHK(hipMemcpy(sq.data(), loc_sc_->sorted.p, sizeof(float) * 3 * np_, hipMemcpyDeviceToHost));
+                std::vector<double> diag((size_t)n_items64, 0.0);
+                for (int it = 0; it < n_items64; ++it) {
+                    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+                    for (size_t q = (size_t)it * 64; q < std::min((size_t)N_, (size_t)(it + 1) * 64); ++q)
+                        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)sq[a * np_ + q]); hi[a] = std::max(hi[a], (double)sq[a * np_ + q]); }
+                    diag[(size_t)it] = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+                }
+                std::vector<int> ord((size_t)n_items64);
+                for (int it = 0; it < n_items64; ++it) ord[(size_t)it] = it;
+                auto whole = [&](int it) { return h[((size_t)it * 4) * kKnnDiagWords + 11]; };
+                std::sort(ord.begin(), ord.end(), [&](int a, int b) { return whole(a) > whole(b); });
+                for (int r = 0; r < 8 && r < n_items64; ++r) {
+                    const int it = ord[(size_t)r];
+                    unsigned long long st = 0, tt = 0;
+                    for (int wv = 0; wv < 4; ++wv) { const unsigned long long c = h[((size_t)it * 4 + wv) * kKnnDiagWords + 10]; st += c & 0xfffffull; tt += (c >> 32) & 0xfffffull; }
+                    std::fprintf(stderr, "[mola_icp debug]   heaviest item %d: %llu cycles, box diagonal of its 64 queries %.2f m, staged points %llu, tile tests %llu\n", it, whole(it),
+                                 diag[(size_t)it], st, tt);
+                }
+                std::vector<unsigned long long> compact, spread;
+                for (int it = 0; it < n_items64; ++it) (diag[(size_t)it] > 3.0 ? spread : compact).push_back(whole(it));
+                std::fprintf(stderr, "[mola_icp debug]   whole item, queries within 3 m of each other (%zu items): %llu / %llu / %llu; spread wider (%zu items): %llu / %llu / %llu\n",
+                             compact.size(), pct(compact, 0.5), pct(compact, 0.9), pct(compact, 1.0), spread.size(), pct(spread, 0.5), pct(spread, 0.9), pct(spread, 1.0));
+            }
         } else
         switch (p.knn) {
             case 3: MOLA_LAUNCH_KNN_COOP(4); break;

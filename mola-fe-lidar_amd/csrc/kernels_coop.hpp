@@ -157,6 +157,23 @@ __device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, con
                 }
                 ucand = __ballot(u0 <= w.hi[0] && u1 <= w.hi[1] && u2 <= w.hi[2] && u3 >= w.lo[0] && u4 >= w.lo[1] &&
                                  u5 >= w.lo[2]);
+                // A query group spread over many top boxes -- 64 consecutive sorted queries that straddle an empty stretch of the
+                // curve: in a sparse scene two of 15 625 items span ~100 m -- must not descend into every one of them: against a
+                // 10M-point map that is 76 dependent box loads and 4 900 per-query tests for ONE item, which then is as long as
+                // the whole launch (0.25 ms; profiles/r04/sharded).  So such a group tests the top boxes per query first, as the
+                // two levels below always do.  Exact for the same reason (a top box contains its super-tiles' boxes).  Ordinary
+                // groups (<= 4 candidate top boxes) do not pay for it.
+                if (__builtin_popcountll(ucand) > 4) {
+                    unsigned long long uc = ucand, keep = 0ull;
+                    while (uc) {
+                        const int t = __builtin_ctzll(uc);
+                        uc &= uc - 1;
+                        if (any_reach(bcast_lane(u0, t), bcast_lane(u1, t), bcast_lane(u2, t), bcast_lane(u3, t), bcast_lane(u4, t),
+                                      bcast_lane(u5, t)))
+                            keep |= 1ull << t;
+                    }
+                    ucand = keep;
+                }
                 ub += 64;
             } else {
                 break;
