@@ -1088,7 +1088,7 @@ int mola_icp_align_cached_put(mola_icp_handle* h, uint64_t from_id, uint64_t to_
         rc = align_on(ws, init_T, p, out);
         out->ms_upload = upload_ms;
         const int rc2 = ws.finish_build(*to);   // (whatever the align did: nothing of the build in flight, the box looked at)
-        if (!rc2 && to->ready) {
+        if (!rc2 && (to->ready || N == 0)) {   // (an empty cloud is cached as mola_icp_cloud_put caches it)
             std::lock_guard<std::mutex> lk(h->cache_mtx);
             h->cache[to_id] = to;
             if (put_done) *put_done = 1;

@@ -637,8 +637,11 @@ def test_align_cached_put_is_put_then_align(pkg, synth, small_scene):
     with pytest.raises(pkg.IcpError, match="no cached cloud"):
         icp.align_cached_put(1234, 78, clouds[1], np.eye(4), shipped)
     assert icp.cloud_count()[0] == 5
+    # an empty scan: cached like cloud_put caches it, the align ends without pairings
+    r = icp.align_cached_put(4, 80, np.zeros((3, 0), np.float32), np.eye(4), shipped)
+    assert r.nIterations == 0 and r.quality == 0.0 and icp.cloud_count()[0] == 6
     # ... and the handle is fine afterwards
     r = icp.align_cached_put(4, 79, clouds[1], np.eye(4), shipped)
-    assert r.nIterations >= 1 and icp.cloud_count()[0] == 6
+    assert r.nIterations >= 1 and icp.cloud_count()[0] == 7
     icp.close()
     ref.close()
