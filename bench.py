@@ -203,7 +203,7 @@ def main():
     # (the headline keeps equal-count shards unless asked otherwise: at 1M x 1M the ranks' steps are within ~10 % of each other and
     # a re-cut can push a rank across the 131k-query line between the cooperative and the persistent matcher; the configs[4] leg,
     # where one stretch of the scan costs several times the rest, re-cuts by default)
-    if world > 1 and args.balance_headline > 0:
+    if world > 1 and args.balance_headline > 0 and not args.share_gpu:
         n_shard, slab, balance, cuts = balance_shards(icp, tg, tl, N, probe_p, args.balance_headline)
     else:
         (n_shard, slab), balance, cuts = place_clouds(icp, tg, tl), None, None
@@ -544,7 +544,7 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
     icp5 = pkg.ICP(device=local_rank)
     p = pkg.Parameters()
     p.matcher_threshold, p.fixed_iterations, p.skip_quality, p.max_iterations = GATE_M, 1, 1, args.c5_steps
-    if world > 1 and args.balance_rounds > 0:
+    if world > 1 and args.balance_rounds > 0 and not args.share_gpu:   # (ranks time-slicing one device measure each other, not their shards)
         n_shard, slab, balance, cuts = balance_shards(icp5, tg5, tl5, N, p, args.balance_rounds)
     else:
         (n_shard, slab), balance, cuts = place_clouds(icp5, tg5, tl5), None, None

@@ -69,7 +69,14 @@ def balanced_cuts(cuts, cost, relax: float = 1.0) -> list[int]:
         target_cut = cuts[j] + frac * (cuts[j + 1] - cuts[j])
         new.append(int(round(cuts[k] + relax * (target_cut - cuts[k]))))
     new.append(cuts[-1])
-    for k in range(1, w + 1):   # monotone, whatever the rounding did
+    # no shard below a quarter of the equal share (a cost vector that says otherwise is a measurement gone wrong -- ranks
+    # time-slicing one device, a probe that hit a cold start -- not a property of the scan), monotone whatever the rounding did
+    n, lo_share = cuts[-1] - cuts[0], (cuts[-1] - cuts[0]) // (4 * w)
+    for k in range(1, w):
+        new[k] = max(new[k], new[k - 1] + lo_share)
+    for k in range(w - 1, 0, -1):
+        new[k] = min(new[k], new[k + 1] - lo_share)
+    for k in range(1, w + 1):
         new[k] = max(new[k], new[k - 1])
     return new
 

@@ -49,8 +49,7 @@ def test_two_self_launched_ranks_share_the_gpu():
     assert j["config"]["ranks_share_gpus"] is True and "query-shard x2, local all-reduce" in j["config"]["parallelism"]
     assert j["config"]["comm_nranks"] == 2        # both ranks joined the mailbox
     assert j["config"]["queries_per_gpu"] == 30000 and j["config"]["shard_balance"] is None      # (the headline: equal counts)
-    bal = j["c5_sharded"]["shard_balance"]                     # (the configs[4] leg re-cuts by cost and keeps the best cuts measured)
-    assert bal["cuts"][0] == 0 and bal["cuts"][-1] == 60000 and len(bal["rounds"]) >= 1
+    assert j["c5_sharded"]["shard_balance"] is None            # (ranks sharing one device: no cost-balanced re-cut -- they would time each other)
     assert j["config"]["map_slab_rank0"]["margin_m"] > 2.0 and "recut" not in j["config"]["map_slab_rank0"]
     c5 = j["c5_sharded"]                          # configs[4]'s shape beside the headline, slab per rank
     assert c5["n_map"] == 150000 and c5["value"] > 0 and c5["map_slab_rank0"]["map_points_kept"] < 150000
