@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 4) void k_nn_coop(const NnBatch<KMAX> batch, i
     float(*sm)[64] = s_m[wave];
     const NnProblem& pb = batch.p[KMAX == 1 ? 0 : blockIdx.y];
     const int N = pb.N;
-    const int item = xcd_item((int)blockIdx.x, (N + kQPW - 1) / kQPW);
+    const int item = lds_boxes ? (int)blockIdx.x : xcd_item((int)blockIdx.x, (N + kQPW - 1) / kQPW);   // (see k_knn_coop)
     if (item * kQPW >= N) return;  // nothing for this workgroup (uniform: before any barrier)
     const float thr2 = pb.thr2;
     const int use_seed = pb.use_seed;

@@ -55,6 +55,16 @@ print("C5 equal-count shards 1 and 5 of 8 (the two that hold a 100-m item): %.4f
 icp.close()
 del tg5
 import bench
+g1, l1, _ = synth.make_pair(100_000, 100_000, seed=42)
+icp = pkg.ICP(device=0)
+icp.set_map(g1); icp.set_local(l1)
+p.max_iterations = 40
+print("100k x 100k point-to-point step: %.4f ms" % step_ms(icp, p, 40, 5), flush=True)
+mc = bench.montecarlo_leg(pkg, synth, icp)
+print("loop-closure Monte-Carlo, 10 guesses at 100k: point-to-point %.2f ms, shipped YAML %.2f ms" % (mc["point_to_point"]["ms"], mc["shipped_loop_closure_yaml"]["ms"]), flush=True)
+b3 = bench.config3_batch(pkg, synth, icp, 64, False, None, shipped=True)
+print("64 pairs through the loop-closure YAML: %.0f pairs/s" % b3["gpu"]["pairs_per_s"], flush=True)
+icp.close()
 meds = [bench.odometry_stream_leg(pkg, synth)["ms_per_scan_median"] for _ in range(3)]
 print("odometry_stream ms_per_scan_median: " + " ".join("%.3f" % m for m in meds), flush=True)
 gg = synth.lidar_scan(synth.pose_from_xyzypr(-10.0, 0.2, 0, 0.01, 0, 0), seed=11)
