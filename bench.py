@@ -513,8 +513,8 @@ def main():
         out["loop_closure_montecarlo"] = montecarlo_leg(pkg, synth, icp)
     if extras and args.e2e:
         out["odometry_stream"] = odometry_stream_leg(pkg, synth)
-        # what a robot sees: the same drive with the scans arriving at the sensor's 10 Hz, not back to back (the GPU idles
-        # ~99 ms between scans and its clocks fall), and on the cloud sizes the reference's filters actually hand to align()
+        # what a robot sees: the same drive with the scans arriving at the sensor's 10 Hz, not back to back (every call follows
+        # ~99 ms of sleep: host wake-up, cold caches; tools/paced_probe.py), and on the cloud sizes the reference's filters actually hand to align()
         out["odometry_stream_10hz"] = odometry_stream_leg(pkg, synth, period_s=0.1, passes=args.paced_passes)
         out["odometry_stream_small"] = odometry_stream_leg(pkg, synth, decimate=10)
         out["odometry_stream_small_10hz"] = odometry_stream_leg(pkg, synth, period_s=0.1, decimate=10, passes=args.paced_passes)
@@ -900,7 +900,7 @@ def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passe
             steady_native += ms_nat[2:]
     lo.close()
     med = float(np.median(steady))
-    arrival = (f"delivered every {period_s * 1e3:.0f} ms of wall time (the sensor's rate: GPU clocks and host caches as a robot meets them)"
+    arrival = (f"delivered every {period_s * 1e3:.0f} ms of wall time (the sensor's rate: host and GPU as a robot meets them)"
                if period_s is not None else "delivered back to back (GPU clocks stay up)")
     return {"workload": f"{passes} x {n_scans} scans of ~{int(np.mean([pc.shape[1] for _, pc in scans]))} points ({'every ' + str(decimate) + 'th point of the ' if decimate > 1 else 'the full '}64-ring scan), 0.1 s and 1 m apart, "
                         f"{arrival}, params/kitti-default.yaml, host buffers in, pose out",
