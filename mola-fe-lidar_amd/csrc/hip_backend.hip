@@ -66,6 +66,7 @@ struct Knobs {
     bool early_pop = false;    // MOLA_ICP_EARLY_POP: the persistent kernels reserve the next entry at the start of the current one
     bool no_bootstrap = false;   // MOLA_ICP_NO_BOOTSTRAP: the first plane-matcher launch of an align sweeps without seeds
     bool bootstrap_nn = false;   // MOLA_ICP_BOOTSTRAP_NN: ... is seeded around each query's nearest neighbour (an NN pass first) instead of around its Hilbert key's place
+    bool no_side_prepare = false;   // MOLA_ICP_NO_SIDE_PREPARE: the two clouds' prepare chains one after the other on one stream
     bool no_quality_lists = false;  // MOLA_ICP_NO_QUALITY_LISTS: the PairedRatio pass behind a point-to-plane loop is always a matcher pass
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
@@ -84,6 +85,7 @@ static Knobs read_knobs()
     k.early_pop = std::getenv("MOLA_ICP_EARLY_POP") != nullptr;
     k.no_fused_rows = std::getenv("MOLA_ICP_NO_FUSED_ROWS") != nullptr;
     k.no_quality_lists = std::getenv("MOLA_ICP_NO_QUALITY_LISTS") != nullptr;
+    k.no_side_prepare = std::getenv("MOLA_ICP_NO_SIDE_PREPARE") != nullptr;
     k.no_bootstrap = std::getenv("MOLA_ICP_NO_BOOTSTRAP") != nullptr;
     k.bootstrap_nn = std::getenv("MOLA_ICP_BOOTSTRAP_NN") != nullptr;
     k.planes_valu = std::getenv("MOLA_ICP_PLANES_VALU") != nullptr;
@@ -221,6 +223,7 @@ HipWorkspace::~HipWorkspace()
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (ev_order_a_) (void)hipEventDestroy(ev_order_a_);
+    if (ev_prep_) (void)hipEventDestroy(ev_prep_);
     if (ev_order_b_) (void)hipEventDestroy(ev_order_b_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
@@ -234,7 +237,7 @@ HipWorkspace::~HipWorkspace()
     if (item_part_host_) (void)hipHostFree(item_part_host_);
     if (quality_host_) (void)hipHostFree(quality_host_);
     item_part_.release();
-    sort_scratch_.release();
+    sort_scratch_.release(); sort_scratch_loc_.release(); loc_meta_.release();
     idx_.release(); d2_.release(); seg_idx_.release(); seg_d2_.release(); outlier_.release(); partials_.release(); acc_dev_.release();
     if (acc_host_) (void)hipHostFree(acc_host_);
     if (meta_host_) (void)hipHostFree(meta_host_);
@@ -265,6 +268,7 @@ int HipWorkspace::init()
     own_stream_ = true;
     HIPCHK(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ev_order_a_, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_prep_, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_order_b_, hipEventDisableTiming));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&acc_host_), sizeof(double) * (kNAcc + 8), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(acc_host_, 0, sizeof(double) * (kNAcc + 8));
@@ -645,14 +649,17 @@ int HipWorkspace::bbox_async(const float* x, const float* y, const float* z, siz
 
 // The prepare chain's form: only the per-block rows (map_meta_: [kBboxRows][6]); the sort's first kernel finishes the box itself
 // and writes it to bbox_dev() and to the pinned slot (map_sort.hip, HilbertKeys) -- no launch and no copy in between.
-int HipWorkspace::bbox_rows_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner)
+int HipWorkspace::bbox_rows_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner,
+                                  hipStream_t st, DevBuf* meta)
 {
     int rc;
-    if ((rc = map_meta_.reserve(sizeof(float) * (6 * kBboxRows + 8)))) return rc;
+    if (!st) st = stream_;
+    if (!meta) meta = &map_meta_;
+    if ((rc = meta->reserve(sizeof(float) * (6 * kBboxRows + 8)))) return rc;
     // (1024 points per workgroup and trip, the four loads of a thread issued together: a 120k-point scan is one trip of 118 workgroups)
     bbox_n_rows_ = (int)std::min<size_t>((size_t)kBboxRows, (n + 1023) / 1024);
     if (bbox_n_rows_ < 1) bbox_n_rows_ = 1;
-    hipLaunchKernelGGL(k_bbox_rows, dim3(bbox_n_rows_), dim3(256), 0, stream_, x, y, z, (int)n, map_meta_.as<float>());
+    hipLaunchKernelGGL(k_bbox_rows, dim3(bbox_n_rows_), dim3(256), 0, st, x, y, z, (int)n, meta->as<float>());
     HIPCHK(hipGetLastError());
     bbox_pending_ |= 1u << slot;
     bbox_owner_[slot] = owner;
@@ -723,20 +730,43 @@ int HipWorkspace::prepare_tiles()
 }
 
 // Once per local cloud: Hilbert order of the queries (a rigid motion keeps them compact) -- four launches.
-int HipWorkspace::prepare_queries()
+int HipWorkspace::prepare_queries(bool aside)
 {
     if (loc_sc_->ready) return MOLA_ICP_OK;
     int rc;
     SortedCloud& sc = *loc_sc_;
-    if ((rc = bbox_rows_async(lx_, ly_, lz_, N_, 1, loc_sc_))) return rc;
+    // aside: on the second stream, with rows / scratch of its own -- next to the map's chain (prepare_both)
+    const hipStream_t st = aside ? aux_stream_ : stream_;
+    DevBuf& meta = aside ? loc_meta_ : map_meta_;
+    DevBuf& scratch = aside ? sort_scratch_loc_ : sort_scratch_;
+    if ((rc = bbox_rows_async(lx_, ly_, lz_, N_, 1, loc_sc_, st, &meta))) return rc;
+    const int n_rows = bbox_n_rows_;
     sc.padded = (N_ + kQPW - 1) / kQPW * kQPW;
     if ((rc = sc.sorted.reserve(sizeof(float) * 3 * sc.padded))) return rc;
     if ((rc = sc.perm.reserve(sizeof(int) * sc.padded))) return rc;
-    if ((rc = hilbert_sort_points(stream_, lx_, ly_, lz_, N_, sc.padded, map_meta_.as<float>(), bbox_n_rows_, bbox_dev(), meta_host_ + 8, sort_scratch_,
+    if ((rc = hilbert_sort_points(st, lx_, ly_, lz_, N_, sc.padded, meta.as<float>(), n_rows, meta.as<float>() + 6 * kBboxRows, meta_host_ + 8, scratch,
                                   sc.sorted.as<float>(), sc.perm.as<int>(), nullptr, 0, nullptr, 0, nullptr)))
         return rc;
     sc.ready = true;
     return MOLA_ICP_OK;
+}
+
+// Both clouds new (mola_icp_align from host buffers: two uploads, two chains of six small launches each): the chains are independent
+// and neither fills the device -- the queries' chain runs on the second stream beside the map's, the matcher waits for both.
+int HipWorkspace::prepare_both()
+{
+    int rc;
+    if (map_sc_->ready || loc_sc_->ready || g_knobs.no_side_prepare || N_ == 0 || M_ == 0) {
+        if ((rc = prepare_tiles())) return rc;
+        return prepare_queries(false);
+    }
+    HIPCHK(hipEventRecord(ev_order_a_, stream_));              // (behind the uploads)
+    HIPCHK(hipStreamWaitEvent(aux_stream_, ev_order_a_, 0));
+    if ((rc = prepare_queries(true))) return rc;
+    HIPCHK(hipEventRecord(ev_prep_, aux_stream_));
+    rc = prepare_tiles();
+    HIPCHK(hipStreamWaitEvent(stream_, ev_prep_, 0));          // (also on a failure above: nothing of the side chain may outrun the main stream's waits)
+    return rc;
 }
 
 int voxel_downsample_device(hipStream_t stream, const float* x, const float* y, const float* z, size_t n, const float bbox[6],
@@ -1087,8 +1117,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     if ((rc = check_slab(T, p.matcher_threshold))) return rc;
     if (N_ == 0 || M_ == 0) { planes_valid_ = true; planes_empty_ = true; return MOLA_ICP_OK; }
     planes_empty_ = false;
-    if ((rc = prepare_tiles())) return rc;
-    if ((rc = prepare_queries())) return rc;
+    if ((rc = prepare_both())) return rc;
     if ((rc = planes_.reserve(sizeof(PlanePair) * loc_sc_->padded))) return rc;
     // the stored lists (knn + 1 entries per query: positions, coordinates, original indices; kernels_planes.hpp: KnnSeeds)
     if ((rc = knn_pos_.reserve(knn_seeds_bytes(loc_sc_->padded, (int)p.knn + 1)))) return rc;
@@ -1729,9 +1758,8 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         else kernel = MOLA_ICP_NN_VALU;
     }
     if (kernel == MOLA_ICP_NN_TILED) {
-        int rc = prepare_tiles();
+        const int rc = prepare_both();
         if (rc) return rc;
-        if ((rc = prepare_queries())) return rc;
     } else if (kernel == MOLA_ICP_NN_MFMA) {
         const int rc = prepare_map();
         if (rc) return rc;

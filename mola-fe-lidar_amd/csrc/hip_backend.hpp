@@ -170,11 +170,13 @@ class HipWorkspace final : public Stages {
    private:
     int prepare_map();    // derived map image for the MFMA matcher
     int prepare_tiles();    // Morton-sorted map + tile boxes for the tiled matcher
-    int prepare_queries();  // Morton-sorted local cloud
+    int prepare_queries(bool aside = false);  // Hilbert-sorted local cloud (aside: on the second stream, beside the map's chain)
+    int prepare_both();
     int bbox_of(const float* x, const float* y, const float* z, size_t n, float out[6]);   // (waits)
     static constexpr int kBboxRows = 256;   // workgroups of k_bbox_partial = partial rows in map_meta_
     int bbox_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner);   // device block + pinned slot, no wait
-    int bbox_rows_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner);   // the partial rows only (the sort finishes the box)
+    int bbox_rows_async(const float* x, const float* y, const float* z, size_t n, int slot, const std::shared_ptr<SortedCloud>& owner,
+                        hipStream_t st = nullptr, DevBuf* meta = nullptr);   // the partial rows only (the sort finishes the box)
     int check_bboxes();                                                                     // after the next wait on stream_
     float* bbox_dev() { return map_meta_.as<float>() + 6 * kBboxRows; }
     unsigned int bbox_pending_ = 0;
@@ -216,6 +218,7 @@ class HipWorkspace final : public Stages {
     // tiled matcher: the map and the local cloud in Hilbert order (own, or borrowed from the handle's cache)
     std::shared_ptr<SortedCloud> map_sc_, loc_sc_;
     DevBuf sort_scratch_;
+    DevBuf sort_scratch_loc_, loc_meta_;   // the queries' prepare chain when it runs beside the map's (prepare_both)
     DevBuf ts_pos_, ts_idx_, ts_d2_;  // the tiled matcher's pairing, in SORTED query order
     DevBuf ts_gs_;                    // ... and each neighbour's coordinates (3 x padded floats): next launch's seeds, accumulate's g
     DevBuf rows_;                     // the matchers' fused stage-0 sums, one row of kNAcc doubles per 64 queries (item_row_mfma)
@@ -247,7 +250,7 @@ class HipWorkspace final : public Stages {
     // the work lists are re-sorted on a side stream, behind the matcher launch whose costs they read and beside the
     // accumulation that follows it (a single-block 22-30 us kernel otherwise on the next matcher's critical path)
     hipStream_t aux_stream_ = nullptr;
-    hipEvent_t ev_order_a_ = nullptr, ev_order_b_ = nullptr;
+    hipEvent_t ev_order_a_ = nullptr, ev_order_b_ = nullptr, ev_prep_ = nullptr;
     bool order_pending_ = false;
     int order_begin();   // aux_stream_ waits for what stream_ holds so far
     int order_end();     // ... and the next matcher launch will wait for what aux_stream_ holds
