@@ -645,3 +645,29 @@ def test_align_cached_put_is_put_then_align(pkg, synth, small_scene):
     assert r.nIterations >= 1 and icp.cloud_count()[0] == 7
     icp.close()
     ref.close()
+
+
+@pytest.mark.gpu
+def test_side_stream_prepare_changes_nothing(pkg, synth, small_scene, monkeypatch):
+    """a call that brings both clouds prepares the queries on a second stream beside the map (HipWorkspace::prepare_both): the same
+    result, bit for bit, as with both chains on one stream (MOLA_ICP_NO_SIDE_PREPARE=1) -- both pipelines, sizes on both sides of
+    the tiled matcher's threshold, repeated calls on one handle (the side stream's scratch is reused)"""
+    shipped = pkg.Parameters.load_from_file(os.path.join(os.path.dirname(os.path.dirname(__file__)), "params", "icp-settings-regular.yaml"))
+    p2p = p2p_params(pkg, max_iterations=30, matcher_threshold=0.6)
+    pairs = [synth.make_pair(n, m, seed=500 + k, scene=small_scene)[:2] for k, (n, m) in enumerate(((9000, 12000), (30000, 20000), (2000, 3000), (45000, 45000)))]
+    res = {}
+    try:
+        for mode in ("side", "one stream"):
+            if mode == "one stream":
+                monkeypatch.setenv("MOLA_ICP_NO_SIDE_PREPARE", "1")
+            else:
+                monkeypatch.delenv("MOLA_ICP_NO_SIDE_PREPARE", raising=False)
+            pkg._lib.lib().mola_icp_debug_reload_env()
+            icp = pkg.ICP(device=0)
+            res[mode] = [icp.align(g, l, np.eye(4), p) for (g, l) in pairs for p in (p2p, shipped)]
+            icp.close()
+    finally:
+        monkeypatch.delenv("MOLA_ICP_NO_SIDE_PREPARE", raising=False)
+        pkg._lib.lib().mola_icp_debug_reload_env()
+    for a, b in zip(res["side"], res["one stream"]):
+        assert np.array_equal(a.optimal_tf, b.optimal_tf) and a.nIterations == b.nIterations and a.quality == b.quality and a.n_pairs == b.n_pairs
