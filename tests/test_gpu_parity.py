@@ -671,3 +671,48 @@ def test_side_stream_prepare_changes_nothing(pkg, synth, small_scene, monkeypatc
         pkg._lib.lib().mola_icp_debug_reload_env()
     for a, b in zip(res["side"], res["one stream"]):
         assert np.array_equal(a.optimal_tf, b.optimal_tf) and a.nIterations == b.nIterations and a.quality == b.quality and a.n_pairs == b.n_pairs
+
+
+@pytest.mark.gpu
+def test_align_cached_put_from_four_threads_on_one_handle(pkg, synth, small_scene):
+    """the reference calls align() from the odometry thread and from pool threads on one ICP object (src/LidarOdometry.cpp:94-96,
+    869): four threads each drive their own chain of scans through mola_icp_align_cached_put on ONE handle (pool workspaces, the
+    shared cloud cache, deferred builds in flight side by side) -- every result equals the serial run's, bit for bit"""
+    import threading
+    shipped = pkg.Parameters.load_from_file(os.path.join(os.path.dirname(os.path.dirname(__file__)), "params", "icp-settings-regular.yaml"))
+    chains = [[synth.make_pair(15_000 + 900 * t + 300 * k, 10, seed=700 + 10 * t + k, scene=small_scene)[1] for k in range(5)] for t in range(4)]
+
+    def run_chain(icp, t, out):
+        base = 1000 * (t + 1)
+        icp.cloud_put(base, chains[t][0])
+        for k in range(1, 5):
+            out.append(icp.align_cached_put(base + k - 1, base + k, chains[t][k], np.eye(4), shipped))
+            icp.cloud_drop(base + k - 1)
+
+    serial = pkg.ICP(device=0)
+    want = [[] for _ in range(4)]
+    for t in range(4):
+        run_chain(serial, t, want[t])
+    serial.close()
+    icp = pkg.ICP(device=0)
+    got, errs = [[] for _ in range(4)], []
+
+    def worker(t):
+        try:
+            for _ in range(3):      # (three times over: the pool's workspaces change hands between the threads)
+                got[t].clear()
+                run_chain(icp, t, got[t])
+                icp.cloud_drop(1000 * (t + 1) + 4)
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [x.start() for x in th]
+    [x.join(300) for x in th]
+    assert not errs, errs
+    for t in range(4):
+        assert len(got[t]) == 4
+        for a, b in zip(got[t], want[t]):
+            assert np.array_equal(a.optimal_tf, b.optimal_tf) and a.nIterations == b.nIterations and a.quality == b.quality
+    assert icp.cloud_count()[0] == 0
+    icp.close()
