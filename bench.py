@@ -7,8 +7,9 @@ accumulation, (all-reduce of the 24-double block when sharded), Horn solve, stal
 quantities.  `--steps K` runs exactly K such iterations (stall test disabled, quality pass
 skipped) between two barrier+synchronize brackets; `value` = K / max-over-ranks seconds.
 
-N GPUs: strong scaling of the SAME 1M x 1M job -- the queries are sharded contiguously over the
-ranks (map replicated), one RCCL all-reduce of the accumulator block per iteration.
+N GPUs: strong scaling of the SAME 1M x 1M job -- every rank keeps a compact slice of the scan's Hilbert order and the part of
+the map that slice can reach, one all-reduce of the accumulator block per iteration (--allreduce local: the node-local
+shared-memory communicator, the default on one node; rccl; hook) -- and, beside it, `c5_sharded`: configs[4], a 10M-point map.
 
 Beside the headline the single-GPU run reports (all outside the timed region, all in the ONE JSON line):
   roofline      the dominant kernel against the HBM roofline: HIP-event duration of the matcher launches of an identical
@@ -21,7 +22,14 @@ Beside the headline the single-GPU run reports (all outside the timed region, al
                 all-core CPU leg SURVEY.md section 8(d)(ii) asks for: max(2, nproc/2) threads, one pair each
                 (src/LidarOdometry.cpp:94-96);
   cpu_baseline  the single-thread CPU leg on a bounded sample of the headline workload, built -O3 -march=native on the
-                machine that runs it.
+                machine that runs it;
+  shipped_point2plane_gn, time_to_pose, cold_start, dense_mfma, loop_closure_montecarlo, config3_batch_shipped
+                the reference's own pipeline (Point2Plane + Gauss-Newton) at 1M, its time to termination, the first align
+                after an idle second, the dense MFMA kernel's roofline, the batched legs through the loop-closure YAML;
+  odometry_stream[_10hz|_small|_small_10hz]
+                the front-end mirror over a synthetic drive: scans back to back / arriving every 100 ms / decimated as the
+                reference's pipeline decimates them (every 10th point);
+  c5_sharded    configs[4] (at N = 1: the whole job on one GPU).
 
     python bench.py                      # 1 GPU, 40 steps, 3 warmup
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
