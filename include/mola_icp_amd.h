@@ -246,7 +246,10 @@ int mola_icp_comm_destroy(mola_icp_handle* h);
  *    like the RCCL id); returns once all `nranks` ranks have joined (then the name is unlinked: nothing is left in /dev/shm),
  *    MOLA_ICP_E_COMM after `timeout_s` (<= 0: 30 s) -- the same time-out bounds every wait of an all-reduce;
  *  - allreduce: sums buf[0, n) (n <= 120, host memory) over the ranks in place; the ranks must make the same calls in the same
- *    order (a rank found ahead, or with another n, is MOLA_ICP_E_COMM on every rank, not a hang);
+ *    order (a rank found ahead, or with another n, is MOLA_ICP_E_COMM on every rank, not a hang).  After MOLA_ICP_E_COMM the
+ *    communicator is finished (this end is out of step with the others): every later call fails at once -- destroy it and create a
+ *    new one on every rank.  A name that still leads to the leftover of a run that crashed inside `create` is harmless: a rank that
+ *    mapped the leftover notices rank 0 replacing it and joins the new segment;
  *  - abort: this rank cannot go on (an error outside the collective): the others' next all-reduce fails at once;
  *  - attach_local: the handle's resident-cloud aligns reduce through `c` (NULL detaches); `c` stays the caller's to destroy,
  *    after mola_icp_comm_destroy(h) or mola_icp_destroy(h).  mola_icp_comm_nranks() then reports the ranks that joined `c`. */

@@ -1470,6 +1470,17 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     return MOLA_ICP_OK;
 }
 
+// An all-reduce hook returned non-zero.  The node-local communicator (local_comm.cpp) has already recorded WHICH rank is ahead,
+// gave up or timed out in this thread's error string -- the diagnostic include/mola_icp_amd.h promises: it is kept, with the code in
+// front; a foreign hook that set nothing gets the plain message.
+static int hook_failed(int r, const std::string& error_before_the_call)
+{
+    const std::string detail = last_error();
+    std::string msg = "all-reduce hook failed with code " + std::to_string(r);
+    if (!detail.empty() && detail != error_before_the_call) msg += ": " + detail;   // (what the hook itself recorded)
+    return fail(MOLA_ICP_E_COMM, msg);
+}
+
 int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
 {
     int rc = init();
@@ -1528,8 +1539,9 @@ int HipWorkspace::accumulate_planes(double acc[kNAccPlaneHost])
     knn_changed_items_ = planes_empty_ ? -1.0 : plane_acc_host_[kNAccPlane];
     if (!comm_ && ar_fn_) {
         if (slab_violation_) acc[kNAccPlane - 1] = std::nan("");
+        const std::string err0 = last_error();
         const int r = ar_fn_(acc, kNAccPlane, 0, ar_user_);
-        if (r) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(r));
+        if (r) return hook_failed(r, err0);
     }
     if ((comm_ || ar_fn_) && std::isnan(acc[kNAccPlane - 1])) { slab_violation_ = false; return fail(MOLA_ICP_E_BADARG, kSlabMsg); }
     return MOLA_ICP_OK;
@@ -2052,8 +2064,9 @@ int HipWorkspace::allreduce(double acc[kNAcc])
 {
     if (comm_) return MOLA_ICP_OK;  // accumulate() already reduced the device block over RCCL
     if (!ar_fn_) return MOLA_ICP_OK;
+    const std::string err0 = last_error();
     const int rc = ar_fn_(acc, kNAcc, 0, ar_user_);
-    if (rc) return fail(MOLA_ICP_E_COMM, "all-reduce hook failed with code " + std::to_string(rc));
+    if (rc) return hook_failed(rc, err0);
     if (std::isnan(acc[16])) { slab_violation_ = false; return fail(MOLA_ICP_E_BADARG, kSlabMsg); }
     return MOLA_ICP_OK;
 }
@@ -2063,12 +2076,22 @@ int HipWorkspace::allreduce(double acc[kNAcc])
 int HipWorkspace::quality_pairs(const Mat4& T, double threshold, const mola_icp_params& p, double acc[kNAcc], bool* done)
 {
     *done = false;
+    // Sharded over a native RCCL communicator the count must go through the collective accumulate() issues (allreduce() is a no-op
+    // there), and EVERY rank must issue it: a rank answering from its lists while another -- undecided queries, an empty shard --
+    // falls back to match() + accumulate() would leave that one alone in ncclAllReduce.  So with comm_ the matcher pass answers on
+    // all ranks.  (The hook / node-local transports sum in allreduce(), which every rank calls once per pass either way.)
+    if (comm_) return MOLA_ICP_OK;
     if (!inited_ || !knn_seed_valid_ || planes_knn_ < 1 || planes_empty_ || g_knobs.no_certify || g_knobs.no_knn_seed || g_knobs.no_quality_lists ||
         !loc_sc_ || !loc_sc_->ready || N_ == 0 || g_knobs.no_direct_readback)
         return MOLA_ICP_OK;
     (void)p;
     int rc;
     HIPCHK(hipSetDevice(device_));
+    // a shard's map slab must hold the reach of the FINAL pose too (the last solve may have moved it out): the count below would
+    // silently be one against a truncated map.  A violation goes the way match() sends it: the matcher pass runs, poisons the pair
+    // count, every rank fails together and the caller re-cuts.
+    if ((rc = check_slab(T, threshold))) return rc;
+    if (slab_violation_) return MOLA_ICP_OK;
     if (!quality_host_) {   // (a block of its own: a record's data word must never sit where another kernel's sequence flag is awaited)
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&quality_host_), sizeof(unsigned long long) * 2 * kQualityBlocks, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(quality_host_, 0, sizeof(unsigned long long) * 2 * kQualityBlocks);

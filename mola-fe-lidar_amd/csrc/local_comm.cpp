@@ -51,7 +51,8 @@ struct alignas(64) Header {
     uint32_t nranks;
     std::atomic<uint32_t> joined;    // ranks that mapped the segment
     std::atomic<uint32_t> left;      // ranks that destroyed their end
-    uint8_t pad[64 - 8 - 3 * 4];
+    std::atomic<uint32_t> ack;       // rank 0, AFTER it has seen every rank join and has unlinked the name: this is the live segment
+    uint8_t pad[64 - 8 - 4 * 4];
 };
 static_assert(sizeof(Header) == 64, "header = one cache line");
 
@@ -87,21 +88,49 @@ public:
         timeout_s_ = timeout_s > 0 ? timeout_s : 30.0;
         bytes_ = sizeof(Header) + sizeof(Row) * 2 * (size_t)nranks;
         const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s_);
-        int fd = -1;
         if (rank == 0) {
             shm_unlink(name_.c_str());  // a leftover of a crashed run under the same name
-            fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            const int fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
             if (fd < 0) return fail(MOLA_ICP_E_COMM, "local communicator: shm_open(" + name_ + ") failed: " + std::strerror(errno));
             owner_ = true;
             if (ftruncate(fd, (off_t)bytes_) != 0) {
                 close(fd);
                 return fail(MOLA_ICP_E_COMM, std::string("local communicator: ftruncate failed: ") + std::strerror(errno));
             }
-        } else {
-            for (;;) {  // rank 0 may not have created it yet; a created segment may not have its size yet
+            void* p = mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (p == MAP_FAILED) return fail(MOLA_ICP_E_COMM, std::string("local communicator: mmap failed: ") + std::strerror(errno));
+            base_ = p;
+            // (a fresh segment is zero-filled: rows start at seq 0, all-reduces count from 1, nobody has joined, no ack)
+            hdr()->nranks = (uint32_t)nranks;
+            hdr()->magic.store(kMagic, std::memory_order_release);
+            hdr()->joined.fetch_add(1, std::memory_order_acq_rel);
+            // collective: nobody leaves before everybody has mapped the segment -- then the name can go (nothing stays in /dev/shm
+            // if a rank dies later; the memory lives until the last mapping is gone)
+            while (hdr()->joined.load(std::memory_order_acquire) < (uint32_t)nranks) {
+                if (std::chrono::steady_clock::now() > t_end)
+                    return fail(MOLA_ICP_E_COMM, "local communicator: only " + std::to_string(hdr()->joined.load()) + " of " +
+                                                     std::to_string(nranks) + " ranks joined " + name_);
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+            // the name goes BEFORE the acknowledgement: a name left behind by a crash can therefore never lead to a segment whose
+            // `ack` is set -- which is what lets a late-comer tell a leftover from the live segment (below)
+            shm_unlink(name_.c_str());
+            unlinked_ = true;
+            hdr()->ack.store(1u, std::memory_order_release);
+            return MOLA_ICP_OK;
+        }
+        // Ranks > 0.  The name may not exist yet, may not have its size yet -- or may still lead to the LEFTOVER of a run that crashed
+        // during its own init (rank 0 removes it only when it gets here): its size, magic and rank count all check out, and its stale
+        // `joined` count can even be complete.  What a leftover never has is rank 0's acknowledgement.  So a rank waits for `ack`
+        // in the segment it mapped, and while it waits it keeps looking at what the name leads to NOW: another inode = rank 0 has
+        // replaced the segment this rank sits in -- drop it and join the new one.
+        for (;;) {
+            int fd = -1;
+            struct stat st {};
+            for (;;) {
                 fd = shm_open(name_.c_str(), O_RDWR, 0600);
                 if (fd >= 0) {
-                    struct stat st;
                     if (fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes_) break;
                     close(fd);
                     fd = -1;
@@ -110,42 +139,58 @@ public:
                     return fail(MOLA_ICP_E_COMM, "local communicator: rank 0 never created " + name_);
                 std::this_thread::sleep_for(std::chrono::milliseconds(1));
             }
-        }
-        void* p = mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (p == MAP_FAILED) return fail(MOLA_ICP_E_COMM, std::string("local communicator: mmap failed: ") + std::strerror(errno));
-        base_ = p;
-        if (rank == 0) {  // (a fresh segment is zero-filled: rows start at seq 0, all-reduces count from 1)
-            hdr()->nranks = (uint32_t)nranks;
-            hdr()->magic.store(kMagic, std::memory_order_release);
-        } else {
-            while (hdr()->magic.load(std::memory_order_acquire) != kMagic) {
-                if (std::chrono::steady_clock::now() > t_end) return fail(MOLA_ICP_E_COMM, "local communicator: rank 0 never initialised " + name_);
-                cpu_relax();
+            void* p = mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (p == MAP_FAILED) return fail(MOLA_ICP_E_COMM, std::string("local communicator: mmap failed: ") + std::strerror(errno));
+            base_ = p;
+            bool joined = false, replaced = false;
+            unsigned spins = 0;
+            for (;;) {
+                if (!joined && hdr()->magic.load(std::memory_order_acquire) == kMagic) {
+                    if (hdr()->nranks != (uint32_t)nranks) {
+                        const uint32_t theirs = hdr()->nranks;
+                        munmap(base_, bytes_);
+                        base_ = nullptr;
+                        return fail(MOLA_ICP_E_COMM, "local communicator: rank 0 created " + name_ + " for " + std::to_string(theirs) +
+                                                         " ranks, this rank was told " + std::to_string(nranks));
+                    }
+                    hdr()->joined.fetch_add(1, std::memory_order_acq_rel);
+                    joined = true;
+                }
+                if (joined && hdr()->ack.load(std::memory_order_acquire) != 0u) break;
+                if ((++spins & 0xff) == 0) {
+                    struct stat now {};
+                    const int fd2 = shm_open(name_.c_str(), O_RDWR, 0600);
+                    if (fd2 >= 0) {
+                        const bool other = fstat(fd2, &now) == 0 && (now.st_ino != st.st_ino || now.st_dev != st.st_dev);
+                        close(fd2);
+                        if (other) { replaced = true; break; }
+                    }
+                    if (std::chrono::steady_clock::now() > t_end) {
+                        const std::string what = joined ? "only " + std::to_string(hdr()->joined.load()) + " of " + std::to_string(nranks) + " ranks joined " + name_ +
+                                                              " (or it is the leftover of a crashed run and rank 0 never came)"
+                                                        : "rank 0 never initialised " + name_;
+                        munmap(base_, bytes_);
+                        base_ = nullptr;
+                        return fail(MOLA_ICP_E_COMM, "local communicator: " + what);
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                } else {
+                    cpu_relax();
+                }
             }
-            if (hdr()->nranks != (uint32_t)nranks)
-                return fail(MOLA_ICP_E_COMM, "local communicator: rank 0 created " + name_ + " for " + std::to_string(hdr()->nranks) +
-                                                 " ranks, this rank was told " + std::to_string(nranks));
+            if (!replaced) return MOLA_ICP_OK;
+            munmap(base_, bytes_);   // (a leftover: its counters are nobody's any more)
+            base_ = nullptr;
         }
-        hdr()->joined.fetch_add(1, std::memory_order_acq_rel);
-        // collective: nobody leaves before everybody has mapped the segment -- then the name can go (nothing stays in /dev/shm
-        // if a rank dies later; the memory lives until the last mapping is gone)
-        while (hdr()->joined.load(std::memory_order_acquire) < (uint32_t)nranks) {
-            if (std::chrono::steady_clock::now() > t_end)
-                return fail(MOLA_ICP_E_COMM, "local communicator: only " + std::to_string(hdr()->joined.load()) + " of " +
-                                                 std::to_string(nranks) + " ranks joined " + name_);
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
-        }
-        if (owner_) {
-            shm_unlink(name_.c_str());
-            unlinked_ = true;
-        }
-        return MOLA_ICP_OK;
     }
 
-    // sum buf[0, n) over the ranks, in place; every rank gets the same bits
+    // sum buf[0, n) over the ranks, in place; every rank gets the same bits.  A call that fails (MOLA_ICP_E_COMM: a peer ahead, gone
+    // or late) leaves this end one all-reduce out of step with the others for good: the communicator is finished -- destroy it and
+    // create a new one on every rank (include/mola_icp_amd.h says the same).
     int allreduce(double* buf, int n)
     {
+        if (broken_) return fail(MOLA_ICP_E_COMM, "local communicator: an earlier all-reduce failed on this rank -- destroy the communicator and create a new one on every rank");
         if (!base_) return fail(MOLA_ICP_E_BADARG, "local communicator: not initialised");
         if (!buf || n < 1 || n > kRowDoubles) return fail(MOLA_ICP_E_BADARG, "local communicator: payload of 1 .. 120 doubles");
         const uint64_t seq = ++seq_;
@@ -206,6 +251,7 @@ private:
     int give_up(const std::string& msg, bool tell = true)
     {
         if (tell) abort_peers();
+        broken_ = true;
         return fail(MOLA_ICP_E_COMM, msg);
     }
 
@@ -215,7 +261,7 @@ private:
     int nranks_ = 0, rank_ = 0;
     double timeout_s_ = 30.0;
     uint64_t seq_ = 0;
-    bool owner_ = false, unlinked_ = false;
+    bool owner_ = false, unlinked_ = false, broken_ = false;
 };
 
 int local_comm_hook(double* buf, int n, int device_ptr, void* user)

@@ -230,13 +230,27 @@ class ShardedICP:
                 shard = shard.contiguous()
             self.icp.set_local(shard)
 
-    def balance(self, params, rounds: int = 2, probe_iterations: int = 4) -> list[int]:
-        """Cuts of equal COST instead of equal count (`balanced_cuts`): every round, each rank times `probe_iterations` fixed
-        iterations of `params` from the guess on the shards in force, the W times are all-gathered, all ranks cut again at the
-        same places; the best cuts measured stay in force.  Worth it where the guess is far off and the align takes many
-        iterations (the cost per query then varies several-fold along the scan and a step is as long as its slowest rank);
-        each round costs a re-cut of the shard and the slab (milliseconds).  Returns the cuts."""
-        import time
+    def _probe_own_cost(self, T0, q, probe_iterations: int) -> float:
+        """What THIS rank's shard costs per iteration, waiting excluded.  The probe is an ordinary sharded align -- every iteration
+        ends in the all-reduce, which waits for the slowest rank -- so its wall time is about the MAXIMUM over the ranks on every
+        rank: a cost vector of wall times is near uniform and `balanced_cuts` would not move a cut.  The matcher's own
+        time does not contain the wait: HIP events around this rank's matcher launches (`set_profiling`: `ms_nn_kernel`)."""
+        self.icp.align_resident(T0, q)            # (clocks, cost orders)
+        self.icp.set_profiling(True)
+        try:
+            r = self.icp.align_resident(T0, q)
+        finally:
+            self.icp.set_profiling(False)
+        return float(r.ms_nn_kernel) * 1e-3 / max(1, probe_iterations)
+
+    def balance(self, params, rounds: int = 2, probe_iterations: int = 4, probe=None) -> list[int]:
+        """Cuts of equal COST instead of equal count (`balanced_cuts`): every round, each rank measures what `probe_iterations` fixed
+        iterations of `params` from the guess cost ITS shard (`_probe_own_cost`: the matcher's own time, not the wall time of the
+        align -- that one contains the wait for the slowest rank), the W costs are all-gathered, all ranks cut again at the same
+        places; the best cuts measured (smallest maximum) stay in force.  Worth it where the guess is far off and the align takes
+        many iterations (the cost per query then varies several-fold along the scan and a step is as long as its slowest rank);
+        each round costs a re-cut of the shard and the slab (milliseconds).  `probe(T0, params, probe_iterations) -> seconds`
+        replaces the measurement (tests; callers with a cost model of their own).  Returns the cuts."""
         import torch
         import torch.distributed as dist
         from ._lib import IcpError
@@ -249,12 +263,10 @@ class ShardedICP:
         cuts = self._cuts or [shard_bounds(n, r, self.world)[0] for r in range(self.world)] + [n]
         best = None
         on_gpu = dist.get_backend(self.group) == "nccl"
+        measure = probe if probe is not None else self._probe_own_cost
         for rnd in range(rounds + 1):
             try:   # (all ranks run the same number of all-reduces: the probe is an ordinary sharded align)
-                self.icp.align_resident(T0, q)
-                t0 = time.perf_counter()
-                self.icp.align_resident(T0, q)
-                mine = (time.perf_counter() - t0) / probe_iterations
+                mine = float(measure(T0, q, probe_iterations))
             except IcpError:
                 mine = float("nan")
             v = torch.zeros(self.world, dtype=torch.float64)
@@ -277,6 +289,7 @@ class ShardedICP:
             self._cuts = best[0]
             self._cut_shard()
             self._cut_slab()
+        self.balance_record = {"best_max_cost_s": None if best is None else best[1]}
         return list(self._cuts or cuts)
 
     def _cut_slab(self):

@@ -118,3 +118,71 @@ def test_balanced_cuts_and_slab_margin():
     assert sharded.balanced_cuts([0, 0, 20], [0.0, 1.0])[1] in range(0, 21)       # an empty shard, a zero cost: no division by zero
     m = sharded.slab_margin_for_guess([-3, -4, 0], [1, 2, 12], gate=1.0, max_dt=0.5, max_drot=np.deg2rad(2.0))
     assert m == pytest.approx(1.0 + 0.5 + 2 * np.sin(np.deg2rad(1.0)) * 13.0)
+
+
+class _FakeIcp:
+    """What ShardedICP.balance touches of an ICP, without a device: it records the shard range it was given; an align 'costs' the
+    integral of a cost density over that range (reported as the matcher's own time, `ms_nn_kernel`, as set_profiling would) and
+    then WAITS for the other rank like the all-reduce at the end of a real iteration does -- so its wall time is the slowest rank's."""
+
+    def __init__(self, density, group_barrier):
+        self.density, self.barrier, self.range, self.profiling = density, group_barrier, None, False
+        self.wall_times = []
+
+    def set_allreduce(self, fn): pass
+    def set_global_sizes(self, n, m): pass
+    def set_map(self, m): pass
+    def set_profiling(self, on): self.profiling = bool(on)
+
+    def set_local_shard(self, pc, rank, world):
+        sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+        self.range = sharded.shard_bounds(pc.shape[1], rank, world)
+
+    def set_local_shard_range(self, pc, lo, hi):
+        self.range = (int(lo), int(hi))
+
+    def align_resident(self, T0, q):
+        import time
+        import types
+        t0 = time.perf_counter()
+        own = float(self.density[self.range[0]:self.range[1]].sum())   # "seconds" of matcher work of this shard
+        time.sleep(own * 1e-3)
+        self.barrier()                                                 # the all-reduce: everybody leaves with the slowest
+        self.wall_times.append(time.perf_counter() - t0)
+        return types.SimpleNamespace(ms_nn_kernel=own * 1e3 * q.max_iterations if self.profiling else 0.0, n_nn_launches=q.max_iterations)
+
+
+def _balance_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    pkg = importlib.import_module("mola-fe-lidar_amd")
+    sharded = importlib.import_module("mola-fe-lidar_amd.sharded")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        n = 4000
+        density = np.where(np.arange(n) < 1000, 8.0, 1.0) / 1000.0     # the first quarter of the curve costs 8x per query
+        fake = _FakeIcp(density, dist.barrier)
+        s = sharded.ShardedICP(fake, collective="hook")
+        s.set_clouds(np.zeros((3, 10), np.float32), np.zeros((3, n), np.float32))
+        cuts = s.balance(pkg.Parameters(), rounds=2, probe_iterations=4)
+        np.savez(os.path.join(outdir, f"bal{rank}.npz"), cuts=np.asarray(cuts), rng=np.asarray(fake.range), wall=np.asarray(fake.wall_times))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_balance_uses_each_ranks_own_cost_and_moves_the_cuts(pkg, tmp_path):
+    """the probe align ends every iteration in the all-reduce, so its WALL time is the slowest rank's on every rank and
+    says nothing about this rank's shard.  balance() must take the matcher's own time: with a cost density of 8 : 1 : 1 : 1 over
+    the quarters of the scan, two ranks must end near the equal-cost cut (query 688), far from the equal-count one (2000)."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_balance_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"bal{k}.npz") for k in range(world)]
+    assert np.array_equal(r[0]["cuts"], r[1]["cuts"])                   # every rank cuts at the same places
+    cut = int(r[0]["cuts"][1])
+    # equal cost is at query 688 (8 * 688 / 1000 = 5.5 = half of 11); two rounds of the piecewise-uniform model go 2000 -> 1222 -> 817
+    assert 650 <= cut <= 900, r[0]["cuts"]
+    assert tuple(r[0]["rng"]) == (0, cut) and tuple(r[1]["rng"]) == (cut, 4000)
+    # ... while the wall times the OLD code used were the same on both ranks to within the barrier's jitter (nothing to cut by)
+    w0, w1 = r[0]["wall"][:2].mean(), r[1]["wall"][:2].mean()
+    assert abs(w0 - w1) < 0.35 * max(w0, w1)
