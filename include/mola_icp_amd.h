@@ -367,12 +367,16 @@ int mola_icp_voxel_downsample(mola_icp_handle* h, const float* x, const float* y
  * odometry sizes and the counter read-back a stream synchronisation per align; n_nn_launches is always filled.
  * (The reference's counterpart is its mrpt::system::CTimeLogger profiler, src/LidarOdometry.cpp:296-297, 858.) */
 int mola_icp_set_profiling(mola_icp_handle* h, int on);
-/* Drop what earlier matches / aligns left behind for the resident clouds in place -- neighbour lists, pairing seeds, the
- * plane cache, the per-item cost orders -- and keep the prepared (sorted) clouds: the next align costs what the FIRST
- * align on this pair cost.  For measurements (bench.py times a registration on state a repeat of the same align would
- * otherwise have warmed) and for callers that re-register the same pair from an unrelated guess.  (No reference
- * counterpart: mp2p_icp::ICP::align() keeps nothing between calls, src/LidarOdometry.cpp:869-871.) */
+/* Drop what earlier ALIGNS left behind for the resident clouds in place -- the last pairing (the next launch's seeds), the
+ * neighbour lists with their certificates, the plane cache: results of matches at that align's poses -- so that the next
+ * align is stateless, as mp2p_icp::ICP::align() keeps nothing between calls (src/LidarOdometry.cpp:869-871).  What belongs to
+ * the CLOUDS stays: their prepared (sorted) form and the per-item cost order of the work queue (a schedule made once per cloud
+ * pair, like the sort; it never changes a result).  For measurements (bench.py's `value`) and for callers that re-register the
+ * same pair from an unrelated guess.
+ * mola_icp_forget_cloud_schedule: all of the above AND the cost order -- the next align costs what the very FIRST align on this
+ * pair cost (bench.py reports it as `value_first_align_on_pair`). */
 int mola_icp_forget_warm_start(mola_icp_handle* h);
+int mola_icp_forget_cloud_schedule(mola_icp_handle* h);
 int mola_icp_set_map_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t M);
 int mola_icp_set_map_device(mola_icp_handle* h, const float* dx, const float* dy, const float* dz, size_t M);
 int mola_icp_set_local_host(mola_icp_handle* h, const float* x, const float* y, const float* z, size_t N);

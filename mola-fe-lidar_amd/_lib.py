@@ -174,6 +174,7 @@ SIGNATURES = {
     "mola_icp_abi_version": (C.c_int, []),
     "mola_icp_set_profiling": (C.c_int, [_H, C.c_int]),
     "mola_icp_forget_warm_start": (C.c_int, [_H]),
+    "mola_icp_forget_cloud_schedule": (C.c_int, [_H]),
     "mola_icp_set_local_shard_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "mola_icp_set_local_shard_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "mola_icp_set_local_shard_range_host": (C.c_int, [_H, _FP, _FP, _FP, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -472,7 +472,15 @@ int mola_icp_forget_warm_start(mola_icp_handle* h)
 {
     if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
     std::lock_guard<std::mutex> lk(h->mtx);
-    if (h->resident) h->resident->forget_warm_start();
+    if (h->resident) h->resident->forget_warm_start(false);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_forget_cloud_schedule(mola_icp_handle* h)
+{
+    if (!h) return fail(MOLA_ICP_E_BADARG, "null handle");
+    std::lock_guard<std::mutex> lk(h->mtx);
+    if (h->resident) h->resident->forget_warm_start(true);
     return MOLA_ICP_OK;
 }
 

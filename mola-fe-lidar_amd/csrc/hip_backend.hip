@@ -912,16 +912,24 @@ void HipWorkspace::use_cached_local(const std::shared_ptr<SortedCloud>& sc)
     knn_seed_valid_ = false;
 }
 
-void HipWorkspace::forget_warm_start()
+// What an align LEAVES for the next one on the same clouds is dropped: the pairing (next launch's seeds), the neighbour lists, their
+// certificates and the plane cache -- results of matches at poses of that align.  What is kept is what belongs to the CLOUDS: their
+// prepared (sorted) form, and the per-item cost order of the work queue -- how dear each stretch of the scan's Hilbert order is
+// against this map is a property of the two clouds (their densities along the curve), it schedules the items and can never change a
+// result; like the prepared form it is made once per cloud pair and used by every align on it (`everything` drops it too: the very
+// first align on a pair).
+void HipWorkspace::forget_warm_start(bool everything)
 {
     planes_valid_ = false;
-    cost_valid_ = false;
-    order_valid_ = false;
-    knn_cost_valid_ = false;
-    knn_order_valid_ = false;
     knn_seed_valid_ = false;
     pairing_valid_ = false;
     seed_valid_ = false;
+    if (everything) {
+        cost_valid_ = false;
+        order_valid_ = false;
+        knn_cost_valid_ = false;
+        knn_order_valid_ = false;
+    }
 }
 
 int HipWorkspace::order_begin()

@@ -157,9 +157,9 @@ class HipWorkspace final : public Stages {
     // per-launch HIP events + executed-pair counters (ms_nn_kernel, nn_pairs_evaluated of the results).  Off by default:
     // the two event packets cost ~8 us per iteration at odometry sizes, the counter read-back a stream synchronisation.
     void set_profiling(bool on) { profiling_ = on; }
-    // drop what earlier matches left for the clouds in place (neighbour lists, pairing seeds, plane cache, per-item cost
-    // orders); the prepared (sorted) clouds stay.  The next align pays what the first align on these clouds paid.
-    void forget_warm_start();
+    // drop what earlier matches left for the clouds in place (neighbour lists, pairing seeds, plane cache); the prepared (sorted)
+    // clouds and their work-queue order stay -- `everything`: the order too (what the very first align on these clouds paid)
+    void forget_warm_start(bool everything = false);
     void reset_stats();
     int collect_stats(double* ms_total, uint32_t* launches, uint32_t* kernel_used, uint64_t* pairs = nullptr);
 

@@ -128,9 +128,13 @@ int validate_params(const mola_icp_params& p)
         if (eff.solver_class != MOLA_ICP_SOLVER_GAUSS_NEWTON)
             return fail(MOLA_ICP_E_UNSUPPORTED, "point-to-point and point-to-plane pairings in one iteration (" + std::to_string(it) +
                                                     ") need mp2p_icp::Solver_GaussNewton (Solver_Horn only consumes point-to-point pairings)");
-        if (p.use_scale_outlier_detector || p.use_robust_kernel)
-            return fail(MOLA_ICP_E_UNSUPPORTED, "pairingsWeightParameters (scale outlier detector / robust kernel) are not available when two "
-                                                    "matchers feed one solve");
+        // pairingsWeightParameters with two matchers: the scale outlier detector prunes the POINT matcher's pairings (two passes of
+        // the centroid-relative test, as in front of Horn) before they enter the Gauss-Newton form -- what the reference's own
+        // params block asks for (params/icp-settings-regular.yaml:14-17); plane pairings carry no such test.  The robust kernel's
+        // weights are defined on point pairings relative to the centroids of a Horn solve: not available here.
+        if (p.use_robust_kernel)
+            return fail(MOLA_ICP_E_UNSUPPORTED, "pairingsWeightParameters.use_robust_kernel is not available when two matchers feed one solve "
+                                                    "(use_scale_outlier_detector is)");
     }
     if (!any) return validate_single(with_entries(p, 0, 0));
     return MOLA_ICP_OK;
@@ -205,6 +209,33 @@ static int solve_on_pairing(Stages& st, const mola_icp_params& p, const Mat4& Tc
     return MOLA_ICP_OK;
 }
 
+// The point matcher's share of a MIXED solve under pairingsWeightParameters.use_scale_outlier_detector
+// (params/icp-settings-regular.yaml:14-17): the pairings that would reach Horn's final solve -- solve_on_pairing's sequence without
+// its solves: unit-weight sums -> centroids -> the centroid-relative test flags outliers; once more with the centroids of what is
+// left.  acc = the 24 sums over the survivors of the second test (unit weights: validate_params refuses the robust kernel here);
+// all zero when nothing is left -- the plane pairings may still carry the solve.
+static int point_sums_without_outliers(Stages& st, const mola_icp_params& p, const Mat4& Tcur, double acc[kNAcc])
+{
+    int rc = st.accumulate(p, Tcur, 0, nullptr, nullptr, true, acc);
+    if (rc) return rc;
+    if ((rc = st.allreduce(acc))) return rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass > 0) {
+            if ((rc = st.accumulate(p, Tcur, 0, nullptr, nullptr, false, acc))) return rc;
+            if ((rc = st.allreduce(acc))) return rc;
+        }
+        if (!(acc[0] > 0)) {
+            for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
+            return MOLA_ICP_OK;
+        }
+        const double cl[3] = {acc[1] / acc[0], acc[2] / acc[0], acc[3] / acc[0]};
+        const double cg[3] = {acc[4] / acc[0], acc[5] / acc[0], acc[6] / acc[0]};
+        if ((rc = st.accumulate(p, Tcur, 1, cl, cg, false, acc))) return rc;
+        if ((rc = st.allreduce(acc))) return rc;
+    }
+    return MOLA_ICP_OK;
+}
+
 // Mixed pairings in one solve (the reference's `matchers:` is "a sequence of one or more", params/icp-settings-regular.yaml:28-39,
 // all initialised together at src/LidarOdometry.cpp:83-84; [EXT] mp2p_icp hands the pairings of every active matcher to the solver).
 // The Gauss-Newton cost of the iteration is  sum_planes (n.(R l + t - c))^2 + sum_points |R l + t - g|^2 -- and a point-to-point
@@ -212,7 +243,8 @@ static int solve_on_pairing(Stages& st, const mola_icp_params& p, const Mat4& Tc
 // x^T A x - 2 b^T x + c0 (x = [R row-major, t]) follows from the 24 sums the point-to-point accumulation already delivers --
 //   A[3k+i][3k+j] += sum l_i l_j,  A[3k+i][9+k] += sum l_i,  A[9+k][9+k] += W,  b[3k+i] += sum l_i g_k,  b[9+k] += sum g_k  (k = x, y, z)
 // -- no kernel of its own.  sum |g|^2 is not among the sums; c0 is set so that the form's value at the matcher's pose equals the
-// accumulated sum of squared distances (acc[17]; it only enters the reported cost / rmse, never the step).  Unit weights.
+// accumulated sum of squared distances (acc[17]; it only enters the reported cost / rmse, never the step).  Unit weights; under the scale
+// outlier detector the sums hold the point pairings that survive it (point_sums_without_outliers).
 void mixed_form(const double acc[kNAcc], const Mat4& T, double pacc[kNAccPlaneHost])
 {
     auto at = [](int a, int b) { if (a > b) { const int t = a; a = b; b = t; } return a * 12 - a * (a - 1) / 2 + (b - a); };   // upper triangle, row-major
@@ -297,8 +329,12 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mol
             if ((rc = st.match_planes(T, pp))) return rc;
             if ((rc = st.accumulate_planes(pacc))) return rc;
             if ((rc = st.match(T, pq.matcher_threshold, pq, nullptr))) return rc;
-            if ((rc = st.accumulate(pq, T, 0, nullptr, nullptr, true, acc))) return rc;
-            if ((rc = st.allreduce(acc))) return rc;
+            if (pq.use_scale_outlier_detector) {
+                if ((rc = point_sums_without_outliers(st, pq, T, acc))) return rc;
+            } else {
+                if ((rc = st.accumulate(pq, T, 0, nullptr, nullptr, true, acc))) return rc;
+                if ((rc = st.allreduce(acc))) return rc;
+            }
             mixed_form(acc, T, pacc);
             pairs_global = pacc[91];
             if (!(pairs_global > 0)) { term = MOLA_ICP_TERM_NO_PAIRINGS; break; }

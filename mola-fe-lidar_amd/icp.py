@@ -463,10 +463,11 @@ class ICP:
         around every matcher launch cost ~8 us per iteration at odometry sizes)"""
         L.check(L.lib().mola_icp_set_profiling(self._h, 1 if on else 0))
 
-    def forget_warm_start(self):
-        """drop the neighbour lists / seeds / plane cache earlier aligns left for the resident clouds (the sorted clouds stay):
-        the next align costs what the first one on this pair cost"""
-        L.check(L.lib().mola_icp_forget_warm_start(self._h))
+    def forget_warm_start(self, schedule: bool = False):
+        """drop the pairing / neighbour lists / seeds / plane cache earlier aligns left for the resident clouds: the next align is
+        stateless.  The sorted clouds and their work-queue cost order (made once per cloud pair) stay; `schedule=True` drops the
+        order too -- the next align costs what the very first one on this pair cost"""
+        L.check((L.lib().mola_icp_forget_cloud_schedule if schedule else L.lib().mola_icp_forget_warm_start)(self._h))
 
     def set_allreduce(self, fn):
         """fn(np.ndarray[float64] of 24) -> None, summing in place across ranks (None = single GPU)."""

@@ -996,6 +996,41 @@ int orc_solve_gauss_newton(const float* lx, const float* ly, const float* lz, si
                                         iters_done);
 }
 
+/* The point matcher's share of a mixed solve under pairingsWeightParameters.use_scale_outlier_detector
+ * (params/icp-settings-regular.yaml:14-17): the pairings that would reach Horn's final solve in orc_solve_pairs -- unit-weight
+ * centroids, the centroid-relative test (orc_accumulate, stage 1), once more with the centroids of what is left -- stay; every
+ * other pairing is removed from idx (-1).  Plane pairings carry no such test.  [EXT-recalled: mp2p_icp applies the detector
+ * inside its Horn / OLAE weighting; what its Gauss-Newton solver does with these parameters in the reference's unpinned version
+ * is unknown -- DESIGN.md section 8.]  Returns the number of pairings left. */
+static size_t drop_scale_outliers(const float* lx, const float* ly, const float* lz, const float* gx, const float* gy, const float* gz,
+                                  int32_t* idx, const float* d2, size_t N, const orc_params* p, const double Tcur[16])
+{
+    uint8_t* outl = (uint8_t*)calloc(N ? N : 1, 1);
+    double acc[ORC_NACC], cl[3] = {0, 0, 0}, cg[3] = {0, 0, 0};
+    int have = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        orc_accumulate(lx, ly, lz, gx, gy, gz, idx, d2, N, p, Tcur, 0, NULL, NULL, outl, acc);
+        if (!(acc[0] > 0)) { have = 0; break; }
+        for (int k = 0; k < 3; k++) { cl[k] = acc[1 + k] / acc[0]; cg[k] = acc[4 + k] / acc[0]; }
+        orc_accumulate(lx, ly, lz, gx, gy, gz, idx, d2, N, p, Tcur, 1, cl, cg, outl, acc);
+        have = 1;
+    }
+    size_t kept = 0;
+    for (size_t i = 0; i < N; i++) {
+        if (idx[i] < 0) continue;
+        int keep = have && !outl[i];
+        if (keep) {   /* stage 1 also passes over pairings closer than 1e-4 to a centroid, without flagging them */
+            const int32_t j = idx[i];
+            const double b[3] = {gx[j] - cg[0], gy[j] - cg[1], gz[j] - cg[2]}, r[3] = {lx[i] - cl[0], ly[i] - cl[1], lz[i] - cl[2]};
+            if (sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]) < 1e-4 || sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) < 1e-4) keep = 0;
+        }
+        if (keep) kept++;
+        else idx[i] = -1;
+    }
+    free(outl);
+    return kept;
+}
+
 /* align with BOTH matchers active in every iteration (Matcher_Points_DistanceThreshold at p->matcher_threshold +
  * Matcher_Point2Plane at plane_threshold) feeding one Gauss-Newton solve; same loop / stall test / quality as orc_align */
 int orc_align_mixed(const float* gx, const float* gy, const float* gz, size_t M, const float* lx, const float* ly,
@@ -1022,6 +1057,7 @@ int orc_align_mixed(const float* gx, const float* gy, const float* gz, size_t M,
             kept_pl = orc_match_point2plane(gx, gy, gz, M, tree, lx, ly, lz, N, T, plane_threshold, plane_eigen_threshold, knn, valid, cen,
                                             nor, NULL);
             kept_pp = orc_match(gx, gy, gz, M, tree, lx, ly, lz, N, T, p->matcher_threshold, idx, d2);
+            if (p->use_scale_outlier_detector) kept_pp = drop_scale_outliers(lx, ly, lz, gx, gy, gz, idx, d2, N, p, T);
         }
         if (!(kept_pl + kept_pp)) { res->termination = ORC_TERM_NO_PAIRINGS; break; }
         double Tn[16], cost;

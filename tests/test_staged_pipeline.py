@@ -194,6 +194,60 @@ def test_two_matchers_in_one_solve_on_the_gpu(pkg, O, synth):
     icp.close()
 
 
+def _regular_yaml_with_a_point_matcher():
+    """the reference's OWN settings file (params/icp-settings-regular.yaml = /root/reference/params/icp-settings-regular.yaml key for
+    key: pairingsWeightParameters.use_scale_outlier_detector true, Solver_GaussNewton, Matcher_Point2Plane) with ONE more entry in its
+    `matchers:` sequence -- nothing else touched"""
+    txt = open(os.path.join(ROOT, "params", "icp-settings-regular.yaml")).read()
+    assert "use_scale_outlier_detector: true" in txt
+    entry = "  - class: mp2p_icp::Matcher_Points_DistanceThreshold\n    params:\n      threshold: 0.35\n"
+    at = txt.index("matchers:\n") + len("matchers:\n")
+    return txt[:at] + entry + txt[at:]
+
+
+def test_two_matchers_under_the_references_weight_parameters_validate(pkg):
+    """two concurrent matchers + use_scale_outlier_detector (the reference's own params block) is accepted; the
+    robust kernel with two matchers stays refused, by name"""
+    p = pkg.Parameters.load_from(_regular_yaml_with_a_point_matcher())
+    assert p.n_extra_matchers == 1 and p.use_scale_outlier_detector == 1 and p.scale_outlier_threshold == pytest.approx(1.1)
+    assert p.matcher_class == pkg._lib.MATCHER_POINTS_DISTANCE_THRESHOLD and p.c.extra_matchers[0].matcher_class == pkg._lib.MATCHER_POINT2PLANE
+    # (the loop validates first: empty clouds -> NoPairings, no refusal)
+    r = pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), p, 0, 0)
+    assert r.terminationReason == pkg.TERM_NO_PAIRINGS
+    p.use_robust_kernel = 1
+    with pytest.raises(pkg.IcpError) as ex:
+        pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), p, 0, 0)
+    assert ex.value.status == pkg._lib.E_UNSUPPORTED and "use_robust_kernel" in str(ex.value)
+
+
+@pytest.mark.gpu
+def test_references_settings_plus_a_point_matcher_equal_the_oracle_on_the_gpu(pkg, O, synth):
+    """the reference's icp-settings-regular.yaml with ONE added Matcher_Points_DistanceThreshold entry loads, aligns and equals the
+    checker (iterations, termination, pose < 1e-7): under use_scale_outlier_detector the point matcher's pairings pass the two-pass
+    centroid-relative test (the weighted accumulation in front of Horn) before they enter the Gauss-Newton form; the plane pairings
+    are untouched by it.  The detector must actually bite on this pair (else the test proves nothing)."""
+    scene = synth.Scene(scene_seed=3, half=12.0, wall_y=5.0, wall_h=4.0, n_boxes=8)
+    Tgt = synth.pose_from_xyzypr(0.20, -0.10, 0.03, np.deg2rad(1.0), np.deg2rad(-0.3), np.deg2rad(0.2))
+    g, l, _ = synth.make_pair(30000, 26000, seed=12, T_gt=Tgt, scene=scene)
+    p = pkg.Parameters.load_from(_regular_yaml_with_a_point_matcher())
+    icp = pkg.ICP(device=0)
+    r = icp.align(g, l, np.eye(4), p)
+    op = O.params(max_iterations=100, matcher_threshold=0.35, quality_threshold=0.10, min_abs_step_trans=5e-5, min_abs_step_rot=1e-5,
+                  use_scale_outlier_detector=True, scale_outlier_threshold=1.1)
+    ref = O.align_mixed(g, l, np.eye(4), op, 0.70, 0.07, 6, 20)
+    assert r.nIterations == ref["n_iterations"] and r.terminationReason == ref["termination"], (r.nIterations, ref["n_iterations"])
+    rot, trans = O.pose_error(r.optimal_tf, ref["T"])
+    assert rot < 1e-7 and trans < 1e-7, (rot, trans)
+    assert r.n_pairs == ref["n_pairs"] and r.quality == pytest.approx(ref["quality"], abs=1e-12)
+    # ... and differs from the same run without the detector: it removed pairings
+    op0 = O.params(max_iterations=100, matcher_threshold=0.35, quality_threshold=0.10, min_abs_step_trans=5e-5, min_abs_step_rot=1e-5)
+    ref0 = O.align_mixed(g, l, np.eye(4), op0, 0.70, 0.07, 6, 20)
+    assert ref0["n_pairs"] > ref["n_pairs"]
+    gt_rot, gt_trans = O.pose_error(r.optimal_tf, Tgt)
+    assert gt_rot < 2e-3 and gt_trans < 2e-2
+    icp.close()
+
+
 def test_loop_switches_matchers_by_iteration(pkg, O, golden):
     """two point-to-point matchers with different gates, iterations 0..2 and 3..: the product's loop over oracle stages sees
     the gate change at iteration 3 and ends where the oracle ends when it is run stage by stage"""

@@ -22,7 +22,9 @@ pick = [k for k in summ if kernel in k]
 # the fast flavour (<false, ...>) is the dominant one; take the entry with the most VALU instructions
 pick.sort(key=lambda k: -summ[k].get("SQ_INSTS_VALU", {}).get("mean", 0))
 c = {name: v["last"] for name, v in summ[pick[0]].items()}     # warm-started launch: the last of each pass
-items = (n + 127) // 128
+# queries per work item: k_nn_tiled runs 64-query items (one query per lane) since round 3, k_nn_coop one 128-query item per workgroup
+item_q = 128 if kernel == "k_nn_coop" else 64
+items = (n + item_q - 1) // item_q
 d = {}
 if "GRBM_GUI_ACTIVE" in c:
     d["kernel_cycles_per_xcd"] = c["GRBM_GUI_ACTIVE"] / 8
@@ -34,8 +36,8 @@ if "SQ_WAVE_CYCLES" in c:
 if c.get("TCP_TCC_READ_REQ_sum"):
     d["l2_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
 if "SQ_INSTS_VALU" in c:
-    d["valu_insts_per_item"] = c["SQ_INSTS_VALU"] / items
-    d["salu_insts_per_item"] = c.get("SQ_INSTS_SALU", 0) / items
+    d[f"valu_insts_per_{item_q}_query_item"] = c["SQ_INSTS_VALU"] / items
+    d[f"salu_insts_per_{item_q}_query_item"] = c.get("SQ_INSTS_SALU", 0) / items
 rec = {"kernel": kernel, "kernel_symbol": pick[0], "n_local": n, "n_map": m, "counters": c, "derived": d,
        "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
        "date": datetime.date.today().isoformat(), "kernel_sources_sha1": kernel_sources_sha1(),

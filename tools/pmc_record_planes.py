@@ -40,8 +40,8 @@ for sym, cs in summ.items():
     if us:
         d["avg_us"] = us
         d["launches_in_trace"] = len(dur[full[0]])
-        d["algorithmic_GBs"] = bytes_alg / (us * 1e-6) / 1e9
-        d["frac_of_hbm_peak"] = d["algorithmic_GBs"] / 8000.0
+        # (no HBM fraction per flavour: a launch average weighs the verification / counting launches of microseconds like full
+        # searches -- bench.py prices the matcher per ITERATION, shipped_point2plane_gn.roofline)
     if "GRBM_GUI_ACTIVE" in c:
         d["kernel_cycles_per_xcd"] = c["GRBM_GUI_ACTIVE"] / 8
         if "SQ_ACTIVE_INST_VALU" in c:
@@ -66,7 +66,7 @@ if tot["launches"]:
     recs_new.append({"kernel": "k_knn_planes" if n > 131072 else "k_knn_coop", "n_local": n, "n_map": m, **stamp,
                      "hbm_bytes_per_launch": tot["hbm"] / tot["launches"],
                      "derived": {"avg_us_over_all_flavours": avg_us, "launches": tot["launches"], "algorithmic_bytes_per_launch": bytes_alg,
-                                 "algorithmic_GBs": bytes_alg / (avg_us * 1e-6) / 1e9, "frac_of_hbm_peak": bytes_alg / (avg_us * 1e-6) / 1e9 / 8000.0},
+                                 },
                      "note": "launch-weighted average over the matcher flavours of the run (see the per-symbol records)"})
 os.makedirs(dst, exist_ok=True)
 path = os.path.join(dst, "counters.json")
