@@ -1358,6 +1358,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         kp.lb = cert.lb;
         kp.use_seed = knn_seed; kp.use_cache = plane_cache_ok; kp.cert_on = cert.on;
         kp.changed_items = tq + kQueues * kQueueStride + 1;
+        kp.cost = knn_cost_.as<unsigned int>();
         if (g_knobs.debug_stats == 4 && p.knn == 6) {   // diagnostics: where the waves of every item spend their cycles
             DevBuf dg;
             if ((rc = dg.reserve(sizeof(unsigned long long) * kKnnDiagWords * 4 * (size_t)n_items64))) return rc;
@@ -1394,6 +1395,17 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
             std::fprintf(stderr, "[mola_icp debug]   per item (median / p90 / max): staged points %llu / %llu / %llu, tile tests %llu / %llu / %llu, super-tiles entered %llu / %llu / %llu, lanes not certified %llu / %llu / %llu; items with a plane solve %llu, items that skipped the sweep %llu of %d\n",
                          pct(staged_v, 0.5), pct(staged_v, 0.9), pct(staged_v, 1.0), pct(tests_v, 0.5), pct(tests_v, 0.9), pct(tests_v, 1.0), pct(supers_v, 0.5), pct(supers_v, 0.9),
                          pct(supers_v, 1.0), pct(open_v, 0.5), pct(open_v, 0.9), pct(open_v, 1.0), n_changed, n_skip, n_items64);
+            {   // what the sweep's visitor did: groups of four staged points, how many took the slow path, lane events in it
+                unsigned long long groups = 0, slow = 0, keypass = 0, dup = 0, ins = 0;
+                for (int it = 0; it < n_items64; ++it)
+                    for (int wv = 0; wv < 4; ++wv) {
+                        const unsigned long long a = h[((size_t)it * 4 + wv) * kKnnDiagWords + 12], b = h[((size_t)it * 4 + wv) * kKnnDiagWords + 13];
+                        groups += a & 0xffffffffull; slow += a >> 32; keypass += b & 0x1fffffull; dup += (b >> 21) & 0x1fffffull; ins += b >> 42;
+                    }
+                std::fprintf(stderr, "[mola_icp debug]   visitor, whole launch: %llu groups of four points, %llu (%.1f %%) took the slow path; lane events inside it: %llu keys below the lane's K-th "
+                                     "(%.2f per query), of which %llu seeds met again, %llu insertions (%.2f per query)\n",
+                             groups, slow, 100.0 * (double)slow / (double)(groups ? groups : 1), keypass, (double)keypass / (double)N_, dup, ins, (double)ins / (double)N_);
+            }
             // ... and is a heavy item a SPREAD one?  (64 consecutive sorted queries that are not compact in space: the sparse far rings
             // of a scan, an empty stretch of the curve): the item's own bounding box, from the sorted queries
             {
@@ -1459,6 +1471,29 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         knn_plan_interval_ = knn_order_valid_ ? (knn_plan_interval_ < 16 ? knn_plan_interval_ * 2 : 16) : 1;
         knn_order_valid_ = true;
         knn_launches_since_order_ = 0;
+    }
+    if (g_knobs.debug_stats == 5 && knn_coop) {   // diagnostics: the items' lifetimes in THIS launch of the product kernel (two clock reads per item)
+        std::vector<unsigned int> c((size_t)n_items64);
+        HIPCHK(hipMemcpyAsync(c.data(), knn_cost_.p, c.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        std::vector<unsigned int> v = c;
+        std::sort(v.begin(), v.end());
+        double sum = 0;
+        for (unsigned int x : v) sum += x;
+        const size_t n = v.size();
+        const int slots = num_cus_ * 4;
+        std::fprintf(stderr, "[mola_icp debug] k_knn_coop item lifetimes (shader cycles): N=%zu items=%zu seed=%d cert=%d bootstrapped=%d step=%.4f | mean %.0f p10 %u p50 %u p90 %u p99 %u max %u | "
+                             "sum / %d workgroup slots = %.0f = %.2f x the heaviest item; items above 2x the median: %zu\n",
+                     N_, n, knn_seed, cert.on, (int)bootstrapped, step, sum / (double)n, v[n / 10], v[n / 2], v[n * 9 / 10], v[n * 99 / 100], v[n - 1], slots, sum / slots,
+                     sum / slots / (double)v[n - 1], (size_t)(v.end() - std::upper_bound(v.begin(), v.end(), 2u * v[n / 2])));
+        // where along the curve the heavy ones sit (16 stretches of the item order: share of the total cost)
+        std::fprintf(stderr, "[mola_icp debug]   cost share of 16 stretches of the item order:");
+        for (int b = 0; b < 16; ++b) {
+            double sb = 0;
+            for (size_t i = n * (size_t)b / 16; i < n * (size_t)(b + 1) / 16; ++i) sb += c[i];
+            std::fprintf(stderr, " %.3f", sb / sum);
+        }
+        std::fprintf(stderr, "\n");
     }
     if (g_knobs.debug_stats == 3) {   // diagnostics: what the certificates did in THIS launch (a synchronisation per launch)
         HIPCHK(hipMemcpyAsync(stats_host_, stats_.p, sizeof(unsigned long long) * kStatSlots * kStatStride, hipMemcpyDeviceToHost, stream_));

@@ -520,6 +520,7 @@ struct KnnProblem {
     float* lb;                      // per query: lower bound on the distance to every point outside its list (KnnCert)
     int use_seed, use_cache, cert_on;
     unsigned int* changed_items;    // 8 slots, kQueueStride words apart: items whose lists changed
+    unsigned int* cost;             // per 64-query item: shader cycles the item took in this launch (null: not recorded) -> the next launch's order
 };
 constexpr int kKnnMaxBatch = 12;    // problems per launch (kernel arguments are limited to 4 KB; = kCoopMaxBatch)
 template <int KMAX> struct KnnBatch { KnnProblem p[KMAX]; };
@@ -540,7 +541,7 @@ struct KnnCoopLds {
 // One cooperative item: the four waves of the workgroup hold the same 64 queries (lane -> qi; >= N: none), deal the candidate
 // tiles among themselves (coop_sweep), merge their lists through LDS; wave 0 runs the plane epilogue.  Called by ALL four waves
 // (barriers inside); nothing of S may be touched by the caller before its next barrier.  CERT: derive the certificates (KnnCert).
-constexpr int kKnnDiagWords = 12;   // MOLA_ICP_DEBUG_STATS=4: shader-clock phases of every wave of every item (see knn_coop_item)
+constexpr int kKnnDiagWords = 14;   // MOLA_ICP_DEBUG_STATS=4: shader-clock phases of every wave of every item (see knn_coop_item)
 template <int K, bool CERT, bool DIAG = false>
 __device__ __forceinline__ void knn_coop_item(KnnCoopLds<K>& S, const KnnProblem& pb, const TiledMap& mp, const lds_f32* lbox, int lds_boxes, int qi,
                                               float thr2, float thr2x, double threshold, double plane_eig_thr,
@@ -549,6 +550,7 @@ __device__ __forceinline__ void knn_coop_item(KnnCoopLds<K>& S, const KnnProblem
 {
     unsigned long long dt[6] = {};
     if (DIAG) dt[0] = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_item0 = (wave == 0 && pb.cost) ? __builtin_amdgcn_s_memtime() : 0ull;
     // (the body is written out with plain locals, as the kernel had it before it became a function: the same lists held in a struct
     //  cost this kernel 40 vector registers -- 123 -> 164 -- and with them its fourth workgroup per CU)
     const int N = pb.N;
@@ -629,6 +631,7 @@ __device__ __forceinline__ void knn_coop_item(KnnCoopLds<K>& S, const KnnProblem
     unsigned long long n_staged = 0ull;
     unsigned long long pc[5] = {};
     unsigned int pn[3] = {};
+    unsigned int dg_groups = 0u, dg_slow = 0u, dg_keypass = 0u, dg_dup = 0u, dg_ins = 0u;   // DIAG: what the visitor did (lane events summed over the wave)
     if (!skip_sweep) {   // (workgroup-uniform: the barriers inside are met by all four waves)
         float(*sm)[64] = S.s_m[wave];
         n_staged = coop_sweep<true>(mp, lbox, lds_boxes != 0, S.s_list, S.s_wbox, S.s_ctl, S.s_tick, lane, wave, sm, q2x, q2y, q2z, reach2, kb2, [&](int nm, int jb0, int jb1) {
@@ -645,16 +648,21 @@ __device__ __forceinline__ void knn_coop_item(KnnCoopLds<K>& S, const KnnProblem
                     d[u] = dv.x; d[u + 1] = dv.y;
                 }
                 const bool cand = fminf(fminf(d[0], d[1]), fminf(d[2], d[3])) <= kd_of(K - 1);
+                if (DIAG) dg_groups += 1u;
                 if (__any(cand)) {
+                    if (DIAG) dg_slow += 1u;
                     const float4 O = *reinterpret_cast<const float4*>(&sm[3][m]);
                     const unsigned int os[4] = {__float_as_uint(O.x), __float_as_uint(O.y), __float_as_uint(O.z), __float_as_uint(O.w)};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int pos = (m + u) < 32 ? jb0 + m + u : jb1 + m + u - 32;
-                        if ((((unsigned long long)__float_as_uint(d[u]) << 32) | os[u]) < kk[K - 1]) {
+                        const bool keypass = (((unsigned long long)__float_as_uint(d[u]) << 32) | os[u]) < kk[K - 1];
+                        if (DIAG) dg_keypass += (unsigned int)__popcll(__ballot(keypass));
+                        if (keypass) {
                             bool dup = false;  // a seed met again by the sweep
 #pragma unroll
                             for (int j = 0; j < K; ++j) dup |= kp[j] == pos;
+                            if (DIAG) { dg_dup += (unsigned int)__popcll(__ballot(dup)); dg_ins += (unsigned int)__popcll(__ballot(!dup)); }
                             if (!dup) insert(d[u], os[u], pos);
                         }
                     }
@@ -698,6 +706,8 @@ __device__ __forceinline__ void knn_coop_item(KnnCoopLds<K>& S, const KnnProblem
             diag[10] = (n_staged & 0xfffffull) | ((unsigned long long)(pn[1] & 0xfffu) << 20) | ((unsigned long long)(pn[2] & 0xfffffu) << 32) |
                        ((unsigned long long)__popcll(~cert_mask) << 52) | ((unsigned long long)(changed ? 1 : 0) << 60) | ((unsigned long long)(skip_sweep ? 1 : 0) << 61);
             diag[11] = t_end - dt[0];
+            diag[12] = (unsigned long long)dg_groups | ((unsigned long long)dg_slow << 32);
+            diag[13] = (unsigned long long)dg_keypass | ((unsigned long long)dg_dup << 21) | ((unsigned long long)dg_ins << 42);
         }
     };
     if (wave != 0) { diag_record(false); return; }   // (no barrier below)
@@ -712,6 +722,10 @@ __device__ __forceinline__ void knn_coop_item(KnnCoopLds<K>& S, const KnnProblem
         unsigned long long* st = cert.stats + (size_t)(blockIdx.x & (kStatSlots - 1)) * kStatStride;
         atomicAdd(st + 1, (unsigned long long)__popcll(cert_mask));
         if (skip_sweep) atomicAdd(st + 2, 1ull);
+    }
+    if (pb.cost && lane == 0) {   // (the leader wave is the item's last: its lifetime is the item's)
+        const unsigned long long c = __builtin_amdgcn_s_memtime() - t_item0;
+        pb.cost[qi >> 6] = (unsigned int)(c < 0xffffffffull ? c : 0xffffffffull);
     }
     diag_record(changed);
 }
