@@ -69,10 +69,10 @@ def main():
     ap.add_argument("--cpu-baseline-iters", type=int, default=5, help="0 disables every CPU leg")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed code path (process group + RCCL communicator) even with one rank")
-    ap.add_argument("--allreduce", choices=["local", "rccl", "hook"], default="local",
-                    help="local: the node-local shared-memory mailbox on the host, where the sums are consumed (one node: what "
-                         "this bench is); rccl: native RCCL on the device block (the multi-node path, and the fallback); "
-                         "hook: torch.distributed from the host hook")
+    ap.add_argument("--allreduce", choices=["both", "local", "rccl", "hook"], default="both",
+                    help="both (default): the timed align runs through the node-local shared-memory mailbox AND through native RCCL on "
+                         "the device block, one after the other -- the line carries both (`allreduce`), `value` is the faster; "
+                         "local / rccl / hook: that transport only (hook: torch.distributed from the host hook)")
     ap.add_argument("--guess-dt", type=float, default=1.0, help="sharded runs: how far (m) the pose may end from the guess -- sizes each rank's map slab")
     ap.add_argument("--guess-drot-deg", type=float, default=3.0, help="sharded runs: how far (deg) the pose may rotate from the guess")
     ap.add_argument("--balance-rounds", type=int, default=3,
@@ -115,7 +115,7 @@ def main():
         args.share_gpu = True
     if args.share_gpu:
         local_rank = local_rank % max(1, torch.cuda.device_count())
-        if args.allreduce == "rccl":   # (RCCL cannot put two ranks on one device)
+        if args.allreduce == "rccl" and world > 1:   # (RCCL cannot put two ranks on one device)
             args.allreduce = "local"
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
@@ -228,35 +228,47 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return int(flag.item()) == 0
 
-    if use_dist:
-        allreduce_used = args.allreduce
-        if allreduce_used == "local":
+    def attach(kind):
+        """attach one transport to the headline's handle on every rank (or on none: the ranks agree); returns (ok, nranks)"""
+        nonlocal local_comm
+        if kind == "local":
             try:
                 local_comm = icp.comm_init_local()
-                comm_nranks = icp.comm_nranks()   # the ranks that joined the mailbox
-                ok = comm_nranks == world
+                n = icp.comm_nranks()   # the ranks that joined the mailbox
+                ok = n == world
             except Exception as e:  # noqa: BLE001
-                print(f"[bench] node-local communicator failed on rank {rank} ({e}); trying RCCL", file=sys.stderr, flush=True)
-                ok = False
+                print(f"[bench] node-local communicator failed on rank {rank} ({e})", file=sys.stderr, flush=True)
+                ok, n = False, None
             if not agree(ok):
                 icp.comm_destroy()
-                local_comm, comm_nranks = None, None
-                allreduce_used = "hook" if args.share_gpu else "rccl"
-        if allreduce_used == "rccl":
+                local_comm = None
+                return False, None
+            return True, n
+        if kind == "rccl":
+            if args.share_gpu and world > 1:   # (RCCL cannot put two ranks on one device)
+                return False, None
             try:
                 icp.comm_init()
-                comm_nranks = icp.comm_nranks()   # what RCCL itself reports (ncclCommCount)
+                n = icp.comm_nranks()   # what RCCL itself reports (ncclCommCount)
                 ok = True
-            except Exception as e:  # keep the run alive: torch.distributed carries the 24 doubles instead
-                print(f"[bench] native RCCL communicator failed on rank {rank} ({e}); using the torch.distributed hook",
-                      file=sys.stderr, flush=True)
-                ok = False
+            except Exception as e:
+                print(f"[bench] native RCCL communicator failed on rank {rank} ({e})", file=sys.stderr, flush=True)
+                ok, n = False, None
             if not agree(ok):
                 if ok:
                     icp.comm_destroy()
-                allreduce_used, comm_nranks = "hook", None
-        if allreduce_used == "hook":
-            icp.set_allreduce(sharded.make_allreduce(device=dev))
+                return False, None
+            return True, n
+        icp.set_allreduce(sharded.make_allreduce(device=dev))
+        return True, None
+
+    def detach(kind):
+        nonlocal local_comm
+        if kind in ("local", "rccl"):
+            icp.comm_destroy()
+            local_comm = None
+        else:
+            icp.set_allreduce(None)
 
     p = pkg.Parameters()
     p.matcher_threshold = GATE_M
@@ -274,10 +286,12 @@ def main():
         torch.cuda.synchronize()
 
     T0 = np.eye(4)
-    if world > 1:
+
+    def rehearse():
         # The whole trajectory of the timed align must stay inside every rank's map slab (the matcher checks it at every
         # pose; a violation on ANY rank reaches all of them through the all-reduce, so they fail -- and re-cut -- together).
         # Rehearse the full run once per margin before anything is timed.
+        nonlocal slab
         p.max_iterations = args.steps
         for attempt in range(4):
             try:
@@ -288,49 +302,95 @@ def main():
                     raise
                 _, slab = place_clouds(icp, tg, tl, margin_scale=2.0 ** (attempt + 1), cuts=cuts)   # (the guess was worse than stated)
                 slab["recut"] = attempt + 1
-    # Device warm-up (untimed, the same count on every rank): the GPU has idled through seconds of host-side cloud
-    # generation and its clocks take a few hundred milliseconds of work to settle -- behind 3 warm-up steps alone the
-    # matcher launch read 106.5 us, behind 300 of them 100.1 us.  Then the W warm-up steps the caller asked for.
-    if args.device_warmup_aligns > 0:
-        p.max_iterations = args.steps
-        for _ in range(args.device_warmup_aligns):
-            icp.align_resident(T0, p)
-    if args.warmup > 0:
-        p.max_iterations = args.warmup
-        icp.align_resident(T0, p)
 
-    # The timed align is STATELESS: what the untimed aligns left for the clouds in place -- the last pairing (next launch's seeds),
-    # the per-item cost orders -- is dropped first (mola_icp_forget_warm_start), as mp2p_icp::ICP::align() keeps nothing between
-    # calls (src/LidarOdometry.cpp:869-871).  The GPU's clocks stay warm; the sorted clouds stay resident (the metric's premise).
-    # The same align once more on the state the first one left = `value_repeat_on_warm_state` (what rounds 1-4 printed as `value`).
-    p.max_iterations = args.steps
-    icp.forget_warm_start()
-    barrier()
-    t0 = time.perf_counter()
-    res = icp.align_resident(T0, p)
-    torch.cuda.synchronize()
-    dt_own = time.perf_counter() - t0      # (this rank's K steps; the closing barrier below is the contract's)
-    barrier()
-    dt = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    res_warm = icp.align_resident(T0, p)
-    torch.cuda.synchronize()
-    barrier()
-    dt_warm = time.perf_counter() - t0
-    icp.forget_warm_start(schedule=True)   # ... and with the clouds' work-queue order gone too: the very first align on a pair
-    barrier()
-    t0 = time.perf_counter()
-    res_first = icp.align_resident(T0, p)
-    torch.cuda.synchronize()
-    barrier()
-    dt_first = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt, dt_own, dt_warm, dt_first], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_own, dt_warm, dt_first = float(t[0]), float(t[1]), float(t[2]), float(t[3])
-    assert np.array_equal(res_first.optimal_tf, res.optimal_tf)
-    assert res.nIterations == args.steps, (res.nIterations, args.steps)
-    assert np.array_equal(res_warm.optimal_tf, res.optimal_tf)   # (the state changes the cost of an align, never its result)
+    def timed_run(warm_aligns):
+        """W warm-up steps, then the timed K steps between barrier + synchronize brackets (max over ranks), then the same align on
+        warm state and as the very first align on the pair.  Returns the seconds and the timed align's result."""
+        # Device warm-up (untimed, the same count on every rank): the GPU has idled through seconds of host-side cloud
+        # generation and its clocks take a few hundred milliseconds of work to settle -- behind 3 warm-up steps alone the
+        # matcher launch read 106.5 us, behind 300 of them 100.1 us.  Then the W warm-up steps the caller asked for.
+        p.max_iterations = args.steps
+        for k in range(warm_aligns):
+            if k == warm_aligns - 1:
+                icp.forget_warm_start()   # (the last one as the timed one will be: an unseeded first launch has run on this transport before the clock starts)
+            icp.align_resident(T0, p)
+        if args.warmup > 0:
+            p.max_iterations = args.warmup
+            icp.align_resident(T0, p)
+        # The timed align is STATELESS: what the untimed aligns left for the clouds in place -- the last pairing (next launch's
+        # seeds), the neighbour lists -- is dropped first (mola_icp_forget_warm_start), as mp2p_icp::ICP::align() keeps nothing
+        # between calls (src/LidarOdometry.cpp:869-871).  The GPU's clocks stay warm; what belongs to the CLOUDS stays resident
+        # (the metric's premise): their sorted form and their work-queue order.  The same align once more on the state the first
+        # one left = `value_repeat_on_warm_state` (what rounds 1-4 printed as `value`); with the work-queue order dropped too =
+        # `value_first_align_on_pair`.
+        p.max_iterations = args.steps
+        icp.forget_warm_start()
+        barrier()
+        t0 = time.perf_counter()
+        res = icp.align_resident(T0, p)
+        torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0      # (this rank's K steps; the closing barrier below is the contract's)
+        barrier()
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        res_warm = icp.align_resident(T0, p)
+        torch.cuda.synchronize()
+        barrier()
+        dt_warm = time.perf_counter() - t0
+        icp.forget_warm_start(schedule=True)
+        barrier()
+        t0 = time.perf_counter()
+        res_first = icp.align_resident(T0, p)
+        torch.cuda.synchronize()
+        barrier()
+        dt_first = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt, dt_own, dt_warm, dt_first], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, dt_own, dt_warm, dt_first = float(t[0]), float(t[1]), float(t[2]), float(t[3])
+        assert res.nIterations == args.steps, (res.nIterations, args.steps)
+        # (the state changes the cost of an align, never its result)
+        assert np.array_equal(res_warm.optimal_tf, res.optimal_tf) and np.array_equal(res_first.optimal_tf, res.optimal_tf)
+        return {"dt": dt, "dt_own": dt_own, "dt_warm": dt_warm, "dt_first": dt_first, "res": res}
+
+    # Sharded: the timed align runs through EVERY transport asked for (default: the node-local mailbox, then native RCCL on the
+    # device block), the line carries each one's step time and the rank count the communicator itself reports (`allreduce`), and
+    # `value` is the faster one's -- so that a run on a node answers "did RCCL see N ranks, and what did it cost" in the default line.
+    per_transport = {}
+    if use_dist:
+        kinds = ["local", "rccl"] if args.allreduce == "both" else [args.allreduce]
+        runs, first = {}, True
+        for kind in kinds:
+            ok, n = attach(kind)
+            if not ok:
+                why = ("two ranks cannot share one device under RCCL (ranks_share_gpus)" if kind == "rccl" and args.share_gpu and world > 1
+                       else "the communicator could not be created on every rank (stderr)")
+                per_transport[kind] = {"ms_per_step": None, "nranks": None, "note": why}
+                continue
+            if first and world > 1:
+                rehearse()
+            runs[kind] = timed_run(args.device_warmup_aligns if first else min(5, args.device_warmup_aligns))
+            first = False
+            per_transport[kind] = {"ms_per_step": runs[kind]["dt"] / args.steps * 1e3, "nranks": n,
+                                   "ms_per_step_repeat_on_warm_state": runs[kind]["dt_warm"] / args.steps * 1e3}
+            detach(kind)
+        if not runs:   # keep the run alive: torch.distributed carries the 24 doubles instead
+            attach("hook")
+            if world > 1:
+                rehearse()
+            runs["hook"] = timed_run(args.device_warmup_aligns)
+            per_transport["hook"] = {"ms_per_step": runs["hook"]["dt"] / args.steps * 1e3, "nranks": None}
+            detach("hook")
+        allreduce_used = min(runs, key=lambda k: runs[k]["dt"])
+        _, comm_nranks = attach(allreduce_used)   # (for the profiled repetitions and the configs[4] leg below)
+        run = runs[allreduce_used]
+        # every transport must have produced the same pose (rank-ordered sums on the host, RCCL's own order on the device: same to
+        # the last bits that survive the solve's rounding)
+        for k, r in runs.items():
+            assert np.allclose(r["res"].optimal_tf, run["res"].optimal_tf, atol=1e-9), (k, allreduce_used)
+    else:
+        run = timed_run(args.device_warmup_aligns)
+    dt, dt_own, dt_warm, dt_first, res = run["dt"], run["dt_own"], run["dt_warm"], run["dt_first"], run["res"]
     # Kernel statistics -- HIP events around every matcher launch, recorded on the library's own stream, and the
     # executed-pair counters -- come from an IDENTICAL repetition right after the timed region (stateless like it): the two event
     # packets per launch cost ~8 us per iteration, which the timed region does not pay (mola_icp_set_profiling, off by default).
@@ -422,6 +482,7 @@ def main():
                    "n_local": N, "n_map": M, "gate_m": GATE_M, "queries_per_gpu": hi - lo,
                    "parallelism": (f"query-shard x{world}, {allreduce_used} all-reduce" if use_dist else "single GPU"),
                    "ranks_share_gpus": bool(args.share_gpu and world > 1), "comm_nranks": comm_nranks,
+                   "allreduce": per_transport if use_dist else None,
                    "nn_kernel": roof["kernel"], "map_slab_rank0": slab, "shard_balance": balance},
         "roofline": roof,
         "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(res.optimal_tf, T_gt))),
@@ -596,41 +657,92 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
     else:
         (n_shard, slab), balance, cuts = place_clouds(icp5, tg5, tl5), None, None
     icp5.set_global_sizes(N, M5)
-    if use_dist:
-        if allreduce_used == "local":
-            icp5.comm_init_local(comm=local_comm)
-        elif allreduce_used == "rccl":
-            icp5.comm_init()
-        else:
-            icp5.set_allreduce(sharded.make_allreduce(device=dev))
     T0 = np.eye(4)
-    for attempt in range(4):   # rehearsal = warm-up (allocations, the slab check over the whole trajectory: see the headline)
+
+    def attach5(kind):
         try:
-            icp5.align_resident(T0, p)
-            break
-        except pkg.IcpError as e:
-            if world == 1 or "map slab" not in str(e) or attempt == 3:
-                raise
-            _, slab = place_clouds(icp5, tg5, tl5, margin_scale=2.0 ** (attempt + 1), cuts=cuts)
-            slab["recut"] = attempt + 1
-    icp5.align_resident(T0, p)
-    dts, dts_warm = [], []
-    for _ in range(3):   # (the median of three timed aligns: one bench line in five caught a 50-ms stall of the box in a single one)
-        for warm in (False, True):   # stateless like the headline (nothing kept from the align before), then the repeat on its state
-            if not warm:
-                icp5.forget_warm_start()
-            barrier()
-            t0 = time.perf_counter()
-            r = icp5.align_resident(T0, p)
-            barrier()
-            dt = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
-            (dts_warm if warm else dts).append(dt)
-    dt = float(np.median(dts))
-    dt_warm = float(np.median(dts_warm))
+            if kind == "local":
+                icp5.comm_init_local()
+                return True, icp5.comm_nranks()
+            if kind == "rccl":
+                if args.share_gpu and world > 1:
+                    return False, None
+                icp5.comm_init()
+                return True, icp5.comm_nranks()
+            icp5.set_allreduce(sharded.make_allreduce(device=dev))
+            return True, None
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] configs[4] leg: {kind} communicator failed on rank {rank} ({e})", file=sys.stderr, flush=True)
+            return False, None
+
+    def detach5(kind):
+        if kind in ("local", "rccl"):
+            icp5.comm_destroy()
+        else:
+            icp5.set_allreduce(None)
+
+    def rehearse5():   # = warm-up (allocations, the slab check over the whole trajectory: see the headline)
+        nonlocal slab
+        for attempt in range(4):
+            try:
+                icp5.align_resident(T0, p)
+                break
+            except pkg.IcpError as e:
+                if world == 1 or "map slab" not in str(e) or attempt == 3:
+                    raise
+                _, slab = place_clouds(icp5, tg5, tl5, margin_scale=2.0 ** (attempt + 1), cuts=cuts)
+                slab["recut"] = attempt + 1
+
+    def timed5():
+        icp5.align_resident(T0, p)
+        dts, dts_warm = [], []
+        for _ in range(3):   # (the median of three timed aligns: one bench line in five caught a 50-ms stall of the box in a single one)
+            for warm in (False, True):   # stateless like the headline (nothing kept from the align before), then the repeat on its state
+                if not warm:
+                    icp5.forget_warm_start()
+                barrier()
+                t0 = time.perf_counter()
+                r = icp5.align_resident(T0, p)
+                barrier()
+                dt = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt = float(t.item())
+                (dts_warm if warm else dts).append(dt)
+        return {"dt": float(np.median(dts)), "dt_warm": float(np.median(dts_warm)), "dts": dts, "r": r}
+
+    per_transport, chosen = {}, None
+    if use_dist:
+        kinds = ["local", "rccl"] if args.allreduce == "both" else [allreduce_used]
+        runs = {}
+        for kind in kinds:
+            ok, n = attach5(kind)
+            flag = torch.tensor([0 if ok else 1], device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)   # (every rank takes the same path)
+            if int(flag.item()) != 0:
+                if ok:
+                    detach5(kind)
+                per_transport[kind] = {"ms_per_step": None, "nranks": None}
+                continue
+            if not runs:
+                rehearse5()
+            runs[kind] = timed5()
+            per_transport[kind] = {"ms_per_step": runs[kind]["dt"] / args.c5_steps * 1e3, "nranks": n}
+            detach5(kind)
+        if not runs:
+            attach5("hook")
+            rehearse5()
+            runs["hook"] = timed5()
+            per_transport["hook"] = {"ms_per_step": runs["hook"]["dt"] / args.c5_steps * 1e3, "nranks": None}
+            detach5("hook")
+        chosen = min(runs, key=lambda k: runs[k]["dt"])
+        attach5(chosen)
+        run = runs[chosen]
+    else:
+        rehearse5()
+        run = timed5()
+    dt, dt_warm, dts, r = run["dt"], run["dt_warm"], run["dts"], run["r"]
     icp5.forget_warm_start()
     icp5.set_profiling(True)
     rp = icp5.align_resident(T0, p)
@@ -645,10 +757,10 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
            "regime": "fixed iterations from the identity: the pair is still far from converged when the leg ends (see pose_err_vs_gt) -- the far-from-converged regime only",
            "n_local": N, "n_map": M5, "queries_per_gpu_rank0": n_shard, "map_slab_rank0": slab, "shard_balance": balance,
            "matcher_ms_per_launch_rank0": k_ms, "pairs_evaluated_per_query_rank0": rp.nn_pairs_evaluated / max(1, rp.n_nn_launches) / max(1, n_shard),
-           "all_reduce": allreduce_used if use_dist else None,
+           "all_reduce": chosen, "allreduce": per_transport if use_dist else None,
            "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(r.optimal_tf, T_gt)))}
-    if use_dist and allreduce_used in ("local", "rccl"):
-        icp5.comm_destroy()   # (detaches the shared mailbox; destroys this handle's own RCCL communicator)
+    if use_dist and chosen is not None:
+        detach5(chosen)
     icp5.close()
     return leg
 

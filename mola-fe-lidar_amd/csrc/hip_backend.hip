@@ -277,6 +277,7 @@ int HipWorkspace::init()
     std::memset(meta_host_, 0, sizeof(float) * 16);
     int rc;
     if ((rc = acc_dev_.reserve(sizeof(double) * (kNAcc + 8) + sizeof(unsigned int) * 2 * kQueues * kQueueStride))) return rc;
+    HIPCHK(hipMemsetAsync(acc_dev_.p, 0, sizeof(double) * (kNAcc + 8) + sizeof(unsigned int) * 2 * kQueues * kQueueStride, stream_));   // (k_reduce_items' finished-blocks word among them)
     if ((rc = stats_.reserve(sizeof(unsigned long long) * kStatSlots * kStatStride))) return rc;
     HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, stream_));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&stats_host_), sizeof(unsigned long long) * kStatSlots * kStatStride, hipHostMallocDefault));
@@ -2035,6 +2036,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     // the first pass of an iteration after a cooperative match: the matcher already summed the unit-weight terms per item
     const bool fused = pairing_sorted_ && rows_valid_ && stage == 0 && reset_outliers;
     const double* rows = partials_.as<double>();
+    bool rows_final = false;
     if (fused) {
         // the matchers' item rows (one per 64 queries: thousands): G blocks sum a slice each; on a single GPU they publish their G
         // rows to the pinned block themselves and THIS thread adds them in order -- else the one-block reduction below takes them
@@ -2046,8 +2048,11 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         }
         const bool direct_items = !comm_ && !g_knobs.no_direct_readback;
         const unsigned long long seq_i = ++readback_seq_;
+        // (sharded over RCCL: the last block to finish also adds the G rows into the device block the collective runs on)
+        unsigned int* done_word = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 6);
         hipLaunchKernelGGL(k_reduce_items, dim3(G), dim3(kNAcc * kRedSlices), 0, stream_, rows_.as<double>(), rows_count_, item_part_.as<double>(),
-                           direct_items ? item_part_host_ : (double*)nullptr, seq_i, acc_dev_.as<double>());
+                           direct_items ? item_part_host_ : (double*)nullptr, seq_i, acc_dev_.as<double>(),
+                           comm_ ? acc_dev_.as<double>() : (double*)nullptr, comm_ ? done_word : (unsigned int*)nullptr);
         HIPCHK(hipGetLastError());
         counters_clean_ = true;
         if (direct_items) {
@@ -2062,6 +2067,7 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
         }
         rows = item_part_.as<double>();
         nblocks = G;
+        rows_final = comm_ != nullptr;   // (acc_dev_ holds the sums already: k_reduce_items' last block)
     } else {
         hipLaunchKernelGGL(k_accumulate, dim3(nblocks), dim3(kAccThreads), 0, stream_, a, partials_.as<double>());
         HIPCHK(hipGetLastError());
@@ -2072,9 +2078,11 @@ int HipWorkspace::accumulate(const mola_icp_params& p, const Mat4& Tcur, int sta
     // device block, then the block is copied.
     const bool direct = !comm_ && !g_knobs.no_direct_readback;
     const unsigned long long seq = ++readback_seq_;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kNAcc * kRedSlices), 0, stream_, rows, nblocks,
-                       acc_dev_.as<double>(), direct ? acc_host_ : (double*)nullptr, seq);
-    HIPCHK(hipGetLastError());
+    if (!rows_final) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kNAcc * kRedSlices), 0, stream_, rows, nblocks,
+                           acc_dev_.as<double>(), direct ? acc_host_ : (double*)nullptr, seq);
+        HIPCHK(hipGetLastError());
+    }
     counters_clean_ = true;
     volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(acc_host_) + kNAcc + 6;
     if (!direct) {

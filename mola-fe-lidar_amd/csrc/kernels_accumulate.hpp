@@ -182,10 +182,14 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_partials(const do
 // sums the rows [g n / G, (g + 1) n / G) in reduce_rows' fixed order into row g of `part` (stride kNAcc) and, single GPU,
 // publishes it at host_out + 32 g with its own sequence flag -- the host adds the G rows in order itself (a second,
 // one-block launch for a few dozen rows would cost more than the sums).  Block 0 also leaves the matcher's counters zero.
+// `final_acc` (sharded over RCCL: the collective runs on ONE device block): the block that finishes LAST adds the G rows in order
+// 0 .. G-1 -- the same bits whichever block that is -- into final_acc[0, kNAcc): no second, one-block launch in front of ncclAllReduce.
+// `done` counts the finished blocks (a device word that is zero between launches: the last block leaves it so).
 constexpr int kItemRedBlocks = 32;
 __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_items(const double* __restrict__ rows, int n_rows, double* __restrict__ part,
                                                                      double* __restrict__ host_out /*pinned, may be null*/,
-                                                                     unsigned long long seq, double* __restrict__ counters_block /*acc_dev_*/)
+                                                                     unsigned long long seq, double* __restrict__ counters_block /*acc_dev_*/,
+                                                                     double* __restrict__ final_acc = nullptr, unsigned int* __restrict__ done = nullptr)
 {
     const int g = (int)blockIdx.x, G = (int)gridDim.x;
     const int lo = (int)(((long long)g * n_rows) / G), hi = (int)(((long long)(g + 1) * n_rows) / G);
@@ -194,6 +198,22 @@ __global__ __launch_bounds__(kNAcc * kRedSlices) void k_reduce_items(const doubl
         if (threadIdx.x == kNAcc) { counters_block[kNAcc] = 0.0; counters_block[kNAcc + 1] = 0.0; }
         if (threadIdx.x >= 32 && threadIdx.x < 32 + 2 * kQueues)
             reinterpret_cast<unsigned int*>(counters_block + kNAcc + 8)[(threadIdx.x - 32) * kQueueStride] = 0u;
+    }
+    if (final_acc) {
+        __shared__ unsigned int s_ticket;
+        __threadfence();        // this block's row is visible device-wide before its ticket is
+        __syncthreads();
+        if (threadIdx.x == 0) s_ticket = atomicAdd(done, 1u);
+        __syncthreads();
+        if (s_ticket == (unsigned int)(G - 1)) {   // (block-uniform)
+            __threadfence();    // ... and the other blocks' rows are read behind their tickets
+            if (threadIdx.x < kNAcc) {
+                double t = 0.0;
+                for (int r = 0; r < G; ++r) t += __builtin_nontemporal_load(part + (size_t)r * kNAcc + threadIdx.x);
+                final_acc[threadIdx.x] = t;
+            }
+            if (threadIdx.x == 0) *done = 0u;
+        }
     }
 }
 

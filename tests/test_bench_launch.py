@@ -48,6 +48,15 @@ def test_two_self_launched_ranks_share_the_gpu():
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0
     assert j["config"]["ranks_share_gpus"] is True and "query-shard x2, local all-reduce" in j["config"]["parallelism"]
     assert j["config"]["comm_nranks"] == 2        # both ranks joined the mailbox
+    # the default line times EVERY transport: both keys are there -- the mailbox with its step time and the two
+    # ranks it saw; RCCL's entry is null here and says why (two ranks cannot share one device under RCCL) -- on a node it carries
+    # ncclCommCount and its own step time, and `value` is the faster of the two
+    ar = j["config"]["allreduce"]
+    assert set(ar) == {"local", "rccl"}
+    assert ar["local"]["nranks"] == 2 and ar["local"]["ms_per_step"] > 0
+    assert ar["rccl"]["nranks"] is None and ar["rccl"]["ms_per_step"] is None and "one device" in ar["rccl"]["note"]
+    assert set(j["c5_sharded"]["allreduce"]) == {"local", "rccl"} and j["c5_sharded"]["allreduce"]["local"]["nranks"] == 2
+    assert j["value"] == pytest.approx(1e3 / ar["local"]["ms_per_step"], rel=1e-9)
     assert j["config"]["queries_per_gpu"] == 30000 and j["config"]["shard_balance"] is None      # (the headline: equal counts)
     assert j["c5_sharded"]["shard_balance"] is None            # (ranks sharing one device: no cost-balanced re-cut -- they would time each other)
     assert j["config"]["map_slab_rank0"]["margin_m"] > 2.0 and "recut" not in j["config"]["map_slab_rank0"]
@@ -75,3 +84,18 @@ def test_one_rank_distributed_path_over_every_collective(allreduce):
         assert j["config"]["comm_nranks"] == 1     # what ncclCommCount / the mailbox's join count reports
     else:
         assert j["config"]["comm_nranks"] is None
+    assert set(j["config"]["allreduce"]) == {allreduce}
+
+
+@pytest.mark.gpu
+def test_one_rank_default_line_carries_both_transports():
+    """one rank through the distributed path with the default --allreduce both: the mailbox and RCCL are both timed, each reports one
+    rank (ncclCommCount for RCCL), `value` is the faster one's and every entry produced the same pose"""
+    r = _run(["--gpus", "1", "--force-dist"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    ar = j["config"]["allreduce"]
+    assert set(ar) == {"local", "rccl"} and ar["local"]["nranks"] == 1 and ar["rccl"]["nranks"] == 1
+    best = min(ar, key=lambda k: ar[k]["ms_per_step"])
+    assert best in j["config"]["parallelism"] and j["ms_per_step"] == pytest.approx(ar[best]["ms_per_step"], rel=1e-9)
+    assert set(j["c5_sharded"]["allreduce"]) == {"local", "rccl"}
