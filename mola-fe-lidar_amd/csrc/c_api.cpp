@@ -625,8 +625,12 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs, const float* const*
                 throw;
             }
         };
+        // (the notification is sent UNDER the lock: the waiter owns this frame -- released first, it could see pending == 0, return and
+        // unwind mutex and condition variable while this worker was still inside notify_all() on them.  Found by ThreadSanitizer through
+        // tests/hosts/race_host.cpp, round 5; with the lock held the waiter cannot leave wait() before the worker is done with both.)
         auto job_done = [&]() {
-            { std::lock_guard<std::mutex> lk(done_mtx); --pending; }
+            std::lock_guard<std::mutex> lk(done_mtx);
+            --pending;
             done_cv.notify_all();
         };
         if (!apart.empty()) {
@@ -944,11 +948,11 @@ int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* 
                         return rcs[k];
                     });
                     if (rcs[k] && errs[k].empty()) errs[k] = last_error();
-                    {
+                    {   // (notified under the lock: see mola_icp_align_batch's job_done)
                         std::lock_guard<std::mutex> lk(dm);
                         --pending;
+                        dcv.notify_all();
                     }
-                    dcv.notify_all();
                 });
                 } catch (...) {
                     { std::lock_guard<std::mutex> lk(dm); --pending; }

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Sanitizer runs of the HOST code, on the CPU (never on the GPU box: GPU AddressSanitizer / XNACK are not available on the pool):
-#   bash tools/sanitize.sh            -> profiles/r04/sanitizers/{asan_ubsan,tsan}_*.txt
+#   bash tools/sanitize.sh            -> profiles/r05/sanitizers/{asan_ubsan,tsan}_*.txt
 # Builds ../lib/san/libmola_icp_amd_<kind>.so (host .cpp with -fsanitize, device objects as they are), then runs the CPU test suite
 # and the plain-C / C++ hosts of tests/hosts against it with the sanitizer runtime preloaded (Python itself is not instrumented).
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd $ROOT
-OUT=profiles/r04/sanitizers; mkdir -p $OUT
+OUT=profiles/r05/sanitizers; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 run_kind() {
   kind=$1; san=$2; rt=$3; opts=$4; skip=${5:-}
@@ -25,7 +25,13 @@ run_kind() {
     env LD_PRELOAD="$pre" $opts LD_LIBRARY_PATH=$d:/opt/rocm/lib timeout -k 10 300 $exe $(echo $h | cut -s -d' ' -f2) > $OUT/${kind}_host_$(echo $h | cut -d' ' -f1).txt 2>&1
     echo "exit code: $?" >> $OUT/${kind}_host_$(echo $h | cut -d' ' -f1).txt
   done
-  n=$(grep -l -E "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer|ERROR: LeakSanitizer" $OUT/${kind}_*.txt 2>/dev/null | wc -l)
+  # the device-only threaded scaffolding (leases, batch lanes, deferred builds, the cloud cache under concurrent put / align / drop):
+  # the real host translation units + the test-only host-memory backend, 8 threads on one handle (tests/hosts/race_host.cpp)
+  make -f tests/hosts/Makefile.race SAN=$san >> $OUT/${kind}_build.log 2>&1 && {
+    env $opts timeout -k 10 900 tests/hosts/_build/race_host_$(echo $san | tr ',' '_') 8 16 > $OUT/${kind}_race_host.txt 2>&1
+    echo "exit code: $?" >> $OUT/${kind}_race_host.txt
+  }
+  n=$(grep -l -E "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer|ERROR: LeakSanitizer" $OUT/${kind}_*.txt 2>/dev/null | grep -v BEFORE_the_fix | wc -l)
   echo "$kind: $(grep -h -E 'passed|failed' $OUT/${kind}_pytest.txt | tail -1) ; files with sanitizer reports: $n" | tee $OUT/${kind}_summary.txt
 }
 run_kind asan_ubsan address,undefined libasan.so "ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=1"
@@ -33,4 +39,4 @@ run_kind asan_ubsan address,undefined libasan.so "ASAN_OPTIONS=detect_leaks=0:ab
 #  come back -- i.e. the bench launcher, the gloo ranks, the compiled hosts -- and without the roctx probe, which dlopens the
 #  profiler's library; those run under ASan + UBSan above)
 run_kind tsan thread libtsan.so "TSAN_OPTIONS=halt_on_error=0:second_deadlock_stack=1:report_signal_unsafe=0" \
-  "--timeout 120 --ignore=tests/test_bench_launch.py --ignore=tests/test_sharded_gloo.py --ignore=tests/test_boundary_hosts.py --ignore=tests/test_gpu_prepare.py --ignore=tests/test_local_comm.py --deselect tests/test_c_abi.py::test_roctx_ranges_are_optional"
+  "--timeout 120 --ignore=tests/test_bench_launch.py --ignore=tests/test_sharded_gloo.py --ignore=tests/test_boundary_hosts.py --ignore=tests/test_gpu_prepare.py --ignore=tests/test_local_comm.py --ignore=tests/test_race_host.py --deselect tests/test_c_abi.py::test_roctx_ranges_are_optional"
