@@ -1473,7 +1473,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         knn_order_valid_ = true;
         knn_launches_since_order_ = 0;
     }
-    if (g_knobs.debug_stats == 5 && knn_coop) {   // diagnostics: the items' lifetimes in THIS launch of the product kernel (two clock reads per item)
+    if (g_knobs.debug_stats == 5 && (knn_coop || (!verify && ql == 1))) {   // diagnostics: the items' lifetimes in THIS launch of the product kernel (two clock reads per item)
         std::vector<unsigned int> c((size_t)n_items64);
         HIPCHK(hipMemcpyAsync(c.data(), knn_cost_.p, c.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
@@ -1483,9 +1483,9 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         for (unsigned int x : v) sum += x;
         const size_t n = v.size();
         const int slots = num_cus_ * 4;
-        std::fprintf(stderr, "[mola_icp debug] k_knn_coop item lifetimes (shader cycles): N=%zu items=%zu seed=%d cert=%d bootstrapped=%d step=%.4f | mean %.0f p10 %u p50 %u p90 %u p99 %u max %u | "
+        std::fprintf(stderr, "[mola_icp debug] %s item lifetimes (shader cycles): N=%zu items=%zu seed=%d cert=%d bootstrapped=%d step=%.4f | mean %.0f p10 %u p50 %u p90 %u p99 %u max %u | "
                              "sum / %d workgroup slots = %.0f = %.2f x the heaviest item; items above 2x the median: %zu\n",
-                     N_, n, knn_seed, cert.on, (int)bootstrapped, step, sum / (double)n, v[n / 10], v[n / 2], v[n * 9 / 10], v[n * 99 / 100], v[n - 1], slots, sum / slots,
+                     knn_coop ? "k_knn_coop (one workgroup per item)" : "k_knn_planes (one wave per item)", N_, n, knn_seed, cert.on, (int)bootstrapped, step, sum / (double)n, v[n / 10], v[n / 2], v[n * 9 / 10], v[n * 99 / 100], v[n - 1], slots, sum / slots,
                      sum / slots / (double)v[n - 1], (size_t)(v.end() - std::upper_bound(v.begin(), v.end(), 2u * v[n / 2])));
         // where along the curve the heavy ones sit (16 stretches of the item order: share of the total cost)
         std::fprintf(stderr, "[mola_icp debug]   cost share of 16 stretches of the item order:");

@@ -34,7 +34,8 @@ run_kind() {
   n=$(grep -l -E "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer|ERROR: LeakSanitizer" $OUT/${kind}_*.txt 2>/dev/null | grep -v BEFORE_the_fix | wc -l)
   echo "$kind: $(grep -h -E 'passed|failed' $OUT/${kind}_pytest.txt | tail -1) ; files with sanitizer reports: $n" | tee $OUT/${kind}_summary.txt
 }
-run_kind asan_ubsan address,undefined libasan.so "ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=1"
+# (tests/test_race_host.py builds and runs sanitizer executables of its own: not under a preloaded runtime -- the race host runs below)
+run_kind asan_ubsan address,undefined libasan.so "ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0 UBSAN_OPTIONS=print_stacktrace=1" "--ignore=tests/test_race_host.py"
 # (ThreadSanitizer: without the tests that start child interpreters or compilers -- torch / g++ under a preloaded TSan runtime do not
 #  come back -- i.e. the bench launcher, the gloo ranks, the compiled hosts -- and without the roctx probe, which dlopens the
 #  profiler's library; those run under ASan + UBSan above)
