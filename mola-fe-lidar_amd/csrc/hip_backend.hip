@@ -1282,7 +1282,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     // heavy-first order of the full sweeps (cycles per item of the last full sweep; re-sorted at launch 1, 2, 4, 8, then every 16th)
     {
         const void* before = knn_cost_.p;
-        if ((rc = knn_cost_.reserve(sizeof(unsigned int) * (size_t)n_items))) return rc;
+        // (the cooperative kernel records a lifetime per 64-query item whatever MOLA_ICP_QPL makes of the persistent kernel's items)
+        if ((rc = knn_cost_.reserve(sizeof(unsigned int) * std::max((size_t)n_items, (N_ + 63) / 64)))) return rc;
         if (knn_cost_.p != before) knn_cost_valid_ = false;
     }
     if ((rc = knn_order_.reserve(sizeof(int) * ((size_t)n_items + kQueues + 1)))) return rc;
