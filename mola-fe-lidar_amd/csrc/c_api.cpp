@@ -251,7 +251,8 @@ bool batch_eligible(const mola_icp_params& p, size_t N, size_t M)
     if (p.n_extra_matchers != 0 || p.n_extra_solvers != 0 || p.n_extra_quality != 0) return false;   // staged pipelines: stand-alone aligns (stream per pair)
     // (the batched plane matcher is the cooperative kernel, one workgroup per 64 queries: it serves the sizes the stand-alone path
     //  gives to it -- up to ~131k queries; larger pairs go one by one through the persistent kernel, a stream per pair)
-    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) return N <= (size_t)kBatchPlanesMaxQueries;
+    // (knn 9 .. 16: the stand-alone path -- the batched launch is instantiated for the list lengths of knn 3 .. 8)
+    if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) return N <= (size_t)kBatchPlanesMaxQueries && p.knn <= 8;
     if (p.matcher_class != MOLA_ICP_MATCHER_POINTS_DISTANCE_THRESHOLD) return false;
     if (p.nn_kernel == MOLA_ICP_NN_TILED) return true;
     return p.nn_kernel == MOLA_ICP_NN_AUTO && N >= 8192 && M >= 8192;

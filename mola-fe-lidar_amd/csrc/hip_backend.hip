@@ -1121,7 +1121,11 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     int rc = init();
     if (rc) return rc;
     HIPCHK(hipSetDevice(device_));
-    if (p.knn < 3 || p.knn > 8) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 8] in this build");
+    if (p.knn < 3 || p.knn > 16) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 16] in this build");
+    // knn 9 .. 16 (the schema names no bound, params/icp-settings-regular.yaml:37; the shipped files say 6): served by the cooperative
+    // kernel alone, at every cloud size -- one instantiation per list length instead of the persistent kernel's four flavours; the first
+    // launch seeded by key, the PairedRatio pass by the matcher (no k_quality_from_lists of that length)
+    const bool wide_knn = p.knn > 8;
     planes_valid_ = false;
     if ((rc = check_slab(T, p.matcher_threshold))) return rc;
     if (N_ == 0 || M_ == 0) { planes_valid_ = true; planes_empty_ = true; return MOLA_ICP_OK; }
@@ -1145,8 +1149,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     {
         const bool have_seed = knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed;
         if (!have_seed && !g_knobs.no_bootstrap && !g_knobs.no_knn_seed && M_ >= 64) {
-            const bool by_key = !g_knobs.bootstrap_nn && map_sc_->keys.p != nullptr && map_sc_->box.p != nullptr;
-            if (!by_key) {
+            const bool by_key = (wide_knn || !g_knobs.bootstrap_nn) && map_sc_->keys.p != nullptr && map_sc_->box.p != nullptr;
+            if (!by_key && !wide_knn) {
                 mola_icp_params pn = p;
                 pn.nn_kernel = MOLA_ICP_NN_AUTO;
                 // (under HALF the plane matcher's gate: a query whose nearest neighbour is farther than that starts without seeds --
@@ -1154,7 +1158,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
                 // 0.25 of the gate: config 0's first iteration 193-197 / 180 / 201 us, odometry stream 0.65-0.71 / 0.63-0.67 / 0.64-0.67 ms)
                 if ((rc = match(T, 0.5 * p.matcher_threshold, pn, nullptr))) return rc;
             }
-            if (by_key || pairing_sorted_) {
+            if (by_key || (pairing_sorted_ && !wide_knn)) {
                 PoseF Pb;
                 for (int r = 0; r < 3; ++r) {
                     for (int c = 0; c < 3; ++c) Pb.R[3 * r + c] = (float)T(r, c);
@@ -1172,14 +1176,27 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
                                (const unsigned int*)nullptr, (const float*)nullptr, slq, slq + loc_sc_->padded,                      \
                                slq + 2 * loc_sc_->padded, (int)N_, Pb, tiled_map(), (int)M_, seeds);                                \
     } while (0)
+#define MOLA_LAUNCH_BOOTSTRAP_KEY(KK)                                                                                                 \
+    hipLaunchKernelGGL((k_bootstrap_seeds<KK, true>), dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, (const int*)nullptr,  \
+                       map_sc_->keys.as<unsigned int>(), map_sc_->box.as<float>(), slq, slq + loc_sc_->padded,                       \
+                       slq + 2 * loc_sc_->padded, (int)N_, Pb, tiled_map(), (int)M_, seeds)
                 switch (p.knn) {
                     case 3: MOLA_LAUNCH_BOOTSTRAP(4); break;
                     case 4: MOLA_LAUNCH_BOOTSTRAP(5); break;
                     case 5: MOLA_LAUNCH_BOOTSTRAP(6); break;
                     case 6: MOLA_LAUNCH_BOOTSTRAP(7); break;
                     case 7: MOLA_LAUNCH_BOOTSTRAP(8); break;
-                    default: MOLA_LAUNCH_BOOTSTRAP(9); break;
+                    case 8: MOLA_LAUNCH_BOOTSTRAP(9); break;
+                    case 9: MOLA_LAUNCH_BOOTSTRAP_KEY(10); break;
+                    case 10: MOLA_LAUNCH_BOOTSTRAP_KEY(11); break;
+                    case 11: MOLA_LAUNCH_BOOTSTRAP_KEY(12); break;
+                    case 12: MOLA_LAUNCH_BOOTSTRAP_KEY(13); break;
+                    case 13: MOLA_LAUNCH_BOOTSTRAP_KEY(14); break;
+                    case 14: MOLA_LAUNCH_BOOTSTRAP_KEY(15); break;
+                    case 15: MOLA_LAUNCH_BOOTSTRAP_KEY(16); break;
+                    default: MOLA_LAUNCH_BOOTSTRAP_KEY(17); break;
                 }
+#undef MOLA_LAUNCH_BOOTSTRAP_KEY
 #undef MOLA_LAUNCH_BOOTSTRAP
                 HIPCHK(hipGetLastError());
                 bootstrapped = true;
@@ -1209,7 +1226,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const TiledMap mp = tiled_map();
     unsigned long long* staged = (profiling_ || g_knobs.debug_stats == 3) ? stats_.as<unsigned long long>() : nullptr;  // evaluated pairs, slotted (statistics only)
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
-    const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
+    // (lists of 10 .. 17 entries: the cooperative kernel's merge area alone is up to 43 KB of the workgroup's 64 -- box levels in LDS only for small maps)
+    const int lds_boxes = box_bytes <= (wide_knn ? (size_t)16 * 1024 : kMaxLdsBoxBytes) ? 1 : 0;  // else the upper levels are read from global memory
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     // Queries per lane: ONE (64-query items).  A lane's K-entry lists for two queries push the insertion flavour to 168
     // VGPR + spills; with one query per lane there are none, items are twice as many and half as long -- better balance
@@ -1225,7 +1243,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     int& fit_ver = knn_fit_[ql - 1][1][kslot];
     int& fit_ins4 = knn_fit_[ql - 1][2][kslot];
     size_t& fit_lds = knn_fit_lds_[ql - 1][kslot];
-    if (fit_ins == 0 || fit_lds != dyn_lds) {
+    if (!wide_knn && (fit_ins == 0 || fit_lds != dyn_lds)) {
 #define MOLA_KNN_FIT(KK)                                                                                                   \
     do {                                                                                                                   \
         if (ql == 1) {                                                                                                     \
@@ -1344,7 +1362,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int n_items64 = (int)((N_ + 63) / 64);   // (the cooperative kernel's items hold 64 queries whatever MOLA_ICP_QPL says)
     // (crossover, ms per 8-iteration align cooperative / persistent -- uniform synthetic clouds: 60k 0.54 / 0.67, 120k 0.83 / 0.78,
     //  160k 1.02 / 0.84, 200k 1.21 / 0.92; a KITTI-like 120k scan pair, dense near the sensor: 1.76 / 1.96.  Up to 131k queries.)
-    const bool knn_coop = g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8;
+    const bool knn_coop = wide_knn || (g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8);
 #define MOLA_LAUNCH_KNN_COOP(KK)                                                                                       \
     hipLaunchKernelGGL((k_knn_coop<KK, 1>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, kb, thr2, thr2x,    \
                        p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, cert.stats, (unsigned long long*)nullptr)
@@ -1444,7 +1462,15 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
             case 5: MOLA_LAUNCH_KNN_COOP(6); break;
             case 6: MOLA_LAUNCH_KNN_COOP(7); break;
             case 7: MOLA_LAUNCH_KNN_COOP(8); break;
-            default: MOLA_LAUNCH_KNN_COOP(9); break;
+            case 8: MOLA_LAUNCH_KNN_COOP(9); break;
+            case 9: MOLA_LAUNCH_KNN_COOP(10); break;
+            case 10: MOLA_LAUNCH_KNN_COOP(11); break;
+            case 11: MOLA_LAUNCH_KNN_COOP(12); break;
+            case 12: MOLA_LAUNCH_KNN_COOP(13); break;
+            case 13: MOLA_LAUNCH_KNN_COOP(14); break;
+            case 14: MOLA_LAUNCH_KNN_COOP(15); break;
+            case 15: MOLA_LAUNCH_KNN_COOP(16); break;
+            default: MOLA_LAUNCH_KNN_COOP(17); break;
         }
     } else
     switch (p.knn) {
@@ -1601,7 +1627,7 @@ int HipWorkspace::copy_planes(uint8_t* valid, double* centroid, double* normal, 
     int rc;
     DevBuf tmp_pairs, tmp_knn;
     if ((rc = tmp_pairs.reserve(sizeof(PlanePair) * N_))) return rc;
-    if ((rc = tmp_knn.reserve(sizeof(int) * N_ * 8))) { tmp_pairs.release(); return rc; }
+    if ((rc = tmp_knn.reserve(sizeof(int) * N_ * (size_t)(planes_knn_ > 8 ? planes_knn_ : 8)))) { tmp_pairs.release(); return rc; }
     hipLaunchKernelGGL(k_unpermute_planes, dim3((unsigned)((N_ + 255) / 256)), dim3(256), 0, stream_, loc_sc_->perm.as<int>(),
                        planes_.as<PlanePair>(), knn_seeds_at(knn_pos_.p, loc_sc_->padded, planes_knn_ + 1), planes_knn_, (int)N_,
                        tmp_pairs.as<PlanePair>(), tmp_knn.as<int>());

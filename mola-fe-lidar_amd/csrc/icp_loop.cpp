@@ -161,7 +161,7 @@ int validate_single(const mola_icp_params& p)
                         "consumes point-to-point pairings)");
         if (p.use_robust_kernel)
             return fail(MOLA_ICP_E_UNSUPPORTED, "use_robust_kernel is not available with mp2p_icp::Matcher_Point2Plane");
-        if (p.knn < 3 || p.knn > 8) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 8]");
+        if (p.knn < 3 || p.knn > 16) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 16]");
         if (!(p.plane_eigen_threshold > 0)) return fail(MOLA_ICP_E_BADARG, "planeEigenThreshold must be > 0");
         if (p.solver_max_iterations == 0) return fail(MOLA_ICP_E_BADARG, "Solver_GaussNewton: maxIterations must be > 0");
     }

@@ -772,8 +772,8 @@ __global__ __launch_bounds__(256) void k_bootstrap_seeds(const int* __restrict__
                                                          const float* __restrict__ slx, const float* __restrict__ sly,
                                                          const float* __restrict__ slz, int N, PoseF P, TiledMap mp, int M, KnnSeeds seeds)
 {
-    constexpr int G = KL <= 8 ? 8 : 12;
-    static_assert(KL <= G && (3 * kTileG) % G == 0, "groups");
+    constexpr int G = KL <= 8 ? 8 : (KL <= 12 ? 12 : (KL <= 16 ? 16 : 24));
+    static_assert(KL <= G && (3 * kTileG) % G == 0 && G % 4 == 0, "groups");
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     float qx, qy, qz;

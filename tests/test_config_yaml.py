@@ -129,7 +129,7 @@ def test_shipped_pipeline_needs_plane_stages(pkg):
         pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), q, 10, 10)
     assert e.value.status == pkg._lib.E_UNSUPPORTED and "Solver_GaussNewton" in str(e.value)
     q = pkg.Parameters.load_from(open(os.path.join(PARAMS, "icp-settings-regular.yaml")).read())
-    q.knn = 12
+    q.knn = 17     # (3 .. 16 are served since round 5)
     with pytest.raises(pkg.IcpError) as e:
         pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), q, 10, 10)
     assert e.value.status == pkg._lib.E_UNSUPPORTED and "knn" in str(e.value)

@@ -604,6 +604,9 @@ def test_native_rccl_single_rank(pkg, icp, golden):
     h.comm_destroy()
     b = h.align_resident(np.eye(4), pp)
     assert a.nIterations == b.nIterations and np.array_equal(a.optimal_tf, b.optimal_tf)
+    # (under a native communicator the PairedRatio count goes through the collective every rank issues -- the lists' own
+    # count, which stays on the rank, stands back; with one rank both give the same number, which is all one device can show)
+    assert a.quality == b.quality and a.n_pairs == b.n_pairs
     h.close()
 
 
