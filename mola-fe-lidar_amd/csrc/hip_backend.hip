@@ -16,6 +16,7 @@
 #include <cmath>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,6 +72,7 @@ struct Knobs {
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
+    bool turn_clock = false;   // MOLA_ICP_TURN_CLOCK: print the host's side of an iteration's turn (product kernels; stderr, every 200 turns)
 };
 static Knobs read_knobs()
 {
@@ -97,6 +99,7 @@ static Knobs read_knobs()
     k.no_direct_readback = std::getenv("MOLA_ICP_NO_DIRECT_READBACK") != nullptr;
     k.no_warm_start = std::getenv("MOLA_ICP_NO_WARM_START") != nullptr;
     k.debug_stats = geti("MOLA_ICP_DEBUG_STATS");
+    k.turn_clock = std::getenv("MOLA_ICP_TURN_CLOCK") != nullptr;
     return k;
 }
 static const char* const kSlabMsg =
@@ -245,6 +248,30 @@ HipWorkspace::~HipWorkspace()
     stats_.release();
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
+
+// MOLA_ICP_TURN_CLOCK: the host's side of an iteration's turn (result block seen -> matcher call entered -> its launch call returned)
+namespace {
+struct TurnClock {
+    std::chrono::steady_clock::time_point seen, entered;
+    bool have_seen = false, have_entered = false;
+    double sum_host = 0, sum_launch = 0;
+    unsigned long long n = 0;
+    void on_seen() { seen = std::chrono::steady_clock::now(); have_seen = true; }
+    void on_enter() { if (have_seen) { entered = std::chrono::steady_clock::now(); have_entered = true; } }
+    void on_launched()
+    {
+        if (!have_seen || !have_entered) return;
+        const auto t = std::chrono::steady_clock::now();
+        sum_host += std::chrono::duration<double, std::micro>(entered - seen).count();
+        sum_launch += std::chrono::duration<double, std::micro>(t - entered).count();
+        have_seen = have_entered = false;
+        if (++n % 200 == 0)
+            std::fprintf(stderr, "[mola_icp debug] host turn over %llu iterations: result seen -> matcher call entered %.2f us, entered -> launch call returned %.2f us\n",
+                         n, sum_host / (double)n, sum_launch / (double)n);
+    }
+};
+thread_local TurnClock g_turn;
+}  // namespace
 
 int HipWorkspace::init()
 {
@@ -1118,6 +1145,7 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
 
 int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 {
+    if (g_knobs.turn_clock) g_turn.on_enter();
     int rc = init();
     if (rc) return rc;
     HIPCHK(hipSetDevice(device_));
@@ -1536,6 +1564,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;
     planes_eig_thr_ = p.plane_eigen_threshold;
+    if (g_knobs.turn_clock) g_turn.on_launched();
     planes_valid_ = true;
     knn_seed_valid_ = true;
     return MOLA_ICP_OK;
@@ -1915,6 +1944,7 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
 
 int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& p, uint64_t* n_pairs)
 {
+    if (g_knobs.turn_clock) g_turn.on_enter();
     int rc = init();
     if (rc) return rc;
     HIPCHK(hipSetDevice(device_));
@@ -1956,6 +1986,7 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
         pairing_valid_ = false;   // (seeds, not a pairing)
     }
     if ((rc = launch_nn(T, thr2, p.nn_kernel))) return rc;
+    if (g_knobs.turn_clock) g_turn.on_launched();
     pairing_valid_ = true;
     seed_valid_ = true;
     if (n_pairs) {
@@ -1998,6 +2029,7 @@ int HipWorkspace::spin_for(volatile unsigned long long* flag, unsigned long long
     for (unsigned long long spins = 0; spins < 400000000ull; ++spins) {  // ~ seconds
         if (*flag == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
+            if (g_knobs.turn_clock) g_turn.on_seen();
             // (the block was published behind everything enqueued before it: a bounding box copied for the host has landed too)
             return bbox_pending_ ? check_bboxes() : MOLA_ICP_OK;
         }
