@@ -72,6 +72,7 @@ struct Knobs {
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
+    int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
     bool turn_clock = false;   // MOLA_ICP_TURN_CLOCK: print the host's side of an iteration's turn (product kernels; stderr, every 200 turns)
 };
 static Knobs read_knobs()
@@ -100,6 +101,7 @@ static Knobs read_knobs()
     k.no_warm_start = std::getenv("MOLA_ICP_NO_WARM_START") != nullptr;
     k.debug_stats = geti("MOLA_ICP_DEBUG_STATS");
     k.turn_clock = std::getenv("MOLA_ICP_TURN_CLOCK") != nullptr;
+    k.quads = std::getenv("MOLA_ICP_QUADS") ? (geti("MOLA_ICP_QUADS") != 0 ? 1 : 0) : -1;
     return k;
 }
 static const char* const kSlabMsg =
@@ -1004,12 +1006,20 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     const int n_items = (int)((N_ + (size_t)(64 * qpl) - 1) / (size_t)(64 * qpl));
+    // The quad flavour (kernels_tiled.hpp: quad_sweep -- per-quad tile lists, four tiles per round straight into LDS): every lane meets
+    // only the tiles its 16-query quad reaches.  Same lease, ms per iteration plain / quads: 1M x 1M 0.1168-0.1202 / 0.1110-0.1170,
+    // 1M x 3M 0.173 / 0.167, 500k x 5M 0.167 / 0.141, 250k x 2.5M 0.109 / 0.100, 1M x 10M 0.285 / 0.234 (profiles/r05/quad_sweep_ab.txt).
+    // The product build's default; the diagnostic builds keep the pass-by-pass sweep and its clocks.  MOLA_ICP_QUADS=0 turns it off.
+    const bool diag_build = (dbg_stats_ && !wave_times_) || wave_times_ != nullptr;
+    const bool quads = qpl == 1 && !diag_build && g_knobs.quads != 0;
     {   // persistent waves with a static first item: every block of the grid must be resident from the start
         // (the query is a runtime call of tens of microseconds on the launch path: once per kernel flavour and LDS size)
-        int& fit = fit_cache_[qpl == 2 ? 0 : 1];
-        size_t& fit_lds = fit_cache_lds_[qpl == 2 ? 0 : 1];
+        const int slot = qpl == 2 ? 0 : (quads ? 2 : 1);
+        int& fit = fit_cache_[slot];
+        size_t& fit_lds = fit_cache_lds_[slot];
         if (fit == 0 || fit_lds != dyn_lds) {
             if (qpl == 2) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (k_nn_tiled<2, true>), 256, dyn_lds));
+            else if (quads) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (k_nn_tiled<1, false, true>), 256, dyn_lds));
             else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (k_nn_tiled<1, true>), 256, dyn_lds));   // (the diagnostic build: the larger one)
             fit_lds = dyn_lds;
         }
@@ -1065,9 +1075,10 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
         item_rows = rows_.as<double>();
     }
     // one launch: an entry that meets an exact distance tie (duplicate points, lattices) is redone by its wave with the exact-key sweep
-#define MOLA_LAUNCH_TILED(QPL, DIAG)                                                                                  \
+#define MOLA_LAUNCH_TILED(QPL, DIAG) MOLA_LAUNCH_TILED_Q(QPL, DIAG, false)
+#define MOLA_LAUNCH_TILED_Q(QPL, DIAG, QUADS)                                                                         \
     do {                                                                                                              \
-        hipLaunchKernelGGL((k_nn_tiled<QPL, DIAG>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, \
+        hipLaunchKernelGGL((k_nn_tiled<QPL, DIAG, QUADS>), dim3(grid), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded, \
                            sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, use_seed ? 1 : 0, ts_pos_.as<int>(),        \
                            ts_idx_.as<int>(), ts_d2_.as<float>(), gs, gs + gs_n, gs + 2 * gs_n, order, item_cost_.as<unsigned int>(), tq, \
                            staged, dbg, lds_boxes, wave_times_, g_knobs.early_pop ? 1 : 0, item_rows);                 \
@@ -1075,8 +1086,9 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     } while (0)
     const bool diag = dbg != nullptr || wave_times_ != nullptr;
     if (qpl == 2) { if (diag) MOLA_LAUNCH_TILED(2, true); else MOLA_LAUNCH_TILED(2, false); }
-    else { if (diag) MOLA_LAUNCH_TILED(1, true); else MOLA_LAUNCH_TILED(1, false); }
+    else { if (diag) MOLA_LAUNCH_TILED(1, true); else if (quads) MOLA_LAUNCH_TILED_Q(1, false, true); else MOLA_LAUNCH_TILED(1, false); }
 #undef MOLA_LAUNCH_TILED
+#undef MOLA_LAUNCH_TILED_Q
     cost_valid_ = true;
     // the NEXT launch's re-sort, if one is due: now, on the side stream -- it reads this launch's costs and runs beside the
     // accumulation and the host's turn-around instead of in front of the next matcher launch

@@ -327,6 +327,233 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
     return n_staged;
 }
 
+// ---- the quad sweep: k_nn_tiled's fast attempt on 64-query items (QPL = 1) --------------------------------------------------------
+// tiled_sweep evaluates every staged tile for all 64 queries of the wave, although a tile matters only to the queries near it: at
+// 1M x 1M an item's queries reach 9.6 tiles between them and 2.5 each, against a 10M-point map 34 and 2.7 (306 / 1 082 evaluated
+// pairs per query).  Here the tile TESTS stay per wave (one box against 64 live bounds, as before) but their ballots are kept per
+// QUAD of 16 lanes -- 16 consecutive sorted queries, a quarter of the item's volume: a tile that passes is entered in the list of
+// every quad with a lane that reaches it (a list = a vector register, entry n in lane n).  Then the quads walk their OWN lists side
+// by side: in round r quad g takes its r-th tile -- four different tiles go from global memory straight into LDS
+// (global_load_lds_dword, the next round's in flight under this round's distances), each quad reads its own 32 points -- so every
+// lane meets only the tiles its quad listed: 5.3 of the item's 9.6 at 1M x 1M, the fullest quad (= the rounds) 6.8; 12.3 / 15.0 of
+// 33.8 against the 10M-point map (LAB_NOTEBOOK.md, round 5).  Exact for the reason tiled_sweep is: a tile a lane does not meet is
+// one no lane of its quad reaches.  Bookkeeping per 8-point group as nn_visit_fast (best, group position, groups at the best): the
+// results are bit-identical.  The price: all tile tests of a list see the bounds as they stood before the first evaluated point.
+constexpr int kQuadBuf = 3 * 2 * 64;   // floats of one round's tiles: x / y / z rows, two blocks of 64 (lanes' first / second point)
+
+__device__ __forceinline__ unsigned long long quad_sweep(const TiledMap& mp, const lds_f32* lbox, bool use_lbox, int* slist, int lane,
+                                                         float* sq /*wave-private, 2 * kQuadBuf floats*/,
+                                                         float qx, float qy, float qz, float reach, float& best, int& bpos, int& cnt)
+{
+    Box w;
+    w.lo[0] = reach >= 0.f ? qx - reach : INFINITY; w.hi[0] = reach >= 0.f ? qx + reach : -INFINITY;
+    w.lo[1] = reach >= 0.f ? qy - reach : INFINITY; w.hi[1] = reach >= 0.f ? qy + reach : -INFINITY;
+    w.lo[2] = reach >= 0.f ? qz - reach : INFINITY; w.hi[2] = reach >= 0.f ? qz + reach : -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
+            w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
+        }
+        // (the same value in every lane: kept in scalar registers from here on)
+        w.lo[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.lo[a])));
+        w.hi[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.hi[a])));
+    }
+    unsigned long long n_rounds = 0;
+    // which lanes can the box (wave-uniform values) hold a point for, under their LIVE bounds (tiled_sweep::any_reach, as a ballot)
+    auto reach_ballot = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> unsigned long long {
+        const float ax = qx - __builtin_amdgcn_fmed3f(qx, m0, m3);
+        const float ay = qy - __builtin_amdgcn_fmed3f(qy, m1, m4);
+        const float az = qz - __builtin_amdgcn_fmed3f(qz, m2, m5);
+        return __ballot(fmaf(az, az, fmaf(ay, ay, ax * ax)) <= best);
+    };
+
+    // ---- the quads' lists: entry n of quad g's list sits in lane n of ql[g]; n0..n3 entries (wave-uniform) ----
+    int ql0 = -1, ql1 = -1, ql2 = -1, ql3 = -1;
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    const int quad = lane >> 4, sub = lane & 15;
+    auto round_loads = [&](int mt, int buf) {   // this lane's two points of its quad's tile -> LDS, no register in between
+        if (mt >= 0) {
+            const int j = mt * kTileG + sub;
+            float* b = sq + buf * kQuadBuf;
+            __builtin_amdgcn_global_load_lds(mp.sx + j, b, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(mp.sx + j + 16, b + 64, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(mp.sy + j, b + 128, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(mp.sy + j + 16, b + 192, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(mp.sz + j, b + 256, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(mp.sz + j + 16, b + 320, 4, 0, 0);
+        }
+    };
+    auto my_tile = [&](int r) -> int {   // the r-th entry of this lane's quad's list, -1 behind its end
+        const int t0 = r < n0 ? __builtin_amdgcn_readlane(ql0, r) : -1;
+        const int t1 = r < n1 ? __builtin_amdgcn_readlane(ql1, r) : -1;
+        const int t2 = r < n2 ? __builtin_amdgcn_readlane(ql2, r) : -1;
+        const int t3 = r < n3 ? __builtin_amdgcn_readlane(ql3, r) : -1;
+        return quad == 0 ? t0 : (quad == 1 ? t1 : (quad == 2 ? t2 : t3));
+    };
+    auto run_rounds = [&]() {
+        const int nr = max(max(n0, n1), max(n2, n3));
+        if (nr == 0) return;
+        int mt = my_tile(0);   // (its loads were issued when the quad's list got its first entry: take_tile)
+        for (int r = 0; r < nr; ++r) {
+            const int mt_next = r + 1 < nr ? my_tile(r + 1) : -1;
+            round_loads(mt_next, (r + 1) & 1);            // the next round's tiles fly under this round's distances
+            if (r + 1 < nr) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // (in order: all but the six just issued have landed)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const float* b = sq + (r & 1) * kQuadBuf + 16 * quad;
+            const bool live = mt >= 0;
+            ++n_rounds;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // 8-point groups: points 0..15 in the first block, 16..31 in the second
+                const float* bx = b + (g >> 1) * 64 + (g & 1) * 8;
+                const float4 X0 = *reinterpret_cast<const float4*>(bx);
+                const float4 X1 = *reinterpret_cast<const float4*>(bx + 4);
+                const float4 Y0 = *reinterpret_cast<const float4*>(bx + 128);
+                const float4 Y1 = *reinterpret_cast<const float4*>(bx + 132);
+                const float4 Z0 = *reinterpret_cast<const float4*>(bx + 256);
+                const float4 Z1 = *reinterpret_cast<const float4*>(bx + 260);
+                const float xs[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
+                const float ys[8] = {Y0.x, Y0.y, Y0.z, Y0.w, Y1.x, Y1.y, Y1.z, Y1.w};
+                const float zs[8] = {Z0.x, Z0.y, Z0.z, Z0.w, Z1.x, Z1.y, Z1.z, Z1.w};
+                float gm = INFINITY;
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    const v2f mx = {xs[u], xs[u + 1]}, my = {ys[u], ys[u + 1]}, mz = {zs[u], zs[u + 1]};
+                    const v2f dd = dist2_pk2(qx, qy, qz, mx, my, mz);
+                    gm = fminf(fminf(gm, dd.x), dd.y);
+                }
+                gm = live ? gm : INFINITY;   // (a quad whose list has ended reads what an earlier round left in its part of the buffer)
+                const int gpos = mt * kTileG + 8 * g;
+                const bool lt = gm < best;
+                const int eq = (int)(gm == best);
+                cnt = lt ? 1 : cnt + eq;
+                bpos = lt ? gpos : bpos;
+                best = fminf(best, gm);
+            }
+            __builtin_amdgcn_wave_barrier();   // (this buffer is the target of the loads issued in the next iteration)
+            mt = mt_next;
+        }
+        n0 = n1 = n2 = n3 = 0;
+    };
+    auto take_tile = [&](int tile, unsigned long long m) {   // a tile some lane reaches: into the list of every quad that has such a lane
+        // (a list's FIRST tile is sent for at once, by the quad's own lanes: the first round then waits for little -- the remaining
+        //  tile tests of the item run under its loads, as tiled_sweep's first pair did)
+        if (m & 0xffffull) { ql0 = lane == n0 ? tile : ql0; if (n0 == 0) round_loads(quad == 0 ? tile : -1, 0); ++n0; }
+        if ((m >> 16) & 0xffffull) { ql1 = lane == n1 ? tile : ql1; if (n1 == 0) round_loads(quad == 1 ? tile : -1, 0); ++n1; }
+        if ((m >> 32) & 0xffffull) { ql2 = lane == n2 ? tile : ql2; if (n2 == 0) round_loads(quad == 2 ? tile : -1, 0); ++n2; }
+        if (m >> 48) { ql3 = lane == n3 ? tile : ql3; if (n3 == 0) round_loads(quad == 3 ? tile : -1, 0); ++n3; }
+        if (max(max(n0, n1), max(n2, n3)) == 64) run_rounds();   // (a list is full: never seen outside a launch without seeds)
+    };
+
+    // ---- the listed super-tiles: tile boxes of entry e+1 in flight while entry e's tiles are tested ----
+    int n_list = 0;
+    auto process_list = [&]() {
+        if (n_list == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int S = __builtin_amdgcn_readfirstlane(slist[0]);
+        int ti = S * kSuper + lane;
+        float f0 = mp.tbox[ti], f1 = mp.tbox[mp.n_tiles_p + ti], f2 = mp.tbox[2 * mp.n_tiles_p + ti],
+              f3 = mp.tbox[3 * mp.n_tiles_p + ti], f4 = mp.tbox[4 * mp.n_tiles_p + ti], f5 = mp.tbox[5 * mp.n_tiles_p + ti];
+        for (int e = 0; e < n_list; ++e) {
+            const float b0 = f0, b1 = f1, b2 = f2, b3 = f3, b4 = f4, b5 = f5;
+            const int Sc = S;
+            if (e + 1 < n_list) {
+                S = __builtin_amdgcn_readfirstlane(slist[e + 1]);
+                ti = S * kSuper + lane;
+                f0 = mp.tbox[ti]; f1 = mp.tbox[mp.n_tiles_p + ti]; f2 = mp.tbox[2 * mp.n_tiles_p + ti];
+                f3 = mp.tbox[3 * mp.n_tiles_p + ti]; f4 = mp.tbox[4 * mp.n_tiles_p + ti]; f5 = mp.tbox[5 * mp.n_tiles_p + ti];
+            }
+            unsigned long long cand = __ballot(b0 <= w.hi[0] && b1 <= w.hi[1] && b2 <= w.hi[2] && b3 >= w.lo[0] &&
+                                               b4 >= w.lo[1] && b5 >= w.lo[2]);
+            while (cand) {
+                const int t = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const unsigned long long m = reach_ballot(bcast_lane(b0, t), bcast_lane(b1, t), bcast_lane(b2, t), bcast_lane(b3, t),
+                                                          bcast_lane(b4, t), bcast_lane(b5, t));
+                if (m) take_tile(Sc * kSuper + t, m);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the list is rewritten from here on
+        n_list = 0;
+        run_rounds();
+    };
+
+    // ---- upper levels (as tiled_sweep: top boxes -> super-tile boxes, per-query tests, a resumable scan) ----
+    auto any_reach = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> bool { return reach_ballot(m0, m1, m2, m3, m4, m5) != 0ull; };
+    const lds_f32* l_ubox = lbox;
+    const lds_f32* l_sbox = lbox + 6 * mp.n_top;
+    int ub = 0, sb = 0;
+    unsigned long long ucand = 0, scand = 0;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
+    bool c_valid = false;
+    auto load_super_boxes = [&]() {
+        const int si = sb + lane;
+        if (use_lbox) {
+            c0 = l_sbox[si]; c1 = l_sbox[mp.n_super + si]; c2 = l_sbox[2 * mp.n_super + si];
+            c3 = l_sbox[3 * mp.n_super + si]; c4 = l_sbox[4 * mp.n_super + si]; c5 = l_sbox[5 * mp.n_super + si];
+        } else {
+            c0 = mp.sbox[si]; c1 = mp.sbox[mp.n_super + si]; c2 = mp.sbox[2 * mp.n_super + si];
+            c3 = mp.sbox[3 * mp.n_super + si]; c4 = mp.sbox[4 * mp.n_super + si]; c5 = mp.sbox[5 * mp.n_super + si];
+        }
+        c_valid = true;
+    };
+    for (;;) {
+        while (n_list < kMaxList) {
+            if (scand) {
+                if (!c_valid) load_super_boxes();
+                const int sl = __builtin_ctzll(scand);
+                scand &= scand - 1;
+                if (any_reach(bcast_lane(c0, sl), bcast_lane(c1, sl), bcast_lane(c2, sl), bcast_lane(c3, sl),
+                              bcast_lane(c4, sl), bcast_lane(c5, sl))) {
+                    if (lane == 0) slist[n_list] = sb + sl;
+                    ++n_list;
+                }
+            } else if (ucand) {
+                sb = (ub - 64 + __builtin_ctzll(ucand)) * 64;
+                ucand &= ucand - 1;
+                load_super_boxes();
+                scand = __ballot(c0 <= w.hi[0] && c1 <= w.hi[1] && c2 <= w.hi[2] && c3 >= w.lo[0] && c4 >= w.lo[1] &&
+                                 c5 >= w.lo[2]);
+            } else if (ub < mp.n_top) {
+                const int ui = ub + lane;
+                float u0 = INFINITY, u1 = INFINITY, u2 = INFINITY, u3 = -INFINITY, u4 = -INFINITY, u5 = -INFINITY;
+                if (ui < mp.n_top) {
+                    if (use_lbox) {
+                        u0 = l_ubox[ui]; u1 = l_ubox[mp.n_top + ui]; u2 = l_ubox[2 * mp.n_top + ui];
+                        u3 = l_ubox[3 * mp.n_top + ui]; u4 = l_ubox[4 * mp.n_top + ui]; u5 = l_ubox[5 * mp.n_top + ui];
+                    } else {
+                        u0 = mp.ubox[ui]; u1 = mp.ubox[mp.n_top + ui]; u2 = mp.ubox[2 * mp.n_top + ui];
+                        u3 = mp.ubox[3 * mp.n_top + ui]; u4 = mp.ubox[4 * mp.n_top + ui]; u5 = mp.ubox[5 * mp.n_top + ui];
+                    }
+                }
+                ucand = __ballot(u0 <= w.hi[0] && u1 <= w.hi[1] && u2 <= w.hi[2] && u3 >= w.lo[0] && u4 >= w.lo[1] &&
+                                 u5 >= w.lo[2]);
+                if (__builtin_popcountll(ucand) > 4) {   // (a spread query group: the top boxes per query first -- see tiled_sweep)
+                    unsigned long long uc = ucand, keep = 0ull;
+                    while (uc) {
+                        const int t = __builtin_ctzll(uc);
+                        uc &= uc - 1;
+                        if (any_reach(bcast_lane(u0, t), bcast_lane(u1, t), bcast_lane(u2, t), bcast_lane(u3, t), bcast_lane(u4, t),
+                                      bcast_lane(u5, t)))
+                            keep |= 1ull << t;
+                    }
+                    ucand = keep;
+                }
+                ub += 64;
+            } else {
+                break;
+            }
+        }
+        if (n_list == 0) break;
+        process_list();
+        c_valid = false;
+    }
+    return n_rounds * (unsigned long long)kTileG;   // points every lane met
+}
+
 // reach of a query whose current best squared distance is `best`: any m with d2_contract <= best lies inside
 // [q - r, q + r] per axis (sqrt rounded up, plus 2 ulp of the largest coordinate)
 __device__ __forceinline__ float reach_of(float best, float qx, float qy, float qz)
@@ -580,8 +807,8 @@ __device__ __forceinline__ void item_row_mfma(float* __restrict__ smf /*256 floa
 //   iteration for a list that is almost always empty.)
 // DIAG = false (the launch path): the per-phase / per-wave diagnostics are compiled out -- as run-time branches that never fire
 // they still held 90 scalar registers' worth of spills and five VGPRs: 101 -> 94 us at C3.
-template <int QPL, bool DIAG>
-__global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
+template <int QPL, bool DIAG, bool QUADS = false /*QPL = 1, !DIAG: the fast attempt walks per-quad tile lists (quad_sweep)*/>
+__global__ __launch_bounds__(256, QUADS ? 4 : 3) void k_nn_tiled(const float* __restrict__ slx, const float* __restrict__ sly,
                                                   const float* __restrict__ slz, int N, TiledMap mp, PoseF P, float thr2,
                                                   int use_seed, int* __restrict__ pos_s, int* __restrict__ idx_s,
                                                   float* __restrict__ d2_s, float* __restrict__ gs_x, float* __restrict__ gs_y,
@@ -598,6 +825,9 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (!DIAG) { dbg_stats = nullptr; wave_times = nullptr; }  // (constants from here on: the diagnostics fold away)
+    // the quad sweep's tiles (QPL = 1, fast attempt): per wave two rounds' worth (double-buffered), x / y / z rows
+    __shared__ __attribute__((aligned(16))) float s_q[QUADS ? 4 : 1][QUADS ? 2 * kQuadBuf : 4];
+    static_assert(!QUADS || (QPL == 1 && !DIAG), "the quad sweep serves 64-query items of the product build");
     float(*sm)[64] = s_m[wave];
     int* slist = s_list[wave];
     const lds_f32* lbox = (const lds_f32*)s_dyn;
@@ -687,10 +917,15 @@ __global__ __launch_bounds__(256, 3) void k_nn_tiled(const float* __restrict__ s
         unsigned long long p_stage = 0ull, p_visit = 0ull, p_boxwait = 0ull, p_tiletest = 0ull;
         unsigned int p_supers = 0u, p_entered = 0u, p_tiles = 0u;
         const unsigned long long t_sweep0 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
-        const unsigned long long n_staged = tiled_sweep<QL, EX>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
+        unsigned long long n_staged;
+        if constexpr (QUADS && QL == 1 && !EX) {
+            n_staged = quad_sweep(mp, lbox, lds_boxes != 0, slist, lane, &s_q[wave][0], qx[0], qy[0], qz[0], reach[0], best[0], bpos[0], tie[0]);
+        } else {
+        n_staged = tiled_sweep<QL, EX>(mp, lbox, lds_boxes != 0, slist, lane, sm, qx, qy, qz, reach, best, [&](int nm, int jb0, int jb1) {
             if constexpr (EX) nn_visit_exact<QL>(sm, nm, jb0, jb1, qx, qy, qz, key, best, bpos);
             else nn_visit_fast<QL>(sm, nm, jb0, jb1, qx, qy, qz, best, bpos, tie);
         }, dbg_stats != nullptr, p_stage, p_visit, p_supers, p_entered, p_tiles, p_boxwait, p_tiletest);
+        }
         const unsigned long long t_sweep1 = (dbg_stats || wave_times) ? __builtin_amdgcn_s_memtime() : 0ull;
         int next_item_v = next_in;
         if (!EX && early_pop) next_item_v = lookup(wq.settle(__builtin_amdgcn_readfirstlane(next_raw_v)));
