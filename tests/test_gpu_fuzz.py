@@ -1,6 +1,6 @@
 """-m gpu: randomised parity -- random cloud sizes (1 ... 40k, the awkward ones over-represented), gates, 5-launch pose
 sequences, queries without neighbours, duplicated map points, and a random kernel flavour per case (cooperative / persistent
-matchers, 64- / 128-query items, queue knobs, blocks per CU): every launch of the NN matcher and of the plane matcher against the
+matchers, 64- / 128-query items, quad / pass-by-pass sweep, queue knobs, blocks per CU): every launch of the NN matcher and of the plane matcher against the
 CPU oracle, bit for bit.  80 cases here (seconds); MOLA_ICP_FUZZ_CASES / MOLA_ICP_FUZZ_SEED run more (860 cases were run on the
 round's final kernels)."""
 import os
@@ -11,7 +11,7 @@ import pytest
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_KNN_COOP", "MOLA_ICP_QPL", "MOLA_ICP_EARLY_POP", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU")
+KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_KNN_COOP", "MOLA_ICP_QPL", "MOLA_ICP_EARLY_POP", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU", "MOLA_ICP_QUADS")
 
 
 def test_random_cases_equal_the_oracle(pkg, O, synth):
@@ -33,6 +33,8 @@ def test_random_cases_equal_the_oracle(pkg, O, synth):
                 env["MOLA_ICP_NO_LPT"] = "1"
             if rng.random() < 0.3:
                 env["MOLA_ICP_BLOCKS_PER_CU"] = str(rng.integers(1, 5))
+            if rng.random() < 0.35:
+                env["MOLA_ICP_QUADS"] = "0"      # (the pass-by-pass sweep instead of the quad sweep: k_nn_tiled's other flavour)
             os.environ.update(env)
             pkg._lib.lib().mola_icp_debug_reload_env()
             N = int(rng.choice([1, 63, 64, 65, 127, 129, 1000, 4097, 9000, 20000, 33333]) if rng.random() < 0.5 else rng.integers(1, max_n))
@@ -96,6 +98,8 @@ def test_large_random_cases_equal_the_oracle_on_a_sample(pkg, O, synth):
                 env["MOLA_ICP_NO_LPT"] = "1"
             if rng.random() < 0.5:
                 env["MOLA_ICP_BLOCKS_PER_CU"] = str(rng.integers(1, 5))
+            if rng.random() < 0.35:
+                env["MOLA_ICP_QUADS"] = "0"
             os.environ.update(env)
             pkg._lib.lib().mola_icp_debug_reload_env()
             N = int(rng.integers(300_000, 900_001))
