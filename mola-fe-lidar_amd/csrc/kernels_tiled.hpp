@@ -369,32 +369,33 @@ __device__ __forceinline__ unsigned long long quad_sweep(const TiledMap& mp, con
         return __ballot(fmaf(az, az, fmaf(ay, ay, ax * ax)) <= best);
     };
 
-    // ---- the quads' lists: entry n of quad g's list sits in lane n of ql[g]; n0..n3 entries (wave-uniform) ----
-    int ql0 = -1, ql1 = -1, ql2 = -1, ql3 = -1;
+    // ---- the quads' lists: entry n of quad g's list sits in lane 16 g + (n & 15) of qla (n < 16) or qlb (n < 32); n0..n3 entries
+    // (wave-uniform).  A lane reads its quad's r-th entry with one ds_bpermute.
+    int qla = -1, qlb = -1;
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     const int quad = lane >> 4, sub = lane & 15;
     auto round_loads = [&](int mt, int buf) {   // this lane's two points of its quad's tile -> LDS, no register in between
         if (mt >= 0) {
-            const int j = mt * kTileG + sub;
+            // (scalar base + a 32-bit byte offset per lane: the address costs no 64-bit vector arithmetic)
+            const unsigned int bo = (unsigned int)(mt * kTileG + sub) * 4u;
             float* b = sq + buf * kQuadBuf;
-            __builtin_amdgcn_global_load_lds(mp.sx + j, b, 4, 0, 0);
-            __builtin_amdgcn_global_load_lds(mp.sx + j + 16, b + 64, 4, 0, 0);
-            __builtin_amdgcn_global_load_lds(mp.sy + j, b + 128, 4, 0, 0);
-            __builtin_amdgcn_global_load_lds(mp.sy + j + 16, b + 192, 4, 0, 0);
-            __builtin_amdgcn_global_load_lds(mp.sz + j, b + 256, 4, 0, 0);
-            __builtin_amdgcn_global_load_lds(mp.sz + j + 16, b + 320, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(mp.sx) + bo, b, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(mp.sx) + bo, b + 64 - 16, 4, 64, 0);   // (+ 64 bytes on BOTH sides: the second 16 points, the second block)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(mp.sy) + bo, b + 128, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(mp.sy) + bo, b + 192 - 16, 4, 64, 0);   // (+ 64 bytes on BOTH sides: the second 16 points, the second block)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(mp.sz) + bo, b + 256, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(mp.sz) + bo, b + 320 - 16, 4, 64, 0);   // (+ 64 bytes on BOTH sides: the second 16 points, the second block)
         }
     };
+    int n_mine = 0;   // (run_rounds: this lane's quad's entry count)
     auto my_tile = [&](int r) -> int {   // the r-th entry of this lane's quad's list, -1 behind its end
-        const int t0 = r < n0 ? __builtin_amdgcn_readlane(ql0, r) : -1;
-        const int t1 = r < n1 ? __builtin_amdgcn_readlane(ql1, r) : -1;
-        const int t2 = r < n2 ? __builtin_amdgcn_readlane(ql2, r) : -1;
-        const int t3 = r < n3 ? __builtin_amdgcn_readlane(ql3, r) : -1;
-        return quad == 0 ? t0 : (quad == 1 ? t1 : (quad == 2 ? t2 : t3));
+        const int t = __shfl(r < 16 ? qla : qlb, (lane & 48) | (r & 15));
+        return r < n_mine ? t : -1;
     };
     auto run_rounds = [&]() {
         const int nr = max(max(n0, n1), max(n2, n3));
         if (nr == 0) return;
+        n_mine = quad == 0 ? n0 : (quad == 1 ? n1 : (quad == 2 ? n2 : n3));
         int mt = my_tile(0);   // (its loads were issued when the quad's list got its first entry: take_tile)
         for (int r = 0; r < nr; ++r) {
             const int mt_next = r + 1 < nr ? my_tile(r + 1) : -1;
@@ -440,11 +441,17 @@ __device__ __forceinline__ unsigned long long quad_sweep(const TiledMap& mp, con
     auto take_tile = [&](int tile, unsigned long long m) {   // a tile some lane reaches: into the list of every quad that has such a lane
         // (a list's FIRST tile is sent for at once, by the quad's own lanes: the first round then waits for little -- the remaining
         //  tile tests of the item run under its loads, as tiled_sweep's first pair did)
-        if (m & 0xffffull) { ql0 = lane == n0 ? tile : ql0; if (n0 == 0) round_loads(quad == 0 ? tile : -1, 0); ++n0; }
-        if ((m >> 16) & 0xffffull) { ql1 = lane == n1 ? tile : ql1; if (n1 == 0) round_loads(quad == 1 ? tile : -1, 0); ++n1; }
-        if ((m >> 32) & 0xffffull) { ql2 = lane == n2 ? tile : ql2; if (n2 == 0) round_loads(quad == 2 ? tile : -1, 0); ++n2; }
-        if (m >> 48) { ql3 = lane == n3 ? tile : ql3; if (n3 == 0) round_loads(quad == 3 ? tile : -1, 0); ++n3; }
-        if (max(max(n0, n1), max(n2, n3)) == 64) run_rounds();   // (a list is full: never seen outside a launch without seeds)
+        auto append = [&](int g, int& n) {
+            const int at = 16 * g + (n & 15);
+            if (n < 16) qla = lane == at ? tile : qla; else qlb = lane == at ? tile : qlb;
+            if (n == 0) round_loads(quad == g ? tile : -1, 0);
+            ++n;
+        };
+        if (m & 0xffffull) append(0, n0);
+        if ((m >> 16) & 0xffffull) append(1, n1);
+        if ((m >> 32) & 0xffffull) append(2, n2);
+        if (m >> 48) append(3, n3);
+        if (max(max(n0, n1), max(n2, n3)) == 32) run_rounds();   // (a list is full: seen in launches without seeds and against maps many times denser than the scan)
     };
 
     // ---- the listed super-tiles: tile boxes of entry e+1 in flight while entry e's tiles are tested ----
@@ -823,7 +830,9 @@ __global__ __launch_bounds__(256, QUADS ? 4 : 3) void k_nn_tiled(const float* __
     __shared__ __attribute__((aligned(16))) float s_m[4][4][64];  // per wave: x, y, z, original index of 64 staged points
     __shared__ int s_list[4][kMaxList];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // the upper box levels, if they fit
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // (the quad flavour: the wave's number as a scalar -- its LDS areas are then scalar bases, M0 of the tile loads needs no read-back)
+    const int wave = QUADS ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
     if constexpr (!DIAG) { dbg_stats = nullptr; wave_times = nullptr; }  // (constants from here on: the diagnostics fold away)
     // the quad sweep's tiles (QPL = 1, fast attempt): per wave two rounds' worth (double-buffered), x / y / z rows
     __shared__ __attribute__((aligned(16))) float s_q[QUADS ? 4 : 1][QUADS ? 2 * kQuadBuf : 4];
