@@ -1009,9 +1009,11 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     // The quad flavour (kernels_tiled.hpp: quad_sweep -- per-quad tile lists, four tiles per round straight into LDS): every lane meets
     // only the tiles its 16-query quad reaches.  Same lease, ms per iteration plain / quads: 1M x 1M 0.1168-0.1202 / 0.1110-0.1170,
     // 1M x 3M 0.173 / 0.167, 500k x 5M 0.167 / 0.141, 250k x 2.5M 0.109 / 0.100, 1M x 10M 0.285 / 0.234 (profiles/r05/quad_sweep_ab.txt).
-    // The product build's default; the diagnostic builds keep the pass-by-pass sweep and its clocks.  MOLA_ICP_QUADS=0 turns it off.
+    // The product build's default for seeded launches; the diagnostic builds keep the pass-by-pass sweep and its clocks.  MOLA_ICP_QUADS=0|1 forces one.
     const bool diag_build = (dbg_stats_ && !wave_times_) || wave_times_ != nullptr;
-    const bool quads = qpl == 1 && !diag_build && g_knobs.quads != 0;
+    // (a launch without seeds keeps the pass-by-pass sweep unless the knob forces the other: its bounds start at the gate and tighten from
+    //  pass to pass, the quad sweep would test every tile of an item against the gate -- one launch, 1M queries x 10M points: 0.68 / 0.81 ms)
+    const bool quads = qpl == 1 && !diag_build && (g_knobs.quads >= 0 ? g_knobs.quads != 0 : use_seed);
     {   // persistent waves with a static first item: every block of the grid must be resident from the start
         // (the query is a runtime call of tens of microseconds on the launch path: once per kernel flavour and LDS size)
         const int slot = qpl == 2 ? 0 : (quads ? 2 : 1);

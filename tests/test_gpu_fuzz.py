@@ -33,8 +33,11 @@ def test_random_cases_equal_the_oracle(pkg, O, synth):
                 env["MOLA_ICP_NO_LPT"] = "1"
             if rng.random() < 0.3:
                 env["MOLA_ICP_BLOCKS_PER_CU"] = str(rng.integers(1, 5))
-            if rng.random() < 0.35:
-                env["MOLA_ICP_QUADS"] = "0"      # (the pass-by-pass sweep instead of the quad sweep: k_nn_tiled's other flavour)
+            u = rng.random()   # (unset: the quad sweep for seeded launches, pass by pass without seeds; "0" / "1": one of them always)
+            if u < 0.3:
+                env["MOLA_ICP_QUADS"] = "0"
+            elif u < 0.5:
+                env["MOLA_ICP_QUADS"] = "1"
             os.environ.update(env)
             pkg._lib.lib().mola_icp_debug_reload_env()
             N = int(rng.choice([1, 63, 64, 65, 127, 129, 1000, 4097, 9000, 20000, 33333]) if rng.random() < 0.5 else rng.integers(1, max_n))
@@ -98,8 +101,11 @@ def test_large_random_cases_equal_the_oracle_on_a_sample(pkg, O, synth):
                 env["MOLA_ICP_NO_LPT"] = "1"
             if rng.random() < 0.5:
                 env["MOLA_ICP_BLOCKS_PER_CU"] = str(rng.integers(1, 5))
-            if rng.random() < 0.35:
+            u = rng.random()
+            if u < 0.3:
                 env["MOLA_ICP_QUADS"] = "0"
+            elif u < 0.5:
+                env["MOLA_ICP_QUADS"] = "1"
             os.environ.update(env)
             pkg._lib.lib().mola_icp_debug_reload_env()
             N = int(rng.integers(300_000, 900_001))

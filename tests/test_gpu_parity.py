@@ -81,14 +81,14 @@ def test_match_ties_lowest_index(pkg, O, icp, kern):
     assert (idx < 512).all() and (idx >= 0).all()
 
 
-@pytest.mark.parametrize("qpl", ["1", "2", "1-plain"])
+@pytest.mark.parametrize("qpl", ["1", "2", "1-plain", "1-quads"])
 def test_tiled_both_item_sizes(pkg, O, synth, small_scene, qpl, monkeypatch):
     """The tiled matcher's flavours, each forced on ragged sizes, exact ties, a warm-started second launch and a full align: 64-query
     items with the quad sweep (the default: per-quad tile lists, tiles straight into LDS), 128-query items, and 64-query items with the
     pass-by-pass sweep (MOLA_ICP_QUADS=0: what the diagnostic builds run)."""
-    if qpl == "1-plain":
+    if qpl in ("1-plain", "1-quads"):   # (unset: the quad sweep for seeded launches only)
+        monkeypatch.setenv("MOLA_ICP_QUADS", "0" if qpl == "1-plain" else "1")
         qpl = "1"
-        monkeypatch.setenv("MOLA_ICP_QUADS", "0")
     monkeypatch.setenv("MOLA_ICP_QPL", qpl)
     monkeypatch.setenv("MOLA_ICP_COOP", "0")     # the persistent-wave kernel also at sizes where the cooperative one is the default
     pkg._lib.lib().mola_icp_debug_reload_env()
