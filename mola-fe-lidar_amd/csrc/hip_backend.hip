@@ -72,6 +72,7 @@ struct Knobs {
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
+    int quad_lds_boxes_kb = 22;   // MOLA_ICP_QUAD_LDS_BOXES_KB: the quad flavour keeps the upper box levels in LDS up to this size (tuning knob)
     int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
     bool turn_clock = false;   // MOLA_ICP_TURN_CLOCK: print the host's side of an iteration's turn (product kernels; stderr, every 200 turns)
 };
@@ -101,6 +102,7 @@ static Knobs read_knobs()
     k.no_warm_start = std::getenv("MOLA_ICP_NO_WARM_START") != nullptr;
     k.debug_stats = geti("MOLA_ICP_DEBUG_STATS");
     k.turn_clock = std::getenv("MOLA_ICP_TURN_CLOCK") != nullptr;
+    if (std::getenv("MOLA_ICP_QUAD_LDS_BOXES_KB")) k.quad_lds_boxes_kb = geti("MOLA_ICP_QUAD_LDS_BOXES_KB");
     k.quads = std::getenv("MOLA_ICP_QUADS") ? (geti("MOLA_ICP_QUADS") != 0 ? 1 : 0) : -1;
     return k;
 }
@@ -1003,8 +1005,6 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     int per_cu = g_knobs.blocks_per_cu > 0 ? g_knobs.blocks_per_cu : (qpl == 1 ? 4 : 3);  // tuning knob
     const TiledMap mp = tiled_map();
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
-    const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;  // else the upper levels are read from global memory
-    const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     const int n_items = (int)((N_ + (size_t)(64 * qpl) - 1) / (size_t)(64 * qpl));
     // The quad flavour (kernels_tiled.hpp: quad_sweep -- per-quad tile lists, four tiles per round straight into LDS): every lane meets
     // only the tiles its 16-query quad reaches.  Same lease, ms per iteration plain / quads: 1M x 1M 0.1168-0.1202 / 0.1110-0.1170,
@@ -1014,6 +1014,12 @@ int HipWorkspace::launch_tiled(const PoseF& P, float thr2, bool use_seed, unsign
     // (a launch without seeds keeps the pass-by-pass sweep unless the knob forces the other: its bounds start at the gate and tighten from
     //  pass to pass, the quad sweep would test every tile of an item against the gate -- one launch, 1M queries x 10M points: 0.68 / 0.81 ms)
     const bool quads = qpl == 1 && !diag_build && (g_knobs.quads >= 0 ? g_knobs.quads != 0 : use_seed);
+    // the upper box levels in LDS, else read from global memory.  The quad flavour's own 17.4 KB leave 22 KB per workgroup at four
+    // workgroups per CU, and the fourth workgroup is worth more than the LDS copy: ms per iteration with a 40-KB / 22-KB limit,
+    // 1M x 2M 0.143-0.149 / 0.125-0.128, 1M x 3M 0.168-0.177 / 0.143-0.148, 2M x 2M 0.214-0.222 / 0.188-0.189 (1M x 1.5M, 17 KB: the same)
+    const size_t lds_box_limit = quads ? (size_t)g_knobs.quad_lds_boxes_kb * 1024 : kMaxLdsBoxBytes;
+    const int lds_boxes = box_bytes <= lds_box_limit ? 1 : 0;
+    const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     {   // persistent waves with a static first item: every block of the grid must be resident from the start
         // (the query is a runtime call of tens of microseconds on the launch path: once per kernel flavour and LDS size)
         const int slot = qpl == 2 ? 0 : (quads ? 2 : 1);
