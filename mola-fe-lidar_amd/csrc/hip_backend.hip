@@ -72,6 +72,7 @@ struct Knobs {
     bool no_fused_rows = false;  // MOLA_ICP_NO_FUSED_ROWS: k_nn_tiled writes no item rows (k_accumulate sums the pairing, as in round 2)
     bool no_lpt = false, no_knn_seed = false, no_knn_verify = false, no_direct_readback = false, no_warm_start = false;
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
+    int lds_boxes_kb = 40;        // MOLA_ICP_LDS_BOXES_KB: the cooperative / plane kernels keep the upper box levels in LDS up to this size (tuning knob; <= 40)
     int quad_lds_boxes_kb = 22;   // MOLA_ICP_QUAD_LDS_BOXES_KB: the quad flavour keeps the upper box levels in LDS up to this size (tuning knob)
     int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
     bool turn_clock = false;   // MOLA_ICP_TURN_CLOCK: print the host's side of an iteration's turn (product kernels; stderr, every 200 turns)
@@ -102,14 +103,46 @@ static Knobs read_knobs()
     k.no_warm_start = std::getenv("MOLA_ICP_NO_WARM_START") != nullptr;
     k.debug_stats = geti("MOLA_ICP_DEBUG_STATS");
     k.turn_clock = std::getenv("MOLA_ICP_TURN_CLOCK") != nullptr;
+    if (std::getenv("MOLA_ICP_LDS_BOXES_KB")) { k.lds_boxes_kb = geti("MOLA_ICP_LDS_BOXES_KB"); if (k.lds_boxes_kb > 40) k.lds_boxes_kb = 40; if (k.lds_boxes_kb < 0) k.lds_boxes_kb = 0; }
     if (std::getenv("MOLA_ICP_QUAD_LDS_BOXES_KB")) k.quad_lds_boxes_kb = geti("MOLA_ICP_QUAD_LDS_BOXES_KB");
     k.quads = std::getenv("MOLA_ICP_QUADS") ? (geti("MOLA_ICP_QUADS") != 0 ? 1 : 0) : -1;
     return k;
 }
+// The upper box levels go into LDS only while that leaves the kernel the workgroups per CU its registers allow (160 KB of LDS per CU):
+// a copy that costs the fourth workgroup costs more than the global reads it saves -- a 120k-point scan against a 2M-point map through
+// k_knn_coop 0.227 -> 0.193 ms per iteration, against 3M points 0.359 -> 0.243; k_nn_tiled's quad flavour 1M x 3M 0.170 -> 0.145
+// (MOLA_ICP_LDS_BOXES_KB caps it further; 40 KB was the limit for every kernel until round 5).
+static size_t lds_box_limit(size_t static_lds_bytes, int workgroups_per_cu);
 static const char* const kSlabMsg =
     "the pose moves a shard's reach outside its map slab: cut the slab again with a larger margin";
 static Knobs g_knobs = read_knobs();
 void reload_env_knobs() { g_knobs = read_knobs(); }
+static size_t lds_box_limit(size_t static_lds_bytes, int workgroups_per_cu)
+{
+    const size_t per_wg = (size_t)160 * 1024 / (size_t)(workgroups_per_cu > 0 ? workgroups_per_cu : 1);
+    const size_t room = per_wg > static_lds_bytes + 512 ? per_wg - static_lds_bytes - 512 : 0;   // (512 B of slack for the allocation granule)
+    const size_t cap = (size_t)g_knobs.lds_boxes_kb * 1024;
+    return room < cap ? room : cap;
+}
+constexpr size_t kNnCoopStaticLds = 10800, kPersistentStaticLds = 5120;   // static LDS of k_nn_coop / of the persistent kernels (s_m, s_list)
+static size_t knn_coop_static_lds(int list_len)   // sizeof(KnnCoopLds<K>), K = knn + 1
+{
+    switch (list_len) {
+        case 4: return sizeof(KnnCoopLds<4>); case 5: return sizeof(KnnCoopLds<5>); case 6: return sizeof(KnnCoopLds<6>); case 7: return sizeof(KnnCoopLds<7>);
+        case 8: return sizeof(KnnCoopLds<8>); case 9: return sizeof(KnnCoopLds<9>); case 10: return sizeof(KnnCoopLds<10>); case 11: return sizeof(KnnCoopLds<11>);
+        case 12: return sizeof(KnnCoopLds<12>); case 13: return sizeof(KnnCoopLds<13>); case 14: return sizeof(KnnCoopLds<14>); case 15: return sizeof(KnnCoopLds<15>);
+        case 16: return sizeof(KnnCoopLds<16>); default: return sizeof(KnnCoopLds<17>);
+    }
+}
+// k_knn_coop's box levels: its workgroups per CU by list length (launch bounds: four up to seven entries, else three), and a workgroup's
+// static + dynamic LDS within 64 KB
+static size_t knn_coop_lds_box_limit(int list_len)
+{
+    const size_t st = knn_coop_static_lds(list_len);
+    const size_t a = lds_box_limit(st, list_len <= 7 ? 4 : 3);
+    const size_t b = st + 1024 < (size_t)64 * 1024 ? (size_t)64 * 1024 - st - 1024 : 0;
+    return a < b ? a : b;
+}
 
 // ---- parked device blocks (DevBuf::pooled) ------------------------------------------------------------------
 // An odometry stream drops one cached cloud per scan: six hipFree calls, ~90 us of a 0.75-ms scan (HIP API trace), each of
@@ -1151,7 +1184,7 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
     if ((rc = fill_nn_problem(P, thr2, use_seed, b.p[0]))) return rc;
     const TiledMap& mp = b.p[0].mp;
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
-    const int lds_boxes = box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
+    const int lds_boxes = box_bytes <= lds_box_limit(kNnCoopStaticLds, 4) ? 1 : 0;   // (k_nn_coop: four workgroups per CU)
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
     if (wave_times_) hipLaunchKernelGGL((k_nn_coop<1, true>), dim3(xcd_grid(n_items)), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
@@ -1274,8 +1307,14 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const TiledMap mp = tiled_map();
     unsigned long long* staged = (profiling_ || g_knobs.debug_stats == 3) ? stats_.as<unsigned long long>() : nullptr;  // evaluated pairs, slotted (statistics only)
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
-    // (lists of 10 .. 17 entries: the cooperative kernel's merge area alone is up to 43 KB of the workgroup's 64 -- box levels in LDS only for small maps)
-    const int lds_boxes = box_bytes <= (wide_knn ? (size_t)16 * 1024 : kMaxLdsBoxBytes) ? 1 : 0;  // else the upper levels are read from global memory
+    // Odometry-size clouds: fewer 64-query items than wave slots -- a persistent launch is one item per wave and as long as its
+    // slowest item; one WORKGROUP per item instead (k_knn_coop: four waves deal the tiles, lists merged through LDS).
+    const int n_items64 = (int)((N_ + 63) / 64);   // (the cooperative kernel's items hold 64 queries whatever MOLA_ICP_QPL says)
+    // (crossover, ms per 8-iteration align cooperative / persistent -- uniform synthetic clouds: 60k 0.54 / 0.67, 120k 0.83 / 0.78,
+    //  160k 1.02 / 0.84, 200k 1.21 / 0.92; a KITTI-like 120k scan pair, dense near the sensor: 1.76 / 1.96.  Up to 131k queries.)
+    const bool knn_coop = wide_knn || (g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8);
+    // the upper box levels in LDS while that costs the kernel no workgroup per CU (lds_box_limit), else read from global memory
+    const int lds_boxes = box_bytes <= (knn_coop ? knn_coop_lds_box_limit((int)p.knn + 1) : lds_box_limit(kPersistentStaticLds, 4)) ? 1 : 0;
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     // Queries per lane: ONE (64-query items).  A lane's K-entry lists for two queries push the insertion flavour to 168
     // VGPR + spills; with one query per lane there are none, items are twice as many and half as long -- better balance
@@ -1405,12 +1444,6 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         if (ql == 1) MOLA_LAUNCH_KNN_QL(KK, 1);                                                                      \
         else MOLA_LAUNCH_KNN_QL(KK, 2);                                                                              \
     } while (0)
-    // Odometry-size clouds: fewer 64-query items than wave slots -- a persistent launch is one item per wave and as long as its
-    // slowest item; one WORKGROUP per item instead (k_knn_coop: four waves deal the tiles, lists merged through LDS).
-    const int n_items64 = (int)((N_ + 63) / 64);   // (the cooperative kernel's items hold 64 queries whatever MOLA_ICP_QPL says)
-    // (crossover, ms per 8-iteration align cooperative / persistent -- uniform synthetic clouds: 60k 0.54 / 0.67, 120k 0.83 / 0.78,
-    //  160k 1.02 / 0.84, 200k 1.21 / 0.92; a KITTI-like 120k scan pair, dense near the sensor: 1.76 / 1.96.  Up to 131k queries.)
-    const bool knn_coop = wide_knn || (g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8);
 #define MOLA_LAUNCH_KNN_COOP(KK)                                                                                       \
     hipLaunchKernelGGL((k_knn_coop<KK, 1>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, kb, thr2, thr2x,    \
                        p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, cert.stats, (unsigned long long*)nullptr)
@@ -2443,12 +2476,12 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
             if (bb > max_box_bytes) max_box_bytes = bb;
         }
         if (n == 0) break;
-        const int lds_boxes = max_box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
-        const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
         // Few items: latency counts -> one WORKGROUP per item (k_nn_coop, rows fused).  Many (a dozen 100k-point problems
         // are ~10^4): issue slots count -> the persistent one-wave-per-item matcher over all problems' items (rows fused too:
         // the same sums, bit for bit).  MOLA_ICP_BATCH_TILED=0|1 forces either.
         const bool tiled = g_knobs.batch_tiled >= 0 ? g_knobs.batch_tiled != 0 : total_items >= 2 * 1024;
+        const int lds_boxes = max_box_bytes <= lds_box_limit(tiled ? kPersistentStaticLds : kNnCoopStaticLds, 4) ? 1 : 0;
+        const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
         if (!tiled) {
             hipLaunchKernelGGL((k_nn_coop<kCoopMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
                                (unsigned long long*)nullptr);
@@ -2688,7 +2721,7 @@ int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_
             if (bb > max_box_bytes) max_box_bytes = bb;
         }
         if (n == 0) break;
-        const int lds_boxes = max_box_bytes <= kMaxLdsBoxBytes ? 1 : 0;
+        const int lds_boxes = max_box_bytes <= knn_coop_lds_box_limit((int)p.knn + 1) ? 1 : 0;
         const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
         unsigned long long* staged = ws_.profiling_ ? sc_.stats.as<unsigned long long>() : nullptr;
 #define MOLA_LAUNCH_KNN_COOP_B(KK)                                                                                          \
