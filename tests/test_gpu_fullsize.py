@@ -203,6 +203,35 @@ def test_config5_10m_map_sequential_shards(pkg, O, synth):
     icp.close()
 
 
+@pytest.mark.parametrize("quads", ["0", "1"])
+def test_dense_map_both_sweeps_of_the_tiled_matcher(pkg, O, synth, quads, monkeypatch):
+    """300k queries against a 3M-point map -- ten map points per query, the upper box levels read from global memory --, a launch WITHOUT
+    seeds under the whole gate (the quad sweep then fills its per-quad tile lists to the brim and drains them in the middle of a list) and
+    two seeded ones, with k_nn_tiled's quad sweep forced for every launch and with the pass-by-pass sweep: a sample of every pairing
+    against the oracle's exact kd-tree, bit for bit, and the pair counts against each other."""
+    monkeypatch.setenv("MOLA_ICP_QUADS", quads)
+    monkeypatch.setenv("MOLA_ICP_COOP", "0")
+    pkg._lib.lib().mola_icp_debug_reload_env()
+    g, l, _ = synth.make_pair(300_000, 3_000_000, seed=11)
+    kd = O.KdTree(g)
+    sel = np.arange(3, l.shape[1], 50)
+    ls = np.ascontiguousarray(l[:, sel])
+    icp = pkg.ICP(device=0)
+    icp.set_map(g)
+    icp.set_local(l)
+    for T in (np.eye(4), synth.pose_from_xyzypr(0.05, -0.02, 0.01, 0.004, 0.001, -0.001), synth.pose_from_xyzypr(0.3, 0.1, 0.0, 0.02, 0.0, 0.0)):
+        idx, d2, n = icp.match(T, 1.0, l.shape[1], pkg.NN_TILED)
+        oidx, od2, _ = O.match(g, ls, T, 1.0, kd)
+        assert np.array_equal(idx[sel], oidx)
+        k = oidx >= 0
+        assert np.array_equal(d2[sel][k], od2[k])
+        assert n == int((idx >= 0).sum())
+    icp.close()
+    monkeypatch.delenv("MOLA_ICP_QUADS")
+    monkeypatch.delenv("MOLA_ICP_COOP")
+    pkg._lib.lib().mola_icp_debug_reload_env()
+
+
 def test_config5_sharded_align_10_iterations(pkg, O, synth):
     """BASELINE configs[4] as an ALIGN: 10M-point map, 1M queries, 8 query shards (the device's own Hilbert cut, as the
     8 ranks would hold them) run one after another on this one GPU inside every iteration -- each shard's matcher at
