@@ -332,7 +332,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
 // 1M x 1M an item's queries reach 9.6 tiles between them and 2.5 each, against a 10M-point map 34 and 2.7 (306 / 1 082 evaluated
 // pairs per query).  Here the tile TESTS stay per wave (one box against 64 live bounds, as before) but their ballots are kept per
 // QUAD of 16 lanes -- 16 consecutive sorted queries, a quarter of the item's volume: a tile that passes is entered in the list of
-// every quad with a lane that reaches it (a list = a vector register, entry n in lane n).  Then the quads walk their OWN lists side
+// every quad with a lane that reaches it (the lists live in two vector registers: entry n of quad g in lane 16 g + n).  The quads walk their OWN lists side
 // by side: in round r quad g takes its r-th tile -- four different tiles go from global memory straight into LDS
 // (global_load_lds_dword, the next round's in flight under this round's distances), each quad reads its own 32 points -- so every
 // lane meets only the tiles its quad listed: 5.3 of the item's 9.6 at 1M x 1M, the fullest quad (= the rounds) 6.8; 12.3 / 15.0 of
