@@ -66,7 +66,9 @@ def main():
     ap.add_argument("--n-map", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--nn-kernel", choices=["auto", "valu", "mfma", "tiled"], default="auto")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=5, help="0 disables every CPU leg")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=-1,
+                    help="iterations of the single-thread CPU leg on the headline pair; -1 (default) = --steps, at most 40 (~0.5 s each: the "
+                         "pose of the WHOLE timed workload is then compared with the CPU checker's); 0 disables every CPU leg")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed code path (process group + RCCL communicator) even with one rank")
     ap.add_argument("--allreduce", choices=["both", "local", "rccl", "hook"], default="both",
@@ -91,6 +93,8 @@ def main():
     ap.add_argument("--paced-passes", type=int, default=3, help="passes of the 24-scan drive timed with the scans delivered at 10 Hz of wall time")
     ap.add_argument("--batch-pairs", type=int, default=64, help="pairs of the configs[3] leg (0 = skip)")
     args = ap.parse_args()
+    if args.cpu_baseline_iters < 0:
+        args.cpu_baseline_iters = min(args.steps, 40)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU
@@ -496,6 +500,20 @@ def main():
         out["c5_sharded"] = c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev, cdev, use_dist, allreduce_used,
                                    local_comm, place_clouds, balance_shards, barrier)
     extras = rank == 0 and world == 1
+    if world > 1 and args.batch_pairs > 0:
+        # configs[3] on N GPUs: independent pairs, no collective -- the pairs dealt over the RANKS (replicas), then once more from
+        # rank 0 alone through the library's own device pool (mola_icp_pool_*) over every visible GPU
+        out["config3_batch"] = config3_replicas(pkg, synth, torch, dist, args, rank, world, local_rank, cdev, n_dev)
+    if world > 1 and rank == 0 and args.cpu_baseline_iters > 0:
+        # the CPU leg belongs in the N > 1 line too (rank 0's host cores; the other ranks wait at the closing barrier)
+        from oracle import oracle as O
+        out["cpu_baseline"], ref_T = cpu_baseline(g, l, args.cpu_baseline_iters, O.use_native())
+        if args.cpu_baseline_iters == args.steps:
+            rot, trans = _pose_err(res.optimal_tf, ref_T)
+            out["pose_err_vs_cpu"] = {"rot_rad": rot, "trans_m": trans, "iterations": args.steps, "whole_timed_workload": True,
+                                      "note": f"the sharded align's pose after all {args.steps} iterations against the CPU checker's", "tolerance": "1e-4 rad / 1e-3 m"}
+    if world > 1:
+        dist.barrier()
 
     if extras and args.nn_kernel in ("auto", "tiled") and args.dense_iters > 0:
         # the dense N x M kernel (no culling) on the same clouds, outside the timed region: its roofline
@@ -613,7 +631,10 @@ def main():
         r5 = icp.align_resident(T0, p)
         rot, trans = _pose_err(r5.optimal_tf, ref_T)
         out["pose_err_vs_cpu"] = {"rot_rad": rot, "trans_m": trans, "iterations": args.cpu_baseline_iters,
-                                  "note": f"compared after {args.cpu_baseline_iters} iterations (the timed region runs {args.steps})",
+                                  "whole_timed_workload": args.cpu_baseline_iters == args.steps,
+                                  "note": (f"the pose after all {args.steps} iterations of the timed workload against the CPU checker's {args.steps}"
+                                           if args.cpu_baseline_iters == args.steps else
+                                           f"compared after {args.cpu_baseline_iters} iterations (the timed region runs {args.steps})"),
                                   "tolerance": "1e-4 rad / 1e-3 m"}
 
     if extras and args.e2e:
@@ -632,7 +653,8 @@ def main():
         # ... and from page-locked scan buffers (profiles/r05/paced_split_probe.txt: what is dearer at 10 Hz is the upload of a pageable
         # scan to a device that has idled, and the call's entry; the iterations are not)
         out["odometry_stream_10hz_pinned"] = odometry_stream_leg(pkg, synth, period_s=0.1, passes=args.paced_passes, pinned=True)
-        out["odometry_stream_small"] = odometry_stream_leg(pkg, synth, decimate=10)
+        # (the decimated drive also runs through the CPU-driven front-end: ~24 aligns of 12k points, seconds of CPU)
+        out["odometry_stream_small"] = odometry_stream_leg(pkg, synth, decimate=10, oracle_front_end=args.cpu_baseline_iters != 0)
         out["odometry_stream_small_10hz"] = odometry_stream_leg(pkg, synth, period_s=0.1, decimate=10, passes=args.paced_passes)
 
     if use_dist:
@@ -701,9 +723,9 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
                 _, slab = place_clouds(icp5, tg5, tl5, margin_scale=2.0 ** (attempt + 1), cuts=cuts)
                 slab["recut"] = attempt + 1
 
-    def timed5():
+    def timed5(T0=T0, warm=True):
         icp5.align_resident(T0, p)
-        if use_dist and args.device_warmup_aligns >= 10:   # (the same settling time behind the transport's collectives as the headline's
+        if warm and use_dist and args.device_warmup_aligns >= 10:   # (the same settling time behind the transport's collectives as the headline's
             for _ in range(150):                          # warm-up; a COUNT, the same on every rank: every align is a series of all-reduces)
                 icp5.align_resident(T0, p)
         dts, dts_warm = [], []
@@ -759,6 +781,23 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
     rp = icp5.align_resident(T0, p)
     icp5.set_profiling(False)
     k_ms = rp.ms_nn_kernel / max(1, rp.n_nn_launches)
+    # ... and the regime an odometry / map-matching align spends its last iterations in: the same job from a guess 5 cm / 0.2 deg off
+    # the ground truth (inside the stated uncertainty of the guess, so the same map slabs hold), through the transport chosen above
+    T_near = np.array(T_gt, dtype=np.float64) @ synth.pose_from_xyzypr(0.03, -0.03, 0.03, np.deg2rad(0.2), 0.0, 0.0)
+    try:
+        near = timed5(T_near, warm=False)
+        icp5.forget_warm_start()
+        icp5.set_profiling(True)
+        rn = icp5.align_resident(T_near, p)
+        icp5.set_profiling(False)
+        near_leg = {"guess": "ground truth perturbed by (0.03, -0.03, 0.03) m and 0.2 deg of yaw", "value": args.c5_steps / near["dt"], "unit": "iterations/s",
+                    "ms_per_step": near["dt"] / args.c5_steps * 1e3, "ms_per_step_repetitions": [x / args.c5_steps * 1e3 for x in near["dts"]],
+                    "ms_per_step_repeat_on_warm_state": near["dt_warm"] / args.c5_steps * 1e3,
+                    "matcher_ms_per_launch_rank0": rn.ms_nn_kernel / max(1, rn.n_nn_launches),
+                    "pairs_evaluated_per_query_rank0": rn.nn_pairs_evaluated / max(1, rn.n_nn_launches) / max(1, n_shard),
+                    "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(near["r"].optimal_tf, T_gt)))}
+    except pkg.IcpError as e:   # (a slab the perturbed guess leaves: reported, never fatal for the line)
+        near_leg = {"error": str(e)}
     leg = {"workload": f"configs[4]: {N} scan points vs a {M5}-point global map, {args.c5_steps} fixed iterations, point-to-point (gate {GATE_M} m) + Horn, "
                        "query-sharded, one map slab per rank, one all-reduce of 24 doubles per iteration",
            "value": args.c5_steps / dt, "unit": "iterations/s", "ms_per_step": dt / args.c5_steps * 1e3,
@@ -769,7 +808,8 @@ def c5_leg(pkg, synth, sharded, torch, dist, args, rank, world, local_rank, dev,
            "n_local": N, "n_map": M5, "queries_per_gpu_rank0": n_shard, "map_slab_rank0": slab, "shard_balance": balance,
            "matcher_ms_per_launch_rank0": k_ms, "pairs_evaluated_per_query_rank0": rp.nn_pairs_evaluated / max(1, rp.n_nn_launches) / max(1, n_shard),
            "all_reduce": chosen, "allreduce": per_transport if use_dist else None,
-           "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(r.optimal_tf, T_gt)))}
+           "pose_err_vs_gt": dict(zip(("rot_rad", "trans_m"), _pose_err(r.optimal_tf, T_gt))),
+           "near_converged": near_leg}
     if use_dist and chosen is not None:
         detach5(chosen)
     icp5.close()
@@ -1039,15 +1079,16 @@ def align_e2e(pkg, synth, icp, g1m, l1m, seed, with_cpu, cpu_flags):
     return out
 
 
-def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passes=1, pinned=False):
+def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passes=1, pinned=False, oracle_front_end=False):
     """rows f1 + f4 (src/LidarOdometry.cpp:190-514): a drive down the scene at 10 m/s, one 64-ring scan (~115k points) every 0.1 s,
     through the front-end mirror (`LidarOdometry.on_new_observation` = `mola_lo_process_scan`) with params/kitti-default.yaml:
     per scan, the new cloud is uploaded, sorted and boxed ONCE (it is `to` now and `from` for the next scan: the cloud cache),
     aligned against the previous scan with the constant-velocity guess, the keyframe / twist bookkeeping runs on the host."""
     lp = pkg.LidarOdometryParams.load_from_file(os.path.join(ROOT, "params", "kitti-default.yaml"), ROOT)
-    scans, pinned_keep = [], []
+    scans, pinned_keep, gt = [], [], []
     for k in range(n_scans):
         pose = synth.pose_from_xyzypr(-14.0 + 1.0 * k, 0.3 * np.sin(0.3 * k), 0.0, 0.005 * k, 0, 0)
+        gt.append(np.array(pose, dtype=np.float64) @ synth.pose_from_xyzypr(0, 0, 1.73, 0, 0, 0))   # the SENSOR's pose (synth.lidar_scan)
         pc = synth.lidar_scan(pose, seed=50 + k)
         # decimate = 10: what the reference's own pipeline hands to align() -- `full_pointcloud_decimation: 10`
         # (params/kitti-default.yaml:27; src/LidarOdometry.cpp:215-224): every tenth point of the scan, ~12k of ~120k
@@ -1063,7 +1104,7 @@ def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passe
     ms, its, ran, kfs, steady, steady_native = [], [], 0, [], [], []
     for rep in range(1 + passes):   # (the first pass warms allocations and clocks; the others are reported)
         lo.reset()
-        ms, its, ran, kfs, ms_nat = [], [], 0, [], []
+        ms, its, ran, kfs, ms_nat, rels = [], [], 0, [], [], []
         paced = period_s is not None and rep >= 1   # (the warming pass runs back to back)
         t_next = time.perf_counter()
         for k, (t, pc) in enumerate(scans):
@@ -1074,6 +1115,7 @@ def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passe
             st = lo.on_new_observation(t + 1000.0 * rep, pc)
             ms.append((time.perf_counter() - t0) * 1e3)
             ms_nat.append(st.ms_native)
+            rels.append(np.array(st.rel_pose) if st.icp is not None else np.eye(4))
             if st.icp is not None:
                 ran += 1
                 its.append(int(st.icp.nIterations))
@@ -1083,6 +1125,9 @@ def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passe
             steady += ms[2:]   # (scan 0 has no partner, scan 1 no velocity yet)
             steady_native += ms_nat[2:]
     lo.close()
+    trajectory = _trajectory_error(rels, gt)
+    if oracle_front_end:   # the same drive through the front-end logic with the CPU checker behind it (src/LidarOdometry.cpp:305-337)
+        trajectory["vs_cpu_front_end"] = _oracle_front_end_trajectory(pkg, lp, scans, rels)
     med = float(np.median(steady))
     arrival = (f"delivered every {period_s * 1e3:.0f} ms of wall time (the sensor's rate: host and GPU as a robot meets them)"
                if period_s is not None else "delivered back to back (GPU clocks stay up)")
@@ -1092,7 +1137,50 @@ def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passe
             "ms_per_scan_p99": float(np.percentile(steady, 99)),
             "ms_per_scan_min": float(np.min(steady)), "ms_per_scan_max": float(np.max(steady)),
             "scans_per_s": 1e3 / med, "realtime_factor_at_10_hz": 100.0 / med, "icp_ran": ran, "iterations_per_scan_median": float(np.median(its)) if its else 0.0,
-            "ms_per_scan": [round(float(v), 3) for v in ms], "keyframes": kfs}
+            "ms_per_scan": [round(float(v), 3) for v in ms], "keyframes": kfs, "trajectory": trajectory}
+
+
+def _trajectory_error(rels, gt):
+    """row f1's end-to-end metric: the scan-to-scan poses the front-end adopted (src/LidarOdometry.cpp:299-311), chained from the
+    first scan's true pose, against the synthetic drive's ground-truth sensor poses"""
+    X = np.array(gt[0])
+    et, er, rel_t = [], [], []
+    for k in range(1, len(gt)):
+        X = X @ rels[k]
+        dt, dr = X[:3, 3] - gt[k][:3, 3], _pose_err(X, gt[k])[0]
+        et.append(float(np.linalg.norm(dt)))
+        er.append(dr)
+        rel_t.append(_pose_err(rels[k], np.linalg.inv(gt[k - 1]) @ gt[k])[1])
+    path = float(sum(np.linalg.norm(gt[k][:3, 3] - gt[k - 1][:3, 3]) for k in range(1, len(gt))))
+    return {"against": "ground-truth sensor poses of the synthetic drive (scan-to-scan poses chained from the first scan's true pose)",
+            "scans": len(gt), "path_m": path, "translation_rmse_m": float(np.sqrt(np.mean(np.square(et)))), "translation_max_m": float(np.max(et)),
+            "final_drift_m": et[-1], "final_drift_percent_of_path": 100.0 * et[-1] / path, "final_rot_err_rad": er[-1],
+            "scan_to_scan_translation_err_median_m": float(np.median(rel_t)), "scan_to_scan_translation_err_max_m": float(np.max(rel_t))}
+
+
+def _oracle_front_end_trajectory(pkg, lp, scans, rels_gpu):
+    """the same scans through the same front-end logic (`mola_lo_process_scan`) with the CPU checker as its registration: per-scan
+    and accumulated difference between the two trajectories (tolerance of the path: 1e-4 rad / 1e-3 m per align)"""
+    from oracle import oracle as O
+
+    def align(f, t, T0, p):
+        op = O.params_from_product(p)
+        r = (O.align_p2pl(f, t, T0, op, p.plane_eigen_threshold, int(p.knn), int(p.solver_max_iterations))
+             if p.matcher_class == pkg._lib.MATCHER_POINT2PLANE else O.align(f, t, T0, op))
+        return r["T"], r["quality"], r["n_iterations"], r["termination"]
+    lo = pkg.LidarOdometry(lp, align_fn=align)
+    Xg, Xc, worst_rot, worst_trans, same_its = np.eye(4), np.eye(4), 0.0, 0.0, True
+    t0 = time.perf_counter()
+    for k, (t, pc) in enumerate(scans):
+        st = lo.on_new_observation(t, pc)
+        rel = np.array(st.rel_pose) if st.icp is not None else np.eye(4)
+        rot, trans = _pose_err(rels_gpu[k], rel)
+        worst_rot, worst_trans = max(worst_rot, rot), max(worst_trans, trans)
+        Xg, Xc = Xg @ rels_gpu[k], Xc @ rel
+    lo.close()
+    rot, trans = _pose_err(Xg, Xc)
+    return {"scans": len(scans), "worst_scan_to_scan": {"rot_rad": worst_rot, "trans_m": worst_trans},
+            "accumulated": {"rot_rad": rot, "trans_m": trans}, "cpu_seconds": time.perf_counter() - t0, "tolerance_per_align": "1e-4 rad / 1e-3 m"}
 
 
 def montecarlo_leg(pkg, synth, icp, n_guesses=10, n=100_000):
@@ -1118,6 +1206,65 @@ def montecarlo_leg(pkg, synth, icp, n_guesses=10, n=100_000):
             res, best = icp.align_multi_init(g, l, guesses, p)
             ts.append(time.perf_counter() - t0)
         out[name] = {"ms": float(np.median(ts)) * 1e3, "iterations": [int(r.nIterations) for r in res], "best": int(best)}
+    return out
+
+
+def config3_replicas(pkg, synth, torch, dist, args, rank, world, local_rank, cdev, n_dev):
+    """BASELINE.json configs[3] as it is meant: "64 independent 100k-pt scan pairs sharded across 8 x MI355X, stream-per-pair, no RCCL"
+    (the batch the reference's pool threads run: src/LidarOdometry.cpp:704-741).  (i) replicas: pair k belongs to rank k % W, every
+    rank runs its pairs through `align_batch` on its own GPU, pairs/s = all pairs / the slowest rank's time; (ii) rank 0 alone, the
+    same pairs through `mola_icp_pool_*` (one handle per visible device inside ONE process) while the other ranks wait.  Both through
+    the point-to-point settings and through params/icp-settings-loop-closure.yaml."""
+    n_pairs = args.batch_pairs
+    mine = [k for k in range(n_pairs) if k % world == rank]
+    pairs = {k: synth.make_pair(100_000, 100_000, seed=100 + k)[:2] for k in (range(n_pairs) if rank == 0 else mine)}
+    p2p = pkg.Parameters()
+    p2p.matcher_threshold, p2p.max_iterations, p2p.min_abs_step_trans, p2p.min_abs_step_rot = GATE_M, 100, 5e-5, 1e-5
+    shipped = pkg.Parameters.load_from_file(os.path.join(ROOT, "params", "icp-settings-loop-closure.yaml"))
+    out = {"workload": f"{n_pairs} independent 100k x 100k pairs (seeds 100..{99 + n_pairs}), <= 100 its with the stall test, host buffers in, no collective",
+           "n_gpus": world, "pairs_per_rank": [len([k for k in range(n_pairs) if k % world == r]) for r in range(world)]}
+    icp_b = pkg.ICP(device=local_rank)
+    my_pairs = [pairs[k] for k in mine]
+    for name, p in (("point_to_point", p2p), ("shipped_loop_closure_yaml", shipped)):
+        tw = time.perf_counter()
+        while my_pairs and time.perf_counter() - tw < 0.5:
+            icp_b.align_batch(my_pairs[:12], [np.eye(4)] * min(len(my_pairs), 12), p)
+        dts = []
+        for _ in range(3):
+            dist.barrier()
+            t0 = time.perf_counter()
+            res = icp_b.align_batch(my_pairs, [np.eye(4)] * len(my_pairs), p) if my_pairs else []
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts.append(float(t.item()))
+        its = torch.tensor([float(sum(r.nIterations for r in res))], dtype=torch.float64, device=cdev)
+        dist.all_reduce(its, op=dist.ReduceOp.SUM)
+        dt = float(np.median(dts))
+        out[name] = {"replicas": {"pairs_per_s": n_pairs / dt, "iterations_per_s": float(its.item()) / dt, "ms": dt * 1e3,
+                                  "ms_repetitions": [x * 1e3 for x in dts], "n_gpus": world,
+                                  "note": "pair k on rank k % W, one align_batch per rank, the slowest rank's wall time (median of three)"}}
+    icp_b.close()
+    dist.barrier()
+    if rank == 0:   # the other ranks have released their batch handles and wait at the barrier below
+        devices = list(range(n_dev)) if not args.share_gpu else [0] * world
+        all_pairs = [pairs[k] for k in range(n_pairs)]
+        try:
+            pool = pkg.DevicePool(devices)
+            for name, p in (("point_to_point", p2p), ("shipped_loop_closure_yaml", shipped)):
+                pool.align_batch(all_pairs[:2 * len(devices)], [np.eye(4)] * min(n_pairs, 2 * len(devices)), p)
+                dts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    res = pool.align_batch(all_pairs, [np.eye(4)] * n_pairs, p)
+                    dts.append(time.perf_counter() - t0)
+                dt = float(np.median(dts))
+                out[name]["device_pool"] = {"pairs_per_s": n_pairs / dt, "iterations_per_s": sum(r.nIterations for r in res) / dt, "ms": dt * 1e3,
+                                            "devices": devices, "note": "ONE process, mola_icp_pool_align_batch over every visible device (the other ranks idle)"}
+            pool.close()
+        except Exception as e:  # noqa: BLE001
+            out["device_pool_error"] = str(e)
+    dist.barrier()
     return out
 
 

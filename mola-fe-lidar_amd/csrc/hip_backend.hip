@@ -44,6 +44,7 @@ namespace mola_icp_amd {
 #include "kernels_dense.hpp"
 #include "kernels_tiled.hpp"
 #include "kernels_coop.hpp"
+#include "q4_launch.hpp"
 #include "kernels_planes.hpp"
 #include "kernels_prepare.hpp"
 #include "kernels_accumulate.hpp"
@@ -74,6 +75,8 @@ struct Knobs {
     int debug_stats = 0;       // MOLA_ICP_DEBUG_STATS
     int lds_boxes_kb = 40;        // MOLA_ICP_LDS_BOXES_KB: the cooperative / plane kernels keep the upper box levels in LDS up to this size (tuning knob; <= 40)
     int quad_lds_boxes_kb = 22;   // MOLA_ICP_QUAD_LDS_BOXES_KB: the quad flavour keeps the upper box levels in LDS up to this size (tuning knob)
+    int q4 = -1;               // MOLA_ICP_Q4 (-1 = by cloud size, 0 = never, 1 = always: k_nn_q4, four lanes per query, instead of k_nn_coop / k_nn_tiled)
+    int q4_lds_boxes_kb = -1;  // MOLA_ICP_Q4_LDS_BOXES_KB: k_nn_q4 keeps the upper box levels in LDS up to this size (-1: what costs it no workgroup per CU)
     int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
     bool turn_clock = false;   // MOLA_ICP_TURN_CLOCK: print the host's side of an iteration's turn (product kernels; stderr, every 200 turns)
 };
@@ -105,6 +108,8 @@ static Knobs read_knobs()
     k.turn_clock = std::getenv("MOLA_ICP_TURN_CLOCK") != nullptr;
     if (std::getenv("MOLA_ICP_LDS_BOXES_KB")) { k.lds_boxes_kb = geti("MOLA_ICP_LDS_BOXES_KB"); if (k.lds_boxes_kb > 40) k.lds_boxes_kb = 40; if (k.lds_boxes_kb < 0) k.lds_boxes_kb = 0; }
     if (std::getenv("MOLA_ICP_QUAD_LDS_BOXES_KB")) k.quad_lds_boxes_kb = geti("MOLA_ICP_QUAD_LDS_BOXES_KB");
+    k.q4 = std::getenv("MOLA_ICP_Q4") ? (geti("MOLA_ICP_Q4") != 0 ? 1 : 0) : -1;
+    if (std::getenv("MOLA_ICP_Q4_LDS_BOXES_KB")) k.q4_lds_boxes_kb = geti("MOLA_ICP_Q4_LDS_BOXES_KB");
     k.quads = std::getenv("MOLA_ICP_QUADS") ? (geti("MOLA_ICP_QUADS") != 0 ? 1 : 0) : -1;
     return k;
 }
@@ -1196,6 +1201,29 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
     return MOLA_ICP_OK;
 }
 
+// Launches with fewer items than wave slots: k_nn_q4 (kernels_q4.hpp) -- one WAVE per 16 queries, four lanes per query, one
+// workgroup per row of 64; pairing + the row of unit-weight sums, one launch.
+static int q4_lds_boxes(size_t box_bytes)
+{
+    if (g_knobs.q4_lds_boxes_kb >= 0) return box_bytes <= (size_t)g_knobs.q4_lds_boxes_kb * 1024 ? 1 : 0;
+    return box_bytes <= lds_box_limit(q4_static_lds(), q4_workgroups_per_cu()) ? 1 : 0;
+}
+int HipWorkspace::launch_q4(const PoseF& P, float thr2, bool use_seed)
+{
+    NnBatch<1> b;
+    int rc;
+    if ((rc = fill_nn_problem(P, thr2, use_seed, b.p[0]))) return rc;
+    const TiledMap& mp = b.p[0].mp;
+    const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
+    const int lds_boxes = q4_lds_boxes(box_bytes);
+    const size_t dyn_lds = lds_boxes ? box_bytes : 0;
+    const int n_items = (int)((N_ + 63) / 64);
+    HIPCHK(q4_launch(stream_, b, lds_boxes ? n_items : xcd_grid(n_items), dyn_lds, lds_boxes, profiling_ ? 1 : 0));
+    rows_valid_ = true;
+    rows_count_ = n_items;
+    return MOLA_ICP_OK;
+}
+
 int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 {
     if (g_knobs.turn_clock) g_turn.on_enter();
@@ -1943,11 +1971,14 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         // (crossover measured with the 64-query persistent kernel, us per ICP iteration cooperative / persistent: 50k 34 / 42,
         //  100k 41 / 43, 150k 50 / 47, 200k 58 / 50, 390k 93 / 65)
         const bool coop = g_knobs.coop >= 0 ? g_knobs.coop != 0 : n128 <= (size_t)num_cus_ * 4;
-        const int rc = coop ? launch_coop(P, thr2, use_seed) : launch_tiled(P, thr2, use_seed, counter);
+        // ... and within that range four lanes per query (k_nn_q4): an item a sixteenth of the cooperative kernel's, the box tests four
+        // at a time.  MOLA_ICP_Q4=0|1 forces either; the diagnostic builds keep the cooperative kernel and its clocks.
+        const bool q4 = !wave_times_ && (g_knobs.q4 >= 0 ? g_knobs.q4 != 0 : (coop && g_knobs.coop < 0));
+        const int rc = q4 ? launch_q4(P, thr2, use_seed) : (coop ? launch_coop(P, thr2, use_seed) : launch_tiled(P, thr2, use_seed, counter));
         if (rc) return rc;
         last_kernel_ = MOLA_ICP_NN_TILED;
         pairing_sorted_ = true;
-        if (!coop) counters_clean_ = false;   // (the cooperative kernel has no queue and no redo list: it leaves the counters as they are)
+        if (!coop && !q4) counters_clean_ = false;   // (the cooperative kernel has no queue and no redo list: it leaves the counters as they are)
         if (profiling_) {
             HIPCHK(hipEventRecord(ev_[ev_used_ + 1], stream_));
             ev_used_ += 2;
@@ -2435,7 +2466,7 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         NnBatchItems<kCoopMaxBatch> bi;
         std::memset(&b, 0, sizeof b);
         std::memset(&bi, 0, sizeof bi);
-        int n = 0, max_items = 0, total_items = 0, total_items_t = 0;
+        int n = 0, max_items = 0, max_items_t = 0, total_items = 0, total_items_t = 0;
         size_t max_box_bytes = 0;
         bool same_map = true;
         const SortedCloud* first_map = nullptr;
@@ -2465,7 +2496,8 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
             bf.seed_valid = true;
             const int items = (int)((pr.loc->n + kQPW - 1) / kQPW);   // 128-query items: the cooperative kernel's, and the rows'
             if (items > max_items) max_items = items;
-            const int items_t = (int)((pr.loc->n + 63) / 64);         // 64-query items: the persistent batched matcher's
+            const int items_t = (int)((pr.loc->n + 63) / 64);         // 64-query items: the persistent batched matcher's, and k_nn_q4's workgroups
+            if (items_t > max_items_t) max_items_t = items_t;
             bi.base[n - 1] = total_items_t;
             total_items += items;
             total_items_t += items_t;
@@ -2482,7 +2514,11 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         const bool tiled = g_knobs.batch_tiled >= 0 ? g_knobs.batch_tiled != 0 : total_items >= 2 * 1024;
         const int lds_boxes = max_box_bytes <= lds_box_limit(tiled ? kPersistentStaticLds : kNnCoopStaticLds, 4) ? 1 : 0;
         const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
-        if (!tiled) {
+        const bool q4 = !tiled && (g_knobs.q4 >= 0 ? g_knobs.q4 != 0 : true);   // (four lanes per query: see HipWorkspace::launch_nn)
+        if (q4) {
+            const int lb = q4_lds_boxes(max_box_bytes);
+            HIPCHK(q4_launch_batch(ws_.stream_, b, xcd_grid(max_items_t), n, lb ? max_box_bytes : 0, lb, ws_.profiling_ ? 1 : 0));
+        } else if (!tiled) {
             hipLaunchKernelGGL((k_nn_coop<kCoopMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, b, lds_boxes,
                                (unsigned long long*)nullptr);
             HIPCHK(hipGetLastError());

@@ -185,6 +185,7 @@ class HipWorkspace final : public Stages {
     int launch_tiled(const struct PoseF& P, float thr2, bool use_seed, unsigned int* counter);
     int fill_nn_problem(const struct PoseF& P, float thr2, bool use_seed, NnProblem& pb);
     int launch_coop(const struct PoseF& P, float thr2, bool use_seed);
+    int launch_q4(const struct PoseF& P, float thr2, bool use_seed);   // k_nn_q4: four lanes per query (kernels_q4.hpp)
     TiledMap tiled_map() const;
     int spin_for(volatile unsigned long long* flag, unsigned long long seq);
     int check_slab(const Mat4& T, double threshold);

@@ -63,8 +63,8 @@ def test_1m_x_1m_properties(pkg, O, synth, big, kern):
 def test_1m_x_1m_config3_run(pkg, O, big):
     """config 3: 1M scan vs 1M map, 40 fixed iterations.  Point-to-point ICP on dense planar
     clouds converges slowly (the same in the oracle), so the checks are: every iteration ran, the
-    pose moved monotonically closer to the seeded T_gt, and the first 3 iterations equal the
-    oracle's (exact kd-tree, fp64 sums) to ~1e-9."""
+    pose moved monotonically closer to the seeded T_gt, the first 3 iterations equal the
+    oracle's (exact kd-tree, fp64 sums) to ~1e-9 -- and so does the pose after all 40."""
     g, l, Tgt = big
     icp = pkg.ICP(device=0)
     r = icp.align(g, l, np.eye(4), p2p_params(pkg, max_iterations=40, fixed_iterations=1))
@@ -82,6 +82,14 @@ def test_1m_x_1m_config3_run(pkg, O, big):
     rot, trans = O.pose_error(r3.optimal_tf, ref["T"])
     assert rot <= 1e-4 and trans <= 1e-3 and rot < 1e-8 and trans < 1e-8, (rot, trans)
     assert r3.n_pairs == ref["n_pairs"] and r3.quality == pytest.approx(ref["quality"], abs=1e-12)
+    # ... and the WHOLE workload: the pose after all 40 iterations against the oracle's 40 (BASELINE.json's tolerance
+    # 1e-4 rad / 1e-3 m; the bit-identical pairings leave fp64 summation order only: ~1e-9)
+    p40 = p2p_params(pkg, max_iterations=40, fixed_iterations=1)
+    ref40 = O.align(g, l, np.eye(4), O.params_from_product(p40))
+    rot, trans = O.pose_error(r.optimal_tf, ref40["T"])
+    assert ref40["n_iterations"] == 40 == r.nIterations and ref40["termination"] == r.terminationReason
+    assert rot <= 1e-4 and trans <= 1e-3 and rot < 1e-7 and trans < 1e-7, (rot, trans)
+    assert r.n_pairs == ref40["n_pairs"] and r.quality == pytest.approx(ref40["quality"], abs=1e-12)
     icp.close()
 
 
