@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOLA_ICP_ABI_VERSION 3
+#define MOLA_ICP_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -141,6 +141,12 @@ typedef struct mola_icp_params {
     double   quality_weight;             /* quality[0].weight (0 is read as 1: a zeroed / pre-ABI-3 struct means one evaluator) */
     uint32_t n_extra_quality;
     mola_icp_quality_entry extra_quality[MOLA_ICP_MAX_EXTRA_STAGES];
+    /* ABI 4 -- alternative READINGS of three behaviours of mp2p_icp that nothing in the reference pins and that are NOT pose- or
+     * goodness-neutral (INTEGRATION.md "When a real mp2p_icp disagrees").  0 = the reading this library
+     * implements by default.  YAML: an optional top-level `readings:` map beside `params:` -- a key outside the reference's schema. */
+    int32_t  reading_outlier_single_pass;        /* scale-outlier detector: ONE weighted pass instead of two     icpreg:14-17 */
+    int32_t  reading_p2pl_all_inside_gate;       /* Matcher_Point2Plane: a plane needs ALL knn inside the gate   icpreg:33-39 */
+    int32_t  reading_quality_denominator_local;  /* PairedRatio = pairings / N(local), not / min(N, M)           icpreg:44-46 */
 } mola_icp_params;
 
 /* ---- result == the fields of mp2p_icp::Results that the reference consumes
@@ -184,6 +190,22 @@ int         mola_icp_device_count(int* count);    /* gfx950 devices visible   */
 /* The MOLA_ICP_* diagnostic / tuning environment variables are read once, when the library is loaded --
  * never on a launch path.  Tests that toggle one on a live process call this to have them read again. */
 int         mola_icp_debug_reload_env(void);
+/* How a host thread waits for the sums of an accumulation pass (one hand-over per ICP iteration).  The reference runs align() from
+ * the odometry thread AND max(2, hw/2) pool threads on one ICP object (src/LidarOdometry.cpp:94-96, 183-184, 711-712, 869): under the
+ * default, MOLA_ICP_WAIT_SPIN, every one of them holds a core at 100 % while its align is in flight.  _YIELD: ~10 us of spinning,
+ * then sched_yield() between polls.  _BLOCK: the thread sleeps on a blocking-sync event behind the publishing kernel.  Process-wide;
+ * also the environment variable MOLA_ICP_WAIT=spin|yield|block (read at load).  Costs per iteration: INTEGRATION.md. */
+/* Priority class of the CALLING THREAD's subsequent calls on any handle: high > 0 = the workspaces (streams) those calls lease run at
+ * the device's greatest stream priority -- their launches are picked ahead of the queued launches of normal-priority calls (the
+ * odometry step beside batches of nearby / loop-closure checks on the same ICP object: src/LidarOdometry.cpp:94-96, 183-184, 711-712,
+ * 869).  Thread-local, default 0.  mola_lo_process_scan raises it for its own duration. */
+int         mola_icp_set_thread_priority(int high);
+int         mola_icp_get_thread_priority(int* high);
+#define MOLA_ICP_WAIT_SPIN  0
+#define MOLA_ICP_WAIT_YIELD 1
+#define MOLA_ICP_WAIT_BLOCK 2
+int         mola_icp_set_wait_policy(int policy);
+int         mola_icp_get_wait_policy(int* policy);
 
 /* ---- parameters ------------------------------------------------------- */
 /* the defaults of mp2p_icp::Parameters + Points_DistanceThreshold/Horn/PairedRatio */
@@ -290,17 +312,21 @@ int mola_icp_align_batch(mola_icp_handle* h, size_t n_pairs,
 
 /* ---- device pool: the replica / task parallelism of the nearby-keyframe + loop-closure checks across the GPUs of one
  * node (BASELINE config[3]: 64 independent pairs over 8 x MI355X, no collective).  The reference runs these checks on
- * `worker_pool_past_KFs_`, max(2, hw/2) CPU threads (src/LidarOdometry.cpp:94-96, 704-741); here one handle per
- * device, pair i goes to device i mod n (round-robin, as SURVEY.md section 8e states), and every device advances its
- * share through mola_icp_align_batch on a host thread of its own.  Results are those of stand-alone aligns. */
+ * `worker_pool_past_KFs_`, max(2, hw/2) CPU threads (src/LidarOdometry.cpp:94-96, 704-741); here one handle and one
+ * persistent host thread per device slot; a call's pairs are cut into chunks that the slots pull from a shared cursor (a
+ * slot whose pairs terminate early serves more of them), each chunk advancing in lockstep through mola_icp_align_batch.
+ * Results are those of stand-alone aligns, whichever slot served a pair. */
 typedef struct mola_icp_pool mola_icp_pool;
 /* devices == NULL or n_devices == 0: every visible device.  A device index may repeat (two handles on one GPU). */
 int mola_icp_pool_create(const int* devices, int n_devices, mola_icp_pool** out);
 int mola_icp_pool_destroy(mola_icp_pool* pool);
 int mola_icp_pool_size(const mola_icp_pool* pool, int* n_handles);
 int mola_icp_pool_handle(mola_icp_pool* pool, int i, mola_icp_handle** h);   /* borrowed: owned by the pool */
-/* the dealing rule on its own (no GPU needed): device_of_pair[i] = i mod n_devices */
+/* the STATIC round-robin rule (device_of_pair[i] = i mod n_devices): what rounds 1-5 dealt by and what a caller may still use to deal
+ * pairs itself; since round 6 mola_icp_pool_align_batch lets the slots pull chunks of pairs from a shared cursor instead */
 int mola_icp_pool_assignment(size_t n_pairs, int n_devices, int* device_of_pair);
+/* pairs each slot served in the pool's last align_batch call (statistics; n_slots >= the pool's size) */
+int mola_icp_pool_last_shares(const mola_icp_pool* pool, size_t* pairs_per_slot, int n_slots);
 int mola_icp_pool_align_batch(mola_icp_pool* pool, size_t n_pairs,
                               const float* const* from_x, const float* const* from_y, const float* const* from_z,
                               const size_t* M,

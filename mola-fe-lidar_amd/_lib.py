@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOLA_ICP_LIB_PATH") or os.path.join(_HERE, "lib", "libmola_icp_amd.so")
 
 NACC = 24
-ABI_VERSION = 3   # MOLA_ICP_ABI_VERSION of include/mola_icp_amd.h
+ABI_VERSION = 4   # MOLA_ICP_ABI_VERSION of include/mola_icp_amd.h
 
 OK = 0
 E_BADARG, E_CONFIG, E_HIP, E_OOM, E_NODEVICE, E_UNSUPPORTED, E_COMM, E_INTERNAL = -1, -2, -3, -4, -5, -6, -7, -8
@@ -72,6 +72,9 @@ class CParams(C.Structure):
         ("quality_weight", C.c_double),
         ("n_extra_quality", C.c_uint32),
         ("extra_quality", CQualityEntry * MAX_EXTRA_STAGES),
+        ("reading_outlier_single_pass", C.c_int32),
+        ("reading_p2pl_all_inside_gate", C.c_int32),
+        ("reading_quality_denominator_local", C.c_int32),
     ]
 
 
@@ -187,6 +190,10 @@ SIGNATURES = {
     "mola_icp_status_string": (C.c_char_p, [C.c_int]),
     "mola_icp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mola_icp_debug_reload_env": (C.c_int, []),
+    "mola_icp_set_wait_policy": (C.c_int, [C.c_int]),
+    "mola_icp_set_thread_priority": (C.c_int, [C.c_int]),
+    "mola_icp_get_thread_priority": (C.c_int, [C.POINTER(C.c_int)]),
+    "mola_icp_get_wait_policy": (C.c_int, [C.POINTER(C.c_int)]),
     "mola_icp_params_default": (C.c_int, [C.POINTER(CParams)]),
     "mola_icp_params_from_yaml": (C.c_int, [C.c_char_p, C.POINTER(CParams)]),
     "mola_icp_params_from_yaml_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CParams)]),
@@ -216,6 +223,7 @@ SIGNATURES = {
     "mola_icp_pool_size": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "mola_icp_pool_handle": (C.c_int, [_H, C.c_int, C.POINTER(_H)]),
     "mola_icp_pool_assignment": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_int)]),
+    "mola_icp_pool_last_shares": (C.c_int, [_H, C.POINTER(C.c_size_t), C.c_int]),
     "mola_icp_pool_align_batch": (C.c_int, [_H, C.c_size_t, C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
                                             C.POINTER(C.c_size_t), C.POINTER(_FP), C.POINTER(_FP), C.POINTER(_FP),
                                             C.POINTER(C.c_size_t), _DP, C.POINTER(CParams), C.POINTER(CResult)]),

@@ -33,6 +33,7 @@ struct mola_icp_handle {
     int device = -1;
     std::mutex mtx;                                   // guards pool + resident
     std::vector<std::unique_ptr<HipWorkspace>> pool;  // idle workspaces for mola_icp_align()
+    std::vector<std::unique_ptr<HipWorkspace>> pool_hi;  // ... whose streams run at the device's greatest priority (mola_icp_set_thread_priority)
     std::unique_ptr<HipWorkspace> resident;           // the resident-cloud API's workspace
     std::atomic<int> profiling{0};                    // mola_icp_set_profiling
     // prepared-cloud objects of finished batched calls, kept for the next one (their device buffers are reused:
@@ -105,10 +106,87 @@ struct mola_icp_handle {
     }
 };
 
+// One handle per device slot and one PERSISTENT worker thread per slot (round 6; a std::thread per device per call before).  A call
+// posts ONE job: the workers pull chunks of pairs from a shared cursor until it runs dry -- a slot whose pairs stall early takes more
+// chunks instead of idling while the others finish a static share (pairs differ in iteration count: src/LidarOdometry.cpp:704-741's
+// batch mixes nearby aligns and loop closures).  Every pair's result is that of its stand-alone align, whichever slot served it.
 struct mola_icp_pool {
     std::vector<mola_icp_handle*> handles;
+    struct Job {
+        size_t n_pairs = 0, chunk = 1;
+        const float* const* fx = nullptr; const float* const* fy = nullptr; const float* const* fz = nullptr; const size_t* M = nullptr;
+        const float* const* tx = nullptr; const float* const* ty = nullptr; const float* const* tz = nullptr; const size_t* N = nullptr;
+        const double* init_T = nullptr;
+        const mola_icp_params* p = nullptr;
+        mola_icp_result* out = nullptr;
+    };
+    std::mutex m;                 // guards everything below
+    std::condition_variable cv_work, cv_done;
+    std::mutex call_m;            // one align_batch call at a time per pool
+    Job job;
+    unsigned long long generation = 0;   // bumped per posted job
+    size_t cursor = 0;            // next pair to hand out
+    int busy = 0;                 // workers that have not finished the current generation
+    bool stop = false;
+    std::vector<int> rcs;
+    std::vector<std::string> msgs;
+    std::vector<size_t> served;   // pairs each slot served in the last call (statistics)
+    std::vector<std::thread> workers;
+
+    void worker(int d)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                j = job;
+            }
+            int rc = MOLA_ICP_OK;
+            std::string msg;
+            size_t n_served = 0;
+            for (;;) {
+                size_t lo, hi;
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    if (cursor >= j.n_pairs) break;
+                    lo = cursor;
+                    hi = std::min(j.n_pairs, lo + j.chunk);
+                    cursor = hi;
+                }
+                const size_t n = hi - lo;
+                rc = mola_icp_align_batch(handles[(size_t)d], n, j.fx + lo, j.fy + lo, j.fz + lo, j.M + lo, j.tx + lo, j.ty + lo, j.tz + lo,
+                                          j.N + lo, j.init_T + 16 * lo, j.p, j.out + lo);
+                if (rc) { msg = mola_icp_last_error(); break; }
+                n_served += n;
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                rcs[(size_t)d] = rc;
+                msgs[(size_t)d] = msg;
+                served[(size_t)d] = n_served;
+                if (rc) cursor = j.n_pairs;   // (a failed slot ends the call: the others stop pulling)
+                if (--busy == 0) cv_done.notify_all();   // (under the lock: the caller may unwind as soon as it sees busy == 0)
+            }
+        }
+    }
+    void start()
+    {
+        const size_t nd = handles.size();
+        rcs.assign(nd, MOLA_ICP_OK); msgs.assign(nd, std::string()); served.assign(nd, 0);
+        for (size_t d = 0; d < nd; ++d) workers.emplace_back([this, d] { worker((int)d); });
+    }
     ~mola_icp_pool()
     {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+            cv_work.notify_all();
+        }
+        for (std::thread& t : workers) t.join();
         for (mola_icp_handle* h : handles) delete h;
     }
 };
@@ -164,21 +242,25 @@ int check_pose(const double T[16])
 }
 
 // borrows a workspace from the handle's pool for one align() call
+thread_local int t_call_priority = 0;   // mola_icp_set_thread_priority: the class of the workspaces this thread's calls lease
+
 struct Lease {
     mola_icp_handle* h;
     std::unique_ptr<HipWorkspace> ws;
     int rc = MOLA_ICP_OK;
-    explicit Lease(mola_icp_handle* hh) : h(hh)
+    bool high = false;
+    explicit Lease(mola_icp_handle* hh) : h(hh), high(t_call_priority > 0)
     {
         {
             std::lock_guard<std::mutex> lk(h->mtx);
-            if (!h->pool.empty()) {
-                ws = std::move(h->pool.back());
-                h->pool.pop_back();
+            auto& pool = high ? h->pool_hi : h->pool;
+            if (!pool.empty()) {
+                ws = std::move(pool.back());
+                pool.pop_back();
             }
         }
         if (!ws) {
-            ws.reset(new HipWorkspace(h->device));
+            ws.reset(new HipWorkspace(h->device, high ? 1 : 0));
             rc = ws->init();
         }
         ws->set_profiling(h->profiling.load() != 0);
@@ -187,7 +269,7 @@ struct Lease {
     {
         if (ws && rc == MOLA_ICP_OK) {
             std::lock_guard<std::mutex> lk(h->mtx);
-            h->pool.push_back(std::move(ws));
+            (high ? h->pool_hi : h->pool).push_back(std::move(ws));
         }
     }
 };
@@ -370,6 +452,33 @@ int mola_icp_device_count(int* count)
         *count = n;
         return MOLA_ICP_OK;
     });
+}
+
+int mola_icp_set_thread_priority(int high)
+{
+    t_call_priority = high > 0 ? 1 : 0;
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_get_thread_priority(int* high)
+{
+    if (!high) return fail(MOLA_ICP_E_BADARG, "null argument");
+    *high = t_call_priority;
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_set_wait_policy(int policy)
+{
+    if (policy < MOLA_ICP_WAIT_SPIN || policy > MOLA_ICP_WAIT_BLOCK) return fail(MOLA_ICP_E_BADARG, "wait policy must be MOLA_ICP_WAIT_SPIN, _YIELD or _BLOCK");
+    set_wait_policy(policy);
+    return MOLA_ICP_OK;
+}
+
+int mola_icp_get_wait_policy(int* policy)
+{
+    if (!policy) return fail(MOLA_ICP_E_BADARG, "null argument");
+    *policy = wait_policy();
+    return MOLA_ICP_OK;
 }
 
 int mola_icp_debug_reload_env(void)
@@ -786,6 +895,7 @@ int mola_icp_pool_create(const int* devices, int n_devices, mola_icp_pool** out)
             if (rc) return rc;
             pool->handles.push_back(h);
         }
+        pool->start();
         *out = pool.release();
         return MOLA_ICP_OK;
     });
@@ -823,40 +933,37 @@ int mola_icp_pool_align_batch(mola_icp_pool* pool, size_t n_pairs, const float* 
         if (n_pairs && (!fx || !fy || !fz || !M || !tx || !ty || !tz || !N))
             return fail(MOLA_ICP_E_BADARG, "null batch array");
         const int nd = (int)pool->handles.size();
-        std::vector<int> dev(n_pairs);
-        int rc = mola_icp_pool_assignment(n_pairs, nd, dev.data());
-        if (rc) return rc;
-        // one host thread per device, each driving its share through its own handle (no collective, no shared state)
-        std::vector<int> rcs((size_t)nd, MOLA_ICP_OK);
-        std::vector<std::string> msgs((size_t)nd);
-        std::vector<std::thread> th;
-        for (int d = 0; d < nd; ++d)
-            th.emplace_back([&, d]() {
-                std::vector<size_t> mine;
-                for (size_t i = 0; i < n_pairs; ++i)
-                    if (dev[i] == d) mine.push_back(i);
-                if (mine.empty()) return;
-                const size_t n = mine.size();
-                std::vector<const float*> a(n), b(n), c(n), e(n), f(n), g(n);
-                std::vector<size_t> Ms(n), Ns(n);
-                std::vector<double> Ts(16 * n);
-                std::vector<mola_icp_result> res(n);
-                for (size_t k = 0; k < n; ++k) {
-                    const size_t i = mine[k];
-                    a[k] = fx[i]; b[k] = fy[i]; c[k] = fz[i]; e[k] = tx[i]; f[k] = ty[i]; g[k] = tz[i];
-                    Ms[k] = M[i]; Ns[k] = N[i];
-                    std::memcpy(&Ts[16 * k], init_T + 16 * i, sizeof(double) * 16);
-                }
-                rcs[(size_t)d] = mola_icp_align_batch(pool->handles[(size_t)d], n, a.data(), b.data(), c.data(), Ms.data(), e.data(),
-                                                      f.data(), g.data(), Ns.data(), Ts.data(), p, res.data());
-                if (rcs[(size_t)d]) { msgs[(size_t)d] = last_error(); return; }
-                for (size_t k = 0; k < n; ++k) out[mine[k]] = res[k];
-            });
-        for (auto& t : th) t.join();
-        for (int d = 0; d < nd; ++d)
-            if (rcs[(size_t)d]) return fail(rcs[(size_t)d], "device slot " + std::to_string(d) + ": " + msgs[(size_t)d]);
+        if (n_pairs == 0) return MOLA_ICP_OK;
+        std::lock_guard<std::mutex> call(pool->call_m);
+        // chunks: half a slot's fair share (a slot takes two on average, more if the others' pairs run long), at most what one
+        // lockstep launch advances together
+        size_t chunk = (n_pairs + (size_t)(2 * nd) - 1) / (size_t)(2 * nd);
+        if (chunk > (size_t)kBatchChunk) chunk = (size_t)kBatchChunk;
+        if (chunk < 1) chunk = 1;
+        {
+            std::unique_lock<std::mutex> lk(pool->m);
+            mola_icp_pool::Job& j = pool->job;
+            j.n_pairs = n_pairs; j.chunk = chunk;
+            j.fx = fx; j.fy = fy; j.fz = fz; j.M = M; j.tx = tx; j.ty = ty; j.tz = tz; j.N = N;
+            j.init_T = init_T; j.p = p; j.out = out;
+            pool->cursor = 0;
+            pool->busy = nd;
+            ++pool->generation;
+            pool->cv_work.notify_all();
+            pool->cv_done.wait(lk, [&] { return pool->busy == 0; });
+            for (int d = 0; d < nd; ++d)
+                if (pool->rcs[(size_t)d]) return fail(pool->rcs[(size_t)d], "device slot " + std::to_string(d) + ": " + pool->msgs[(size_t)d]);
+        }
         return MOLA_ICP_OK;
     });
+}
+
+int mola_icp_pool_last_shares(const mola_icp_pool* pool, size_t* pairs_per_slot, int n_slots)
+{
+    if (!pool || !pairs_per_slot || n_slots < (int)pool->handles.size()) return fail(MOLA_ICP_E_BADARG, "bad argument");
+    std::lock_guard<std::mutex> lk(const_cast<mola_icp_pool*>(pool)->m);
+    for (size_t d = 0; d < pool->handles.size(); ++d) pairs_per_slot[d] = pool->served[d];
+    return MOLA_ICP_OK;
 }
 
 int mola_icp_align_multi_init(mola_icp_handle* h, const float* fx, const float* fy, const float* fz, size_t M,

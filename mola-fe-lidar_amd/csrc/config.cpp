@@ -157,6 +157,14 @@ void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p)
         }
     }
 
+    // the readings (a key of this implementation: absent in the reference -> all 0 = the default readings)
+    if (auto* rd = cfg.find("readings")) {
+        if (!rd->is_map()) throw std::runtime_error("`readings` must be a map of booleans");
+        if (auto* n = rd->find("outlier_single_pass")) p.reading_outlier_single_pass = n->as_bool();
+        if (auto* n = rd->find("p2pl_all_inside_gate")) p.reading_p2pl_all_inside_gate = n->as_bool();
+        if (auto* n = rd->find("quality_denominator_local")) p.reading_quality_denominator_local = n->as_bool();
+    }
+
     {
         const YamlNode& seq = cfg.at("solvers");
         parse_solver(entry_of_seq(seq, "solvers", 0, 1 + MOLA_ICP_MAX_EXTRA_STAGES), p.solver_class, p.solver_max_iterations,

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <iterator>
 #include <map>
 #include <memory>
@@ -78,6 +79,7 @@ struct Knobs {
     int q4 = -1;               // MOLA_ICP_Q4 (-1 = by cloud size, 0 = never, 1 = always: k_nn_q4, four lanes per query, instead of k_nn_coop / k_nn_tiled)
     int q4_lds_boxes_kb = -1;  // MOLA_ICP_Q4_LDS_BOXES_KB: k_nn_q4 keeps the upper box levels in LDS up to this size (-1: what costs it no workgroup per CU)
     int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
+    int wait_policy = 0;       // MOLA_ICP_WAIT=spin|yield|block: how the host thread waits for a pass's sums (0 spin -- the default --, 1 yield, 2 block)
     bool turn_clock = false;   // MOLA_ICP_TURN_CLOCK: print the host's side of an iteration's turn (product kernels; stderr, every 200 turns)
 };
 static Knobs read_knobs()
@@ -106,6 +108,7 @@ static Knobs read_knobs()
     k.no_warm_start = std::getenv("MOLA_ICP_NO_WARM_START") != nullptr;
     k.debug_stats = geti("MOLA_ICP_DEBUG_STATS");
     k.turn_clock = std::getenv("MOLA_ICP_TURN_CLOCK") != nullptr;
+    if (const char* e = std::getenv("MOLA_ICP_WAIT")) k.wait_policy = std::strcmp(e, "yield") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
     if (std::getenv("MOLA_ICP_LDS_BOXES_KB")) { k.lds_boxes_kb = geti("MOLA_ICP_LDS_BOXES_KB"); if (k.lds_boxes_kb > 40) k.lds_boxes_kb = 40; if (k.lds_boxes_kb < 0) k.lds_boxes_kb = 0; }
     if (std::getenv("MOLA_ICP_QUAD_LDS_BOXES_KB")) k.quad_lds_boxes_kb = geti("MOLA_ICP_QUAD_LDS_BOXES_KB");
     k.q4 = std::getenv("MOLA_ICP_Q4") ? (geti("MOLA_ICP_Q4") != 0 ? 1 : 0) : -1;
@@ -122,14 +125,39 @@ static const char* const kSlabMsg =
     "the pose moves a shard's reach outside its map slab: cut the slab again with a larger margin";
 static Knobs g_knobs = read_knobs();
 void reload_env_knobs() { g_knobs = read_knobs(); }
+static size_t g_lds_per_cu = (size_t)160 * 1024;   // (gfx950; HipWorkspace::init reads the device's own figure)
 static size_t lds_box_limit(size_t static_lds_bytes, int workgroups_per_cu)
 {
-    const size_t per_wg = (size_t)160 * 1024 / (size_t)(workgroups_per_cu > 0 ? workgroups_per_cu : 1);
+    const size_t per_wg = g_lds_per_cu / (size_t)(workgroups_per_cu > 0 ? workgroups_per_cu : 1);
     const size_t room = per_wg > static_lds_bytes + 512 ? per_wg - static_lds_bytes - 512 : 0;   // (512 B of slack for the allocation granule)
     const size_t cap = (size_t)g_knobs.lds_boxes_kb * 1024;
     return room < cap ? room : cap;
 }
-constexpr size_t kNnCoopStaticLds = 10800, kPersistentStaticLds = 5120;   // static LDS of k_nn_coop / of the persistent kernels (s_m, s_list)
+// What the plane kernels receive as planeEigenThreshold: its SIGN carries the reading `p2pl_all_inside_gate` (mola_icp_params: a plane
+// needs ALL knn neighbours inside the gate instead of >= 3; plane_epilogue decodes it) -- so the flag also takes part wherever the
+// threshold is compared to decide whether cached planes may be reused.
+static inline double plane_eig_arg(const mola_icp_params& p)
+{
+    return p.reading_p2pl_all_inside_gate ? -std::fabs(p.plane_eigen_threshold) : std::fabs(p.plane_eigen_threshold);
+}
+constexpr size_t kQ4MaxQueries = 230000;   // k_nn_q4 serves launches up to this many queries (HipWorkspace::launch_nn)
+// static LDS of a kernel, asked of the code object itself (once per kernel): nothing here is hand-copied from the kernels' __shared__
+// declarations, so an edit there moves the occupancy cliff with it
+template <class Kernel> static size_t static_lds_of(Kernel kernel, size_t fallback)
+{
+    hipFuncAttributes fa{};
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess && fa.sharedSizeBytes ? (size_t)fa.sharedSizeBytes : fallback;
+}
+static size_t nn_coop_static_lds()
+{
+    static const size_t v = static_lds_of(&k_nn_coop<1, false>, 10800);
+    return v;
+}
+static size_t persistent_static_lds()   // (k_nn_tiled_batch: s_m + s_list, as the other persistent kernels without the quad buffers)
+{
+    static const size_t v = static_lds_of(&k_nn_tiled_batch<kCoopMaxBatch, 1>, 5120);
+    return v;
+}
 static size_t knn_coop_static_lds(int list_len)   // sizeof(KnnCoopLds<K>), K = knn + 1
 {
     switch (list_len) {
@@ -256,8 +284,8 @@ void DevBuf::release()
     cap = 0;
 }
 
-HipWorkspace::HipWorkspace(int device)
-    : device_(device), map_sc_(std::make_shared<SortedCloud>()), loc_sc_(std::make_shared<SortedCloud>())
+HipWorkspace::HipWorkspace(int device, int priority)
+    : device_(device), priority_(priority), map_sc_(std::make_shared<SortedCloud>()), loc_sc_(std::make_shared<SortedCloud>())
 {
 }
 
@@ -269,6 +297,7 @@ HipWorkspace::~HipWorkspace()
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (ev_order_a_) (void)hipEventDestroy(ev_order_a_);
     if (ev_prep_) (void)hipEventDestroy(ev_prep_);
+    if (ev_block_) (void)hipEventDestroy(ev_block_);
     if (ev_order_b_) (void)hipEventDestroy(ev_order_b_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();
@@ -332,10 +361,18 @@ int HipWorkspace::init()
         return fail(MOLA_ICP_E_NODEVICE,
                     std::string("device is ") + prop.gcnArchName + " but the kernels are built for gfx950 only");
     num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.maxSharedMemoryPerMultiProcessor >= (size_t)64 * 1024) g_lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;   // (160 KB on gfx950)
     HIPCHK(hipSetDevice(device_));
-    HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    // Stream priority: the reference's odometry thread and its max(2, hw/2) pool threads call align() on the same ICP object at the
+    // same time (src/LidarOdometry.cpp:94-96, 183-184, 711-712, 869); the odometry step is the one with a deadline (10 Hz), so the
+    // workspaces it leases run on streams of the device's greatest priority: their launches are picked ahead of queued launches
+    // of the nearby / loop-closure batches (mola_icp_set_thread_priority; running waves are not preempted).
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const int prio = priority_ > 0 ? prio_greatest : 0;
+    HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio));
     own_stream_ = true;
-    HIPCHK(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, prio));
     HIPCHK(hipEventCreateWithFlags(&ev_order_a_, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_prep_, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_order_b_, hipEventDisableTiming));
@@ -1189,7 +1226,7 @@ int HipWorkspace::launch_coop(const PoseF& P, float thr2, bool use_seed)
     if ((rc = fill_nn_problem(P, thr2, use_seed, b.p[0]))) return rc;
     const TiledMap& mp = b.p[0].mp;
     const size_t box_bytes = sizeof(float) * 6u * ((size_t)mp.n_top + (size_t)mp.n_super);
-    const int lds_boxes = box_bytes <= lds_box_limit(kNnCoopStaticLds, 4) ? 1 : 0;   // (k_nn_coop: four workgroups per CU)
+    const int lds_boxes = box_bytes <= lds_box_limit(nn_coop_static_lds(), 4) ? 1 : 0;   // (k_nn_coop: four workgroups per CU)
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     const int n_items = (int)((N_ + kQPW - 1) / kQPW);
     if (wave_times_) hipLaunchKernelGGL((k_nn_coop<1, true>), dim3(xcd_grid(n_items)), dim3(256), dyn_lds, stream_, b, lds_boxes, wave_times_);
@@ -1342,7 +1379,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     //  160k 1.02 / 0.84, 200k 1.21 / 0.92; a KITTI-like 120k scan pair, dense near the sensor: 1.76 / 1.96.  Up to 131k queries.)
     const bool knn_coop = wide_knn || (g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8);
     // the upper box levels in LDS while that costs the kernel no workgroup per CU (lds_box_limit), else read from global memory
-    const int lds_boxes = box_bytes <= (knn_coop ? knn_coop_lds_box_limit((int)p.knn + 1) : lds_box_limit(kPersistentStaticLds, 4)) ? 1 : 0;
+    const int lds_boxes = box_bytes <= (knn_coop ? knn_coop_lds_box_limit((int)p.knn + 1) : lds_box_limit(persistent_static_lds(), 4)) ? 1 : 0;
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     // Queries per lane: ONE (64-query items).  A lane's K-entry lists for two queries push the insertion flavour to 168
     // VGPR + spills; with one query per lane there are none, items are twice as many and half as long -- better balance
@@ -1393,7 +1430,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int knn_seed = (bootstrapped || (knn_seed_valid_ && planes_knn_ == (int)p.knn && !g_knobs.no_knn_seed)) ? 1 : 0;
     // the cached plane of an unchanged neighbour list carries the planar / non-planar decision of the launch that
     // solved it: reusable only under the same planeEigenThreshold (the seeds themselves do not depend on it)
-    const int plane_cache_ok = (knn_seed && !bootstrapped && planes_eig_thr_ == p.plane_eigen_threshold) ? 1 : 0;
+    const int plane_cache_ok = (knn_seed && !bootstrapped && planes_eig_thr_ == plane_eig_arg(p)) ? 1 : 0;
     // the counting flavour pays off when few items will need the insertion flavour afterwards: judged by the
     // number of items whose lists changed in the previous iteration (read back with its accumulators)
     // ... and only inside a converging sequence of poses: the first launch of another align on the same clouds starts far from
@@ -1423,7 +1460,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int* knn_order = nullptr;
     if ((rc = order_join())) return rc;   // a re-sort launched behind the last launch (below)
     // (with at most one item per wave there is nothing to balance, and heavy-first would put the heaviest four on ONE CU)
-    if (knn_cost_valid_ && !g_knobs.no_lpt && n_items > grid * 4) {
+    // (the cooperative kernel has no queue and consumes no order: no re-sort for it, and no per-item clock reads outside MOLA_ICP_DEBUG_STATS=5)
+    if (knn_cost_valid_ && !g_knobs.no_lpt && !knn_coop && n_items > grid * 4) {
         if (!knn_order_valid_ || knn_launches_since_order_ >= knn_plan_interval_) {
             hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, stream_, knn_cost_.as<unsigned int>(), n_items, knn_order_.as<int>());
             HIPCHK(hipGetLastError());
@@ -1434,7 +1472,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         ++knn_launches_since_order_;
         knn_order = knn_order_.as<int>();
     }
-    knn_cost_valid_ = true;
+    knn_cost_valid_ = !knn_coop;   // (only the persistent flavours record item costs in the product build)
     unsigned int* tq = reinterpret_cast<unsigned int*>(acc_dev_.as<double>() + kNAcc + 8);
     // certified lists (kernels_planes.hpp, KnnCert): the bound and the pose of the launch that wrote these seeds
     KnnCert cert{};
@@ -1452,7 +1490,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
 #define MOLA_LAUNCH_KNN(KK, VER, QLL, QUEUE, LIST) MOLA_LAUNCH_KNN_D(KK, VER, QLL, false, QUEUE, LIST)
 #define MOLA_LAUNCH_KNN_D(KK, VER, QLL, DENSE, QUEUE, LIST)                                                               \
     hipLaunchKernelGGL((k_knn_planes<KK, VER, QLL, DENSE>), dim3(VER ? grid_ver : (DENSE ? grid4 : grid)), dim3(256), dyn_lds, stream_, sl, sl + loc_sc_->padded,   \
-                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, p.plane_eigen_threshold,   \
+                       sl + 2 * loc_sc_->padded, (int)N_, mp, P, thr2, thr2x, p.matcher_threshold, plane_eig_arg(p),   \
                        planes_.as<PlanePair>(), plane_cache_.as<PlanePair>(), seeds, knn_seed, plane_cache_ok, QUEUE, \
                        counter + 2, LIST, ((QUEUE) == tq ? tq + kQueues * kQueueStride : tq) + 1, staged, lds_boxes, knn_order, knn_cost_.as<unsigned int>(), g_knobs.early_pop ? 1 : 0, cert)
 #define MOLA_LAUNCH_KNN_QL(KK, QLL)                                                                                  \
@@ -1474,7 +1512,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     } while (0)
 #define MOLA_LAUNCH_KNN_COOP(KK)                                                                                       \
     hipLaunchKernelGGL((k_knn_coop<KK, 1>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, kb, thr2, thr2x,    \
-                       p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, cert.stats, (unsigned long long*)nullptr)
+                       p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, cert.stats, (unsigned long long*)nullptr)
     if (knn_coop) {
         KnnBatch<1> kb;
         KnnProblem& kp = kb.p[0];
@@ -1487,13 +1525,13 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         kp.lb = cert.lb;
         kp.use_seed = knn_seed; kp.use_cache = plane_cache_ok; kp.cert_on = cert.on;
         kp.changed_items = tq + kQueues * kQueueStride + 1;
-        kp.cost = knn_cost_.as<unsigned int>();
+        kp.cost = g_knobs.debug_stats == 5 ? knn_cost_.as<unsigned int>() : nullptr;   // (diagnostics only: two clock reads and a store per item)
         if (g_knobs.debug_stats == 4 && p.knn == 6) {   // diagnostics: where the waves of every item spend their cycles
             DevBuf dg;
             if ((rc = dg.reserve(sizeof(unsigned long long) * kKnnDiagWords * 4 * (size_t)n_items64))) return rc;
             HIPCHK(hipMemsetAsync(dg.p, 0, sizeof(unsigned long long) * kKnnDiagWords * 4 * (size_t)n_items64, stream_));
             hipLaunchKernelGGL((k_knn_coop<7, 1, true>), dim3(xcd_grid(n_items64)), dim3(256), dyn_lds, stream_, kb, thr2, thr2x, p.matcher_threshold,
-                               p.plane_eigen_threshold, staged, lds_boxes, cert.stats, dg.as<unsigned long long>());
+                               plane_eig_arg(p), staged, lds_boxes, cert.stats, dg.as<unsigned long long>());
             HIPCHK(hipGetLastError());
             std::vector<unsigned long long> h((size_t)kKnnDiagWords * 4 * (size_t)n_items64);
             HIPCHK(hipMemcpyAsync(h.data(), dg.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
@@ -1601,7 +1639,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         ev_used_ += 2;
     }
     // the next launch's re-sort, if one is due, on the side stream (see launch_tiled)
-    if (!g_knobs.no_lpt && n_items > grid * 4 && (!knn_order_valid_ || knn_launches_since_order_ >= knn_plan_interval_)) {
+    if (!g_knobs.no_lpt && !knn_coop && n_items > grid * 4 && (!knn_order_valid_ || knn_launches_since_order_ >= knn_plan_interval_)) {
         if ((rc = order_begin())) return rc;
         hipLaunchKernelGGL(k_order_items, dim3(1), dim3(1024), 0, aux_stream_, knn_cost_.as<unsigned int>(), n_items, knn_order_.as<int>());
         if ((rc = order_end())) return rc;
@@ -1644,7 +1682,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     }
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;
-    planes_eig_thr_ = p.plane_eigen_threshold;
+    planes_eig_thr_ = plane_eig_arg(p);
     if (g_knobs.turn_clock) g_turn.on_launched();
     planes_valid_ = true;
     knn_seed_valid_ = true;
@@ -1973,7 +2011,9 @@ int HipWorkspace::launch_nn(const Mat4& T, float thr2, int kernel)
         const bool coop = g_knobs.coop >= 0 ? g_knobs.coop != 0 : n128 <= (size_t)num_cus_ * 4;
         // ... and within that range four lanes per query (k_nn_q4): an item a sixteenth of the cooperative kernel's, the box tests four
         // at a time.  MOLA_ICP_Q4=0|1 forces either; the diagnostic builds keep the cooperative kernel and its clocks.
-        const bool q4 = !wave_times_ && (g_knobs.q4 >= 0 ? g_knobs.q4 != 0 : (coop && g_knobs.coop < 0));
+        // (crossover measured against the 64-query persistent kernel, us per ICP iteration q4 / persistent: 200k 42.6 / 46.4, 260k 49.2 / 48.8;
+        //  against k_nn_coop: 12k 24.1 / 30.0, 100k 28.0 / 39.0, 125k x a 1M-point map 55 / 78 -- profiles/r06/q4_ab.txt)
+        const bool q4 = !wave_times_ && (g_knobs.q4 >= 0 ? g_knobs.q4 != 0 : (g_knobs.coop < 0 && N_ <= kQ4MaxQueries));
         const int rc = q4 ? launch_q4(P, thr2, use_seed) : (coop ? launch_coop(P, thr2, use_seed) : launch_tiled(P, thr2, use_seed, counter));
         if (rc) return rc;
         last_kernel_ = MOLA_ICP_NN_TILED;
@@ -2108,9 +2148,19 @@ int HipWorkspace::check_slab(const Mat4& T, double threshold)
 }
 
 // waits for `seq` in a pinned flag written by the device (k_reduce_partials / k_publish); a real stream wait as fallback
+// Wait policy (MOLA_ICP_WAIT, mola_icp_set_wait_policy): spin -- the default: the lowest latency, one host core at 100 % per in-flight
+// align (the reference runs max(2, hw/2) pool threads plus the odometry thread on one ICP object: src/LidarOdometry.cpp:94-96, 869);
+// yield -- spin for ~10 us, then sched_yield() between polls: the core is shared with whoever is runnable; block -- spin briefly,
+// then sleep on a blocking-sync event recorded behind the publishing kernel (an interrupt wakes the thread: no core is burnt, the
+// wake-up costs tens of microseconds).  Costs per iteration: INTEGRATION.md.
+void set_wait_policy(int policy) { g_knobs.wait_policy = policy == 1 ? 1 : (policy == 2 ? 2 : 0); }
+int wait_policy() { return g_knobs.wait_policy; }
+
 int HipWorkspace::spin_for(volatile unsigned long long* flag, unsigned long long seq)
 {
-    for (unsigned long long spins = 0; spins < 400000000ull; ++spins) {  // ~ seconds
+    const int policy = g_knobs.wait_policy;
+    const unsigned long long spin_limit = policy == 0 ? 400000000ull /* ~ seconds */ : (policy == 1 ? 4000ull : 600ull);
+    for (unsigned long long spins = 0; spins < spin_limit; ++spins) {
         if (*flag == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
             if (g_knobs.turn_clock) g_turn.on_seen();
@@ -2118,6 +2168,22 @@ int HipWorkspace::spin_for(volatile unsigned long long* flag, unsigned long long
             return bbox_pending_ ? check_bboxes() : MOLA_ICP_OK;
         }
         __builtin_ia32_pause();
+    }
+    if (policy == 1) {   // yield: the device has a bounded amount of work in front of the flag; a stream wait ends a hang
+        const auto t0 = std::chrono::steady_clock::now();
+        while (*flag != seq) {
+            sched_yield();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+        }
+        if (*flag == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (g_knobs.turn_clock) g_turn.on_seen();
+            return bbox_pending_ ? check_bboxes() : MOLA_ICP_OK;
+        }
+    } else if (policy == 2) {   // block: sleep until everything enqueued so far -- the publishing kernel included -- has run
+        if (!ev_block_) HIPCHK(hipEventCreateWithFlags(&ev_block_, hipEventBlockingSync | hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_block_, stream_));
+        HIPCHK(hipEventSynchronize(ev_block_));
     }
     HIPCHK(hipStreamSynchronize(stream_));
     if (*flag != seq) return fail(MOLA_ICP_E_HIP, "the device did not publish its result block");
@@ -2512,7 +2578,7 @@ int HipBatch::match(const uint8_t* active, const Mat4* T, double threshold, cons
         // are ~10^4): issue slots count -> the persistent one-wave-per-item matcher over all problems' items (rows fused too:
         // the same sums, bit for bit).  MOLA_ICP_BATCH_TILED=0|1 forces either.
         const bool tiled = g_knobs.batch_tiled >= 0 ? g_knobs.batch_tiled != 0 : total_items >= 2 * 1024;
-        const int lds_boxes = max_box_bytes <= lds_box_limit(tiled ? kPersistentStaticLds : kNnCoopStaticLds, 4) ? 1 : 0;
+        const int lds_boxes = max_box_bytes <= lds_box_limit(tiled ? persistent_static_lds() : nn_coop_static_lds(), 4) ? 1 : 0;
         const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
         const bool q4 = !tiled && (g_knobs.q4 >= 0 ? g_knobs.q4 != 0 : true);   // (four lanes per query: see HipWorkspace::launch_nn)
         if (q4) {
@@ -2675,7 +2741,7 @@ int HipBatch::init_planes(int knn)
         b.knn_seed_valid = false;   // (a reused buffer holds another problem's lists)
         b.planes_valid = false;
         b.planes_knn = knn;
-        b.planes_eig_thr = -1.0;
+        b.planes_eig_thr = std::nan("");   // (never equal to a threshold: no cached planes)
         if (pr.loc->n == 0 || pr.map->n == 0) continue;
         const size_t np = pr.loc->padded;
         if ((rc = b.planes.reserve(sizeof(PlanePair) * np))) return rc;
@@ -2742,7 +2808,7 @@ int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_
             kp.lb = bf.knn_lb.as<float>();
             const int seed = (bf.knn_seed_valid && bf.planes_knn == (int)p.knn && !g_knobs.no_knn_seed) ? 1 : 0;
             kp.use_seed = seed;
-            kp.use_cache = (seed && bf.planes_eig_thr == p.plane_eigen_threshold) ? 1 : 0;
+            kp.use_cache = (seed && bf.planes_eig_thr == plane_eig_arg(p)) ? 1 : 0;
             kp.cert_on = (seed && !g_knobs.no_certify) ? 1 : 0;
             kp.changed_items = nullptr;   // (only the persistent kernel's counting flavour reads the count)
             for (int q = 0; q < 9; ++q) bf.knn_last_P[q] = kp.P.R[q];
@@ -2750,7 +2816,7 @@ int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_
             bf.knn_seed_valid = true;
             bf.planes_valid = true;
             bf.planes_knn = (int)p.knn;
-            bf.planes_eig_thr = p.plane_eigen_threshold;
+            bf.planes_eig_thr = plane_eig_arg(p);
             const int items = (int)((pr.loc->n + 63) / 64);
             if (items > max_items) max_items = items;
             const size_t bb = sizeof(float) * 6u * ((size_t)kp.mp.n_top + (size_t)kp.mp.n_super);
@@ -2762,7 +2828,7 @@ int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_
         unsigned long long* staged = ws_.profiling_ ? sc_.stats.as<unsigned long long>() : nullptr;
 #define MOLA_LAUNCH_KNN_COOP_B(KK)                                                                                          \
     hipLaunchKernelGGL((k_knn_coop<KK, kKnnMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, kb, thr2, thr2x, \
-                       p.matcher_threshold, p.plane_eigen_threshold, staged, lds_boxes, (unsigned long long*)nullptr, (unsigned long long*)nullptr)
+                       p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, (unsigned long long*)nullptr, (unsigned long long*)nullptr)
         switch (p.knn) {
             case 3: MOLA_LAUNCH_KNN_COOP_B(4); break;
             case 4: MOLA_LAUNCH_KNN_COOP_B(5); break;

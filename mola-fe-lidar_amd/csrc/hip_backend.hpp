@@ -30,6 +30,8 @@ int rccl_comm_destroy(void* comm);
 int local_comm_hook(double* buf, int n, int device_ptr, void* user);
 
 void reload_env_knobs();  // re-reads the MOLA_ICP_* diagnostic variables (tests); they are otherwise read once per process
+void set_wait_policy(int policy);   // 0 spin, 1 yield, 2 block (HipWorkspace::spin_for)
+int wait_policy();
 
 struct DevBuf {
     void* p = nullptr;
@@ -74,7 +76,7 @@ struct BatchBuffers {
     DevBuf planes, plane_cache, knn_pos, knn_lb, plane_partials;
     bool knn_seed_valid = false, planes_valid = false;
     int planes_knn = 0;
-    double planes_eig_thr = -1.0;
+    double planes_eig_thr = __builtin_nan("");   // planeEigenThreshold (sign = the all-inside-gate reading) the cached planes were decided with; NaN: none
     float knn_last_P[12] = {};
 };
 struct BatchScratch {
@@ -99,7 +101,7 @@ struct BatchScratch {
 class HipWorkspace final : public Stages {
     friend class HipBatch;
    public:
-    explicit HipWorkspace(int device);
+    explicit HipWorkspace(int device, int priority = 0);   // priority > 0: its streams are created at the device's greatest priority
     ~HipWorkspace() override;
     HipWorkspace(const HipWorkspace&) = delete;
     HipWorkspace& operator=(const HipWorkspace&) = delete;
@@ -192,6 +194,7 @@ class HipWorkspace final : public Stages {
     int launch_nn(const Mat4& T, float thr2, int kernel);
 
     int device_;
+    int priority_ = 0;   // stream priority class (0 normal, 1 high: the odometry path beside batches of checks)
     bool inited_ = false;
     hipStream_t stream_ = nullptr;
     bool own_stream_ = false;
@@ -236,7 +239,7 @@ class HipWorkspace final : public Stages {
     double* plane_acc_host_ = nullptr;
     bool planes_valid_ = false, planes_empty_ = false;
     int planes_knn_ = 0;
-    double planes_eig_thr_ = -1.0;  // planeEigenThreshold the planes in plane_cache_ were decided with
+    double planes_eig_thr_ = __builtin_nan("");  // planeEigenThreshold (sign = the all-inside-gate reading) the planes in plane_cache_ were decided with; NaN: none
     double knn_changed_items_ = -1.0;  // items whose neighbour lists changed in the last iteration (-1: unknown)
     bool knn_seed_valid_ = false;  // knn_pos_ holds the last launch's neighbours for the clouds in place
     DevBuf stats_;                    // the cooperative matcher's slotted statistics counters
@@ -252,6 +255,7 @@ class HipWorkspace final : public Stages {
     // accumulation that follows it (a single-block 22-30 us kernel otherwise on the next matcher's critical path)
     hipStream_t aux_stream_ = nullptr;
     hipEvent_t ev_order_a_ = nullptr, ev_order_b_ = nullptr, ev_prep_ = nullptr;
+    hipEvent_t ev_block_ = nullptr;   // MOLA_ICP_WAIT=block: a blocking-sync event behind the publishing kernel (created on first use)
     bool order_pending_ = false;
     int order_begin();   // aux_stream_ waits for what stream_ holds so far
     int order_end();     // ... and the next matcher launch will wait for what aux_stream_ holds

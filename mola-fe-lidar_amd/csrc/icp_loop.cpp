@@ -193,7 +193,7 @@ static int solve_on_pairing(Stages& st, const mola_icp_params& p, const Mat4& Tc
         if (!solve_horn(acc, nullptr, nullptr, Tnew)) *solver_error = true;
         return MOLA_ICP_OK;
     }
-    const int passes = p.use_scale_outlier_detector ? 2 : 1;
+    const int passes = (p.use_scale_outlier_detector && !p.reading_outlier_single_pass) ? 2 : 1;   // (the reading: mola_icp_params)
     for (int pass = 0; pass < passes; ++pass) {
         if (pass > 0) {
             if ((rc = st.accumulate(p, Tcur, 0, nullptr, nullptr, false, acc))) return rc;
@@ -214,12 +214,13 @@ static int solve_on_pairing(Stages& st, const mola_icp_params& p, const Mat4& Tc
 // its solves: unit-weight sums -> centroids -> the centroid-relative test flags outliers; once more with the centroids of what is
 // left.  acc = the 24 sums over the survivors of the second test (unit weights: validate_params refuses the robust kernel here);
 // all zero when nothing is left -- the plane pairings may still carry the solve.
-static int point_sums_without_outliers(Stages& st, const mola_icp_params& p, const Mat4& Tcur, double acc[kNAcc])
+static int point_sums_without_outliers(Stages& st, const mola_icp_params& p, const Mat4& Tcur, double acc[kNAcc], double* gated)
 {
     int rc = st.accumulate(p, Tcur, 0, nullptr, nullptr, true, acc);
     if (rc) return rc;
     if ((rc = st.allreduce(acc))) return rc;
-    for (int pass = 0; pass < 2; ++pass) {
+    *gated = acc[16];   // every pairing the matcher gated: what the iteration REPORTS (as solve_on_pairing does); the survivors feed the solve
+    for (int pass = 0; pass < (p.reading_outlier_single_pass ? 1 : 2); ++pass) {
         if (pass > 0) {
             if ((rc = st.accumulate(p, Tcur, 0, nullptr, nullptr, false, acc))) return rc;
             if ((rc = st.allreduce(acc))) return rc;
@@ -329,19 +330,26 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mol
             if ((rc = st.match_planes(T, pp))) return rc;
             if ((rc = st.accumulate_planes(pacc))) return rc;
             if ((rc = st.match(T, pq.matcher_threshold, pq, nullptr))) return rc;
+            // The iteration's pairings = everything the two matchers gated (what it reports and what decides NoPairings: the same
+            // rule as solve_on_pairing's); under pairingsWeightParameters.use_scale_outlier_detector the point pairings the detector
+            // flags leave the SOLVE only -- A and b hold the survivors' terms, the rmse is taken over them (plane pairings carry no
+            // such test: the detector is defined on point pairs).
+            double gated_points = 0;
             if (pq.use_scale_outlier_detector) {
-                if ((rc = point_sums_without_outliers(st, pq, T, acc))) return rc;
+                if ((rc = point_sums_without_outliers(st, pq, T, acc, &gated_points))) return rc;
             } else {
                 if ((rc = st.accumulate(pq, T, 0, nullptr, nullptr, true, acc))) return rc;
                 if ((rc = st.allreduce(acc))) return rc;
+                gated_points = acc[16];
             }
+            pairs_global = pacc[91] + gated_points;
             mixed_form(acc, T, pacc);
-            pairs_global = pacc[91];
+            const double in_solve = pacc[91];
             if (!(pairs_global > 0)) { term = MOLA_ICP_TERM_NO_PAIRINGS; break; }
             double cost = 0;
-            if (!solve_gauss_newton_planes(pacc, T, pp.solver_max_iterations, Tn, &cost)) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }
+            if (!(in_solve > 0) || !solve_gauss_newton_planes(pacc, T, pp.solver_max_iterations, Tn, &cost)) { term = MOLA_ICP_TERM_SOLVER_ERROR; break; }
             plane_pairs = pairs_global;
-            plane_rmse = std::sqrt((cost > 0 ? cost : 0.0) / pairs_global);
+            plane_rmse = std::sqrt((cost > 0 ? cost : 0.0) / in_solve);
             std::memcpy(last_pacc, pacc, sizeof last_pacc);
         } else if (p.matcher_class == MOLA_ICP_MATCHER_POINT2PLANE) {
             // row f3: plane pairings -> ONE accumulation pass (the quadratic form of the cost) -> host Gauss-Newton
@@ -383,7 +391,7 @@ int run_icp_loop(Stages& st, const Mat4& init, const mola_icp_params& p_all, mol
     if (p.skip_quality) quality = -1.0;
     else if (st.n_local_total() > 0 && st.n_map_total() > 0) {
         TraceRange tr_q("mola_icp.quality");
-        const double denom = (double)(st.n_local_total() < st.n_map_total() ? st.n_local_total() : st.n_map_total());
+        const double denom = (double)((p_all.reading_quality_denominator_local || st.n_local_total() < st.n_map_total()) ? st.n_local_total() : st.n_map_total());
         // one PairedRatio pass per `quality:` entry, combined by weight (a single entry: that entry's ratio, whatever its weight)
         double wsum = 0, qsum = 0;
         for (uint32_t e = 0; e <= p_all.n_extra_quality && e <= MOLA_ICP_MAX_EXTRA_STAGES; ++e) {
@@ -511,7 +519,7 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
             }
         }
         if (weighted) {
-            const int passes = p.use_scale_outlier_detector ? 2 : 1;
+            const int passes = (p.use_scale_outlier_detector && !p.reading_outlier_single_pass) ? 2 : 1;
             for (int pass = 0; pass < passes && any(sub); ++pass) {
                 if (pass > 0)
                     if ((rc = st.accumulate(sub.data(), p, Tcur.data(), 0, nullptr, nullptr, false, acc))) return rc;
@@ -558,7 +566,7 @@ int run_icp_loop_batch(BatchStages& st, const Mat4* init, const mola_icp_params&
             for (int k = 0; k < K; ++k)
                 if (active[k]) {
                     const uint64_t nl = st.n_local_total(k), nm = st.n_map_total(k);
-                    quality[k] = acc[k][16] / (double)(nl < nm ? nl : nm);
+                    quality[k] = acc[k][16] / (double)((p.reading_quality_denominator_local || nl < nm) ? nl : nm);
                 }
         }
     }

@@ -103,6 +103,10 @@ __device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&k
 {
     constexpr int K = KL - 1;
     bool item_changed = false;
+    // (the sign of the threshold carries a reading switch of mola_icp_params: negative = a plane needs ALL K neighbours inside the gate,
+    //  not just >= 3 -- hip_backend.hip, plane_eig_arg)
+    const int min_inside = __builtin_signbit(plane_eig_thr) ? K : 3;
+    plane_eig_thr = fabs(plane_eig_thr);
     {
             const bool in = i < N;
             const size_t ic = in ? (size_t)i : (size_t)(N - 1);
@@ -144,7 +148,7 @@ __device__ __forceinline__ bool plane_epilogue(const TiledMap& mp, const int (&k
                         seeds.oidx[at] = ko[j];
                     }
                 }
-                if (solve && m >= 3) {
+                if (solve && m >= min_inside) {
                     // (the points stay fp32 in registers and are widened where they are used: exact, and 36 registers fewer
                     //  than three arrays of doubles)
                     double mean[3] = {0, 0, 0};

@@ -161,6 +161,13 @@ int mola_lo_process_scan(mola_lo* lo, double timestamp, const float* x, const fl
                          mola_lo_step* out)
 {
     if (!lo || !out || (n && (!x || !y || !z))) return fail(MOLA_ICP_E_BADARG, "null argument");
+    // the odometry step is the call with a deadline (the sensor's rate; the reference sheds load when it falls behind: cpp:171-179): its
+    // device work runs at the greatest stream priority, ahead of queued launches of nearby / loop-closure checks on the same handle
+    struct HighPriority {
+        int before = 0;
+        HighPriority() { (void)mola_icp_get_thread_priority(&before); (void)mola_icp_set_thread_priority(1); }
+        ~HighPriority() { (void)mola_icp_set_thread_priority(before); }
+    } high_priority;
     try {
         std::memset(out, 0, sizeof *out);
         fill_step_pose(out->rel_pose, Mat4::identity());

@@ -143,19 +143,25 @@ public:
             close(fd);
             if (p == MAP_FAILED) return fail(MOLA_ICP_E_COMM, std::string("local communicator: mmap failed: ") + std::strerror(errno));
             base_ = p;
-            bool joined = false, replaced = false;
+            bool joined = false, replaced = false, mismatch = false;
             unsigned spins = 0;
             for (;;) {
-                if (!joined && hdr()->magic.load(std::memory_order_acquire) == kMagic) {
-                    if (hdr()->nranks != (uint32_t)nranks) {
-                        const uint32_t theirs = hdr()->nranks;
-                        munmap(base_, bytes_);
-                        base_ = nullptr;
-                        return fail(MOLA_ICP_E_COMM, "local communicator: rank 0 created " + name_ + " for " + std::to_string(theirs) +
-                                                         " ranks, this rank was told " + std::to_string(nranks));
+                if (!joined && !mismatch && hdr()->magic.load(std::memory_order_acquire) == kMagic) {
+                    // another rank count than this rank was told: the LEFTOVER of a crashed run of another size (rank 0 will replace it:
+                    // the inode check below) -- or a live segment this rank has no place in.  Only `ack` tells the two apart (a leftover
+                    // never has it), so the verdict waits for it; the segment is not joined meanwhile.
+                    if (hdr()->nranks != (uint32_t)nranks) mismatch = true;
+                    else {
+                        hdr()->joined.fetch_add(1, std::memory_order_acq_rel);
+                        joined = true;
                     }
-                    hdr()->joined.fetch_add(1, std::memory_order_acq_rel);
-                    joined = true;
+                }
+                if (mismatch && hdr()->ack.load(std::memory_order_acquire) != 0u) {
+                    const uint32_t theirs = hdr()->nranks;
+                    munmap(base_, bytes_);
+                    base_ = nullptr;
+                    return fail(MOLA_ICP_E_COMM, "local communicator: rank 0 created " + name_ + " for " + std::to_string(theirs) +
+                                                     " ranks, this rank was told " + std::to_string(nranks));
                 }
                 if (joined && hdr()->ack.load(std::memory_order_acquire) != 0u) break;
                 if ((++spins & 0xff) == 0) {
@@ -167,9 +173,14 @@ public:
                         if (other) { replaced = true; break; }
                     }
                     if (std::chrono::steady_clock::now() > t_end) {
-                        const std::string what = joined ? "only " + std::to_string(hdr()->joined.load()) + " of " + std::to_string(nranks) + " ranks joined " + name_ +
+                        // (this rank leaves: its place in the count goes with it, so that a rank 0 that is still waiting fails at ITS
+                        //  time-out instead of acknowledging a segment with a rank missing)
+                        if (joined) hdr()->joined.fetch_sub(1, std::memory_order_acq_rel);
+                        const std::string what = mismatch ? name_ + " was made for " + std::to_string(hdr()->nranks) + " ranks (this rank was told " + std::to_string(nranks) +
+                                                                ") and rank 0 never replaced it"
+                                                 : joined ? "only " + std::to_string(hdr()->joined.load()) + " of " + std::to_string(nranks) + " ranks joined " + name_ +
                                                               " (or it is the leftover of a crashed run and rank 0 never came)"
-                                                        : "rank 0 never initialised " + name_;
+                                                          : "rank 0 never initialised " + name_;
                         munmap(base_, bytes_);
                         base_ = nullptr;
                         return fail(MOLA_ICP_E_COMM, "local communicator: " + what);

@@ -235,6 +235,13 @@ class DevicePool:
     def align_batch(self, pairs, init_guesses, params: "Parameters") -> list["Results"]:
         return _align_batch(L.lib().mola_icp_pool_align_batch, self._h, pairs, init_guesses, params)
 
+    def last_shares(self) -> list[int]:
+        """pairs each device slot served in the last align_batch call (the slots pull chunks from a shared cursor)"""
+        n = len(self)
+        arr = (C.c_size_t * n)()
+        L.check(L.lib().mola_icp_pool_last_shares(self._h, arr, n))
+        return [int(v) for v in arr]
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             L.lib().mola_icp_pool_destroy(self._h)
@@ -323,6 +330,12 @@ class ICP:
         n, b = C.c_size_t(), C.c_size_t()
         L.check(L.lib().mola_icp_cloud_count(self._h, C.byref(n), C.byref(b)))
         return n.value, b.value
+
+    @staticmethod
+    def set_wait_policy(policy: str | int):
+        """how host threads wait for a pass's sums: "spin" (default), "yield", "block" (mola_icp_set_wait_policy; process-wide)"""
+        code = {"spin": 0, "yield": 1, "block": 2}.get(policy, policy)
+        L.check(L.lib().mola_icp_set_wait_policy(int(code)))
 
     @staticmethod
     def device_pool_trim(device: int = 0, keep_bytes: int = 0) -> int:

@@ -1057,15 +1057,19 @@ int orc_align_mixed(const float* gx, const float* gy, const float* gz, size_t M,
             kept_pl = orc_match_point2plane(gx, gy, gz, M, tree, lx, ly, lz, N, T, plane_threshold, plane_eigen_threshold, knn, valid, cen,
                                             nor, NULL);
             kept_pp = orc_match(gx, gy, gz, M, tree, lx, ly, lz, N, T, p->matcher_threshold, idx, d2);
-            if (p->use_scale_outlier_detector) kept_pp = drop_scale_outliers(lx, ly, lz, gx, gy, gz, idx, d2, N, p, T);
         }
-        if (!(kept_pl + kept_pp)) { res->termination = ORC_TERM_NO_PAIRINGS; break; }
+        /* the pairings of the iteration = everything the matchers gated (what orc_align reports, and what decides NoPairings); the
+         * detector then removes point pairings from the SOLVE only: its survivors' terms form the cost, rmse is taken over them */
+        const size_t gated = kept_pl + kept_pp;
+        if (N && M && p->use_scale_outlier_detector) kept_pp = drop_scale_outliers(lx, ly, lz, gx, gy, gz, idx, d2, N, p, T);
+        if (!gated) { res->termination = ORC_TERM_NO_PAIRINGS; break; }
+        if (!(kept_pl + kept_pp)) { res->termination = ORC_TERM_SOLVER_ERROR; break; }   /* gated pairings, none left for the solve */
         double Tn[16], cost;
         if (orc_solve_gauss_newton_mixed(lx, ly, lz, N, valid, cen, nor, idx, gx, gy, gz, T, solver_max_iters, Tn, &cost, NULL)) {
             res->termination = ORC_TERM_SOLVER_ERROR;
             break;
         }
-        res->n_pairs = kept_pl + kept_pp;
+        res->n_pairs = gated;
         res->rmse = sqrt(cost / (double)(kept_pl + kept_pp));
         memcpy(T, Tn, sizeof T);
         double dxyz, drot;

@@ -51,6 +51,9 @@ int rccl_allreduce_sum_f64(void*, double*, size_t, hipStream_t) { return fail(MO
 int rccl_comm_count(void*, int*) { return fail(MOLA_ICP_E_COMM, "fake backend: no RCCL"); }
 int rccl_comm_destroy(void*) { return MOLA_ICP_OK; }
 void reload_env_knobs() {}
+static std::atomic<int> g_fake_wait_policy{0};
+void set_wait_policy(int policy) { g_fake_wait_policy = policy; }
+int wait_policy() { return g_fake_wait_policy; }
 
 // ---- "device" memory = host memory ---------------------------------------------------------------------------------------------
 int DevBuf::reserve(size_t bytes)
@@ -159,7 +162,7 @@ int copy_soa(DevBuf& buf, const float* x, const float* y, const float* z, size_t
 }  // namespace
 
 // ---- HipWorkspace -----------------------------------------------------------------------------------------------------------------
-HipWorkspace::HipWorkspace(int device) : device_(device), map_sc_(std::make_shared<SortedCloud>()), loc_sc_(std::make_shared<SortedCloud>())
+HipWorkspace::HipWorkspace(int device, int priority) : device_(device), priority_(priority), map_sc_(std::make_shared<SortedCloud>()), loc_sc_(std::make_shared<SortedCloud>())
 {
     const long live = g_fake_live_workspaces.fetch_add(1) + 1;
     long peak = g_fake_peak_workspaces.load();

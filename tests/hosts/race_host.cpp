@@ -168,7 +168,30 @@ int main(int argc, char** argv)
     };
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t);
+    // ... and, beside them, the device pool (round 6: persistent slot threads pulling chunks from a shared cursor) called from two
+    // threads at once, one of them in the high-priority class (mola_icp_set_thread_priority is thread-local)
+    std::atomic<long> calls_pool{0};
+    mola_icp_pool* pool = nullptr;
+    const int slots[3] = {0, 0, 0};
+    CHECK(mola_icp_pool_create(slots, 3, &pool) == 0, "pool_create");
+    auto pool_worker = [&](int t) {
+        CHECK(mola_icp_set_thread_priority(t & 1) == 0, "set_thread_priority");
+        for (int r = 0; r < rounds; ++r) {
+            const int n = 7 + 5 * ((t + r) % 3);
+            std::vector<mola_icp_result> out((size_t)n);
+            CHECK(mola_icp_pool_align_batch(pool, (size_t)n, fx.data(), fy.data(), fz.data(), M.data(), tx.data(), ty.data(), tz.data(), N.data(), inits.data(), &p, out.data()) == 0, "pool_align_batch");
+            for (int i = 0; i < n; ++i) CHECK(same(out[(size_t)i], ref[(size_t)i]), "pool result = stand-alone align");
+            size_t shares[3] = {0, 0, 0};
+            CHECK(mola_icp_pool_last_shares(pool, shares, 3) == 0, "pool_last_shares");
+            calls_pool += 1;
+        }
+        int hi = -1;
+        CHECK(mola_icp_get_thread_priority(&hi) == 0 && hi == (t & 1), "the priority class is the thread's own");
+    };
+    for (int t = 0; t < 2; ++t) th.emplace_back(pool_worker, t);
     for (auto& x : th) x.join();
+    CHECK(mola_icp_pool_destroy(pool) == 0, "pool_destroy");
+    CHECK(calls_pool.load() == 2 * rounds, "pool calls");
     for (uint64_t id = 5; id <= 10; ++id) (void)mola_icp_cloud_drop(h, id);
     size_t count = 99, bytes = 0;
     CHECK(mola_icp_cloud_count(h, &count, &bytes) == 0 && count == 0, "every cloud dropped at the end");

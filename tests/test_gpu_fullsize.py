@@ -335,13 +335,36 @@ def test_config4_64_pairs_of_100k_batch_and_device_pool(pkg, O, synth):
     for r, s in zip(rp, singles[:16]):
         assert r.nIterations == s.nIterations and np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality
     pool.close()
-    # ... and the multi-handle dispatch exercised on this one GPU: two device slots, pairs 0,2,4,.. / 1,3,5,..
+    # ... and the multi-handle dispatch exercised on this one GPU: two device slots pulling chunks of the call's pairs
     pool2 = pkg.DevicePool([0, 0])
     assert len(pool2) == 2
     rp = pool2.align_batch(pairs[:25], [np.eye(4)] * 25, p)
     for r, s in zip(rp, singles[:25]):
         assert r.nIterations == s.nIterations and np.array_equal(r.optimal_tf, s.optimal_tf) and r.quality == s.quality
+    assert sum(pool2.last_shares()) == 25 and all(n > 0 for n in pool2.last_shares())   # both slots pulled chunks from the shared cursor
     assert pool2.align_batch([], [], p) == []
+    # a MIXED batch (pairs that stop after a few iterations next to pairs that run the full hundred): the slots pull chunks until the
+    # cursor runs dry -- every result still its stand-alone align's, and no slot is left without work
+    inits25 = [made[k][2] if k % 3 == 0 else np.eye(4) for k in range(25)]
+    rp = pool2.align_batch(pairs[:25], inits25, p)
+    assert len({r.nIterations for r in rp}) > 1 and sum(pool2.last_shares()) == 25
+    for k in (0, 1, 3, 12, 24):
+        s1 = icp.align(pairs[k][0], pairs[k][1], inits25[k], p)
+        assert rp[k].nIterations == s1.nIterations and np.array_equal(rp[k].optimal_tf, s1.optimal_tf) and rp[k].quality == s1.quality
+    # the pool is reusable from several host threads (calls are serialised per pool)
+    import threading
+    outs = [None, None]
+
+    def call(i):
+        outs[i] = pool2.align_batch(pairs[:6], [np.eye(4)] * 6, p)
+    th = [threading.Thread(target=call, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for o in outs:
+        for r, s in zip(o, singles[:6]):
+            assert np.array_equal(r.optimal_tf, s.optimal_tf)
     pool2.close()
     icp.close()
 

@@ -9,12 +9,19 @@ pytestmark = pytest.mark.gpu
 
 
 def _fill_device(torch, keep_free_bytes):
-    """occupy all of the device's free memory but `keep_free_bytes` with ONE torch block (released by the caller)"""
+    """occupy the device's free memory down to < `keep_free_bytes`: one large torch block, then blocks of that size until the allocator
+    refuses (what hipMemGetInfo calls free and what hipMalloc will actually hand out differ by a reserve).  Released by the caller."""
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info(0)
-    n = free - keep_free_bytes
-    assert n > 0
-    return torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    hogs = [torch.empty(max(1, free - 8 * keep_free_bytes), dtype=torch.uint8, device="cuda:0")]
+    for _ in range(4096):
+        try:
+            hogs.append(torch.empty(keep_free_bytes, dtype=torch.uint8, device="cuda:0"))
+        except RuntimeError:   # torch.cuda.OutOfMemoryError
+            break
+    else:
+        raise AssertionError("the device never ran out of memory")
+    return hogs
 
 
 def _small_pair_is_right(pkg, O, synth, icp):
@@ -35,7 +42,7 @@ def test_cloud_put_that_does_not_fit_returns_oom_and_the_handle_survives(pkg, O,
     icp.cloud_put(7, small)
     before = icp.cloud_count()
     big = synth.make_pair(1000, 3_000_000, seed=2)[0]    # 36 MB as given, ~100 MB prepared
-    hog = _fill_device(torch, 24 << 20)
+    hog = _fill_device(torch, 16 << 20)
     try:
         with pytest.raises(pkg.IcpError) as e:
             icp.cloud_put(8, big)
@@ -59,7 +66,7 @@ def test_set_map_that_does_not_fit_returns_oom_and_the_handle_survives(pkg, O, s
     icp = pkg.ICP(device=0)
     pkg.ICP.device_pool_trim(0, 0)
     g, l, _ = synth.make_pair(50_000, 3_000_000, seed=4)
-    hog = _fill_device(torch, 24 << 20)
+    hog = _fill_device(torch, 16 << 20)
     try:
         with pytest.raises(pkg.IcpError) as e:
             icp.align(g, l, np.eye(4), p2p_params(pkg, max_iterations=3))

@@ -240,6 +240,31 @@ def test_leftover_segment_of_a_crashed_init_is_not_joined(pkg):
             os.unlink("/dev/shm/" + name)
 
 
+def test_leftover_segment_of_another_rank_count_is_not_fatal(pkg):
+    """the leftover is that of a crashed run with ANOTHER rank count (4 where this run has 2).  Rank 1, first to come, must not
+    fail on the count -- only a live segment (rank 0's acknowledgement) can make that verdict -- but wait for rank 0 to replace it."""
+    import struct
+    name = _name("leftover4")
+    blob = bytearray(64 + 1024 * 2 * 4)
+    struct.pack_into("<QIIII", blob, 0, 0x4d4f4c414c434f4d, 4, 4, 0, 0)
+    with open("/dev/shm/" + name, "wb") as f:
+        f.write(blob)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_leftover_worker, args=(name, 1, 0.0, q)), ctx.Process(target=_leftover_worker, args=(name, 0, 1.0, q))]
+        for p in ps:
+            p.start()
+        got = dict(q.get(timeout=60) for _ in ps)
+        for p in ps:
+            p.join(30)
+        assert got[0] == [3.0] * 24 and got[1] == [3.0] * 24, got
+        assert not os.path.exists("/dev/shm/" + name)
+    finally:
+        if os.path.exists("/dev/shm/" + name):
+            os.unlink("/dev/shm/" + name)
+
+
 def test_a_bad_argument_does_not_finish_the_communicator(pkg):
     """(MOLA_ICP_E_COMM does: test_ranks_that_disagree_fail_on_every_rank[missing])"""
     sharded = importlib.import_module("mola-fe-lidar_amd.sharded")

@@ -159,3 +159,38 @@ def test_lockstep_batch_loop_equals_single_loops(pkg, O, golden, synth, small_sc
     with pytest.raises(pkg.IcpError) as e:                     # the lockstep loop is point-to-point only
         pkg.run_loop_batch([(stages[0].match, stages[0].accumulate, 1, 1)], [np.eye(4)], pp)
     assert e.value.status == pkg._lib.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("field,switch", [("reading_outlier_single_pass", "outlier_single_pass"),
+                                           ("reading_quality_denominator_local", "quality_denominator")])
+def test_loop_follows_the_reading_switches(pkg, O, golden, field, switch):
+    """mola_icp_params.reading_* (ABI 4): the product's loop under a switch == the oracle under the same switch -- and the switch
+    does change the run (more local points than map points, so that the quality denominator matters)"""
+    g, l = np.ascontiguousarray(golden["A_map"][:, ::2]), golden["A_local"]
+    assert l.shape[1] > g.shape[1]
+    p = p2p_params(pkg, use_scale_outlier_detector=1, scale_outlier_threshold=1.1, max_iterations=60)
+    setattr(p, field, 1)
+    r, _ = _run(pkg, O, g, l, p)
+    try:
+        O.set_readings(**{switch: 1})
+        ref = O.align(g, l, np.eye(4), O.params_from_product(p))
+        O.set_readings()
+        base = O.align(g, l, np.eye(4), O.params_from_product(p))
+    finally:
+        O.set_readings()
+    assert (r.nIterations, r.terminationReason) == (ref["n_iterations"], ref["termination"])
+    np.testing.assert_allclose(r.optimal_tf, ref["T"], atol=1e-10)
+    assert r.quality == pytest.approx(ref["quality"], abs=1e-12)
+    assert (not np.allclose(ref["T"], base["T"], atol=1e-9)) or abs(ref["quality"] - base["quality"]) > 1e-6
+
+
+def test_readings_yaml_key(pkg):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "params", "icp-settings-regular.yaml")).read()
+    p = pkg.Parameters.load_from(text)
+    assert (p.reading_outlier_single_pass, p.reading_p2pl_all_inside_gate, p.reading_quality_denominator_local) == (0, 0, 0)
+    p = pkg.Parameters.load_from(text + "\nreadings:\n  outlier_single_pass: true\n  p2pl_all_inside_gate: true\n  quality_denominator_local: false\n")
+    assert (p.reading_outlier_single_pass, p.reading_p2pl_all_inside_gate, p.reading_quality_denominator_local) == (1, 1, 0)
+    with pytest.raises(pkg.IcpError):
+        pkg.Parameters.load_from(text + "\nreadings: 3\n")
