@@ -33,9 +33,12 @@ namespace mola_icp_amd {
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t e_ = (expr);                                                                               \
-        if (e_ != hipSuccess)                                                                                 \
+        if (e_ != hipSuccess) {                                                                               \
+            (void)hipGetLastError(); /* the runtime latches the error: a later hipGetLastError() check of a  \
+                                        healthy call would report it again (found by tests/test_gpu_oom.py) */ \
             return fail(e_ == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP,                          \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                                   \
+        }                                                                                                     \
     } while (0)
 
 }  // namespace mola_icp_amd
@@ -260,6 +263,7 @@ int DevBuf::reserve(size_t bytes)
     }
     if (e != hipSuccess) {
         p = nullptr;
+        (void)hipGetLastError();   // (not latched for the next call's check: the handle stays usable -- SURVEY section 5, "never abort")
         return fail(e == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
     cap = want;
@@ -2121,6 +2125,7 @@ int HipWorkspace::match(const Mat4& T, double threshold, const mola_icp_params& 
             hipLaunchKernelGGL(k_count_kept, dim3((unsigned)std::min<size_t>((N_ + 255) / 256, 256)), dim3(256), 0, stream_, ts_idx_.as<int>(),
                                (int)N_, counter);
             HIPCHK(hipGetLastError());
+            counters_clean_ = false;   // (the count stays in counter[0]: a dense kernel's next launch must find it zero)
         }
         HIPCHK(hipMemcpyAsync(hc, counter, sizeof(unsigned int), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));

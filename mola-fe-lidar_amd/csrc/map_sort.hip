@@ -35,9 +35,11 @@ namespace mola_icp_amd {
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t e_ = (expr);                                                                               \
-        if (e_ != hipSuccess)                                                                                 \
+        if (e_ != hipSuccess) {                                                                               \
+            (void)hipGetLastError(); /* (not latched for the next call's check) */                            \
             return fail(e_ == hipErrorOutOfMemory ? MOLA_ICP_E_OOM : MOLA_ICP_E_HIP,                          \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                                   \
+        }                                                                                                     \
     } while (0)
 
 constexpr int kSortRun = 2048;                 // items per sorted run (one workgroup of 256 threads, 18 KB of LDS)

@@ -17,7 +17,12 @@ for (n, m) in sizes:
     g, l, _ = synth.make_pair(n, m, seed=42)
     row, ref = [], None
     for q in ("0", "1", "0", "1"):
-        os.environ["MOLA_ICP_Q4"] = q
+        if os.environ.get("Q4_AB_MODE") == "fuse":   # (with tools/experiments/q4_fused_row_reduction.patch applied: k_nn_q4's rows reduced by k_reduce_items ("0") / inside the launch ("1"))
+            os.environ.pop("MOLA_ICP_Q4_NO_FUSE", None)
+            if q == "0":
+                os.environ["MOLA_ICP_Q4_NO_FUSE"] = "1"
+        else:
+            os.environ["MOLA_ICP_Q4"] = q
         lib.lib().mola_icp_debug_reload_env()
         icp = pkg.ICP(device=0); icp.set_map(g); icp.set_local(l)
         icp.align_resident(np.eye(4), p); icp.align_resident(np.eye(4), p)
@@ -34,6 +39,6 @@ for (n, m) in sizes:
         if ref is None:
             ref = (idx.copy(), d2.copy(), np.array(r.optimal_tf))
         same = np.array_equal(idx, ref[0]) and np.array_equal(d2, ref[1]) and np.array_equal(np.array(r.optimal_tf), ref[2])
-        row.append("%s %.1f (launch %.1f)%s" % ("q4" if q == "1" else "base", float(np.median(ts)), k_us, "" if same else " MISMATCH"))
+        row.append("%s %.1f (launch %.1f)%s" % (("q4" if q == "1" else "base") if os.environ.get("Q4_AB_MODE") != "fuse" else ("fused" if q == "1" else "2 launches"), float(np.median(ts)), k_us, "" if same else " MISMATCH"))
         icp.close()
     print("%8d queries x %9d map points: us per iteration  %s" % (n, m, "   ".join(row)), flush=True)
