@@ -242,7 +242,9 @@ def test_references_settings_plus_a_point_matcher_equal_the_oracle_on_the_gpu(pk
     # ... and differs from the same run without the detector: it removed pairings
     op0 = O.params(max_iterations=100, matcher_threshold=0.35, quality_threshold=0.10, min_abs_step_trans=5e-5, min_abs_step_rot=1e-5)
     ref0 = O.align_mixed(g, l, np.eye(4), op0, 0.70, 0.07, 6, 20)
-    assert ref0["n_pairs"] > ref["n_pairs"]
+    # (the REPORTED pairings are what the matchers gated, with and without the detector -- ADVICE r5 --; the detector removes point
+    #  pairings from the SOLVE: another cost, another pose)
+    assert ref0["n_pairs"] == ref["n_pairs"] and ref0["rmse"] != ref["rmse"] and O.pose_error(ref0["T"], ref["T"])[1] > 1e-7
     gt_rot, gt_trans = O.pose_error(r.optimal_tf, Tgt)
     assert gt_rot < 2e-3 and gt_trans < 2e-2
     icp.close()
