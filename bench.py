@@ -1143,7 +1143,7 @@ def odometry_stream_leg(pkg, synth, n_scans=24, period_s=None, decimate=1, passe
             "ms_per_scan": [round(float(v), 3) for v in ms], "keyframes": kfs, "trajectory": trajectory}
 
 
-def mixed_load_leg(pkg, synth, n_scans=24, period_s=0.1):
+def mixed_load_leg(pkg, synth, n_scans=24, period_s=0.1, n_threads=None):
     """The reference's concurrent load as a measured case (src/LidarOdometry.cpp:94-96, 183-184, 711-712, 767-788, 869): ONE handle; the
     odometry stream at the sensor's 10 Hz on its own thread -- its device work on streams of the greatest priority (mola_lo_process_scan
     raises the calling thread's class) -- while T threads loop loop-closure checks (10 Monte-Carlo guesses on a 100k x 100k pair each,
@@ -1156,7 +1156,7 @@ def mixed_load_leg(pkg, synth, n_scans=24, period_s=0.1):
         pose = synth.pose_from_xyzypr(-14.0 + 1.0 * k, 0.3 * np.sin(0.3 * k), 0.0, 0.005 * k, 0, 0)
         scans.append((100.0 + 0.1 * k, synth.lidar_scan(pose, seed=50 + k)))
     g, l, _ = synth.make_pair(100_000, 100_000, seed=42)
-    n_thr = min(8, max(2, (os.cpu_count() or 4) // 2))
+    n_thr = n_threads or min(8, max(2, (os.cpu_count() or 4) // 2))
     lod = importlib.import_module("mola-fe-lidar_amd.lidar_odometry")
     icp = pkg.ICP(device=0)
     lo = pkg.LidarOdometry(lp, icp=icp)

@@ -193,7 +193,7 @@ int         mola_icp_debug_reload_env(void);
 /* How a host thread waits for the sums of an accumulation pass (one hand-over per ICP iteration).  The reference runs align() from
  * the odometry thread AND max(2, hw/2) pool threads on one ICP object (src/LidarOdometry.cpp:94-96, 183-184, 711-712, 869): under the
  * default, MOLA_ICP_WAIT_SPIN, every one of them holds a core at 100 % while its align is in flight.  _YIELD: ~10 us of spinning,
- * then sched_yield() between polls.  _BLOCK: the thread sleeps on a blocking-sync event behind the publishing kernel.  Process-wide;
+ * then sched_yield() between polls.  _BLOCK: the thread sleeps between polls (no core burnt, ~55-60 us per hand-over).  Process-wide;
  * also the environment variable MOLA_ICP_WAIT=spin|yield|block (read at load).  Costs per iteration: INTEGRATION.md. */
 /* Priority class of the CALLING THREAD's subsequent calls on any handle: high > 0 = the workspaces (streams) those calls lease run at
  * the device's greatest stream priority -- their launches are picked ahead of the queued launches of normal-priority calls (the

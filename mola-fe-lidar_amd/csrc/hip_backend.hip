@@ -26,6 +26,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace mola_icp_amd {
@@ -82,6 +83,7 @@ struct Knobs {
     int q4 = -1;               // MOLA_ICP_Q4 (-1 = by cloud size, 0 = never, 1 = always: k_nn_q4, four lanes per query, instead of k_nn_coop / k_nn_tiled)
     int q4_lds_boxes_kb = -1;  // MOLA_ICP_Q4_LDS_BOXES_KB: k_nn_q4 keeps the upper box levels in LDS up to this size (-1: what costs it no workgroup per CU)
     int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
+    bool no_stream_priority = false;   // MOLA_ICP_NO_STREAM_PRIORITY: every workspace's streams at the default priority (A/B of bench.py's mixed_load leg)
     int wait_policy = 0;       // MOLA_ICP_WAIT=spin|yield|block: how the host thread waits for a pass's sums (0 spin -- the default --, 1 yield, 2 block)
     bool turn_clock = false;   // MOLA_ICP_TURN_CLOCK: print the host's side of an iteration's turn (product kernels; stderr, every 200 turns)
 };
@@ -111,6 +113,7 @@ static Knobs read_knobs()
     k.no_warm_start = std::getenv("MOLA_ICP_NO_WARM_START") != nullptr;
     k.debug_stats = geti("MOLA_ICP_DEBUG_STATS");
     k.turn_clock = std::getenv("MOLA_ICP_TURN_CLOCK") != nullptr;
+    k.no_stream_priority = std::getenv("MOLA_ICP_NO_STREAM_PRIORITY") != nullptr;
     if (const char* e = std::getenv("MOLA_ICP_WAIT")) k.wait_policy = std::strcmp(e, "yield") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
     if (std::getenv("MOLA_ICP_LDS_BOXES_KB")) { k.lds_boxes_kb = geti("MOLA_ICP_LDS_BOXES_KB"); if (k.lds_boxes_kb > 40) k.lds_boxes_kb = 40; if (k.lds_boxes_kb < 0) k.lds_boxes_kb = 0; }
     if (std::getenv("MOLA_ICP_QUAD_LDS_BOXES_KB")) k.quad_lds_boxes_kb = geti("MOLA_ICP_QUAD_LDS_BOXES_KB");
@@ -373,7 +376,7 @@ int HipWorkspace::init()
     // of the nearby / loop-closure batches (mola_icp_set_thread_priority; running waves are not preempted).
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    const int prio = priority_ > 0 ? prio_greatest : 0;
+    const int prio = (priority_ > 0 && !g_knobs.no_stream_priority) ? prio_greatest : 0;
     HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio));
     own_stream_ = true;
     HIPCHK(hipStreamCreateWithPriority(&aux_stream_, hipStreamNonBlocking, prio));
@@ -2156,8 +2159,7 @@ int HipWorkspace::check_slab(const Mat4& T, double threshold)
 // Wait policy (MOLA_ICP_WAIT, mola_icp_set_wait_policy): spin -- the default: the lowest latency, one host core at 100 % per in-flight
 // align (the reference runs max(2, hw/2) pool threads plus the odometry thread on one ICP object: src/LidarOdometry.cpp:94-96, 869);
 // yield -- spin for ~10 us, then sched_yield() between polls: the core is shared with whoever is runnable; block -- spin briefly,
-// then sleep on a blocking-sync event recorded behind the publishing kernel (an interrupt wakes the thread: no core is burnt, the
-// wake-up costs tens of microseconds).  Costs per iteration: INTEGRATION.md.
+// then SLEEP between polls (no core is burnt; every hand-over pays the timer's wake-up, ~55-60 us).  Costs per iteration: INTEGRATION.md.
 void set_wait_policy(int policy) { g_knobs.wait_policy = policy == 1 ? 1 : (policy == 2 ? 2 : 0); }
 int wait_policy() { return g_knobs.wait_policy; }
 
@@ -2185,10 +2187,20 @@ int HipWorkspace::spin_for(volatile unsigned long long* flag, unsigned long long
             if (g_knobs.turn_clock) g_turn.on_seen();
             return bbox_pending_ ? check_bboxes() : MOLA_ICP_OK;
         }
-    } else if (policy == 2) {   // block: sleep until everything enqueued so far -- the publishing kernel included -- has run
-        if (!ev_block_) HIPCHK(hipEventCreateWithFlags(&ev_block_, hipEventBlockingSync | hipEventDisableTiming));
-        HIPCHK(hipEventRecord(ev_block_, stream_));
-        HIPCHK(hipEventSynchronize(ev_block_));
+    } else if (policy == 2) {
+        // block: the thread SLEEPS between polls (20 us requested; the kernel's timer slack makes it ~55-60).  The first form -- a
+        // blocking-sync HIP event recorded behind the publishing kernel + hipEventSynchronize -- cost +6 us per iteration and left the calling
+        // thread's CPU share at 1.00: on ROCm 7.2 that wait polls too (profiles/r06/wait_policy.txt).
+        const auto t0 = std::chrono::steady_clock::now();
+        while (*flag != seq) {
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+        }
+        if (*flag == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (g_knobs.turn_clock) g_turn.on_seen();
+            return bbox_pending_ ? check_bboxes() : MOLA_ICP_OK;
+        }
     }
     HIPCHK(hipStreamSynchronize(stream_));
     if (*flag != seq) return fail(MOLA_ICP_E_HIP, "the device did not publish its result block");
