@@ -304,7 +304,6 @@ HipWorkspace::~HipWorkspace()
     if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
     if (ev_order_a_) (void)hipEventDestroy(ev_order_a_);
     if (ev_prep_) (void)hipEventDestroy(ev_prep_);
-    if (ev_block_) (void)hipEventDestroy(ev_block_);
     if (ev_order_b_) (void)hipEventDestroy(ev_order_b_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     map_own_.release(); loc_own_.release(); map_img_.release(); map_meta_.release();

@@ -255,7 +255,6 @@ class HipWorkspace final : public Stages {
     // accumulation that follows it (a single-block 22-30 us kernel otherwise on the next matcher's critical path)
     hipStream_t aux_stream_ = nullptr;
     hipEvent_t ev_order_a_ = nullptr, ev_order_b_ = nullptr, ev_prep_ = nullptr;
-    hipEvent_t ev_block_ = nullptr;   // MOLA_ICP_WAIT=block: a blocking-sync event behind the publishing kernel (created on first use)
     bool order_pending_ = false;
     int order_begin();   // aux_stream_ waits for what stream_ holds so far
     int order_end();     // ... and the next matcher launch will wait for what aux_stream_ holds

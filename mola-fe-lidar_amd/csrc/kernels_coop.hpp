@@ -101,13 +101,7 @@ __device__ __forceinline__ unsigned long long coop_sweep(const TiledMap& mp, con
             }
         }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
-                w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
-            }
-        }
+        for (int a = 0; a < 3; ++a) { w.lo[a] = wave_min_f(w.lo[a]); w.hi[a] = wave_max_f(w.hi[a]); }
         if (lane == 0) {
             s_wbox[0] = w.lo[0]; s_wbox[1] = w.lo[1]; s_wbox[2] = w.lo[2];
             s_wbox[3] = w.hi[0]; s_wbox[4] = w.hi[1]; s_wbox[5] = w.hi[2];

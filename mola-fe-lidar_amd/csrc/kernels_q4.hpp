@@ -42,27 +42,13 @@ constexpr int kQ4ListCap = 64;
 #define Q4_STAMP(k) do { } while (0)
 #endif                              // list entries live in one vector register, entry n in lane n
 
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
-constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;             // quad_perm [1,0,3,2] / [2,3,0,1]
-constexpr int kDppRor4 = 0x124, kDppRor8 = 0x128;           // row_ror:4 / row_ror:8 (a row = 16 lanes = four queries)
-
 __device__ __forceinline__ float quad_min(float v)
 {
     v = fminf(v, dpp_f<kDppXor1>(v));
     return fminf(v, dpp_f<kDppXor2>(v));
 }
-// min / max over the wave's 16 queries (every sub-lane of a query holds the same value), as a scalar: two rotations inside the
-// rows of 16 lanes (four queries each), then the two row broadcasts of a wave-wide DPP reduction (row_bcast:15 into rows 1 and 3,
-// row_bcast:31 into rows 2 and 3) -- lane 63 holds the result; no LDS-crossbar trip
-template <int CTRL, int ROWS> __device__ __forceinline__ float dpp_rows_f(float v)   // (rows outside ROWS keep v: op(v, v) = v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWS, 0xf, false));
-}
-constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+// min / max over the wave's 16 queries (every sub-lane of a query holds the same value), as a scalar: kernels_tiled.hpp's wave
+// reduction without its first two rotations (the four sub-lanes of a query already agree)
 __device__ __forceinline__ float wave_min_q(float v)
 {
     v = fminf(v, dpp_f<kDppRor4>(v)); v = fminf(v, dpp_f<kDppRor8>(v));

@@ -44,6 +44,37 @@ __device__ __forceinline__ v2f dist2_pk2(float qx, float qy, float qz, v2f mx, v
 
 struct Box { float lo[3], hi[3]; };
 
+// ---- wave-wide min / max on the DPP path (round 6) ----------------------------------------------------------------------------
+// Every tiled kernel starts an item with the box of its wave's queries: six reductions over 64 lanes.  As __shfl_xor butterflies
+// (six ds_bpermute with their index arithmetic per value) that was ~250 instructions of the 2 540 a 64-query item of k_nn_tiled
+// issues; as DPP row rotations (four steps inside the rows of 16 lanes) + the two row broadcasts of a wave-wide reduction
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) it is seven instructions a value, none through the LDS
+// crossbar; lane 63 holds the result, returned as a scalar.  min / max are exact and order-free: no result changes.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL, int ROWS> __device__ __forceinline__ float dpp_rows_f(float v)   // (rows outside ROWS keep v: op(v, v) = v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;                                   // quad_perm [1,0,3,2] / [2,3,0,1]
+constexpr int kDppRor1 = 0x121, kDppRor2 = 0x122, kDppRor4 = 0x124, kDppRor8 = 0x128;   // row_ror:n (a row = 16 lanes)
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    v = fminf(v, dpp_f<kDppRor1>(v)); v = fminf(v, dpp_f<kDppRor2>(v)); v = fminf(v, dpp_f<kDppRor4>(v)); v = fminf(v, dpp_f<kDppRor8>(v));
+    v = fminf(v, dpp_rows_f<kDppBcast15, 0xA>(v)); v = fminf(v, dpp_rows_f<kDppBcast31, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    v = fmaxf(v, dpp_f<kDppRor1>(v)); v = fmaxf(v, dpp_f<kDppRor2>(v)); v = fmaxf(v, dpp_f<kDppRor4>(v)); v = fmaxf(v, dpp_f<kDppRor8>(v));
+    v = fmaxf(v, dpp_rows_f<kDppBcast15, 0xA>(v)); v = fmaxf(v, dpp_rows_f<kDppBcast31, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ bool box_overlap(const float* __restrict__ b, int stride, int i, const Box& w)
 {
     // b: SoA [6][stride] = minx,miny,minz,maxx,maxy,maxz ; empty boxes are (+inf,-inf)
@@ -124,13 +155,7 @@ __device__ __forceinline__ unsigned long long tiled_sweep(const TiledMap& mp, co
         }
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
-            w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
-        }
-    }
+    for (int a = 0; a < 3; ++a) { w.lo[a] = wave_min_f(w.lo[a]); w.hi[a] = wave_max_f(w.hi[a]); }
     unsigned long long n_staged = 0;
 
     // Can the box (m0..m5 = min xyz, max xyz; wave-uniform values) hold a point with d2 <= bound2 for ANY query of
@@ -350,16 +375,7 @@ __device__ __forceinline__ unsigned long long quad_sweep(const TiledMap& mp, con
     w.lo[1] = reach >= 0.f ? qy - reach : INFINITY; w.hi[1] = reach >= 0.f ? qy + reach : -INFINITY;
     w.lo[2] = reach >= 0.f ? qz - reach : INFINITY; w.hi[2] = reach >= 0.f ? qz + reach : -INFINITY;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            w.lo[a] = fminf(w.lo[a], __shfl_xor(w.lo[a], off));
-            w.hi[a] = fmaxf(w.hi[a], __shfl_xor(w.hi[a], off));
-        }
-        // (the same value in every lane: kept in scalar registers from here on)
-        w.lo[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.lo[a])));
-        w.hi[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.hi[a])));
-    }
+    for (int a = 0; a < 3; ++a) { w.lo[a] = wave_min_f(w.lo[a]); w.hi[a] = wave_max_f(w.hi[a]); }   // (scalars from here on)
     unsigned long long n_rounds = 0;
     // which lanes can the box (wave-uniform values) hold a point for, under their LIVE bounds (tiled_sweep::any_reach, as a ballot)
     auto reach_ballot = [&](float m0, float m1, float m2, float m3, float m4, float m5) -> unsigned long long {
