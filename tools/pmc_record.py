@@ -24,7 +24,7 @@ pick = [k for k in summ if kernel in k]
 pick.sort(key=lambda k: (-summ[k].get("SQ_INSTS_VALU", {}).get("n", 0), -summ[k].get("SQ_INSTS_VALU", {}).get("mean", 0)))
 c = {name: v["last"] for name, v in summ[pick[0]].items()}     # warm-started launch: the last of each pass
 # queries per work item: k_nn_tiled runs 64-query items (one query per lane) since round 3, k_nn_coop one 128-query item per workgroup
-item_q = 128 if kernel == "k_nn_coop" else 64
+item_q = 128 if kernel == "k_nn_coop" else (16 if kernel == "k_nn_q4" else 64)   # (k_nn_q4: one wave per 16 queries)
 items = (n + item_q - 1) // item_q
 d = {}
 if "GRBM_GUI_ACTIVE" in c:
