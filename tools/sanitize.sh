@@ -1,11 +1,11 @@
 #!/bin/bash
 # Sanitizer runs of the HOST code, on the CPU (never on the GPU box: GPU AddressSanitizer / XNACK are not available on the pool):
-#   bash tools/sanitize.sh            -> profiles/r05/sanitizers/{asan_ubsan,tsan}_*.txt
+#   bash tools/sanitize.sh            -> profiles/r06/sanitizers/{asan_ubsan,tsan}_*.txt
 # Builds ../lib/san/libmola_icp_amd_<kind>.so (host .cpp with -fsanitize, device objects as they are), then runs the CPU test suite
 # and the plain-C / C++ hosts of tests/hosts against it with the sanitizer runtime preloaded (Python itself is not instrumented).
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd $ROOT
-OUT=profiles/r05/sanitizers; mkdir -p $OUT
+OUT=profiles/r06/sanitizers; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 run_kind() {
   kind=$1; san=$2; rt=$3; opts=$4; skip=${5:-}
