@@ -50,6 +50,7 @@ namespace mola_icp_amd {
 #include "kernels_tiled.hpp"
 #include "kernels_coop.hpp"
 #include "q4_launch.hpp"
+#include "knn_q4_launch.hpp"
 #include "kernels_planes.hpp"
 #include "kernels_prepare.hpp"
 #include "kernels_accumulate.hpp"
@@ -81,6 +82,7 @@ struct Knobs {
     int lds_boxes_kb = 40;        // MOLA_ICP_LDS_BOXES_KB: the cooperative / plane kernels keep the upper box levels in LDS up to this size (tuning knob; <= 40)
     int quad_lds_boxes_kb = 22;   // MOLA_ICP_QUAD_LDS_BOXES_KB: the quad flavour keeps the upper box levels in LDS up to this size (tuning knob)
     int q4 = -1;               // MOLA_ICP_Q4 (-1 = by cloud size, 0 = never, 1 = always: k_nn_q4, four lanes per query, instead of k_nn_coop / k_nn_tiled)
+    int knn_q4 = -1;           // MOLA_ICP_KNN_Q4 (-1 = k_knn_coop's sizes near the previous pose + every launch up to 0.56M queries beyond them; 0 = never; 1 = every launch): k_knn_q4, four lanes per query
     int q4_lds_boxes_kb = -1;  // MOLA_ICP_Q4_LDS_BOXES_KB: k_nn_q4 keeps the upper box levels in LDS up to this size (-1: what costs it no workgroup per CU)
     int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
     bool no_stream_priority = false;   // MOLA_ICP_NO_STREAM_PRIORITY: every workspace's streams at the default priority (A/B of bench.py's mixed_load leg)
@@ -117,6 +119,7 @@ static Knobs read_knobs()
     if (const char* e = std::getenv("MOLA_ICP_WAIT")) k.wait_policy = std::strcmp(e, "yield") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
     if (std::getenv("MOLA_ICP_LDS_BOXES_KB")) { k.lds_boxes_kb = geti("MOLA_ICP_LDS_BOXES_KB"); if (k.lds_boxes_kb > 40) k.lds_boxes_kb = 40; if (k.lds_boxes_kb < 0) k.lds_boxes_kb = 0; }
     if (std::getenv("MOLA_ICP_QUAD_LDS_BOXES_KB")) k.quad_lds_boxes_kb = geti("MOLA_ICP_QUAD_LDS_BOXES_KB");
+    k.knn_q4 = std::getenv("MOLA_ICP_KNN_Q4") ? (geti("MOLA_ICP_KNN_Q4") != 0 ? 1 : 0) : -1;
     k.q4 = std::getenv("MOLA_ICP_Q4") ? (geti("MOLA_ICP_Q4") != 0 ? 1 : 0) : -1;
     if (std::getenv("MOLA_ICP_Q4_LDS_BOXES_KB")) k.q4_lds_boxes_kb = geti("MOLA_ICP_Q4_LDS_BOXES_KB");
     k.quads = std::getenv("MOLA_ICP_QUADS") ? (geti("MOLA_ICP_QUADS") != 0 ? 1 : 0) : -1;
@@ -181,6 +184,22 @@ static size_t knn_coop_lds_box_limit(int list_len)
     const size_t a = lds_box_limit(st, list_len <= 7 ? 4 : 3);
     const size_t b = st + 1024 < (size_t)64 * 1024 ? (size_t)64 * 1024 - st - 1024 : 0;
     return a < b ? a : b;
+}
+
+// k_knn_q4's box levels (kernels_knn_q4.hpp): what its own static LDS leaves at its launch bounds
+static size_t knn_q4_lds_box_limit(int list_len)
+{
+    const size_t st = knn_q4_static_lds(list_len);
+    const size_t a = lds_box_limit(st, knn_q4_workgroups_per_cu());
+    const size_t b = st + 1024 < (size_t)64 * 1024 ? (size_t)64 * 1024 - st - 1024 : 0;
+    return a < b ? a : b;
+}
+// ... and whether a launch k_knn_coop would serve goes to k_knn_q4 instead (the diagnostic flavours are k_knn_coop's)
+constexpr double kKnnQ4MaxStep = 0.25;   // metres of pose step (HipWorkspace::match_planes)
+constexpr size_t kKnnQ4MaxQueries = 560000;
+static bool use_knn_q4(int list_len)
+{
+    return g_knobs.knn_q4 != 0 && knn_q4_has(list_len) && g_knobs.debug_stats != 4 && g_knobs.debug_stats != 5;
 }
 
 // ---- parked device blocks (DevBuf::pooled) ------------------------------------------------------------------
@@ -1383,9 +1402,25 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     const int n_items64 = (int)((N_ + 63) / 64);   // (the cooperative kernel's items hold 64 queries whatever MOLA_ICP_QPL says)
     // (crossover, ms per 8-iteration align cooperative / persistent -- uniform synthetic clouds: 60k 0.54 / 0.67, 120k 0.83 / 0.78,
     //  160k 1.02 / 0.84, 200k 1.21 / 0.92; a KITTI-like 120k scan pair, dense near the sensor: 1.76 / 1.96.  Up to 131k queries.)
-    const bool knn_coop = wide_knn || (g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : (size_t)n_items64 <= (size_t)num_cus_ * 8);
+    // the pose step against the previous launch on these clouds (a heuristic input only -- rotation weighed with a 30 m lever; no result depends on it)
+    double step = 0.0;
+    {
+        double dr = 0.0, dt = 0.0;
+        for (int k = 0; k < 9; ++k) { const double d = (double)P.R[k] - (double)knn_last_P_[k]; dr += d * d; }
+        for (int k = 0; k < 3; ++k) { const double d = (double)P.t[k] - (double)knn_last_P_[9 + k]; dt += d * d; }
+        step = std::sqrt(dt) + 30.0 * std::sqrt(dr);
+    }
+    // four lanes per query (kernels_knn_q4.hpp) where the launch is as long as an item's chain: near the previous pose.  Far from it the lists change
+    // wholesale, a launch is bound by its insertions and k_knn_coop's wider items are the better shape (a KITTI-like 120k pair, us per launch
+    // k_knn_q4 / k_knn_coop by step: 2 m 218 / 172, 1 m 156 / 158, 0.3-0.8 m 178-180 / 169-171, 0.13 m 78 / 84, 0.05 m 66 / 68, <= 0.01 m 49-55 / 62-64).
+    // Between k_knn_coop's range and ~0.56M queries the alternative is the persistent kernel, which k_knn_q4 beats at any step (20-iteration shipped
+    // aligns, ms per iteration k_knn_q4 / persistent: 150k 0.069 / 0.083, 200k 0.075 / 0.097, 300k 0.097 / 0.109, 500k 0.136 / 0.150, 650k 0.167 / 0.156).
+    const bool coop_size = (size_t)n_items64 <= (size_t)num_cus_ * 8;
+    const bool knn_q4 = use_knn_q4((int)p.knn + 1) &&
+                        (g_knobs.knn_q4 == 1 || (g_knobs.knn_coop != 0 && (coop_size ? step <= kKnnQ4MaxStep : N_ <= kKnnQ4MaxQueries)));
+    const bool knn_coop = wide_knn || knn_q4 || (g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : coop_size);   // one workgroup per item (either kernel)
     // the upper box levels in LDS while that costs the kernel no workgroup per CU (lds_box_limit), else read from global memory
-    const int lds_boxes = box_bytes <= (knn_coop ? knn_coop_lds_box_limit((int)p.knn + 1) : lds_box_limit(persistent_static_lds(), 4)) ? 1 : 0;
+    const int lds_boxes = box_bytes <= (knn_q4 ? knn_q4_lds_box_limit((int)p.knn + 1) : (knn_coop ? knn_coop_lds_box_limit((int)p.knn + 1) : lds_box_limit(persistent_static_lds(), 4))) ? 1 : 0;
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     // Queries per lane: ONE (64-query items).  A lane's K-entry lists for two queries push the insertion flavour to 168
     // VGPR + spills; with one query per lane there are none, items are twice as many and half as long -- better balance
@@ -1442,13 +1477,6 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     // ... and only inside a converging sequence of poses: the first launch of another align on the same clouds starts far from
     // where the last one ended -- every list changes, the counting pass (0.27 ms at C3) would queue every item.  Judged by the
     // pose step against the previous one (a heuristic: rotation weighed with a 30 m lever; results do not depend on it).
-    double step = 0.0;
-    {
-        double dr = 0.0, dt = 0.0;
-        for (int k = 0; k < 9; ++k) { const double d = (double)P.R[k] - (double)knn_last_P_[k]; dr += d * d; }
-        for (int k = 0; k < 3; ++k) { const double d = (double)P.t[k] - (double)knn_last_P_[9 + k]; dt += d * d; }
-        step = std::sqrt(dt) + 30.0 * std::sqrt(dr);
-    }
     const bool converging = step <= 4.0 * knn_last_step_ + 1e-9;
     knn_last_step_ = knn_seed ? step : 1e30;   // (after an unseeded launch any step counts as "converging")
     const bool verify = knn_seed && !bootstrapped && knn_changed_items_ >= 0.0 && knn_changed_items_ < 0.3 * (double)n_items && converging &&
@@ -1532,7 +1560,9 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         kp.use_seed = knn_seed; kp.use_cache = plane_cache_ok; kp.cert_on = cert.on;
         kp.changed_items = tq + kQueues * kQueueStride + 1;
         kp.cost = g_knobs.debug_stats == 5 ? knn_cost_.as<unsigned int>() : nullptr;   // (diagnostics only: two clock reads and a store per item)
-        if (g_knobs.debug_stats == 4 && p.knn == 6) {   // diagnostics: where the waves of every item spend their cycles
+        if (knn_q4) {
+            HIPCHK(knn_q4_launch(stream_, (int)p.knn + 1, kb, xcd_grid(n_items64), dyn_lds, thr2, thr2x, p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, cert.stats));
+        } else if (g_knobs.debug_stats == 4 && p.knn == 6) {   // diagnostics: where the waves of every item spend their cycles
             DevBuf dg;
             if ((rc = dg.reserve(sizeof(unsigned long long) * kKnnDiagWords * 4 * (size_t)n_items64))) return rc;
             HIPCHK(hipMemsetAsync(dg.p, 0, sizeof(unsigned long long) * kKnnDiagWords * 4 * (size_t)n_items64, stream_));
@@ -1683,8 +1713,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         for (int k = 0; k < kStatSlots; ++k) { staged64 += stats_host_[(size_t)k * kStatStride]; certified += stats_host_[(size_t)k * kStatStride + 1]; skipped += stats_host_[(size_t)k * kStatStride + 2]; }
         HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, stream_));
         std::fprintf(stderr, "[mola_icp debug] plane matcher launch: N=%zu items=%d %s seed=%d cert=%d bootstrapped=%d step=%.5f m | certified queries %llu (%.1f %%), items that skipped the sweep %llu (%.1f %%), pairs/query %.1f\n",
-                     N_, n_items64, knn_coop ? "coop" : (verify ? "persistent+count" : "persistent"), knn_seed, cert.on, (int)bootstrapped, step, certified,
-                     100.0 * (double)certified / (double)N_, skipped, 100.0 * (double)skipped / (double)n_items64, 64.0 * (double)staged64 / (double)N_);
+                     N_, n_items64, knn_q4 ? "q4 (sweeps skipped: per 16-query wave)" : (knn_coop ? "coop" : (verify ? "persistent+count" : "persistent")), knn_seed, cert.on, (int)bootstrapped, step, certified,
+                     100.0 * (double)certified / (double)N_, skipped, 100.0 * (double)skipped / (double)(knn_q4 ? 4 * n_items64 : n_items64), 64.0 * (double)staged64 / (double)N_);
     }
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;
@@ -2839,12 +2869,16 @@ int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_
             if (bb > max_box_bytes) max_box_bytes = bb;
         }
         if (n == 0) break;
-        const int lds_boxes = max_box_bytes <= knn_coop_lds_box_limit((int)p.knn + 1) ? 1 : 0;
+        const bool knn_q4 = use_knn_q4((int)p.knn + 1);
+        const int lds_boxes = max_box_bytes <= (knn_q4 ? knn_q4_lds_box_limit((int)p.knn + 1) : knn_coop_lds_box_limit((int)p.knn + 1)) ? 1 : 0;
         const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
         unsigned long long* staged = ws_.profiling_ ? sc_.stats.as<unsigned long long>() : nullptr;
 #define MOLA_LAUNCH_KNN_COOP_B(KK)                                                                                          \
     hipLaunchKernelGGL((k_knn_coop<KK, kKnnMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, kb, thr2, thr2x, \
                        p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, (unsigned long long*)nullptr, (unsigned long long*)nullptr)
+        if (knn_q4) {
+            HIPCHK(knn_q4_launch_batch(ws_.stream_, (int)p.knn + 1, kb, xcd_grid(max_items), n, dyn_lds, thr2, thr2x, p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, nullptr));
+        } else
         switch (p.knn) {
             case 3: MOLA_LAUNCH_KNN_COOP_B(4); break;
             case 4: MOLA_LAUNCH_KNN_COOP_B(5); break;

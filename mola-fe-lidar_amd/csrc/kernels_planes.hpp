@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256) void k_bootstrap_seeds(const int* __restrict__
 
 // The nearest-neighbour matcher's seeds from the plane matcher's lists (the quality pass behind a point-to-plane loop: its queries
 // start from the first entry of their lists -- the nearest map point at the loop's last pose -- instead of from nothing)
-__global__ __launch_bounds__(256) void k_nn_seeds_from_lists(KnnSeeds seeds, int N, int* __restrict__ pos_s, int* __restrict__ idx_s,
+inline __global__ __launch_bounds__(256) void k_nn_seeds_from_lists(KnnSeeds seeds, int N, int* __restrict__ pos_s, int* __restrict__ idx_s,
                                                              float* __restrict__ gsx, float* __restrict__ gsy, float* __restrict__ gsz)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(256) void k_quality_from_lists(const float* __restr
 // x = [R row-major (9), t (3)]  with  phi = [n (x) l, n],  d = n.c :   A = sum phi phi^T (78 unique),
 // b = sum phi d (12), c0 = sum d^2, count.  ONE pass -> the whole Gauss-Newton inner loop runs on the host.
 constexpr int kNAccPlane = 92;  // 78 + 12 + 1 + 1
-__global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+inline __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restrict__ slx, const float* __restrict__ sly,
                                                            const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
                                                            int N, double* __restrict__ partials)
 {
@@ -1061,7 +1061,7 @@ __device__ __forceinline__ void accumulate_planes_mfma_rows(const float* __restr
     else if (col == 13 && row == 13) out[91] = t;
 }
 
-__global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __restrict__ slx, const float* __restrict__ sly,
+inline __global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __restrict__ slx, const float* __restrict__ sly,
                                                                 const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
                                                                 int N, double* __restrict__ partials)
 {
@@ -1077,7 +1077,7 @@ struct PlaneAccBatch {
     double* partials[kKnnMaxBatch];
     int N[kKnnMaxBatch], nblocks[kKnnMaxBatch], slot[kKnnMaxBatch];
 };
-__global__ __launch_bounds__(256) void k_accumulate_planes_mfma_batch(const PlaneAccBatch b)
+inline __global__ __launch_bounds__(256) void k_accumulate_planes_mfma_batch(const PlaneAccBatch b)
 {
     const int y = (int)blockIdx.y, nb = b.nblocks[y];
     if ((int)blockIdx.x >= nb) return;
@@ -1146,7 +1146,7 @@ __device__ __forceinline__ void reduce_rows_wide(const double* __restrict__ part
     }
 }
 
-__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
+inline __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
                                                       double* __restrict__ acc, const unsigned int* __restrict__ counters,
                                                       double* __restrict__ host_out, unsigned long long seq)
 {
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__
 // K problems: block y sums problem y's rows (the same order as its own k_reduce_rows launch) into acc + kPlaneAccStride * slot and
 // publishes them at host_out + kPlaneAccStride * slot (sequence flag in slot n + 2 of that stride)
 constexpr int kPlaneAccStride = 96;
-__global__ __launch_bounds__(1024) void k_reduce_rows_batch(const PlaneAccBatch b, int n, double* __restrict__ acc,
+inline __global__ __launch_bounds__(1024) void k_reduce_rows_batch(const PlaneAccBatch b, int n, double* __restrict__ acc,
                                                             double* __restrict__ host_out, unsigned long long seq)
 {
     const int y = (int)blockIdx.x, sl = b.slot[y];
@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(1024) void k_reduce_rows_batch(const PlaneAccBatch 
 }
 
 // plane pairing in sorted query order -> original order (tests / callers that want the pairing)
-__global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict__ qperm, const PlanePair* __restrict__ in,
+inline __global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict__ qperm, const PlanePair* __restrict__ in,
                                                           KnnSeeds seeds, int K, int N, PlanePair* __restrict__ out, int* __restrict__ knn_idx)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
