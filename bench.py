@@ -886,7 +886,7 @@ def kernel_sources_sha1():
     h = hashlib.sha1()
     d = os.path.join(ROOT, "mola-fe-lidar_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.startswith("kernels_") or f in ("hip_backend.hip", "map_sort.hip", "q4_launch.hip"):
+        if f.startswith("kernels_") or f in ("hip_backend.hip", "map_sort.hip", "q4_launch.hip", "knn_q4_launch.hip"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
     if (lane == 0) ring[0] = 0.f;   // (a plain store to the ring: the tiles arrive by LDS-DMA, which the compiler does not count as one)
     if (threadIdx.x == 0) s_done = 0;
 #ifdef MOLA_KQ4_DIAG
-    unsigned long long* dbg_w = g_kq4_dbg && blockIdx.y == 0 && blockIdx.x < 2048 && lane == 0 ? g_kq4_dbg + 8 * (size_t)(blockIdx.x * 4 + wave) : nullptr;
+    unsigned long long* dbg_w = g_kq4_dbg && blockIdx.y == 0 && blockIdx.x < 2048 && lane == 0 ? g_kq4_dbg + 16 * (size_t)(blockIdx.x * 4 + wave) : nullptr;
 #endif
     KQ4_STAMP(0);
 
@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
     const bool skip_sweep = !__any(open);
     if (!valid) qx = qy = qz = 1.0e18f;   // padding lane: no staged point comes near it
     unsigned int tiles = 0u;
+#ifdef MOLA_KQ4_DIAG
+    unsigned int dg_slow = 0u, dg_key = 0u, dg_dup = 0u, dg_ins = 0u, dg_tests = 0u;
+#endif
     KQ4_STAMP(2);
     bool inserted = false;   // this sub-lane's list is no longer the seeded one
 
@@ -227,6 +230,9 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
         // one group of box tests: the next (up to) four candidates of `cand`, sub-lane s of every query takes candidate s (k_nn_q4)
         const int s8 = 8 * s;
         auto test4 = [&](float r0, float r1, float r2, float r3, float r4, float r5, unsigned long long& cand, float bound, auto&& on_pass) {
+#ifdef MOLA_KQ4_DIAG
+            ++dg_tests;
+#endif
             const int c0 = kq4_ff1(cand); kq4_bitset0(cand, c0);
             const int c1 = kq4_ff1(cand); kq4_bitset0(cand, c1);
             const int c2 = kq4_ff1(cand); kq4_bitset0(cand, c2);
@@ -269,6 +275,9 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
             // (a certified query's first K entries are proven and its bound comes from the certificate: it takes no part -- in a late launch nine
             //  lanes in ten are certified, and every tile near them holds their own list members, at distances inside their lists)
             if (__any(open && gm <= kd_of(K - 1))) {   // some lane may have to insert: rare once the lists have tightened
+#ifdef MOLA_KQ4_DIAG
+                ++dg_slow;
+#endif
                 const uint4 O0 = *reinterpret_cast<const uint4*>(p + 96), O1 = *reinterpret_cast<const uint4*>(p + 100);
                 const unsigned int os[8] = {O0.x, O0.y, O0.z, O0.w, O1.x, O1.y, O1.z, O1.w};
 #pragma unroll
@@ -277,6 +286,9 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
                         bool dup = false;   // a stored neighbour met again by the sweep
 #pragma unroll
                         for (int j = 0; j < K; ++j) dup |= kp[j] == gpos + u;
+#ifdef MOLA_KQ4_DIAG
+                        dg_key += (unsigned int)__popcll(__ballot(true)); dg_dup += (unsigned int)__popcll(__ballot(dup)); dg_ins += (unsigned int)__popcll(__ballot(!dup));
+#endif
                         if (!dup) { insert(d[u], os[u], gpos + u); inserted = true; }
                     }
                 }
@@ -454,7 +466,10 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
     }
     KQ4_STAMP(4);
 #ifdef MOLA_KQ4_DIAG
-    if (dbg_w) { dbg_w[6] = (unsigned long long)tiles | ((unsigned long long)(skip_sweep ? 1 : 0) << 32) | ((unsigned long long)(__popcll(cert_mask) >> 2) << 40); }
+    if (dbg_w) {
+        dbg_w[6] = (unsigned long long)tiles | ((unsigned long long)(skip_sweep ? 1 : 0) << 32) | ((unsigned long long)(__popcll(cert_mask) >> 2) << 40);
+        dbg_w[8] = dg_slow; dbg_w[9] = dg_key; dbg_w[10] = dg_dup; dbg_w[11] = dg_ins; dbg_w[12] = dg_tests;
+    }
 #endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     int ticket = 0;

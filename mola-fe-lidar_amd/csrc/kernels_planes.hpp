@@ -530,6 +530,10 @@ constexpr int kKnnMaxBatch = 12;    // problems per launch (kernel arguments are
 template <int KMAX> struct KnnBatch { KnnProblem p[KMAX]; };
 static_assert(sizeof(KnnBatch<kKnnMaxBatch>) <= 3900, "KnnBatch must fit the kernel-argument segment");
 
+// (knn_q4_launch.hip -- k_knn_q4's translation unit -- needs the types and plane_epilogue above, not the kernels below: the non-template
+//  ones among them may be defined in one translation unit only)
+#ifndef MOLA_ICP_PLANE_TYPES_ONLY
+
 // LDS of one cooperative item (k_knn_coop, k_knn_coop_groups)
 template <int K>
 struct KnnCoopLds {
@@ -853,7 +857,7 @@ __global__ __launch_bounds__(256) void k_bootstrap_seeds(const int* __restrict__
 
 // The nearest-neighbour matcher's seeds from the plane matcher's lists (the quality pass behind a point-to-plane loop: its queries
 // start from the first entry of their lists -- the nearest map point at the loop's last pose -- instead of from nothing)
-inline __global__ __launch_bounds__(256) void k_nn_seeds_from_lists(KnnSeeds seeds, int N, int* __restrict__ pos_s, int* __restrict__ idx_s,
+__global__ __launch_bounds__(256) void k_nn_seeds_from_lists(KnnSeeds seeds, int N, int* __restrict__ pos_s, int* __restrict__ idx_s,
                                                              float* __restrict__ gsx, float* __restrict__ gsy, float* __restrict__ gsz)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(256) void k_quality_from_lists(const float* __restr
 // x = [R row-major (9), t (3)]  with  phi = [n (x) l, n],  d = n.c :   A = sum phi phi^T (78 unique),
 // b = sum phi d (12), c0 = sum d^2, count.  ONE pass -> the whole Gauss-Newton inner loop runs on the host.
 constexpr int kNAccPlane = 92;  // 78 + 12 + 1 + 1
-inline __global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restrict__ slx, const float* __restrict__ sly,
+__global__ __launch_bounds__(256) void k_accumulate_planes(const float* __restrict__ slx, const float* __restrict__ sly,
                                                            const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
                                                            int N, double* __restrict__ partials)
 {
@@ -1061,7 +1065,7 @@ __device__ __forceinline__ void accumulate_planes_mfma_rows(const float* __restr
     else if (col == 13 && row == 13) out[91] = t;
 }
 
-inline __global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __restrict__ slx, const float* __restrict__ sly,
+__global__ __launch_bounds__(256) void k_accumulate_planes_mfma(const float* __restrict__ slx, const float* __restrict__ sly,
                                                                 const float* __restrict__ slz, const PlanePair* __restrict__ pairs,
                                                                 int N, double* __restrict__ partials)
 {
@@ -1077,7 +1081,7 @@ struct PlaneAccBatch {
     double* partials[kKnnMaxBatch];
     int N[kKnnMaxBatch], nblocks[kKnnMaxBatch], slot[kKnnMaxBatch];
 };
-inline __global__ __launch_bounds__(256) void k_accumulate_planes_mfma_batch(const PlaneAccBatch b)
+__global__ __launch_bounds__(256) void k_accumulate_planes_mfma_batch(const PlaneAccBatch b)
 {
     const int y = (int)blockIdx.y, nb = b.nblocks[y];
     if ((int)blockIdx.x >= nb) return;
@@ -1146,7 +1150,7 @@ __device__ __forceinline__ void reduce_rows_wide(const double* __restrict__ part
     }
 }
 
-inline __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
+__global__ __launch_bounds__(1024) void k_reduce_rows(const double* __restrict__ partials, int nblocks, int n,
                                                       double* __restrict__ acc, const unsigned int* __restrict__ counters,
                                                       double* __restrict__ host_out, unsigned long long seq)
 {
@@ -1156,7 +1160,7 @@ inline __global__ __launch_bounds__(1024) void k_reduce_rows(const double* __res
 // K problems: block y sums problem y's rows (the same order as its own k_reduce_rows launch) into acc + kPlaneAccStride * slot and
 // publishes them at host_out + kPlaneAccStride * slot (sequence flag in slot n + 2 of that stride)
 constexpr int kPlaneAccStride = 96;
-inline __global__ __launch_bounds__(1024) void k_reduce_rows_batch(const PlaneAccBatch b, int n, double* __restrict__ acc,
+__global__ __launch_bounds__(1024) void k_reduce_rows_batch(const PlaneAccBatch b, int n, double* __restrict__ acc,
                                                             double* __restrict__ host_out, unsigned long long seq)
 {
     const int y = (int)blockIdx.x, sl = b.slot[y];
@@ -1164,7 +1168,7 @@ inline __global__ __launch_bounds__(1024) void k_reduce_rows_batch(const PlaneAc
 }
 
 // plane pairing in sorted query order -> original order (tests / callers that want the pairing)
-inline __global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict__ qperm, const PlanePair* __restrict__ in,
+__global__ __launch_bounds__(256) void k_unpermute_planes(const int* __restrict__ qperm, const PlanePair* __restrict__ in,
                                                           KnnSeeds seeds, int K, int N, PlanePair* __restrict__ out, int* __restrict__ knn_idx)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1177,5 +1181,7 @@ inline __global__ __launch_bounds__(256) void k_unpermute_planes(const int* __re
             knn_idx[(size_t)o * K + j] = (j < in[i].n_neigh && seeds.pos[at] >= 0) ? (int)seeds.oidx[at] : -1;
         }
 }
+
+#endif  // MOLA_ICP_PLANE_TYPES_ONLY
 
 }  // namespace mola_icp_amd

@@ -1,4 +1,5 @@
 // knn_q4_launch.hip -- k_knn_q4's instantiations and launches (a translation unit of its own: the kernel is rebuilt without the big one)
+#define MOLA_ICP_PLANE_TYPES_ONLY   // (kernels_planes.hpp: types + plane_epilogue; its kernels belong to hip_backend.hip)
 #include "knn_q4_launch.hpp"
 
 #include "kernels_knn_q4.hpp"
@@ -39,26 +40,28 @@ static unsigned long long* kq4_dbg_buf()
 {
     static unsigned long long* buf = nullptr;
     if (!buf) {
-        (void)hipMalloc(reinterpret_cast<void**>(&buf), 8 * 8192 * sizeof(unsigned long long));
+        (void)hipMalloc(reinterpret_cast<void**>(&buf), 16 * 8192 * sizeof(unsigned long long));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kq4_dbg), &buf, sizeof buf);
     }
     return buf;
 }
 static void kq4_diag_report(int n_waves, int use_seed, int cert_on)
 {
-    std::vector<unsigned long long> w(8 * (size_t)n_waves);
+    std::vector<unsigned long long> w(16 * (size_t)n_waves);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(w.data(), kq4_dbg_buf(), w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     const char* names[5] = {"loads+boxes", "seeds+cert", "sweep", "merge+records", "epilogue"};
     std::vector<double> ph[3][5], life[3], tiles;   // [all | sweeping | last wave of its workgroup]
     unsigned long long t_min = ~0ull, t_max = 0ull;
     size_t skipped = 0, solved = 0, lasts = 0;
+    unsigned long long c_tiles = 0, c_slow = 0, c_key = 0, c_dup = 0, c_ins = 0, c_tests = 0;
     for (int i = 0; i < n_waves; ++i) {
-        const unsigned long long* r = &w[8 * (size_t)i];
+        const unsigned long long* r = &w[16 * (size_t)i];
         if (!r[0] || !r[4]) continue;
         const bool skip = (r[6] >> 32) & 1ull, last = r[5] != 0;
         skipped += skip; lasts += last; solved += last && r[7];
         if (!skip) tiles.push_back((double)(r[6] & 0xffffffffull));
+        c_tiles += r[6] & 0xffffffffull; c_slow += r[8]; c_key += r[9]; c_dup += r[10]; c_ins += r[11]; c_tests += r[12];
         const unsigned long long end = last ? r[5] : r[4];
         t_min = std::min(t_min, r[0]); t_max = std::max(t_max, end);
         for (int cls = 0; cls < 3; ++cls) {
@@ -73,6 +76,7 @@ static void kq4_diag_report(int n_waves, int use_seed, int cert_on)
     auto med = [](std::vector<double>& v, double q) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
     std::fprintf(stderr, "[kq4 diag] seed=%d cert=%d: %zu waves (%zu skipped the sweep; %zu last waves, %zu with a plane solve), launch span %.0f ticks (100 MHz), tiles per sweeping wave p50 %.0f p90 %.0f max %.0f\n",
                  use_seed, cert_on, life[0].size(), skipped, lasts, solved, (double)(t_max - t_min), med(tiles, 0.5), med(tiles, 0.9), med(tiles, 1.0));
+    std::fprintf(stderr, "[kq4 diag]   %llu tiles evaluated, %llu took the insertion path; lane events in it: %llu keys below the lane's last (%llu list members met again, %llu insertions); %llu groups of four box tests\n", c_tiles, c_slow, c_key, c_dup, c_ins, c_tests);
     const char* cls_names[3] = {"all waves", "sweeping", "last of wg"};
     for (int cls = 0; cls < 3; ++cls) {
         std::fprintf(stderr, "[kq4 diag]   %-10s lifetime p50 %.0f p90 %.0f max %.0f |", cls_names[cls], med(life[cls], 0.5), med(life[cls], 0.9), med(life[cls], 1.0));
@@ -86,7 +90,7 @@ hipError_t knn_q4_launch(hipStream_t stream, int list_len, const KnnBatch<1>& b,
                          double plane_eig_thr, unsigned long long* staged, int lds_boxes, unsigned long long* cert_stats)
 {
 #ifdef MOLA_KQ4_DIAG
-    (void)hipMemsetAsync(kq4_dbg_buf(), 0, 8 * 8192 * sizeof(unsigned long long), stream);
+    (void)hipMemsetAsync(kq4_dbg_buf(), 0, 16 * 8192 * sizeof(unsigned long long), stream);
 #endif
     switch (list_len) {
 #define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, 1>), dim3(grid), dim3(256), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
