@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOLA_ICP_ABI_VERSION 4
+#define MOLA_ICP_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -147,6 +147,12 @@ typedef struct mola_icp_params {
     int32_t  reading_outlier_single_pass;        /* scale-outlier detector: ONE weighted pass instead of two     icpreg:14-17 */
     int32_t  reading_p2pl_all_inside_gate;       /* Matcher_Point2Plane: a plane needs ALL knn inside the gate   icpreg:33-39 */
     int32_t  reading_quality_denominator_local;  /* PairedRatio = pairings / N(local), not / min(N, M)           icpreg:44-46 */
+    /* ABI 5 -- pairingsWeightParameters.use_robust_kernel (icpreg:18-21) with Matcher_Point2Plane ALONE.  0: refused by name (the
+     * kernel's weights are defined on POINT pairings relative to a Horn solve's centroids; what mp2p_icp does with the flag when a
+     * solve holds plane pairings only is not pinned by anything in the reference).  !=0: accepted, and plane pairings keep unit
+     * weights -- the reading under which the flag, like use_scale_outlier_detector in the reference's own params block, acts on point
+     * pairings and finds none.  (Point AND plane pairings in one solve with the flag set stay refused.) */
+    int32_t  reading_robust_kernel_skips_planes;
 } mola_icp_params;
 
 /* ---- result == the fields of mp2p_icp::Results that the reference consumes

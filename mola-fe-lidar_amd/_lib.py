@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOLA_ICP_LIB_PATH") or os.path.join(_HERE, "lib", "libmola_icp_amd.so")
 
 NACC = 24
-ABI_VERSION = 4   # MOLA_ICP_ABI_VERSION of include/mola_icp_amd.h
+ABI_VERSION = 5   # MOLA_ICP_ABI_VERSION of include/mola_icp_amd.h
 
 OK = 0
 E_BADARG, E_CONFIG, E_HIP, E_OOM, E_NODEVICE, E_UNSUPPORTED, E_COMM, E_INTERNAL = -1, -2, -3, -4, -5, -6, -7, -8
@@ -75,6 +75,7 @@ class CParams(C.Structure):
         ("reading_outlier_single_pass", C.c_int32),
         ("reading_p2pl_all_inside_gate", C.c_int32),
         ("reading_quality_denominator_local", C.c_int32),
+        ("reading_robust_kernel_skips_planes", C.c_int32),
     ]
 
 

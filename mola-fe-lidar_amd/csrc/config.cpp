@@ -163,6 +163,7 @@ void params_from_yaml_node(const YamlNode& cfg, mola_icp_params& p)
         if (auto* n = rd->find("outlier_single_pass")) p.reading_outlier_single_pass = n->as_bool();
         if (auto* n = rd->find("p2pl_all_inside_gate")) p.reading_p2pl_all_inside_gate = n->as_bool();
         if (auto* n = rd->find("quality_denominator_local")) p.reading_quality_denominator_local = n->as_bool();
+        if (auto* n = rd->find("robust_kernel_skips_planes")) p.reading_robust_kernel_skips_planes = n->as_bool();
     }
 
     {

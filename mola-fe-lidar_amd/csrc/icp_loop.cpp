@@ -159,8 +159,12 @@ int validate_single(const mola_icp_params& p)
             return fail(MOLA_ICP_E_UNSUPPORTED,
                         "mp2p_icp::Matcher_Point2Plane pairings need mp2p_icp::Solver_GaussNewton (Solver_Horn only "
                         "consumes point-to-point pairings)");
-        if (p.use_robust_kernel)
-            return fail(MOLA_ICP_E_UNSUPPORTED, "use_robust_kernel is not available with mp2p_icp::Matcher_Point2Plane");
+        // pairingsWeightParameters.use_robust_kernel with plane pairings only: refused by name, or -- under the reading that the flag acts on
+        // point pairings and finds none, as use_scale_outlier_detector does in the reference's own params block -- accepted without effect
+        // (mola_icp_params.reading_robust_kernel_skips_planes; the plane pipeline never consults the weight parameters)
+        if (p.use_robust_kernel && !p.reading_robust_kernel_skips_planes)
+            return fail(MOLA_ICP_E_UNSUPPORTED, "use_robust_kernel is not available with mp2p_icp::Matcher_Point2Plane (readings: robust_kernel_skips_planes "
+                                                "accepts it with unit weights on the plane pairings)");
         if (p.knn < 3 || p.knn > 16) return fail(MOLA_ICP_E_UNSUPPORTED, "Matcher_Point2Plane: knn must be in [3, 16]");
         if (!(p.plane_eigen_threshold > 0)) return fail(MOLA_ICP_E_BADARG, "planeEigenThreshold must be > 0");
         if (p.solver_max_iterations == 0) return fail(MOLA_ICP_E_BADARG, "Solver_GaussNewton: maxIterations must be > 0");

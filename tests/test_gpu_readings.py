@@ -116,3 +116,26 @@ def test_batched_aligns_follow_the_readings(pkg, O, pair):
     for r in res:
         assert np.array_equal(r.optimal_tf, alone.optimal_tf) and r.nIterations == alone.nIterations
     icp.close()
+
+
+def test_robust_kernel_flag_on_the_shipped_pipeline(pkg, O, pair):
+    """`use_robust_kernel: true` in icp-settings-regular.yaml (its matcher is Matcher_Point2Plane): refused by name by default; under
+    `readings: robust_kernel_skips_planes` the align is the flag-less align bit for bit -- the plane pairings keep unit weights --, stand-alone
+    and in a lockstep batch, and equals the oracle's"""
+    g, l = pair
+    text = open(os.path.join(ROOT, "params", "icp-settings-regular.yaml")).read()
+    base = pkg.Parameters.load_from(text)
+    flagged = text.replace("use_robust_kernel: false", "use_robust_kernel: true")
+    icp = pkg.ICP(device=0)
+    with pytest.raises(pkg.IcpError) as ex:
+        icp.align(g, l, np.eye(4), pkg.Parameters.load_from(flagged))
+    assert ex.value.status == pkg._lib.E_UNSUPPORTED and "robust_kernel_skips_planes" in str(ex.value)
+    p = pkg.Parameters.load_from(flagged + "\nreadings:\n  robust_kernel_skips_planes: true\n")
+    ref = icp.align(g, l, np.eye(4), base)
+    r = icp.align(g, l, np.eye(4), p)
+    assert np.array_equal(r.optimal_tf, ref.optimal_tf) and r.nIterations == ref.nIterations and r.quality == ref.quality and r.n_pairs == ref.n_pairs
+    for rb in icp.align_batch([(g, l), (g, l)], [np.eye(4)] * 2, p):
+        assert np.array_equal(rb.optimal_tf, ref.optimal_tf) and rb.nIterations == ref.nIterations
+    oref = O.align_p2pl(g, l, np.eye(4), O.params_from_product(p), p.plane_eigen_threshold, int(p.knn), p.solver_max_iterations)
+    _same(pkg, O, r, oref)
+    icp.close()

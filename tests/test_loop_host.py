@@ -194,3 +194,24 @@ def test_readings_yaml_key(pkg):
     assert (p.reading_outlier_single_pass, p.reading_p2pl_all_inside_gate, p.reading_quality_denominator_local) == (1, 1, 0)
     with pytest.raises(pkg.IcpError):
         pkg.Parameters.load_from(text + "\nreadings: 3\n")
+    assert p.reading_robust_kernel_skips_planes == 0
+    assert pkg.Parameters.load_from(text + "\nreadings:\n  robust_kernel_skips_planes: true\n").reading_robust_kernel_skips_planes == 1
+
+
+def test_robust_kernel_with_plane_pairings_only_is_refused_by_name_or_read_as_having_nothing_to_act_on(pkg):
+    """pairingsWeightParameters.use_robust_kernel flipped to true in the reference's OWN params block (icp-settings-regular.yaml:19; the
+    matcher there is Matcher_Point2Plane): refused with a message that names the reading switch, accepted under it (ABI 5) -- the loop
+    validates before it touches a cloud, so empty clouds tell the two apart (the last refusal a key of that block
+    could trigger)"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "params", "icp-settings-regular.yaml")).read()
+    assert "use_robust_kernel: false" in text
+    text = text.replace("use_robust_kernel: false", "use_robust_kernel: true")
+    p = pkg.Parameters.load_from(text)
+    assert p.use_robust_kernel == 1 and p.robust_kernel_scale == 400.0
+    with pytest.raises(pkg.IcpError) as ex:
+        pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), p, 0, 0)
+    assert ex.value.status == pkg._lib.E_UNSUPPORTED and "robust_kernel_skips_planes" in str(ex.value)
+    q = pkg.Parameters.load_from(text + "\nreadings:\n  robust_kernel_skips_planes: true\n")
+    assert pkg.run_loop(lambda T, thr: 0, lambda *a: np.zeros(24), np.eye(4), q, 0, 0).terminationReason == pkg.TERM_NO_PAIRINGS
