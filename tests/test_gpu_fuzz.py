@@ -11,7 +11,8 @@ import pytest
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_KNN_COOP", "MOLA_ICP_QPL", "MOLA_ICP_EARLY_POP", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU", "MOLA_ICP_QUADS")
+KNOBS = ("MOLA_ICP_COOP", "MOLA_ICP_KNN_COOP", "MOLA_ICP_QPL", "MOLA_ICP_EARLY_POP", "MOLA_ICP_NO_LPT", "MOLA_ICP_BLOCKS_PER_CU", "MOLA_ICP_QUADS",
+         "MOLA_ICP_Q4", "MOLA_ICP_KNN_Q4")
 
 
 def test_random_cases_equal_the_oracle(pkg, O, synth):
@@ -38,6 +39,13 @@ def test_random_cases_equal_the_oracle(pkg, O, synth):
                 env["MOLA_ICP_QUADS"] = "0"
             elif u < 0.5:
                 env["MOLA_ICP_QUADS"] = "1"
+            # (round 6: the four-lanes-per-query kernels -- unset = the product's rule, "0" never, "1" at every launch, whatever the size)
+            u = rng.random()
+            if u < 0.5:
+                env["MOLA_ICP_Q4"] = "1" if u < 0.35 else "0"
+            u = rng.random()
+            if u < 0.5:
+                env["MOLA_ICP_KNN_Q4"] = "1" if u < 0.35 else "0"
             os.environ.update(env)
             pkg._lib.lib().mola_icp_debug_reload_env()
             N = int(rng.choice([1, 63, 64, 65, 127, 129, 1000, 4097, 9000, 20000, 33333]) if rng.random() < 0.5 else rng.integers(1, max_n))
@@ -106,6 +114,11 @@ def test_large_random_cases_equal_the_oracle_on_a_sample(pkg, O, synth):
                 env["MOLA_ICP_QUADS"] = "0"
             elif u < 0.5:
                 env["MOLA_ICP_QUADS"] = "1"
+            u = rng.random()   # (300k .. 900k queries: k_knn_q4's own range ends at 0.56M; "1" runs it -- and k_nn_q4 -- beyond)
+            if u < 0.5:
+                env["MOLA_ICP_KNN_Q4"] = "1" if u < 0.3 else "0"
+            if rng.random() < 0.3:
+                env["MOLA_ICP_Q4"] = "1"
             os.environ.update(env)
             pkg._lib.lib().mola_icp_debug_reload_env()
             N = int(rng.integers(300_000, 900_001))
