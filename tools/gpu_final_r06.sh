@@ -28,10 +28,13 @@ c)
   echo "== headline counters"; bash tools/rocprof_headline.sh r06_headline > $O/rocprof_headline.log 2>&1; tail -5 $O/rocprof_headline.log
   echo "== odometry-size matcher counters (k_nn_q4)"; bash tools/rocprof_small.sh r06_small > $O/rocprof_small.log 2>&1; tail -5 $O/rocprof_small.log
   echo "== odometry stream timeline"; bash tools/rocprof_odometry.sh > $O/rocprof_odometry.log 2>&1; tail -3 gpurun_out/prof_odometry/timeline.txt
+  echo "== plane matcher at 120k x 120k (k_knn_q4 + the far launches' k_knn_coop): counters"; bash tools/rocprof_planes.sh r06_knn_q4 120000 > $O/rocprof_planes.log 2>&1; tail -3 $O/rocprof_planes.log
   echo "== 100k x 100k iteration timeline"; bash tools/rocprof_timeline_any.sh 100000 p2p 12 > $O/p2p_100k_timeline.txt 2>&1; tail -8 $O/p2p_100k_timeline.txt
   ;;
 d)
   echo "== k_nn_q4 against the matchers it replaces"; timeout -k 10 400 python tools/q4_ab.py 12000x12000 50000x50000 100000x100000 120000x120000 125000x1000000 200000x200000 260000x260000 > $O/q4_ab.txt 2>&1; cat $O/q4_ab.txt
+  echo "== the plane matcher's launches per odometry scan, device time: k_knn_coop, then k_knn_q4"; KNN_Q4=0 bash tools/gpu_kq4_trace.sh final_r06/kq4_trace_coop product; bash tools/gpu_kq4_trace.sh final_r06/kq4_trace_q4 product
+  echo "== shipped-pipeline batch"; for q in 0 1; do MOLA_ICP_KNN_Q4=$q timeout -k 10 200 python tools/batch_shipped_probe.py 2>&1 | tail -1; done
   echo "== wait policies"; timeout -k 10 400 python tools/wait_policy_probe.py > $O/wait_policy.txt 2>&1; cat $O/wait_policy.txt
   ;;
 esac
