@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   if [ $v = product ]; then unset MOLA_ICP_LIB_PATH; else export MOLA_ICP_LIB_PATH=$ROOT/mola-fe-lidar_amd/lib/variants/$v.so; fi
   rm -rf $O/trace_$v
-  MOLA_ICP_KNN_Q4=${KNN_Q4:-1} rocprofv3 --kernel-trace --output-format csv -d $O/trace_$v -- python3 $ROOT/tools/prof_odometry_stream.py 24 > $O/trace_$v.log 2>&1
+  MOLA_ICP_KNN_Q4=${KNN_Q4:-1} rocprofv3 --kernel-trace --output-format csv -d $O/trace_$v -- python3 $ROOT/tools/prof_odometry_stream.py 24 ${DECIMATE:-1} > $O/trace_$v.log 2>&1
   f=$(find $O/trace_$v -name "*kernel_trace.csv" | head -1)
   python3 - "$f" "$v" <<'PY'
 import csv, sys
