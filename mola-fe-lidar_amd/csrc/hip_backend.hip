@@ -82,7 +82,8 @@ struct Knobs {
     int lds_boxes_kb = 40;        // MOLA_ICP_LDS_BOXES_KB: the cooperative / plane kernels keep the upper box levels in LDS up to this size (tuning knob; <= 40)
     int quad_lds_boxes_kb = 22;   // MOLA_ICP_QUAD_LDS_BOXES_KB: the quad flavour keeps the upper box levels in LDS up to this size (tuning knob)
     int q4 = -1;               // MOLA_ICP_Q4 (-1 = by cloud size, 0 = never, 1 = always: k_nn_q4, four lanes per query, instead of k_nn_coop / k_nn_tiled)
-    int knn_q4 = -1;           // MOLA_ICP_KNN_Q4 (-1 = k_knn_coop's sizes near the previous pose + every launch up to 0.56M queries beyond them; 0 = never; 1 = every launch): k_knn_q4, four lanes per query
+    int knn_q4 = -1;           // MOLA_ICP_KNN_Q4 (-1 = k_knn_coop's sizes near the previous pose + every launch up to 3M queries beyond them; 0 = never; 1 = every launch): k_knn_q4, four / two lanes per query
+    int knn_q4_lpq = 0;        // MOLA_ICP_KNN_Q4_LPQ (0 = by the launch's size, 2 / 4: k_knn_q4's lanes per query)
     int q4_lds_boxes_kb = -1;  // MOLA_ICP_Q4_LDS_BOXES_KB: k_nn_q4 keeps the upper box levels in LDS up to this size (-1: what costs it no workgroup per CU)
     int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
     bool no_stream_priority = false;   // MOLA_ICP_NO_STREAM_PRIORITY: every workspace's streams at the default priority (A/B of bench.py's mixed_load leg)
@@ -120,6 +121,7 @@ static Knobs read_knobs()
     if (std::getenv("MOLA_ICP_LDS_BOXES_KB")) { k.lds_boxes_kb = geti("MOLA_ICP_LDS_BOXES_KB"); if (k.lds_boxes_kb > 40) k.lds_boxes_kb = 40; if (k.lds_boxes_kb < 0) k.lds_boxes_kb = 0; }
     if (std::getenv("MOLA_ICP_QUAD_LDS_BOXES_KB")) k.quad_lds_boxes_kb = geti("MOLA_ICP_QUAD_LDS_BOXES_KB");
     k.knn_q4 = std::getenv("MOLA_ICP_KNN_Q4") ? (geti("MOLA_ICP_KNN_Q4") != 0 ? 1 : 0) : -1;
+    if (std::getenv("MOLA_ICP_KNN_Q4_LPQ")) k.knn_q4_lpq = geti("MOLA_ICP_KNN_Q4_LPQ") == 2 ? 2 : (geti("MOLA_ICP_KNN_Q4_LPQ") == 4 ? 4 : 0);
     k.q4 = std::getenv("MOLA_ICP_Q4") ? (geti("MOLA_ICP_Q4") != 0 ? 1 : 0) : -1;
     if (std::getenv("MOLA_ICP_Q4_LDS_BOXES_KB")) k.q4_lds_boxes_kb = geti("MOLA_ICP_Q4_LDS_BOXES_KB");
     k.quads = std::getenv("MOLA_ICP_QUADS") ? (geti("MOLA_ICP_QUADS") != 0 ? 1 : 0) : -1;
@@ -187,16 +189,26 @@ static size_t knn_coop_lds_box_limit(int list_len)
 }
 
 // k_knn_q4's box levels (kernels_knn_q4.hpp): what its own static LDS leaves at its launch bounds
-static size_t knn_q4_lds_box_limit(int list_len)
+static size_t knn_q4_lds_box_limit(int list_len, int lpq)
 {
-    const size_t st = knn_q4_static_lds(list_len);
-    const size_t a = lds_box_limit(st, knn_q4_workgroups_per_cu());
+    const size_t st = knn_q4_static_lds(list_len, lpq);
+    const size_t a = lds_box_limit(st, knn_q4_workgroups_per_cu(lpq));
     const size_t b = st + 1024 < (size_t)64 * 1024 ? (size_t)64 * 1024 - st - 1024 : 0;
     return a < b ? a : b;
 }
 // ... and whether a launch k_knn_coop would serve goes to k_knn_q4 instead (the diagnostic flavours are k_knn_coop's)
 constexpr double kKnnQ4MaxStep = 0.25;   // metres of pose step (HipWorkspace::match_planes)
-constexpr size_t kKnnQ4MaxQueries = 560000;
+constexpr size_t kKnnQ4MaxQueries4 = 560000, kKnnQ4MaxQueries2 = 3000000;   // ... at four lanes per query only (lists of ten) / with two available
+// k_knn_q4's lanes per query for a launch of `workgroups` 64-query workgroups: four while their waves (four each) fit the wave slots the kernel
+// has at four lanes per query; two beyond that -- half the waves, each ~1.3x as long: 20-iteration shipped aligns, ms per iteration four | two
+// lanes: 100k 0.054 | 0.051, 300k 0.098 | 0.084, 500k 0.136 | 0.120; 24 pairs of 100k in lockstep 1 774 | 2 156 pairs/s -- except a launch on
+// key-bootstrapped seeds of an odometry-size scan, which is bound by its insertions (a KITTI-like 120k scan: 95-100 | 119-122 us)
+static int knn_q4_lanes_per_query(int list_len, size_t workgroups, int num_cus, bool insertion_bound)
+{
+    if (g_knobs.knn_q4_lpq && knn_q4_has(list_len, g_knobs.knn_q4_lpq)) return g_knobs.knn_q4_lpq;
+    const size_t slots = (size_t)num_cus * 4u * (size_t)knn_q4_workgroups_per_cu(4);
+    return (workgroups * 4u > slots && !insertion_bound && knn_q4_has(list_len, 2)) ? 2 : 4;
+}
 static bool use_knn_q4(int list_len)
 {
     return g_knobs.knn_q4 != 0 && knn_q4_has(list_len) && g_knobs.debug_stats != 4 && g_knobs.debug_stats != 5;
@@ -1413,14 +1425,16 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     // four lanes per query (kernels_knn_q4.hpp) where the launch is as long as an item's chain: near the previous pose.  Far from it the lists change
     // wholesale, a launch is bound by its insertions and k_knn_coop's wider items are the better shape (a KITTI-like 120k pair, us per launch
     // k_knn_q4 / k_knn_coop by step: 2 m 218 / 172, 1 m 156 / 158, 0.3-0.8 m 178-180 / 169-171, 0.13 m 78 / 84, 0.05 m 66 / 68, <= 0.01 m 49-55 / 62-64).
-    // Between k_knn_coop's range and ~0.56M queries the alternative is the persistent kernel, which k_knn_q4 beats at any step (20-iteration shipped
-    // aligns, ms per iteration k_knn_q4 / persistent: 150k 0.069 / 0.083, 200k 0.075 / 0.097, 300k 0.097 / 0.109, 500k 0.136 / 0.150, 650k 0.167 / 0.156).
+    // Beyond k_knn_coop's range the alternative is the persistent kernel, which k_knn_q4 beats at any step up to ~3M queries with two lanes per query
+    // (20-iteration shipped aligns, ms per iteration k_knn_q4 | persistent: 150k 0.064 | 0.083, 300k 0.084 | 0.109, 650k 0.129 | 0.159, 1M 0.182 | 0.221,
+    // 2M 0.353 | 0.395, 3M 0.552 | 0.566) and up to 0.56M with four (lists of ten entries: 500k 0.136 | 0.150, 650k 0.167 | 0.156).
     const bool coop_size = (size_t)n_items64 <= (size_t)num_cus_ * 8;
     const bool knn_q4 = use_knn_q4((int)p.knn + 1) &&
-                        (g_knobs.knn_q4 == 1 || (g_knobs.knn_coop != 0 && (coop_size ? step <= kKnnQ4MaxStep : N_ <= kKnnQ4MaxQueries)));
+                        (g_knobs.knn_q4 == 1 || (g_knobs.knn_coop != 0 && (coop_size ? step <= kKnnQ4MaxStep : N_ <= (knn_q4_has((int)p.knn + 1, 2) ? kKnnQ4MaxQueries2 : kKnnQ4MaxQueries4))));
     const bool knn_coop = wide_knn || knn_q4 || (g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : coop_size);   // one workgroup per item (either kernel)
     // the upper box levels in LDS while that costs the kernel no workgroup per CU (lds_box_limit), else read from global memory
-    const int lds_boxes = box_bytes <= (knn_q4 ? knn_q4_lds_box_limit((int)p.knn + 1) : (knn_coop ? knn_coop_lds_box_limit((int)p.knn + 1) : lds_box_limit(persistent_static_lds(), 4))) ? 1 : 0;
+    const int kq4_lpq = knn_q4 ? knn_q4_lanes_per_query((int)p.knn + 1, (size_t)n_items64, num_cus_, coop_size && bootstrapped) : 4;
+    const int lds_boxes = box_bytes <= (knn_q4 ? knn_q4_lds_box_limit((int)p.knn + 1, kq4_lpq) : (knn_coop ? knn_coop_lds_box_limit((int)p.knn + 1) : lds_box_limit(persistent_static_lds(), 4))) ? 1 : 0;
     const size_t dyn_lds = lds_boxes ? box_bytes : 0;
     // Queries per lane: ONE (64-query items).  A lane's K-entry lists for two queries push the insertion flavour to 168
     // VGPR + spills; with one query per lane there are none, items are twice as many and half as long -- better balance
@@ -1561,7 +1575,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         kp.changed_items = tq + kQueues * kQueueStride + 1;
         kp.cost = g_knobs.debug_stats == 5 ? knn_cost_.as<unsigned int>() : nullptr;   // (diagnostics only: two clock reads and a store per item)
         if (knn_q4) {
-            HIPCHK(knn_q4_launch(stream_, (int)p.knn + 1, kb, xcd_grid(n_items64), dyn_lds, thr2, thr2x, p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, cert.stats));
+            HIPCHK(knn_q4_launch(stream_, (int)p.knn + 1, kb, xcd_grid(n_items64), dyn_lds, thr2, thr2x, p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, cert.stats, kq4_lpq));
         } else if (g_knobs.debug_stats == 4 && p.knn == 6) {   // diagnostics: where the waves of every item spend their cycles
             DevBuf dg;
             if ((rc = dg.reserve(sizeof(unsigned long long) * kKnnDiagWords * 4 * (size_t)n_items64))) return rc;
@@ -1713,8 +1727,8 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         for (int k = 0; k < kStatSlots; ++k) { staged64 += stats_host_[(size_t)k * kStatStride]; certified += stats_host_[(size_t)k * kStatStride + 1]; skipped += stats_host_[(size_t)k * kStatStride + 2]; }
         HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, stream_));
         std::fprintf(stderr, "[mola_icp debug] plane matcher launch: N=%zu items=%d %s seed=%d cert=%d bootstrapped=%d step=%.5f m | certified queries %llu (%.1f %%), items that skipped the sweep %llu (%.1f %%), pairs/query %.1f\n",
-                     N_, n_items64, knn_q4 ? "q4 (sweeps skipped: per 16-query wave)" : (knn_coop ? "coop" : (verify ? "persistent+count" : "persistent")), knn_seed, cert.on, (int)bootstrapped, step, certified,
-                     100.0 * (double)certified / (double)N_, skipped, 100.0 * (double)skipped / (double)(knn_q4 ? 4 * n_items64 : n_items64), 64.0 * (double)staged64 / (double)N_);
+                     N_, n_items64, knn_q4 ? (kq4_lpq == 2 ? "q4, two lanes per query (sweeps skipped: per 32-query wave)" : "q4 (sweeps skipped: per 16-query wave)") : (knn_coop ? "coop" : (verify ? "persistent+count" : "persistent")), knn_seed, cert.on, (int)bootstrapped, step, certified,
+                     100.0 * (double)certified / (double)N_, skipped, 100.0 * (double)skipped / (double)(knn_q4 ? kq4_lpq * n_items64 : n_items64), 64.0 * (double)staged64 / (double)N_);
     }
     last_kernel_ = MOLA_ICP_NN_TILED;
     planes_knn_ = (int)p.knn;
@@ -2870,14 +2884,15 @@ int HipBatch::match_planes(const uint8_t* active, const Mat4* T, const mola_icp_
         }
         if (n == 0) break;
         const bool knn_q4 = use_knn_q4((int)p.knn + 1);
-        const int lds_boxes = max_box_bytes <= (knn_q4 ? knn_q4_lds_box_limit((int)p.knn + 1) : knn_coop_lds_box_limit((int)p.knn + 1)) ? 1 : 0;
+        const int kq4_lpq = knn_q4 ? knn_q4_lanes_per_query((int)p.knn + 1, (size_t)max_items * (size_t)n, ws_.num_cus_, false) : 4;
+        const int lds_boxes = max_box_bytes <= (knn_q4 ? knn_q4_lds_box_limit((int)p.knn + 1, kq4_lpq) : knn_coop_lds_box_limit((int)p.knn + 1)) ? 1 : 0;
         const size_t dyn_lds = lds_boxes ? max_box_bytes : 0;
         unsigned long long* staged = ws_.profiling_ ? sc_.stats.as<unsigned long long>() : nullptr;
 #define MOLA_LAUNCH_KNN_COOP_B(KK)                                                                                          \
     hipLaunchKernelGGL((k_knn_coop<KK, kKnnMaxBatch>), dim3(xcd_grid(max_items), n), dim3(256), dyn_lds, ws_.stream_, kb, thr2, thr2x, \
                        p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, (unsigned long long*)nullptr, (unsigned long long*)nullptr)
         if (knn_q4) {
-            HIPCHK(knn_q4_launch_batch(ws_.stream_, (int)p.knn + 1, kb, xcd_grid(max_items), n, dyn_lds, thr2, thr2x, p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, nullptr));
+            HIPCHK(knn_q4_launch_batch(ws_.stream_, (int)p.knn + 1, kb, xcd_grid(max_items), n, dyn_lds, thr2, thr2x, p.matcher_threshold, plane_eig_arg(p), staged, lds_boxes, nullptr, kq4_lpq));
         } else
         switch (p.knn) {
             case 3: MOLA_LAUNCH_KNN_COOP_B(4); break;

@@ -37,7 +37,7 @@ __device__ unsigned long long* g_kq4_dbg = nullptr;
 #else
 #define KQ4_STAMP(k) do { } while (0)
 #endif
-// a wave's records for the epilogue: row r of query q at word 16 * wave + 16 * r + q of its ring (the skew by the wave keeps the 64
+// a wave's records for the epilogue: row r of query q at word QW * wave + QW * r + q of its ring, QW = its queries (the skew by the wave keeps the 64
 // lanes of the epilogue on 64 different banks); rows: key low / key high / position per entry, the moved query, the certificate
 // (a wave-uniform 64-bit mask the compiler may have chosen to keep in vector registers -- it does with the scan's state here -- named
 //  as the scalar it is: free where the value already lives in scalar registers)
@@ -50,14 +50,31 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long m)
 __device__ __forceinline__ int kq4_ff1(unsigned long long m) { return sff1_b64(uniform64(m)); }
 __device__ __forceinline__ void kq4_bitset0(unsigned long long& m, int bit) { m = uniform64(m); sbitset0_b64(m, bit); }
 template <int K> constexpr int kq4_rows() { return 3 * K + 4; }
-static_assert(16 * 3 + 16 * kq4_rows<17>() <= kKq4RingFloats, "the records of a wave must fit its ring");
+// LPQ lanes per query: 4 (16 queries per wave, four waves per workgroup) or 2 (32 queries per wave, two waves per workgroup: half as many
+// waves of about 1.3x the chain -- for launches whose waves at four lanes per query outnumber the wave slots)
+template <int LPQ> constexpr int kq4_wg_per_cu() { return kKq4WorkgroupsPerCu * (4 / LPQ); }   // the same waves per SIMD either way
+// min / max over the wave's queries (every sub-lane of a query holds the same value) as a scalar
+template <int LPQ> __device__ __forceinline__ float wave_min_qn(float v)
+{
+    if constexpr (LPQ == 2) v = fminf(v, dpp_f<kDppRor2>(v));
+    return wave_min_q(v);
+}
+template <int LPQ> __device__ __forceinline__ float wave_max_qn(float v)
+{
+    if constexpr (LPQ == 2) v = fmaxf(v, dpp_f<kDppRor2>(v));
+    return wave_max_q(v);
+}
 
-template <int K /*list length: knn + 1*/, int KMAX /*problems per launch: blockIdx.y*/>
-__global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBatch<KMAX> batch, float thr2, float thr2x, double threshold, double plane_eig_thr,
+template <int K /*list length: knn + 1*/, int KMAX /*problems per launch: blockIdx.y*/, int LPQ = 4 /*lanes per query*/>
+__global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD -- with four-wave workgroups also workgroups per CU*/) void k_knn_q4(const KnnBatch<KMAX> batch, float thr2, float thr2x, double threshold, double plane_eig_thr,
                                                                      unsigned long long* __restrict__ staged_total /*slotted, may be null*/, int lds_boxes,
                                                                      unsigned long long* __restrict__ cert_stats /*diagnostics, may be null*/)
 {
-    __shared__ __attribute__((aligned(16))) float s_ring[4][kKq4RingFloats];
+    constexpr int QW = 64 / LPQ;   // queries per wave
+    constexpr int NW = LPQ;        // waves per workgroup (64 queries)
+    static_assert(LPQ == 4 || LPQ == 2, "four or two lanes per query");
+    static_assert(QW * (NW - 1) + QW * kq4_rows<K>() <= kKq4RingFloats, "the records of a wave must fit its ring");
+    __shared__ __attribute__((aligned(16))) float s_ring[NW][kKq4RingFloats];
     __shared__ int s_done;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63;
@@ -71,13 +88,13 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
     if (lane == 0) ring[0] = 0.f;   // (a plain store to the ring: the tiles arrive by LDS-DMA, which the compiler does not count as one)
     if (threadIdx.x == 0) s_done = 0;
 #ifdef MOLA_KQ4_DIAG
-    unsigned long long* dbg_w = g_kq4_dbg && blockIdx.y == 0 && blockIdx.x < 2048 && lane == 0 ? g_kq4_dbg + 16 * (size_t)(blockIdx.x * 4 + wave) : nullptr;
+    unsigned long long* dbg_w = g_kq4_dbg && blockIdx.y == 0 && blockIdx.x < 2048 && lane == 0 ? g_kq4_dbg + 16 * (size_t)(blockIdx.x * NW + wave) : nullptr;
 #endif
     KQ4_STAMP(0);
 
     // ---- round trip A: the lane's query, its stored list (position, coordinates, original index per entry) and its certificate ----
-    const int s = lane & 3, q = lane >> 2;
-    const int qi = item * 64 + wave * 16 + q;
+    const int s = lane & (LPQ - 1), q = lane / LPQ;
+    const int qi = item * 64 + wave * QW + q;
     const bool valid = qi < N;
     const int ic = valid ? qi : N - 1;
     const unsigned int ic4 = (unsigned int)ic * 4u;
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int tq = open ? (pass ? tq1 : tq0) : -1;
-                unsigned long long rem = __ballot(tq >= 0 && tq != pre0 && tq != pre1 && tq != pre2 && tq != pre3) & 0x1111111111111111ull;
+                unsigned long long rem = __ballot(tq >= 0 && tq != pre0 && tq != pre1 && tq != pre2 && tq != pre3) & (LPQ == 4 ? 0x1111111111111111ull : 0x5555555555555555ull);   // one lane per query
                 while (rem && n_tl < kQ4Bank) {
                     const int t = __builtin_amdgcn_readlane(tq, kq4_ff1(rem));
                     rem &= ~__ballot(tq == t);
@@ -216,18 +233,18 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
         float reach = __builtin_amdgcn_sqrtf(kb * 1.000002f) * 1.00001f + fmaxf(fabsf(qx), fmaxf(fabsf(qy), fabsf(qz))) * 2.4e-7f + 1e-30f;
         if (!open) reach = -1.0f;
         Box w;
-        w.lo[0] = wave_min_q(reach >= 0.f ? qx - reach : INFINITY); w.hi[0] = wave_max_q(reach >= 0.f ? qx + reach : -INFINITY);
-        w.lo[1] = wave_min_q(reach >= 0.f ? qy - reach : INFINITY); w.hi[1] = wave_max_q(reach >= 0.f ? qy + reach : -INFINITY);
-        w.lo[2] = wave_min_q(reach >= 0.f ? qz - reach : INFINITY); w.hi[2] = wave_max_q(reach >= 0.f ? qz + reach : -INFINITY);
+        w.lo[0] = wave_min_qn<LPQ>(reach >= 0.f ? qx - reach : INFINITY); w.hi[0] = wave_max_qn<LPQ>(reach >= 0.f ? qx + reach : -INFINITY);
+        w.lo[1] = wave_min_qn<LPQ>(reach >= 0.f ? qy - reach : INFINITY); w.hi[1] = wave_max_qn<LPQ>(reach >= 0.f ? qy + reach : -INFINITY);
+        w.lo[2] = wave_min_qn<LPQ>(reach >= 0.f ? qz - reach : INFINITY); w.hi[2] = wave_max_qn<LPQ>(reach >= 0.f ? qz + reach : -INFINITY);
 
         // the query's live bound: the smallest of its four sub-lanes' (all >= 0, or all -1: the bit patterns order as integers)
         auto live_bound = [&]() -> float {
             int v = __float_as_int(kb);
             v = min(v, dpp_i<kDppXor1>(v));
-            v = min(v, dpp_i<kDppXor2>(v));
+            if constexpr (LPQ == 4) v = min(v, dpp_i<kDppXor2>(v));
             return __int_as_float(v);
         };
-        // one group of box tests: the next (up to) four candidates of `cand`, sub-lane s of every query takes candidate s (k_nn_q4)
+        // one group of box tests: the next (up to) LPQ candidates of `cand`, sub-lane s of every query takes candidate s (k_nn_q4)
         const int s8 = 8 * s;
         auto test4 = [&](float r0, float r1, float r2, float r3, float r4, float r5, unsigned long long& cand, float bound, auto&& on_pass) {
 #ifdef MOLA_KQ4_DIAG
@@ -235,9 +252,13 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
 #endif
             const int c0 = kq4_ff1(cand); kq4_bitset0(cand, c0);
             const int c1 = kq4_ff1(cand); kq4_bitset0(cand, c1);
-            const int c2 = kq4_ff1(cand); kq4_bitset0(cand, c2);
-            const int c3 = kq4_ff1(cand); kq4_bitset0(cand, c3);
-            const unsigned int pack = ((unsigned int)c0 & 0xffu) | (((unsigned int)c1 & 0xffu) << 8) | (((unsigned int)c2 & 0xffu) << 16) | ((unsigned int)c3 << 24);
+            int c2 = -1, c3 = -1;
+            if constexpr (LPQ == 4) {
+                c2 = kq4_ff1(cand); kq4_bitset0(cand, c2);
+                c3 = kq4_ff1(cand); kq4_bitset0(cand, c3);
+            }
+            const unsigned int pack = LPQ == 4 ? (((unsigned int)c0 & 0xffu) | (((unsigned int)c1 & 0xffu) << 8) | (((unsigned int)c2 & 0xffu) << 16) | ((unsigned int)c3 << 24))
+                                               : (((unsigned int)c0 & 0xffu) | (((unsigned int)c1 & 0xffu) << 8));
             const unsigned int sel = __builtin_amdgcn_ubfe(pack, (unsigned int)s8, 8u);
             const int src = (int)(sel << 2);
             const float m0 = bperm_f(src, r0), m1 = bperm_f(src, r1), m2 = bperm_f(src, r2);
@@ -246,17 +267,23 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
             const float ay = qy - __builtin_amdgcn_fmed3f(qy, m1, m4);
             const float az = qz - __builtin_amdgcn_fmed3f(qz, m2, m5);
             const unsigned long long m = __ballot(sel != 0xffu && fmaf(az, az, fmaf(ay, ay, ax * ax)) <= bound);
-            unsigned int P = (unsigned int)m | (unsigned int)(m >> 32);
+            unsigned int P = (unsigned int)m | (unsigned int)(m >> 32);   // candidate j passed iff a lane with sub-lane j is set
             P |= P >> 16; P |= P >> 8; P |= P >> 4;
+            if constexpr (LPQ == 2) P |= P >> 2;
             if (P & 1u) on_pass(c0);
             if (P & 2u) on_pass(c1);
-            if (P & 4u) on_pass(c2);
-            if (P & 8u) on_pass(c3);
+            if constexpr (LPQ == 4) {
+                if (P & 4u) on_pass(c2);
+                if (P & 8u) on_pass(c3);
+            }
         };
-        // the lane's 8 points of one tile (LDS: x[32] y[32] z[32] index[32]) against its query's list
+        // the lane's 32 / LPQ points of one tile (LDS: x[32] y[32] z[32] index[32]), eight at a time, against its query's list
         auto eval_tile = [&](int t, const float* b) {
-            const float* p = b + s8;
-            const int gpos = t * kTileG + s8;
+#pragma unroll
+          for (int h = 0; h < 4 / LPQ; ++h) {
+            const int g8 = 8 * ((4 / LPQ) * s + h);
+            const float* p = b + g8;
+            const int gpos = t * kTileG + g8;
             const float4 X0 = *reinterpret_cast<const float4*>(p), X1 = *reinterpret_cast<const float4*>(p + 4);
             const float4 Y0 = *reinterpret_cast<const float4*>(p + 32), Y1 = *reinterpret_cast<const float4*>(p + 36);
             const float4 Z0 = *reinterpret_cast<const float4*>(p + 64), Z1 = *reinterpret_cast<const float4*>(p + 68);
@@ -294,6 +321,7 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
                 }
                 kb = open ? kd_of(K - 1) : -1.0f;   // live bound (see k_knn_planes)
             }
+          }
         };
         auto run_tiles = [&]() {
             if (n_tl == 0) return;
@@ -418,7 +446,7 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
         // ---- the four lists of a query become one: two symmetric steps, both partners end with the same merged list ----
         if (__any(inserted)) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
+            for (int st = 0; st < (LPQ == 4 ? 2 : 1); ++st) {
                 unsigned int plo[K], phi[K];
                 int pp[K];
 #pragma unroll
@@ -445,29 +473,29 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
 
     // ---- the wave's records for the epilogue (row r by sub-lane r & 3: every sub-lane holds the merged list) ----
     {
-        int* rec = reinterpret_cast<int*>(ring) + 16 * wave + q;
+        int* rec = reinterpret_cast<int*>(ring) + QW * wave + q;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if (s == ((3 * j) & 3)) rec[16 * (3 * j)] = (int)(unsigned int)(kk[j] & 0xffffffffull);
-            if (s == ((3 * j + 1) & 3)) rec[16 * (3 * j + 1)] = (int)(unsigned int)(kk[j] >> 32);
-            if (s == ((3 * j + 2) & 3)) rec[16 * (3 * j + 2)] = kp[j];
+            if (s == ((3 * j) & (LPQ - 1))) rec[QW * (3 * j)] = (int)(unsigned int)(kk[j] & 0xffffffffull);
+            if (s == ((3 * j + 1) & (LPQ - 1))) rec[QW * (3 * j + 1)] = (int)(unsigned int)(kk[j] >> 32);
+            if (s == ((3 * j + 2) & (LPQ - 1))) rec[QW * (3 * j + 2)] = kp[j];
         }
-        if (s == ((3 * K) & 3)) rec[16 * (3 * K)] = __float_as_int(qx);
-        if (s == ((3 * K + 1) & 3)) rec[16 * (3 * K + 1)] = __float_as_int(qy);
-        if (s == ((3 * K + 2) & 3)) rec[16 * (3 * K + 2)] = __float_as_int(qz);
-        if (s == ((3 * K + 3) & 3)) rec[16 * (3 * K + 3)] = __float_as_int(lbw);
+        if (s == ((3 * K) & (LPQ - 1))) rec[QW * (3 * K)] = __float_as_int(qx);
+        if (s == ((3 * K + 1) & (LPQ - 1))) rec[QW * (3 * K + 1)] = __float_as_int(qy);
+        if (s == ((3 * K + 2) & (LPQ - 1))) rec[QW * (3 * K + 2)] = __float_as_int(qz);
+        if (s == ((3 * K + 3) & (LPQ - 1))) rec[QW * (3 * K + 3)] = __float_as_int(lbw);
     }
-    if (lane == 0 && tiles && staged_total)   // units of 64 (query, point) pairs: a tile = 32 points x 16 queries
-        atomicAdd(staged_total + (size_t)((blockIdx.x * 4 + wave) & (kStatSlots - 1)) * kStatStride, (unsigned long long)tiles * 8ull);
+    if (lane == 0 && tiles && staged_total)   // units of 64 (query, point) pairs: a tile = 32 points x QW queries
+        atomicAdd(staged_total + (size_t)((blockIdx.x * NW + wave) & (kStatSlots - 1)) * kStatStride, (unsigned long long)tiles * (unsigned long long)(QW / 2));
     if (cert_stats && lane == 0 && cert_mask) {   // [1] certified queries, [2] sweeps skipped -- per 16-query wave here, not per 64-query item
-        unsigned long long* st = cert_stats + (size_t)((blockIdx.x * 4 + wave) & (kStatSlots - 1)) * kStatStride;
-        atomicAdd(st + 1, (unsigned long long)(__popcll(cert_mask) >> 2));
+        unsigned long long* st = cert_stats + (size_t)((blockIdx.x * NW + wave) & (kStatSlots - 1)) * kStatStride;
+        atomicAdd(st + 1, (unsigned long long)(__popcll(cert_mask) / LPQ));
         if (skip_sweep) atomicAdd(st + 2, 1ull);
     }
     KQ4_STAMP(4);
 #ifdef MOLA_KQ4_DIAG
     if (dbg_w) {
-        dbg_w[6] = (unsigned long long)tiles | ((unsigned long long)(skip_sweep ? 1 : 0) << 32) | ((unsigned long long)(__popcll(cert_mask) >> 2) << 40);
+        dbg_w[6] = (unsigned long long)tiles | ((unsigned long long)(skip_sweep ? 1 : 0) << 32) | ((unsigned long long)(__popcll(cert_mask) / LPQ) << 40);
         dbg_w[8] = dg_slow; dbg_w[9] = dg_key; dbg_w[10] = dg_dup; dbg_w[11] = dg_ins; dbg_w[12] = dg_tests;
     }
 #endif
@@ -475,24 +503,24 @@ __global__ __launch_bounds__(256, kKq4WorkgroupsPerCu) void k_knn_q4(const KnnBa
     int ticket = 0;
     if (lane == 0) ticket = atomicAdd(&s_done, 1);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != 3) return;
+    if (ticket != NW - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 
     // ---- the LAST wave of the workgroup: the plane epilogue of its 64 queries, one per lane (as k_knn_coop's leader) ----
     {
-        const int w2 = lane >> 4, q2 = lane & 15;
-        const int* rec = reinterpret_cast<const int*>(&s_ring[w2][0]) + 16 * w2 + q2;
+        const int w2 = lane / QW, q2 = lane % QW;
+        const int* rec = reinterpret_cast<const int*>(&s_ring[w2][0]) + QW * w2 + q2;
         int ep[K];
         float ed[K];
         unsigned int eo[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            eo[j] = (unsigned int)rec[16 * (3 * j)];
-            ed[j] = __int_as_float(rec[16 * (3 * j + 1)]);
-            ep[j] = rec[16 * (3 * j + 2)];
+            eo[j] = (unsigned int)rec[QW * (3 * j)];
+            ed[j] = __int_as_float(rec[QW * (3 * j + 1)]);
+            ep[j] = rec[QW * (3 * j + 2)];
         }
-        const float ex = __int_as_float(rec[16 * (3 * K)]), ey = __int_as_float(rec[16 * (3 * K + 1)]), ez = __int_as_float(rec[16 * (3 * K + 2)]);
-        const float elb = __int_as_float(rec[16 * (3 * K + 3)]);
+        const float ex = __int_as_float(rec[QW * (3 * K)]), ey = __int_as_float(rec[QW * (3 * K + 1)]), ez = __int_as_float(rec[QW * (3 * K + 2)]);
+        const float elb = __int_as_float(rec[QW * (3 * K + 3)]);
         const int qe = item * 64 + lane;
         if (qe < N) pb.lb[qe] = elb > 0.f ? elb : sqrtf(ed[K - 1]) * kCertDown;
         const bool changed = plane_epilogue<K>(mp, ep, ed, eo, ex, ey, ez, qe, N, thr2, threshold, plane_eig_thr, pb.out, pb.cache, pb.seeds, use_seed, pb.use_cache);

@@ -12,26 +12,37 @@ namespace mola_icp_amd {
 
 // list lengths 4 .. 10 = knn 3 .. 9 (the reference's settings use 6: params/icp-settings-regular.yaml:37); longer lists keep k_knn_coop
 #define MOLA_KQ4_LENGTHS(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+// ... at two lanes per query 4 .. 9 (a wave's 32 lists must fit its ring)
+#define MOLA_KQ4_LENGTHS2(X) X(4) X(5) X(6) X(7) X(8) X(9)
 
-bool knn_q4_has(int list_len) { return list_len >= 4 && list_len <= 10; }
-int knn_q4_workgroups_per_cu() { return kKq4WorkgroupsPerCu; }
+bool knn_q4_has(int list_len, int lpq) { return list_len >= 4 && list_len <= (lpq == 2 ? 9 : 10) && (lpq == 2 || lpq == 4); }
+int knn_q4_workgroups_per_cu(int lpq) { return lpq == 2 ? kq4_wg_per_cu<2>() : kq4_wg_per_cu<4>(); }
 
-size_t knn_q4_static_lds(int list_len)
+size_t knn_q4_static_lds(int list_len, int lpq)
 {
-    static size_t bytes[18] = {};
-    if (!knn_q4_has(list_len)) return 0;
-    if (!bytes[list_len]) {
+    static size_t bytes[2][18] = {};
+    if (!knn_q4_has(list_len, lpq)) return 0;
+    size_t& b = bytes[lpq == 2 ? 1 : 0][list_len];
+    if (!b) {
         hipFuncAttributes fa{};
         hipError_t e = hipErrorInvalidValue;
-        switch (list_len) {
-#define X(KK) case KK: e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_knn_q4<KK, 1>)); break;
-            MOLA_KQ4_LENGTHS(X)
+        if (lpq == 2) {
+            switch (list_len) {
+#define X(KK) case KK: e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_knn_q4<KK, 1, 2>)); break;
+                MOLA_KQ4_LENGTHS2(X)
 #undef X
+            }
+        } else {
+            switch (list_len) {
+#define X(KK) case KK: e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_knn_q4<KK, 1, 4>)); break;
+                MOLA_KQ4_LENGTHS(X)
+#undef X
+            }
         }
-        bytes[list_len] = e == hipSuccess && fa.sharedSizeBytes ? fa.sharedSizeBytes : sizeof(float) * 4 * kKq4RingFloats + 16;
+        b = e == hipSuccess && fa.sharedSizeBytes ? fa.sharedSizeBytes : sizeof(float) * (size_t)lpq * kKq4RingFloats + 16;
         (void)hipGetLastError();
     }
-    return bytes[list_len];
+    return b;
 }
 
 #ifdef MOLA_KQ4_DIAG
@@ -87,32 +98,48 @@ static void kq4_diag_report(int n_waves, int use_seed, int cert_on)
 #endif
 
 hipError_t knn_q4_launch(hipStream_t stream, int list_len, const KnnBatch<1>& b, int grid, size_t dyn_lds, float thr2, float thr2x, double threshold,
-                         double plane_eig_thr, unsigned long long* staged, int lds_boxes, unsigned long long* cert_stats)
+                         double plane_eig_thr, unsigned long long* staged, int lds_boxes, unsigned long long* cert_stats, int lpq)
 {
 #ifdef MOLA_KQ4_DIAG
     (void)hipMemsetAsync(kq4_dbg_buf(), 0, 16 * 8192 * sizeof(unsigned long long), stream);
 #endif
-    switch (list_len) {
-#define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, 1>), dim3(grid), dim3(256), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
-        MOLA_KQ4_LENGTHS(X)
+    if (!knn_q4_has(list_len, lpq)) return hipErrorInvalidValue;
+    if (lpq == 2) {
+        switch (list_len) {
+#define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, 1, 2>), dim3(grid), dim3(128), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
+            MOLA_KQ4_LENGTHS2(X)
 #undef X
-        default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (list_len) {
+#define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, 1, 4>), dim3(grid), dim3(256), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
+            MOLA_KQ4_LENGTHS(X)
+#undef X
+        }
     }
     const hipError_t e = hipGetLastError();
 #ifdef MOLA_KQ4_DIAG
-    kq4_diag_report(grid * 4 < 8192 ? grid * 4 : 8192, b.p[0].use_seed, b.p[0].cert_on);
+    kq4_diag_report(grid * lpq < 8192 ? grid * lpq : 8192, b.p[0].use_seed, b.p[0].cert_on);
 #endif
     return e;
 }
 
 hipError_t knn_q4_launch_batch(hipStream_t stream, int list_len, const KnnBatch<kKnnMaxBatch>& b, int grid_x, int n_problems, size_t dyn_lds, float thr2,
-                               float thr2x, double threshold, double plane_eig_thr, unsigned long long* staged, int lds_boxes, unsigned long long* cert_stats)
+                               float thr2x, double threshold, double plane_eig_thr, unsigned long long* staged, int lds_boxes, unsigned long long* cert_stats, int lpq)
 {
-    switch (list_len) {
-#define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, kKnnMaxBatch>), dim3(grid_x, n_problems), dim3(256), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
-        MOLA_KQ4_LENGTHS(X)
+    if (!knn_q4_has(list_len, lpq)) return hipErrorInvalidValue;
+    if (lpq == 2) {
+        switch (list_len) {
+#define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, kKnnMaxBatch, 2>), dim3(grid_x, n_problems), dim3(128), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
+            MOLA_KQ4_LENGTHS2(X)
 #undef X
-        default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (list_len) {
+#define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, kKnnMaxBatch, 4>), dim3(grid_x, n_problems), dim3(256), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
+            MOLA_KQ4_LENGTHS(X)
+#undef X
+        }
     }
     return hipGetLastError();
 }
