@@ -562,7 +562,7 @@ def main():
         bytes_alg = 12.0 * N + 12.0 * M + (112.0 + 4.0 * (int(ps.knn) + 1) + 4.0) * N
         pairs_it = rs.nn_pairs_evaluated / max(1, int(rs.nIterations))
         roof_s = {"bound": "hbm", "achieved": bytes_alg / (it_ms * 1e-3) / 1e9 if it_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                  "kernel": "k_knn_q4 (two lanes per query)" if N <= 3_000_000 and int(ps.knn) <= 8 else "k_knn_planes", "matcher_ms_per_iteration": it_ms, "bytes_per_iteration": bytes_alg,
+                  "kernel": "k_knn_q4 (one lane per query)" if N > 245_000 and int(ps.knn) <= 9 else "k_knn_q4", "matcher_ms_per_iteration": it_ms, "bytes_per_iteration": bytes_alg,
                   "launches": int(rs.n_nn_launches), "iterations": int(rs.nIterations),
                   "note": f"matcher time of the {int(rs.nIterations)}-iteration run (HIP events around its {rs.n_nn_launches} launches: key bootstrap, "
                           "list-seeded searches, certified / counting launches) divided by the ITERATIONS, first align on the pair "

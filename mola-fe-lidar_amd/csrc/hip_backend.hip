@@ -82,8 +82,8 @@ struct Knobs {
     int lds_boxes_kb = 40;        // MOLA_ICP_LDS_BOXES_KB: the cooperative / plane kernels keep the upper box levels in LDS up to this size (tuning knob; <= 40)
     int quad_lds_boxes_kb = 22;   // MOLA_ICP_QUAD_LDS_BOXES_KB: the quad flavour keeps the upper box levels in LDS up to this size (tuning knob)
     int q4 = -1;               // MOLA_ICP_Q4 (-1 = by cloud size, 0 = never, 1 = always: k_nn_q4, four lanes per query, instead of k_nn_coop / k_nn_tiled)
-    int knn_q4 = -1;           // MOLA_ICP_KNN_Q4 (-1 = k_knn_coop's sizes near the previous pose + every launch up to 3M queries beyond them; 0 = never; 1 = every launch): k_knn_q4, four / two lanes per query
-    int knn_q4_lpq = 0;        // MOLA_ICP_KNN_Q4_LPQ (0 = by the launch's size, 2 / 4: k_knn_q4's lanes per query)
+    int knn_q4 = -1;           // MOLA_ICP_KNN_Q4 (-1 = k_knn_coop's sizes near the previous pose + every launch beyond them; 0 = never; 1 = every launch): k_knn_q4, four / two / one lane(s) per query
+    int knn_q4_lpq = 0;        // MOLA_ICP_KNN_Q4_LPQ (0 = by the launch's size, 1 / 2 / 4: k_knn_q4's lanes per query)
     int q4_lds_boxes_kb = -1;  // MOLA_ICP_Q4_LDS_BOXES_KB: k_nn_q4 keeps the upper box levels in LDS up to this size (-1: what costs it no workgroup per CU)
     int quads = -1;            // MOLA_ICP_QUADS (-1 = by cloud sizes, 0 = never, 1 = always: k_nn_tiled's quad flavour)
     bool no_stream_priority = false;   // MOLA_ICP_NO_STREAM_PRIORITY: every workspace's streams at the default priority (A/B of bench.py's mixed_load leg)
@@ -121,7 +121,7 @@ static Knobs read_knobs()
     if (std::getenv("MOLA_ICP_LDS_BOXES_KB")) { k.lds_boxes_kb = geti("MOLA_ICP_LDS_BOXES_KB"); if (k.lds_boxes_kb > 40) k.lds_boxes_kb = 40; if (k.lds_boxes_kb < 0) k.lds_boxes_kb = 0; }
     if (std::getenv("MOLA_ICP_QUAD_LDS_BOXES_KB")) k.quad_lds_boxes_kb = geti("MOLA_ICP_QUAD_LDS_BOXES_KB");
     k.knn_q4 = std::getenv("MOLA_ICP_KNN_Q4") ? (geti("MOLA_ICP_KNN_Q4") != 0 ? 1 : 0) : -1;
-    if (std::getenv("MOLA_ICP_KNN_Q4_LPQ")) k.knn_q4_lpq = geti("MOLA_ICP_KNN_Q4_LPQ") == 2 ? 2 : (geti("MOLA_ICP_KNN_Q4_LPQ") == 4 ? 4 : 0);
+    if (std::getenv("MOLA_ICP_KNN_Q4_LPQ")) k.knn_q4_lpq = geti("MOLA_ICP_KNN_Q4_LPQ") == 2 ? 2 : (geti("MOLA_ICP_KNN_Q4_LPQ") == 4 ? 4 : (geti("MOLA_ICP_KNN_Q4_LPQ") == 1 ? 1 : 0));
     k.q4 = std::getenv("MOLA_ICP_Q4") ? (geti("MOLA_ICP_Q4") != 0 ? 1 : 0) : -1;
     if (std::getenv("MOLA_ICP_Q4_LDS_BOXES_KB")) k.q4_lds_boxes_kb = geti("MOLA_ICP_Q4_LDS_BOXES_KB");
     k.quads = std::getenv("MOLA_ICP_QUADS") ? (geti("MOLA_ICP_QUADS") != 0 ? 1 : 0) : -1;
@@ -198,16 +198,20 @@ static size_t knn_q4_lds_box_limit(int list_len, int lpq)
 }
 // ... and whether a launch k_knn_coop would serve goes to k_knn_q4 instead (the diagnostic flavours are k_knn_coop's)
 constexpr double kKnnQ4MaxStep = 0.25;   // metres of pose step (HipWorkspace::match_planes)
-constexpr size_t kKnnQ4MaxQueries4 = 560000, kKnnQ4MaxQueries2 = 3000000;   // ... at four lanes per query only (lists of ten) / with two available
-// k_knn_q4's lanes per query for a launch of `workgroups` 64-query workgroups: four while their waves (four each) fit the wave slots the kernel
-// has at four lanes per query; two beyond that -- half the waves, each ~1.3x as long: 20-iteration shipped aligns, ms per iteration four | two
-// lanes: 100k 0.054 | 0.051, 300k 0.098 | 0.084, 500k 0.136 | 0.120; 24 pairs of 100k in lockstep 1 774 | 2 156 pairs/s -- except a launch on
-// key-bootstrapped seeds of an odometry-size scan, which is bound by its insertions (a KITTI-like 120k scan: 95-100 | 119-122 us)
+constexpr size_t kKnnQ4MaxQueries = 16000000;   // (beyond: the persistent kernel -- untested territory for k_knn_q4, not a measured crossover)
+// k_knn_q4's lanes per query for a launch of `workgroups` 64-query workgroups.  FOUR while their waves (four each) fit the wave slots the kernel
+// has, and for a launch on key-bootstrapped seeds of an odometry-size scan, which is bound by its insertions (a KITTI-like 120k scan: 95-100 us at
+// four lanes, 119-122 at two).  Beyond that TWO -- half the waves, each ~1.3x as long -- up to ~245k queries, then ONE (a wave = a whole row of 64,
+// no lists to merge, the epilogue from registers).  20-iteration shipped aligns, ms per iteration four | two | one lane(s): 100k 0.054 | 0.051 | -,
+// 120k - | 0.057 | 0.061, 300k 0.098 | 0.085 | 0.079, 1M 0.262 | 0.181 | 0.169, 3M - | 0.547 | 0.490, 5M - | 0.967 | 0.849 (the persistent
+// k_knn_planes: 1M 0.221, 3M 0.566, 5M 0.938); 24 pairs of 100k in lockstep 1 774 | 2 196 | 2 254 pairs/s.
 static int knn_q4_lanes_per_query(int list_len, size_t workgroups, int num_cus, bool insertion_bound)
 {
     if (g_knobs.knn_q4_lpq && knn_q4_has(list_len, g_knobs.knn_q4_lpq)) return g_knobs.knn_q4_lpq;
     const size_t slots = (size_t)num_cus * 4u * (size_t)knn_q4_workgroups_per_cu(4);
-    return (workgroups * 4u > slots && !insertion_bound && knn_q4_has(list_len, 2)) ? 2 : 4;
+    if (workgroups * 4u <= slots || insertion_bound) return 4;
+    if (workgroups * 4u > slots * 3u || !knn_q4_has(list_len, 2)) return 1;
+    return 2;
 }
 static bool use_knn_q4(int list_len)
 {
@@ -1425,12 +1429,11 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
     // four lanes per query (kernels_knn_q4.hpp) where the launch is as long as an item's chain: near the previous pose.  Far from it the lists change
     // wholesale, a launch is bound by its insertions and k_knn_coop's wider items are the better shape (a KITTI-like 120k pair, us per launch
     // k_knn_q4 / k_knn_coop by step: 2 m 218 / 172, 1 m 156 / 158, 0.3-0.8 m 178-180 / 169-171, 0.13 m 78 / 84, 0.05 m 66 / 68, <= 0.01 m 49-55 / 62-64).
-    // Beyond k_knn_coop's range the alternative is the persistent kernel, which k_knn_q4 beats at any step up to ~3M queries with two lanes per query
-    // (20-iteration shipped aligns, ms per iteration k_knn_q4 | persistent: 150k 0.064 | 0.083, 300k 0.084 | 0.109, 650k 0.129 | 0.159, 1M 0.182 | 0.221,
-    // 2M 0.353 | 0.395, 3M 0.552 | 0.566) and up to 0.56M with four (lists of ten entries: 500k 0.136 | 0.150, 650k 0.167 | 0.156).
+    // Beyond k_knn_coop's range the alternative is the persistent kernel, which k_knn_q4 beats at any step and at every size measured (150k ... 5M
+    // queries: knn_q4_lanes_per_query above).
     const bool coop_size = (size_t)n_items64 <= (size_t)num_cus_ * 8;
     const bool knn_q4 = use_knn_q4((int)p.knn + 1) &&
-                        (g_knobs.knn_q4 == 1 || (g_knobs.knn_coop != 0 && (coop_size ? step <= kKnnQ4MaxStep : N_ <= (knn_q4_has((int)p.knn + 1, 2) ? kKnnQ4MaxQueries2 : kKnnQ4MaxQueries4))));
+                        (g_knobs.knn_q4 == 1 || (g_knobs.knn_coop != 0 && (coop_size ? step <= kKnnQ4MaxStep : N_ <= kKnnQ4MaxQueries)));
     const bool knn_coop = wide_knn || knn_q4 || (g_knobs.knn_coop >= 0 ? g_knobs.knn_coop != 0 : coop_size);   // one workgroup per item (either kernel)
     // the upper box levels in LDS while that costs the kernel no workgroup per CU (lds_box_limit), else read from global memory
     const int kq4_lpq = knn_q4 ? knn_q4_lanes_per_query((int)p.knn + 1, (size_t)n_items64, num_cus_, coop_size && bootstrapped) : 4;
@@ -1727,7 +1730,7 @@ int HipWorkspace::match_planes(const Mat4& T, const mola_icp_params& p)
         for (int k = 0; k < kStatSlots; ++k) { staged64 += stats_host_[(size_t)k * kStatStride]; certified += stats_host_[(size_t)k * kStatStride + 1]; skipped += stats_host_[(size_t)k * kStatStride + 2]; }
         HIPCHK(hipMemsetAsync(stats_.p, 0, sizeof(unsigned long long) * kStatSlots * kStatStride, stream_));
         std::fprintf(stderr, "[mola_icp debug] plane matcher launch: N=%zu items=%d %s seed=%d cert=%d bootstrapped=%d step=%.5f m | certified queries %llu (%.1f %%), items that skipped the sweep %llu (%.1f %%), pairs/query %.1f\n",
-                     N_, n_items64, knn_q4 ? (kq4_lpq == 2 ? "q4, two lanes per query (sweeps skipped: per 32-query wave)" : "q4 (sweeps skipped: per 16-query wave)") : (knn_coop ? "coop" : (verify ? "persistent+count" : "persistent")), knn_seed, cert.on, (int)bootstrapped, step, certified,
+                     N_, n_items64, knn_q4 ? (kq4_lpq == 1 ? "q4, one lane per query" : (kq4_lpq == 2 ? "q4, two lanes per query (sweeps skipped: per 32-query wave)" : "q4 (sweeps skipped: per 16-query wave)")) : (knn_coop ? "coop" : (verify ? "persistent+count" : "persistent")), knn_seed, cert.on, (int)bootstrapped, step, certified,
                      100.0 * (double)certified / (double)N_, skipped, 100.0 * (double)skipped / (double)(knn_q4 ? kq4_lpq * n_items64 : n_items64), 64.0 * (double)staged64 / (double)N_);
     }
     last_kernel_ = MOLA_ICP_NN_TILED;

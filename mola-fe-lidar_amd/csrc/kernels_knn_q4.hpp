@@ -56,12 +56,14 @@ template <int LPQ> constexpr int kq4_wg_per_cu() { return kKq4WorkgroupsPerCu * 
 // min / max over the wave's queries (every sub-lane of a query holds the same value) as a scalar
 template <int LPQ> __device__ __forceinline__ float wave_min_qn(float v)
 {
-    if constexpr (LPQ == 2) v = fminf(v, dpp_f<kDppRor2>(v));
+    if constexpr (LPQ == 1) v = fminf(v, dpp_f<kDppRor1>(v));
+    if constexpr (LPQ <= 2) v = fminf(v, dpp_f<kDppRor2>(v));
     return wave_min_q(v);
 }
 template <int LPQ> __device__ __forceinline__ float wave_max_qn(float v)
 {
-    if constexpr (LPQ == 2) v = fmaxf(v, dpp_f<kDppRor2>(v));
+    if constexpr (LPQ == 1) v = fmaxf(v, dpp_f<kDppRor1>(v));
+    if constexpr (LPQ <= 2) v = fmaxf(v, dpp_f<kDppRor2>(v));
     return wave_max_q(v);
 }
 
@@ -72,8 +74,8 @@ __global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD
 {
     constexpr int QW = 64 / LPQ;   // queries per wave
     constexpr int NW = LPQ;        // waves per workgroup (64 queries)
-    static_assert(LPQ == 4 || LPQ == 2, "four or two lanes per query");
-    static_assert(QW * (NW - 1) + QW * kq4_rows<K>() <= kKq4RingFloats, "the records of a wave must fit its ring");
+    static_assert(LPQ == 4 || LPQ == 2 || LPQ == 1, "four, two or one lane(s) per query");
+    static_assert(LPQ == 1 || QW * (NW - 1) + QW * kq4_rows<K>() <= kKq4RingFloats, "the records of a wave must fit its ring");   // (one lane per query: no records, the wave runs its own epilogue)
     __shared__ __attribute__((aligned(16))) float s_ring[NW][kKq4RingFloats];
     __shared__ int s_done;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int tq = open ? (pass ? tq1 : tq0) : -1;
-                unsigned long long rem = __ballot(tq >= 0 && tq != pre0 && tq != pre1 && tq != pre2 && tq != pre3) & (LPQ == 4 ? 0x1111111111111111ull : 0x5555555555555555ull);   // one lane per query
+                unsigned long long rem = __ballot(tq >= 0 && tq != pre0 && tq != pre1 && tq != pre2 && tq != pre3) & (LPQ == 4 ? 0x1111111111111111ull : (LPQ == 2 ? 0x5555555555555555ull : ~0ull));   // one lane per query
                 while (rem && n_tl < kQ4Bank) {
                     const int t = __builtin_amdgcn_readlane(tq, kq4_ff1(rem));
                     rem &= ~__ballot(tq == t);
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD
         // the query's live bound: the smallest of its four sub-lanes' (all >= 0, or all -1: the bit patterns order as integers)
         auto live_bound = [&]() -> float {
             int v = __float_as_int(kb);
-            v = min(v, dpp_i<kDppXor1>(v));
+            if constexpr (LPQ >= 2) v = min(v, dpp_i<kDppXor1>(v));
             if constexpr (LPQ == 4) v = min(v, dpp_i<kDppXor2>(v));
             return __int_as_float(v);
         };
@@ -251,6 +253,16 @@ __global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD
             ++dg_tests;
 #endif
             const int c0 = kq4_ff1(cand); kq4_bitset0(cand, c0);
+            if constexpr (LPQ == 1) {   // one candidate, the same for every query: its box comes as scalars (callers pass a non-empty mask)
+                const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0), c0)), m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1), c0));
+                const float m2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2), c0)), m3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r3), c0));
+                const float m4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r4), c0)), m5 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r5), c0));
+                const float ax = qx - __builtin_amdgcn_fmed3f(qx, m0, m3);
+                const float ay = qy - __builtin_amdgcn_fmed3f(qy, m1, m4);
+                const float az = qz - __builtin_amdgcn_fmed3f(qz, m2, m5);
+                if (__any(fmaf(az, az, fmaf(ay, ay, ax * ax)) <= bound)) on_pass(c0);
+                return;
+            }
             const int c1 = kq4_ff1(cand); kq4_bitset0(cand, c1);
             int c2 = -1, c3 = -1;
             if constexpr (LPQ == 4) {
@@ -444,9 +456,9 @@ __global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD
 
         KQ4_STAMP(3);
         // ---- the four lists of a query become one: two symmetric steps, both partners end with the same merged list ----
-        if (__any(inserted)) {
+        if (LPQ > 1 && __any(inserted)) {
 #pragma unroll
-            for (int st = 0; st < (LPQ == 4 ? 2 : 1); ++st) {
+            for (int st = 0; st < (LPQ == 4 ? 2 : (LPQ == 2 ? 1 : 0)); ++st) {
                 unsigned int plo[K], phi[K];
                 int pp[K];
 #pragma unroll
@@ -471,6 +483,7 @@ __global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD
         }
     }
 
+    if constexpr (LPQ > 1) {
     // ---- the wave's records for the epilogue (row r by sub-lane r & 3: every sub-lane holds the merged list) ----
     {
         int* rec = reinterpret_cast<int*>(ring) + QW * wave + q;
@@ -485,6 +498,7 @@ __global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD
         if (s == ((3 * K + 2) & (LPQ - 1))) rec[QW * (3 * K + 2)] = __float_as_int(qz);
         if (s == ((3 * K + 3) & (LPQ - 1))) rec[QW * (3 * K + 3)] = __float_as_int(lbw);
     }
+    }
     if (lane == 0 && tiles && staged_total)   // units of 64 (query, point) pairs: a tile = 32 points x QW queries
         atomicAdd(staged_total + (size_t)((blockIdx.x * NW + wave) & (kStatSlots - 1)) * kStatStride, (unsigned long long)tiles * (unsigned long long)(QW / 2));
     if (cert_stats && lane == 0 && cert_mask) {   // [1] certified queries, [2] sweeps skipped -- per 16-query wave here, not per 64-query item
@@ -493,6 +507,17 @@ __global__ __launch_bounds__(64 * LPQ, kKq4WorkgroupsPerCu /*HIP: waves per SIMD
         if (skip_sweep) atomicAdd(st + 2, 1ull);
     }
     KQ4_STAMP(4);
+    if constexpr (LPQ == 1) {   // one lane per query: the wave holds a whole row of 64 and runs its epilogue from registers
+        float ed[K];
+        unsigned int eo[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { ed[j] = kd_of(j); eo[j] = (unsigned int)(kk[j] & 0xffffffffull); }
+        if (valid) pb.lb[qi] = lbw > 0.f ? lbw : sqrtf(ed[K - 1]) * kCertDown;
+        const bool changed = plane_epilogue<K>(mp, kp, ed, eo, qx, qy, qz, qi, N, thr2, threshold, plane_eig_thr, pb.out, pb.cache, pb.seeds, use_seed, pb.use_cache);
+        if (lane == 0 && changed && pb.changed_items) atomicAdd(pb.changed_items + (size_t)(blockIdx.x & (kQueues - 1)) * kQueueStride, 1u);
+        KQ4_STAMP(5);
+        return;
+    }
 #ifdef MOLA_KQ4_DIAG
     if (dbg_w) {
         dbg_w[6] = (unsigned long long)tiles | ((unsigned long long)(skip_sweep ? 1 : 0) << 32) | ((unsigned long long)(__popcll(cert_mask) / LPQ) << 40);

@@ -15,18 +15,24 @@ namespace mola_icp_amd {
 // ... at two lanes per query 4 .. 9 (a wave's 32 lists must fit its ring)
 #define MOLA_KQ4_LENGTHS2(X) X(4) X(5) X(6) X(7) X(8) X(9)
 
-bool knn_q4_has(int list_len, int lpq) { return list_len >= 4 && list_len <= (lpq == 2 ? 9 : 10) && (lpq == 2 || lpq == 4); }
-int knn_q4_workgroups_per_cu(int lpq) { return lpq == 2 ? kq4_wg_per_cu<2>() : kq4_wg_per_cu<4>(); }
+bool knn_q4_has(int list_len, int lpq) { return list_len >= 4 && list_len <= (lpq == 2 ? 9 : 10) && (lpq == 1 || lpq == 2 || lpq == 4); }
+int knn_q4_workgroups_per_cu(int lpq) { return lpq == 1 ? kq4_wg_per_cu<1>() : (lpq == 2 ? kq4_wg_per_cu<2>() : kq4_wg_per_cu<4>()); }
 
 size_t knn_q4_static_lds(int list_len, int lpq)
 {
-    static size_t bytes[2][18] = {};
+    static size_t bytes[3][18] = {};
     if (!knn_q4_has(list_len, lpq)) return 0;
-    size_t& b = bytes[lpq == 2 ? 1 : 0][list_len];
+    size_t& b = bytes[lpq == 1 ? 2 : (lpq == 2 ? 1 : 0)][list_len];
     if (!b) {
         hipFuncAttributes fa{};
         hipError_t e = hipErrorInvalidValue;
-        if (lpq == 2) {
+        if (lpq == 1) {
+            switch (list_len) {
+#define X(KK) case KK: e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_knn_q4<KK, 1, 1>)); break;
+                MOLA_KQ4_LENGTHS(X)
+#undef X
+            }
+        } else if (lpq == 2) {
             switch (list_len) {
 #define X(KK) case KK: e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_knn_q4<KK, 1, 2>)); break;
                 MOLA_KQ4_LENGTHS2(X)
@@ -104,7 +110,13 @@ hipError_t knn_q4_launch(hipStream_t stream, int list_len, const KnnBatch<1>& b,
     (void)hipMemsetAsync(kq4_dbg_buf(), 0, 16 * 8192 * sizeof(unsigned long long), stream);
 #endif
     if (!knn_q4_has(list_len, lpq)) return hipErrorInvalidValue;
-    if (lpq == 2) {
+    if (lpq == 1) {
+        switch (list_len) {
+#define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, 1, 1>), dim3(grid), dim3(64), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
+            MOLA_KQ4_LENGTHS(X)
+#undef X
+        }
+    } else if (lpq == 2) {
         switch (list_len) {
 #define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, 1, 2>), dim3(grid), dim3(128), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
             MOLA_KQ4_LENGTHS2(X)
@@ -128,7 +140,13 @@ hipError_t knn_q4_launch_batch(hipStream_t stream, int list_len, const KnnBatch<
                                float thr2x, double threshold, double plane_eig_thr, unsigned long long* staged, int lds_boxes, unsigned long long* cert_stats, int lpq)
 {
     if (!knn_q4_has(list_len, lpq)) return hipErrorInvalidValue;
-    if (lpq == 2) {
+    if (lpq == 1) {
+        switch (list_len) {
+#define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, kKnnMaxBatch, 1>), dim3(grid_x, n_problems), dim3(64), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
+            MOLA_KQ4_LENGTHS(X)
+#undef X
+        }
+    } else if (lpq == 2) {
         switch (list_len) {
 #define X(KK) case KK: hipLaunchKernelGGL((k_knn_q4<KK, kKnnMaxBatch, 2>), dim3(grid_x, n_problems), dim3(128), dyn_lds, stream, b, thr2, thr2x, threshold, plane_eig_thr, staged, lds_boxes, cert_stats); break;
             MOLA_KQ4_LENGTHS2(X)

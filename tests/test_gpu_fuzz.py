@@ -47,7 +47,7 @@ def test_random_cases_equal_the_oracle(pkg, O, synth):
             if u < 0.5:
                 env["MOLA_ICP_KNN_Q4"] = "1" if u < 0.35 else "0"
             if rng.random() < 0.5:
-                env["MOLA_ICP_KNN_Q4_LPQ"] = str(rng.choice([2, 4]))
+                env["MOLA_ICP_KNN_Q4_LPQ"] = str(rng.choice([1, 2, 4]))
             os.environ.update(env)
             pkg._lib.lib().mola_icp_debug_reload_env()
             N = int(rng.choice([1, 63, 64, 65, 127, 129, 1000, 4097, 9000, 20000, 33333]) if rng.random() < 0.5 else rng.integers(1, max_n))
@@ -122,7 +122,7 @@ def test_large_random_cases_equal_the_oracle_on_a_sample(pkg, O, synth):
             if rng.random() < 0.3:
                 env["MOLA_ICP_Q4"] = "1"
             if rng.random() < 0.4:
-                env["MOLA_ICP_KNN_Q4_LPQ"] = str(rng.choice([2, 4]))
+                env["MOLA_ICP_KNN_Q4_LPQ"] = str(rng.choice([1, 2, 4]))
             os.environ.update(env)
             pkg._lib.lib().mola_icp_debug_reload_env()
             N = int(rng.integers(300_000, 900_001))

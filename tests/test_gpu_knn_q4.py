@@ -1,4 +1,4 @@
-"""-m gpu: k_knn_q4 (the plane matcher with four or two lanes per query, csrc/kernels_knn_q4.hpp): every instantiated list length against the
+"""-m gpu: k_knn_q4 (the plane matcher with four, two or one lane(s) per query, csrc/kernels_knn_q4.hpp): every instantiated list length against the
 oracle at a first launch and at seeded / certified launches behind it, ragged tails, a map too large for the LDS copy of the box
 levels, exact distance ties, the switch (MOLA_ICP_KNN_Q4=0|1: the same lists, planes and aligns from the kernels it replaces, also when
 the kernel changes between the launches of one align), and the lockstep batches."""
@@ -34,9 +34,9 @@ def _against_oracle(O, g, l, T, p, out, kd, step=1):
 
 
 @pytest.mark.parametrize("knn,n,lpq", [(3, 9000, 4), (4, 8207, 2), (5, 12_345, 4), (6, 20_011, 2), (6, 20_011, 4), (7, 9001, 2), (8, 8192, 2), (8, 8192, 4),
-                                       (9, 10_000, 4), (3, 777, 2), (6, 33, 2)])
+                                       (9, 10_000, 4), (3, 777, 2), (6, 33, 2), (6, 20_011, 1), (9, 10_000, 1), (3, 9001, 1), (6, 33, 1)])
 def test_every_list_length_first_seeded_and_certified_launches(pkg, O, synth, knn, n, lpq):
-    """list lengths 4 .. 10 at four lanes per query, 4 .. 9 at two; N not a multiple of 16, 32 or 64 (the last wave / workgroup partly padding,
+    """list lengths 4 .. 10 at four lanes per query and at one, 4 .. 9 at two; N not a multiple of 16, 32 or 64 (the last wave / workgroup partly padding,
     a cloud smaller than one wave's share): a first launch (key-bootstrapped
     seeds), a launch 1 cm away (seeded, few certificates), one 0.1 mm further (nearly every query certified: most waves skip the sweep)"""
     g, l, _ = synth.make_pair(n, 30_000, seed=3 + knn)
@@ -56,7 +56,7 @@ def test_every_list_length_first_seeded_and_certified_launches(pkg, O, synth, kn
     icp.close()
 
 
-@pytest.mark.parametrize("lpq", [4, 2])
+@pytest.mark.parametrize("lpq", [4, 2, 1])
 def test_large_map_box_levels_from_global_memory(pkg, O, synth, lpq):
     """30 011 queries against a 2M-point map: sixteen top boxes, 977 super-tiles -- 24 KB of box levels, more than k_knn_q4 keeps in LDS
     beside its rings; a far launch (lists overflow and resume) and a near one"""
@@ -76,7 +76,7 @@ def test_large_map_box_levels_from_global_memory(pkg, O, synth, lpq):
     icp.close()
 
 
-@pytest.mark.parametrize("lpq", [4, 2])
+@pytest.mark.parametrize("lpq", [4, 2, 1])
 def test_exact_ties_resolve_by_original_index(pkg, O, lpq):
     """a lattice map with every point duplicated, queries at cell centres: sixteen points at the same distance compete for six places --
     the packed (d2, original index) keys of the four sub-lanes' lists and of their merge must order them as the oracle does"""
@@ -111,7 +111,7 @@ def test_the_switch_changes_nothing(pkg, synth):
         g, l, _ = synth.make_pair(n, m, seed=23)
         outs = []
         try:
-            for q, lpq in (("1", "4"), ("0", None), (None, None), ("1", "2")):
+            for q, lpq in (("1", "4"), ("0", None), (None, None), ("1", "2"), ("1", "1")):
                 _reload(pkg, MOLA_ICP_KNN_Q4=q, MOLA_ICP_KNN_Q4_LPQ=lpq)
                 icp = pkg.ICP(device=0)
                 a = icp.align(g, l, np.eye(4), p)
@@ -137,7 +137,7 @@ def test_loop_closure_guesses_in_one_launch(pkg, synth):
     guesses = [synth.pose_from_xyzypr(*(rng.normal(0, 1, 3) * 0.2), rng.normal(0, 1) * 0.02, 0, 0) for _ in range(10)]
     outs = []
     try:
-        for q, lpq in (("1", "4"), ("0", None), ("1", "2")):
+        for q, lpq in (("1", "4"), ("0", None), ("1", "2"), ("1", "1")):
             _reload(pkg, MOLA_ICP_KNN_Q4=q, MOLA_ICP_KNN_Q4_LPQ=lpq)
             icp = pkg.ICP(device=0)
             res, best = icp.align_multi_init(g, l, guesses, p)
