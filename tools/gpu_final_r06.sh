@@ -29,6 +29,7 @@ c)
   echo "== odometry-size matcher counters (k_nn_q4)"; bash tools/rocprof_small.sh r06_small > $O/rocprof_small.log 2>&1; tail -5 $O/rocprof_small.log
   echo "== odometry stream timeline"; bash tools/rocprof_odometry.sh > $O/rocprof_odometry.log 2>&1; tail -3 gpurun_out/prof_odometry/timeline.txt
   echo "== plane matcher at 120k x 120k (k_knn_q4 + the far launches' k_knn_coop): counters"; bash tools/rocprof_planes.sh r06_knn_q4 120000 > $O/rocprof_planes.log 2>&1; tail -3 $O/rocprof_planes.log
+  echo "== plane matcher at 1M x 1M (k_knn_q4, one lane per query: the shipped pipeline's matcher at configs[2]): counters"; bash tools/rocprof_planes.sh r06_knn_q4_1m 1000000 > $O/rocprof_planes_1m.log 2>&1; tail -3 $O/rocprof_planes_1m.log
   echo "== 100k x 100k iteration timeline"; bash tools/rocprof_timeline_any.sh 100000 p2p 12 > $O/p2p_100k_timeline.txt 2>&1; tail -8 $O/p2p_100k_timeline.txt
   ;;
 d)
