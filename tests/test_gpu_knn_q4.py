@@ -104,10 +104,10 @@ def test_exact_ties_resolve_by_original_index(pkg, O, lpq):
 def test_the_switch_changes_nothing(pkg, synth):
     """the shipped pipeline (Point2Plane + Gauss-Newton) through k_knn_q4 everywhere, nowhere, and by the default rule (far launches on
     k_knn_coop, near ones on k_knn_q4 -- the kernel changes INSIDE the align, and with it who wrote the seeds the next launch reads):
-    the same pose, iteration count, quality and pairing, bit for bit; a size beyond k_knn_coop's range too (k_knn_q4 / the persistent
-    kernel), and a lockstep batch"""
+    the same pose, iteration count, quality and pairing, bit for bit; sizes beyond k_knn_coop's range too (k_knn_q4 with two lanes per query,
+    with one / the persistent kernel), and a lockstep batch"""
     p = pkg.Parameters.load_from_file(REGULAR)
-    for n, m in ((40_000, 60_000), (150_000, 150_000)):
+    for n, m in ((40_000, 60_000), (150_000, 150_000), (300_000, 280_000)):   # (by the default rule: four+two / two / one lane(s) per query)
         g, l, _ = synth.make_pair(n, m, seed=23)
         outs = []
         try:
