@@ -1,9 +1,10 @@
-// kernels_knn_q4.hpp -- k_knn_q4: the point-to-plane matcher (mp2p_icp::Matcher_Point2Plane, params/icp-settings-regular.yaml:33-39) for
-// launches with FEWER ITEMS THAN WAVE SLOTS -- the odometry stream's scans, the loop-closure Monte-Carlo -- four lanes per query.
+// kernels_knn_q4.hpp -- k_knn_q4: the point-to-plane matcher (mp2p_icp::Matcher_Point2Plane, params/icp-settings-regular.yaml:33-39) with
+// LPQ = four, two or one lane(s) per query -- every launch of the plane matcher except the far launches of odometry-size clouds
+// (k_knn_coop) and lists longer than ten entries.
 // Device code of the ICP core for gfx950; compiled by knn_q4_launch.hip alone.  Numeric contract: hip_backend.hip / DESIGN.md.
 //
 // k_nn_q4 (kernels_q4.hpp) showed what shortens a launch that is as long as one item's chain: a smaller item.  The same shape for the
-// neighbour LISTS of the plane matcher:
+// neighbour LISTS of the plane matcher, at LPQ = 4:
 //   * an item = 16 consecutive sorted queries on ONE wave, lane 4 q + s = query q, sub-lane s; box tests four boxes per instruction
 //     group; a listed tile goes from global memory straight into the wave's LDS ring -- here with its row of ORIGINAL INDICES (the
 //     tie-break half of a list key): 32 lanes x 16 bytes per tile, so ONE global_load_lds_dwordx4 carries two whole tiles;
@@ -15,7 +16,14 @@
 //   * ONE workgroup = four waves = 64 queries: a wave leaves its 16 lists in its own ring, and whichever wave finishes LAST (an LDS
 //     ticket, no barrier) runs the plane epilogue for all 64 -- one query per lane, the fp64 covariance and eigen-solve on full waves
 //     exactly as in k_knn_coop (plane_epilogue: same lists -> same planes, seeds, cached planes, certificates).
-// Certified lists (KnnCert) as in k_knn_coop; a wave whose 16 queries are all certified skips the sweep (k_knn_coop decides that per
+// A launch costs ~20 us + 0.45 us per 1 000 queries at four lanes: beyond the kernel's wave slots (~80k queries) fewer, longer waves win --
+//   * LPQ = 2: 32 queries per wave, two waves per workgroup; sub-lane s evaluates points 16 s .. 16 s + 15 of a tile in two groups of
+//     eight, box tests two per group, one merge step;
+//   * LPQ = 1: a wave = a whole row of 64 queries = the workgroup; a test's candidate box reaches the lanes as scalars, nothing to
+//     merge, no records, no ticket -- the wave runs plane_epilogue from its registers.  k_knn_planes' item without the persistent
+//     kernel's machinery, and faster than it at every size measured (profiles/r06/k_knn_q4_development.txt).
+// Which one a launch gets: hip_backend.hip, knn_q4_lanes_per_query.
+// Certified lists (KnnCert) as in k_knn_coop; a wave whose queries are all certified skips the sweep (k_knn_coop decides that per
 // 64).  Results are identical to k_knn_coop / k_knn_planes: the lists are THE K nearest by (d2, original index), whatever finds them.
 #pragma once
 #include "kernels_planes.hpp"
@@ -37,8 +45,6 @@ __device__ unsigned long long* g_kq4_dbg = nullptr;
 #else
 #define KQ4_STAMP(k) do { } while (0)
 #endif
-// a wave's records for the epilogue: row r of query q at word QW * wave + QW * r + q of its ring, QW = its queries (the skew by the wave keeps the 64
-// lanes of the epilogue on 64 different banks); rows: key low / key high / position per entry, the moved query, the certificate
 // (a wave-uniform 64-bit mask the compiler may have chosen to keep in vector registers -- it does with the scan's state here -- named
 //  as the scalar it is: free where the value already lives in scalar registers)
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long m)
@@ -49,9 +55,10 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long m)
 }
 __device__ __forceinline__ int kq4_ff1(unsigned long long m) { return sff1_b64(uniform64(m)); }
 __device__ __forceinline__ void kq4_bitset0(unsigned long long& m, int bit) { m = uniform64(m); sbitset0_b64(m, bit); }
+// a wave's records for the epilogue (LPQ > 1): row r of query q at word QW * wave + QW * r + q of its ring, QW = its queries (the skew by the wave
+// keeps the 64 lanes of the epilogue on 64 different banks); rows: key low / key high / position per entry, the moved query, the certificate
 template <int K> constexpr int kq4_rows() { return 3 * K + 4; }
-// LPQ lanes per query: 4 (16 queries per wave, four waves per workgroup) or 2 (32 queries per wave, two waves per workgroup: half as many
-// waves of about 1.3x the chain -- for launches whose waves at four lanes per query outnumber the wave slots)
+// workgroups per CU at LPQ lanes per query (a workgroup = LPQ waves = 64 queries): the same waves per SIMD whatever LPQ
 template <int LPQ> constexpr int kq4_wg_per_cu() { return kKq4WorkgroupsPerCu * (4 / LPQ); }   // the same waves per SIMD either way
 // min / max over the wave's queries (every sub-lane of a query holds the same value) as a scalar
 template <int LPQ> __device__ __forceinline__ float wave_min_qn(float v)

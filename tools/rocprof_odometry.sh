@@ -2,9 +2,9 @@
 # kernel timeline of one steady-state scan of the odometry stream (tools/prof_odometry_stream.py): bash tools/rocprof_odometry.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/prof_odometry; mkdir -p $OUT
+OUT=$ROOT/gpurun_out/prof_odometry; rm -rf $OUT/trace; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ROOT/tools/prof_odometry_stream.py 24 > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ROOT/tools/prof_odometry_stream.py 24 ${DECIMATE:-1} > $OUT/trace.log 2>&1
 find $OUT/trace -name "*kernel_trace.csv" -exec cp {} $OUT/kernel_trace.csv \;
 python3 - <<PY > $OUT/timeline.txt
 import csv
